@@ -1,0 +1,184 @@
+/* TEST INFRASTRUCTURE ONLY.  Shim around the UNMODIFIED reference GeoAc2D translation units
+ * (compiled from /root/reference by oracle/Makefile, never copied).  It calls the reference's own
+ * functions in the order GeoAc2D_RunProp does (GeoAc2D_main.cpp:170-232) and returns binary-double
+ * records instead of 6 digit text.  See oracle/ref_shim.h for the ABI.
+ * Here phi_deg[i] is the `azimuth=` value (one per ray; the CLI uses one for the whole run) and
+ * cfg->src[0] is z_src.
+ */
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+
+#include "GeoAc.Parameters.h"
+#include "Atmo_State.h"
+#include "G2S_Spline1D.h"
+#include "GeoAc.EquationSets.h"
+#include "GeoAc.Solver.h"
+#include "GeoAc.Interface.h"
+
+#include "ref_shim.h"
+
+static double** g_solution = 0;
+static int      g_length = 0;
+static int      g_eqcnt_built = 0;
+
+static void ensure_solution(){
+    int length = GeoAc_ray_limit * int(1.0/(GeoAc_ds_min*10));      /* GeoAc2D_main.cpp:120 */
+    if(g_solution && (g_length != length || g_eqcnt_built != GeoAc_EqCnt)){
+        GeoAc_DeleteSolutionArray(g_solution, g_length);
+        g_solution = 0;
+    }
+    if(!g_solution){
+        GeoAc_BuildSolutionArray(g_solution, length);
+        g_length = length; g_eqcnt_built = GeoAc_EqCnt;
+    }
+}
+
+extern "C" int ref_load(const char* met_file, const char* format){
+    z_grnd = 0.0;                                                   /* GeoAc2D_main.cpp:75, load (:79) precedes z_grnd= (:92) */
+    tweak_abs = 0.3;
+    Spline_Single_G2S((char*)met_file, (char*)format);
+    return Temp_Spline.length;
+}
+
+static void apply_cfg(const ref_fan_cfg* cfg){
+    z_grnd = cfg->z_grnd;
+    tweak_abs = cfg->tweak_abs;
+    if(cfg->vert_limit == cfg->vert_limit)   GeoAc_vert_limit  = cfg->vert_limit;
+    if(cfg->range_limit == cfg->range_limit) GeoAc_range_limit = cfg->range_limit;
+    bool CalcAmp = cfg->calc_amp != 0;
+    if(cfg->mode & GEOAC_MODE_WRITE_CAUSTICS) CalcAmp = true;      /* GeoAc2D_main.cpp:105 */
+    GeoAc_ConfigureCalcAmp(CalcAmp);
+    ensure_solution();
+}
+
+extern "C" int64_t ref_fan(const ref_fan_cfg* cfg, int n, const double* theta_deg, const double* phi_deg,
+                           double* rec, double* smp, int64_t smp_cap, int64_t* n_smp){
+    apply_cfg(cfg);
+    double** solution = g_solution;
+    const bool CalcAmp = GeoAc_CalcAmp;
+    const bool WriteCaustics = (cfg->mode & GEOAC_MODE_WRITE_CAUSTICS) != 0;
+    const int bounces = cfg->bounces;
+    const double freq = cfg->freq;
+    double z_src = std::max(cfg->src[0], z_grnd);                   /* :104 */
+
+    memset(rec, 0, sizeof(double) * (size_t)n * (bounces + 1) * GEOAC_REC_STRIDE);
+    int64_t total_steps = 0, ns = 0;
+    double D = 0, D_prev = 0, travel_time_sum, attenuation, z_max;
+    int k = 0; bool BreakCheck;
+
+    for(int i = 0; i < n; i++){
+        double theta = theta_deg[i], azimuth = phi_deg[i];
+        GeoAc_theta = theta*Pi/180.0;                               /* :172 */
+        GeoAc_phi = Pi/2.0 - azimuth*Pi/180.0;                      /* :173 */
+        GeoAc_SetInitialConditions(solution, 0.0, z_src);
+        travel_time_sum = 0.0; attenuation = 0.0; z_max = 0.0;
+
+        for(int bnc_cnt = 0; bnc_cnt <= bounces; bnc_cnt++){
+            double* R = rec + ((size_t)i * (bounces + 1) + bnc_cnt) * GEOAC_REC_STRIDE;
+            k = GeoAc_Propagate_RK4(solution, BreakCheck);
+            total_steps += k;
+            R[GEOAC_REC_STEPS] = k;
+            R[GEOAC_REC_BROKE] = BreakCheck ? 1.0 : 0.0;
+
+            if(WriteCaustics) D_prev = GeoAc_Jacobian(solution,1);
+            for(int m = 1; m < k; m++){
+                GeoAc_TravelTimeSegment(travel_time_sum, solution, m-1, m);
+                GeoAc_SB_AttenSegment(attenuation, solution, m-1, m, freq);
+                if(WriteCaustics) D = GeoAc_Jacobian(solution,m);
+                if(m % 25 == 0){
+                    if(smp && ns < smp_cap){
+                        double* S = smp + ns * GEOAC_SMP_STRIDE;
+                        S[GEOAC_SMP_RAY] = i; S[GEOAC_SMP_LEG] = bnc_cnt; S[GEOAC_SMP_M] = m; S[GEOAC_SMP_KIND] = 0;
+                        S[4] = solution[m][0];
+                        S[5] = std::max(solution[m][1],0.0);
+                        S[6] = CalcAmp ? 20.0*log10(GeoAc_Amplitude(solution,m)) : 0.0;
+                        S[7] = -attenuation;
+                        S[8] = travel_time_sum;
+                        S[9] = 0;
+                    }
+                    ns++;
+                }
+                if(WriteCaustics && D*D_prev < 0.0){
+                    if(smp && ns < smp_cap){
+                        double* S = smp + ns * GEOAC_SMP_STRIDE;
+                        S[GEOAC_SMP_RAY] = i; S[GEOAC_SMP_LEG] = bnc_cnt; S[GEOAC_SMP_M] = m; S[GEOAC_SMP_KIND] = 1;
+                        S[4] = solution[m][0];
+                        S[5] = solution[m][1];
+                        S[6] = travel_time_sum;
+                        S[7] = 0; S[8] = 0; S[9] = 0;
+                    }
+                    ns++;
+                }
+                if(WriteCaustics) D_prev = D;
+            }
+            R[GEOAC_REC_TTIME] = travel_time_sum;
+            R[GEOAC_REC_ATTEN] = attenuation;
+
+            if(BreakCheck) break;
+            for(int m = 0; m < k; m++) z_max = std::max(z_max, solution[m][1]);
+
+            R[GEOAC_REC_VALID]  = 1.0;
+            R[GEOAC_REC_TURN]   = z_max;
+            R[GEOAC_REC_INCL]   = -theta;
+            R[GEOAC_REC_BACKAZ] = 0.0;
+            R[GEOAC_REC_RANGE]  = solution[k][0];
+            if(CalcAmp){
+                R[GEOAC_REC_AMP]   = GeoAc_Amplitude(solution,k);
+                R[GEOAC_REC_JACOB] = GeoAc_Jacobian(solution,k);
+            }
+            for(int e = 0; e < GeoAc_EqCnt; e++) R[GEOAC_REC_STATE + e] = solution[k][e];
+
+            GeoAc_SetReflectionConditions(solution,k);
+        }
+        GeoAc_ClearSolutionArray(solution,k);                       /* :228 */
+    }
+    if(n_smp) *n_smp = ns;
+    return total_steps;
+}
+
+extern "C" void ref_atmo_probe(int n, const double* x, double* out9, double* rho_out){
+    for(int i = 0; i < n; i++){
+        double r = x[i];
+        out9[9*i+0] = c(0,0,r);  out9[9*i+1] = c_diff(0,0,r,2);  out9[9*i+2] = c_ddiff(0,0,r,2,2);
+        out9[9*i+3] = u(0,0,r);  out9[9*i+4] = u_diff(0,0,r,2);  out9[9*i+5] = u_ddiff(0,0,r,2,2);
+        out9[9*i+6] = v(0,0,r);  out9[9*i+7] = v_diff(0,0,r,2);  out9[9*i+8] = v_ddiff(0,0,r,2,2);
+        rho_out[i] = rho(0,0,r);
+    }
+}
+
+extern "C" void ref_absorption_probe(int n, const double* x, const double* f, double zg, double tweak, double* out){
+    double zg0 = z_grnd, tw0 = tweak_abs;
+    z_grnd = zg; tweak_abs = tweak;
+    for(int i = 0; i < n; i++) out[i] = SuthBass_Alpha(0.0, 0.0, x[i], f[i]);
+    z_grnd = zg0; tweak_abs = tw0;
+}
+
+extern "C" int ref_tables(int cap, double* x, double* T, double* u_, double* v_, double* rho_,
+                          double* sT, double* su, double* sv, double* srho){
+    int n = Temp_Spline.length;
+    if(n > cap) return -n;
+    for(int i = 0; i < n; i++){
+        x[i] = Temp_Spline.x_vals[i];
+        T[i] = Temp_Spline.f_vals[i];       sT[i] = Temp_Spline.slopes[i];
+        u_[i] = Windu_Spline.f_vals[i];     su[i] = Windu_Spline.slopes[i];
+        v_[i] = Windv_Spline.f_vals[i];     sv[i] = Windv_Spline.slopes[i];
+        rho_[i] = Density_Spline.f_vals[i]; srho[i] = Density_Spline.slopes[i];
+    }
+    return n;
+}
+
+extern "C" int ref_trace_leg0(const ref_fan_cfg* cfg, double theta_deg, double phi_deg, int max_rows, double* out, int* E){
+    apply_cfg(cfg);
+    double z_src = std::max(cfg->src[0], z_grnd);
+    GeoAc_theta = theta_deg*Pi/180.0;
+    GeoAc_phi = Pi/2.0 - phi_deg*Pi/180.0;
+    GeoAc_SetInitialConditions(g_solution, 0.0, z_src);
+    bool BreakCheck;
+    int k = GeoAc_Propagate_RK4(g_solution, BreakCheck);
+    *E = GeoAc_EqCnt;
+    for(int m = 0; m <= k && m < max_rows; m++)
+        for(int e = 0; e < GeoAc_EqCnt; e++) out[(size_t)m*GeoAc_EqCnt + e] = g_solution[m][e];
+    GeoAc_ClearSolutionArray(g_solution, k);
+    return BreakCheck ? -k : k;
+}
