@@ -1,0 +1,192 @@
+"""ctypes mirror of include/geoac_hip.h + include/geoac_host.h (libgeoac_hip.so, built in-tree by
+geoac_amd/csrc/Makefile or __graft_entry__.build()).  Names follow the reference's vocabulary:
+rays, legs (bounces), launch angles theta/phi, arrivals."""
+import ctypes
+import os
+
+import numpy as np
+
+EQ_2D, EQ_3D, EQ_GLOBAL, EQ_3D_RNGDEP, EQ_GLOBAL_RNGDEP = 0, 1, 2, 3, 4
+REC_STRIDE = 32
+REC = dict(VALID=0, STEPS=1, BROKE=2, TTIME=3, ATTEN=4, TURN=5, INCL=6, BACKAZ=7, AMP=8, RANGE=9, JACOB=10, STATE=12)
+MODE_WRITE_RAYS, MODE_WRITE_CAUSTICS = 1, 2
+
+_dp = ctypes.POINTER(ctypes.c_double)
+
+
+class GeoAcError(RuntimeError):
+    pass
+
+
+class Params(ctypes.Structure):
+    """geoac_params (include/geoac_hip.h): the reference's globals + *_RunProp locals."""
+    _fields_ = [("ds_min", ctypes.c_double), ("ds_max", ctypes.c_double), ("ray_limit", ctypes.c_double),
+                ("vert_limit", ctypes.c_double), ("range_limit", ctypes.c_double), ("z_grnd", ctypes.c_double),
+                ("r_earth", ctypes.c_double), ("tweak_abs", ctypes.c_double), ("freq", ctypes.c_double),
+                ("src", ctypes.c_double * 3), ("bounces", ctypes.c_int), ("calc_amp", ctypes.c_int),
+                ("mode", ctypes.c_int), ("sample_stride", ctypes.c_int)]
+
+
+def library_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libgeoac_hip.so")
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libgeoac_hip.so; raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise GeoAcError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                         f"or `make -C geoac_amd/csrc` (there is no CPU fallback)")
+    lib = ctypes.CDLL(path)
+    lib.geoac_strerror.restype = ctypes.c_char_p
+    lib.geoac_last_error.restype = ctypes.c_char_p
+    lib.geoac_last_error.argtypes = [ctypes.c_void_p]
+    lib.geoac_version.restype = ctypes.c_char_p
+    lib.geoac_fan_enumerate.restype = ctypes.c_long
+    lib.geoac_fan_enumerate.argtypes = [ctypes.c_double] * 6 + [ctypes.c_long, _dp, _dp]
+    _lib = lib
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _arr(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+# ---------------- host set-up helpers (include/geoac_host.h) ----------------
+def met_load(path, eqset, fmt="zTuvdp"):
+    """read a .met profile the way Spline_Single_G2S does; returns dict x,T,u,v,rho (x = radius for Global)."""
+    lib = load_library()
+    rows = lib.geoac_met_rows(path.encode())
+    if rows < 3:
+        raise GeoAcError(f"cannot read profile {path} (rows={rows})")
+    a = [np.zeros(rows) for _ in range(5)]
+    n = lib.geoac_met_load(path.encode(), fmt.encode(), eqset, rows, *[_p(t) for t in a])
+    if n != rows:
+        raise GeoAcError(f"geoac_met_load({path}) -> {n}")
+    return dict(zip(("x", "T", "u", "v", "rho"), a))
+
+
+def natural_spline_slopes(x, f):
+    lib = load_library()
+    x, f = _arr(x), _arr(f)
+    s = np.zeros(len(x))
+    lib.geoac_natural_spline_slopes(len(x), _p(x), _p(f), _p(s))
+    return s
+
+
+def fan_enumerate(theta_min=0.5, theta_max=45.0, theta_step=0.5, phi_min=-90.0, phi_max=-90.0, phi_step=1.0):
+    """launch angles of the reference's double loop (repeated addition; phi outer, theta inner)."""
+    lib = load_library()
+    n = lib.geoac_fan_enumerate(theta_min, theta_max, theta_step, phi_min, phi_max, phi_step, 0, None, None)
+    if n < 0:
+        raise GeoAcError("fan_enumerate: bad step")
+    th, ph = np.zeros(n), np.zeros(n)
+    lib.geoac_fan_enumerate(theta_min, theta_max, theta_step, phi_min, phi_max, phi_step, n, _p(th), _p(ph))
+    return th, ph
+
+
+def default_params(eqset):
+    p = Params()
+    rc = load_library().geoac_default_params(eqset, ctypes.byref(p))
+    if rc:
+        raise GeoAcError("geoac_default_params failed")
+    return p
+
+
+# ---------------- the GPU fan context ----------------
+class FanContext:
+    """One geoac_ctx: a GPU, a stream, an atmosphere, a parameter set; runs fans of launch angles."""
+
+    def __init__(self, eqset, device=0, stream=None):
+        self.lib = load_library()
+        self.eqset = eqset
+        self._h = ctypes.c_void_p()
+        rc = self.lib.geoac_create(ctypes.byref(self._h), eqset, device)
+        if rc:
+            raise GeoAcError(f"geoac_create: {self.lib.geoac_strerror(rc).decode()}")
+        if stream is not None:
+            self._chk(self.lib.geoac_set_stream(self._h, ctypes.c_void_p(stream)))
+        self.params = default_params(eqset)
+        self.n_rays = 0
+
+    def _chk(self, rc):
+        if rc:
+            msg = self.lib.geoac_last_error(self._h)
+            raise GeoAcError(f"{self.lib.geoac_strerror(rc).decode()}: {msg.decode() if msg else ''}")
+
+    def close(self):
+        if self._h:
+            self.lib.geoac_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload_atmo_1d(self, x, T, u, v, rho, slopes4=None):
+        x, T, u, v, rho = (_arr(a) for a in (x, T, u, v, rho))
+        if slopes4 is None:
+            slopes4 = np.concatenate([natural_spline_slopes(x, f) for f in (T, u, v, rho)])
+        slopes4 = _arr(slopes4)
+        self._chk(self.lib.geoac_upload_atmo_1d(self._h, len(x), _p(x), _p(T), _p(u), _p(v), _p(rho), _p(slopes4)))
+
+    def load_met(self, path, fmt="zTuvdp"):
+        a = met_load(path, self.eqset, fmt)
+        self.upload_atmo_1d(a["x"], a["T"], a["u"], a["v"], a["rho"])
+        return a
+
+    def set_params(self, **kw):
+        for k, val in kw.items():
+            if k == "src":
+                self.params.src = (ctypes.c_double * 3)(*val)
+            else:
+                setattr(self.params, k, val)
+        self._chk(self.lib.geoac_set_params(self._h, ctypes.byref(self.params)))
+
+    def set_angles(self, theta_deg, phi_deg):
+        th, ph = _arr(theta_deg), _arr(phi_deg)
+        assert len(th) == len(ph)
+        self.n_rays = len(th)
+        self._chk(self.lib.geoac_fan_set_angles(self._h, len(th), _p(th), _p(ph)))
+
+    def launch(self):
+        self._chk(self.lib.geoac_fan_launch(self._h))
+
+    def fetch(self):
+        legs = self.params.bounces + 1
+        rec = np.zeros((self.n_rays, legs, REC_STRIDE))
+        steps = ctypes.c_uint64(0)
+        self._chk(self.lib.geoac_fan_fetch(self._h, _p(rec), ctypes.byref(steps)))
+        return rec, int(steps.value)
+
+    def records_dev(self):
+        ptr = ctypes.c_void_p(); nbytes = ctypes.c_size_t()
+        self._chk(self.lib.geoac_fan_records_dev(self._h, ctypes.byref(ptr), ctypes.byref(nbytes)))
+        return ptr.value, nbytes.value
+
+    def total_steps(self):
+        steps = ctypes.c_uint64(0)
+        self._chk(self.lib.geoac_fan_fetch(self._h, None, ctypes.byref(steps)))
+        return int(steps.value)
+
+    def run(self, theta_deg, phi_deg):
+        self.set_angles(theta_deg, phi_deg)
+        self.launch()
+        return self.fetch()
+
+    def timing(self):
+        ms = (ctypes.c_double * 3)(); st = (ctypes.c_uint64 * 3)()
+        self._chk(self.lib.geoac_last_timing(self._h, ms, st))
+        return dict(ms_total=ms[0], ms_rk4=ms[1], ms_post=ms[2], epochs=int(st[0]), path_bytes_w=int(st[1]), path_bytes_r=int(st[2]))

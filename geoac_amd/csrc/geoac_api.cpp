@@ -1,0 +1,378 @@
+// geoac_api.cpp - the C ABI of include/geoac_hip.h: context management, table building, the epoch loop.
+// Compiled with hipcc together with geoac_kernels.hip into libgeoac_hip.so.  No CPU compute fallback
+// exists here: every compute entry point needs a HIP device and fails loudly without one.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/geoac_hip.h"
+#include "geoac_device.h"
+
+extern "C" hipError_t geoac_launch_init(const GeoacDevParams* P, hipStream_t s);
+extern "C" hipError_t geoac_launch_rk4(const GeoacDevParams* P, int block, hipStream_t s);
+extern "C" hipError_t geoac_launch_postpass(const GeoacDevParams* P, int rows, hipStream_t s);
+
+namespace {
+
+const double kPi = 3.141592653589793238462643;
+const double kGam = 1.4, kRgas = 287.05, kGamR = 0.00040187;
+
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    hipError_t ensure(size_t need){
+        if(need <= bytes && p) return hipSuccess;
+        if(p){ hipFree(p); p = nullptr; bytes = 0; }
+        hipError_t e = hipMalloc(&p, need);
+        if(e == hipSuccess) bytes = need;
+        return e;
+    }
+    void release(){ if(p) hipFree(p); p = nullptr; bytes = 0; }
+};
+
+}  // namespace
+
+struct geoac_ctx {
+    int eqset = 0, device = 0;
+    hipStream_t stream = nullptr; bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    geoac_params prm{};
+    bool have_params = false, have_atmo = false, have_angles = false, ran = false;
+    // host copy of the 1-D atmosphere (for the SuthBass reference state)
+    std::vector<double> x, T, u, v, rho, sl;
+    int n_nodes = 0;
+    // device
+    DevBuf seg, rhot, theta, phi, state, path, contrib, nrows, legend, nlegend, rec, counters;
+    unsigned long long* h_counters = nullptr;     // pinned
+    int n_rays = 0, n_pad = 0, legs = 0;
+    // last launch
+    double ms_total = 0, ms_rk4 = 0, ms_post = 0;
+    unsigned long long n_epochs = 0, path_bytes_w = 0, path_bytes_r = 0, total_steps = 0, err_flags = 0;
+    int s_rows_override = 0;
+    std::string err;
+};
+
+namespace {
+
+int fail(geoac_ctx* c, int code, const std::string& msg){ if(c) c->err = msg; return code; }
+int hipfail(geoac_ctx* c, hipError_t e, const char* where){
+    return fail(c, GEOAC_E_HIP, std::string(where) + ": " + hipGetErrorString(e));
+}
+#define HIPCHK(call) do { hipError_t e_ = (call); if(e_ != hipSuccess) return hipfail(ctx, e_, #call); } while(0)
+
+// value of the reference-form cubic at node arrays (host; used only for the SuthBass ground state)
+double host_spline_f(const std::vector<double>& xv, const std::vector<double>& fv, const double* sl, double x){
+    int n = (int)xv.size();
+    if(x > xv[n - 1]) x = xv[n - 1];
+    if(x < xv[0]) x = xv[0];
+    int k = 0;
+    while(k < n - 2 && x > xv[k + 1]) k++;
+    double h = xv[k + 1] - xv[k];
+    double X = (x - xv[k]) / h;
+    double df = fv[k + 1] - fv[k];
+    double A = sl[k] * h - df, B = -sl[k + 1] * h + df;
+    return (1.0 - X) * fv[k] + X * fv[k + 1] + X * (1.0 - X) * (A * (1.0 - X) + B * X);
+}
+
+// cubic of Eval_Spline_f (G2S_Spline1D.cpp:245-281) expanded in powers of t = x - x_k:
+//   f = f_k + s_k t + (B - 2A)/h^2 t^2 + (A - B)/h^3 t^3,  A = s_k h - df,  B = -s_{k+1} h + df
+void seg_coeffs(double x0, double x1, double f0, double f1, double s0, double s1, double* c){
+    long double h = (long double)x1 - (long double)x0;
+    long double df = (long double)f1 - (long double)f0;
+    long double A = (long double)s0 * h - df, B = -(long double)s1 * h + df;
+    c[0] = f0;
+    c[1] = s0;
+    c[2] = (double)((B - 2.0L * A) / (h * h));
+    c[3] = (double)((A - B) / (h * h * h));
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* geoac_version(void){ return "geoac_hip 0.1 (gfx950)"; }
+
+const char* geoac_strerror(int code){
+    switch(code){
+        case GEOAC_OK: return "ok";
+        case GEOAC_E_INVALID: return "invalid argument or call order";
+        case GEOAC_E_NODEVICE: return "no usable HIP device (this library has no CPU fallback)";
+        case GEOAC_E_HIP: return "HIP runtime error";
+        case GEOAC_E_UNSUPPORTED: return "equation set or mode not implemented";
+        case GEOAC_E_CAPACITY: return "capacity exceeded (step_limit or buffer)";
+        case GEOAC_E_NOMEM: return "out of memory";
+        default: return "unknown error";
+    }
+}
+
+const char* geoac_last_error(geoac_ctx* ctx){ return ctx ? ctx->err.c_str() : ""; }
+
+int geoac_default_params(int eqset, geoac_params* p){
+    if(!p) return GEOAC_E_INVALID;
+    memset(p, 0, sizeof(*p));
+    p->ds_min = 0.001; p->ds_max = 0.5;                         // GeoAc.Parameters.cpp:19-20
+    if(eqset == GEOAC_EQ_GLOBAL || eqset == GEOAC_EQ_GLOBAL_RNGDEP){
+        p->ray_limit = 10000.0;                                 // GeoAc.Parameters.Global.cpp:23
+        p->range_limit = 1500.0;                                // G2S_GlobalSpline1D.cpp:27
+        p->r_earth = 6370.0;                                    // G2S_GlobalSpline1D.cpp:35
+        p->src[0] = 0.0; p->src[1] = 30.0; p->src[2] = 0.0;     // GeoAcGlobal_main.cpp:120
+    } else {
+        p->ray_limit = 5000.0;                                  // GeoAc.Parameters.cpp:23
+        p->range_limit = 10000.0;                               // G2S_Spline1D.cpp:27
+        p->r_earth = 0.0;
+    }
+    p->vert_limit = NAN;                                        // = top of the profile, set at upload (GeoAc_SetPropRegion)
+    p->z_grnd = 0.0; p->tweak_abs = 0.3; p->freq = 0.1;
+    p->bounces = 2; p->calc_amp = 1; p->mode = 0; p->sample_stride = 25;
+    return GEOAC_OK;
+}
+
+int geoac_create(geoac_ctx** out, int eqset, int device){
+    if(!out) return GEOAC_E_INVALID;
+    *out = nullptr;
+    if(eqset < GEOAC_EQ_2D || eqset > GEOAC_EQ_GLOBAL_RNGDEP) return GEOAC_E_INVALID;
+    int ndev = 0;
+    if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GEOAC_E_NODEVICE;
+    if(device < 0 || device >= ndev) return GEOAC_E_NODEVICE;
+    if(hipSetDevice(device) != hipSuccess) return GEOAC_E_NODEVICE;
+    geoac_ctx* ctx = new geoac_ctx();
+    ctx->eqset = eqset; ctx->device = device;
+    if(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess){ delete ctx; return GEOAC_E_HIP; }
+    ctx->own_stream = true;
+    hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
+    if(hipHostMalloc((void**)&ctx->h_counters, 8 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess){
+        delete ctx; return GEOAC_E_HIP;
+    }
+    geoac_default_params(eqset, &ctx->prm);
+    const char* sr = getenv("GEOAC_S_ROWS");
+    if(sr) ctx->s_rows_override = atoi(sr);
+    *out = ctx;
+    return GEOAC_OK;
+}
+
+int geoac_destroy(geoac_ctx* ctx){
+    if(!ctx) return GEOAC_E_INVALID;
+    hipSetDevice(ctx->device);
+    if(ctx->stream) hipStreamSynchronize(ctx->stream);
+    DevBuf* bufs[] = { &ctx->seg, &ctx->rhot, &ctx->theta, &ctx->phi, &ctx->state, &ctx->path, &ctx->contrib,
+                       &ctx->nrows, &ctx->legend, &ctx->nlegend, &ctx->rec, &ctx->counters };
+    for(DevBuf* b : bufs) b->release();
+    if(ctx->h_counters) hipHostFree(ctx->h_counters);
+    if(ctx->ev0) hipEventDestroy(ctx->ev0);
+    if(ctx->ev1) hipEventDestroy(ctx->ev1);
+    if(ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return GEOAC_OK;
+}
+
+int geoac_set_stream(geoac_ctx* ctx, void* hip_stream){
+    if(!ctx) return GEOAC_E_INVALID;
+    if(ctx->own_stream && ctx->stream){ hipStreamSynchronize(ctx->stream); hipStreamDestroy(ctx->stream); }
+    ctx->stream = (hipStream_t)hip_stream; ctx->own_stream = false;
+    return GEOAC_OK;
+}
+
+int geoac_upload_atmo_1d(geoac_ctx* ctx, int n, const double* x, const double* T, const double* u,
+                         const double* v, const double* rho, const double* slopes4){
+    if(!ctx || n < 3 || !x || !T || !u || !v || !rho || !slopes4) return fail(ctx, GEOAC_E_INVALID, "upload_atmo_1d: bad arguments");
+    if(ctx->eqset != GEOAC_EQ_2D && ctx->eqset != GEOAC_EQ_3D && ctx->eqset != GEOAC_EQ_GLOBAL)
+        return fail(ctx, GEOAC_E_UNSUPPORTED, "1-D atmosphere on a range-dependent equation set");
+    for(int i = 1; i < n; i++) if(!(x[i] > x[i - 1])) return fail(ctx, GEOAC_E_INVALID, "upload_atmo_1d: abscissa not strictly increasing");
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->n_nodes = n;
+    ctx->x.assign(x, x + n); ctx->T.assign(T, T + n); ctx->u.assign(u, u + n); ctx->v.assign(v, v + n); ctx->rho.assign(rho, rho + n);
+    ctx->sl.assign(slopes4, slopes4 + 4 * (size_t)n);
+    const double* sT = slopes4; const double* su = slopes4 + n; const double* sv = slopes4 + 2 * (size_t)n; const double* sr = slopes4 + 3 * (size_t)n;
+    int nseg = n - 1;
+    std::vector<double> seg((size_t)nseg * GEOAC_SEGW), rt((size_t)nseg * 4);
+    for(int k = 0; k < nseg; k++){
+        double* s = &seg[(size_t)k * GEOAC_SEGW];
+        s[0] = x[k]; s[1] = x[k + 1];
+        seg_coeffs(x[k], x[k + 1], T[k], T[k + 1], sT[k], sT[k + 1], s + 2);
+        seg_coeffs(x[k], x[k + 1], u[k], u[k + 1], su[k], su[k + 1], s + 6);
+        seg_coeffs(x[k], x[k + 1], v[k], v[k + 1], sv[k], sv[k + 1], s + 10);
+        seg_coeffs(x[k], x[k + 1], rho[k], rho[k + 1], sr[k], sr[k + 1], &rt[(size_t)k * 4]);
+    }
+    HIPCHK(ctx->seg.ensure(seg.size() * sizeof(double)));
+    HIPCHK(ctx->rhot.ensure(rt.size() * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(ctx->seg.p, seg.data(), seg.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->rhot.p, rt.data(), rt.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    // GeoAc_SetPropRegion (G2S_Spline1D.cpp:22-28 / G2S_GlobalSpline1D.cpp:22-30): vert_limit = top node
+    if(!(ctx->prm.vert_limit == ctx->prm.vert_limit)) ctx->prm.vert_limit = x[n - 1];
+    ctx->have_atmo = true;
+    return GEOAC_OK;
+}
+
+int geoac_set_params(geoac_ctx* ctx, const geoac_params* p){
+    if(!ctx || !p) return GEOAC_E_INVALID;
+    if(p->bounces < 0 || p->bounces + 1 > GEOAC_MAXLEGS) return fail(ctx, GEOAC_E_INVALID, "bounces out of range (0..63)");
+    if(!(p->ds_min > 0) || !(p->ds_max >= p->ds_min)) return fail(ctx, GEOAC_E_INVALID, "ds_min/ds_max");
+    ctx->prm = *p;
+    if(!(ctx->prm.vert_limit == ctx->prm.vert_limit) && ctx->have_atmo) ctx->prm.vert_limit = ctx->x[ctx->n_nodes - 1];
+    if(ctx->prm.mode & GEOAC_MODE_WRITE_CAUSTICS) ctx->prm.calc_amp = 1;      // GeoAcGlobal_main.cpp:166
+    if(ctx->prm.sample_stride <= 0) ctx->prm.sample_stride = 25;
+    ctx->have_params = true;
+    return GEOAC_OK;
+}
+
+int geoac_fan_set_angles(geoac_ctx* ctx, int n_rays, const double* theta_deg, const double* phi_deg){
+    if(!ctx || n_rays <= 0 || !theta_deg || !phi_deg) return fail(ctx, GEOAC_E_INVALID, "fan_set_angles: bad arguments");
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->n_rays = n_rays;
+    ctx->n_pad = (n_rays + 63) / 64 * 64;
+    HIPCHK(ctx->theta.ensure(sizeof(double) * (size_t)ctx->n_pad));
+    HIPCHK(ctx->phi.ensure(sizeof(double) * (size_t)ctx->n_pad));
+    HIPCHK(hipMemcpyAsync(ctx->theta.p, theta_deg, sizeof(double) * (size_t)n_rays, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->phi.p, phi_deg, sizeof(double) * (size_t)n_rays, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->have_angles = true;
+    return GEOAC_OK;
+}
+
+int geoac_fan_launch(geoac_ctx* ctx){
+    if(!ctx) return GEOAC_E_INVALID;
+    if(!ctx->have_atmo || !ctx->have_angles) return fail(ctx, GEOAC_E_INVALID, "fan_launch: atmosphere and angles must be uploaded first");
+    if(ctx->eqset != GEOAC_EQ_GLOBAL) return fail(ctx, GEOAC_E_UNSUPPORTED, "only the Global stratified set is implemented on the GPU so far");
+    if(ctx->prm.mode != 0) return fail(ctx, GEOAC_E_UNSUPPORTED, "WriteRays / WriteCaustics sample capture is not implemented on the GPU yet");
+    HIPCHK(hipSetDevice(ctx->device));
+    const geoac_params& p = ctx->prm;
+    GeoacDevParams P{};
+    P.eqset = ctx->eqset; P.calc_amp = p.calc_amp ? 1 : 0; P.mode = p.mode; P.bounces = p.bounces;
+    P.n_rays = ctx->n_rays; P.n_pad = ctx->n_pad;
+    P.E = p.calc_amp ? 18 : 6; P.pathw = 6;
+    P.nseg = ctx->n_nodes - 1;
+    P.step_limit = (long long)(p.ray_limit * (int)(1.0 / (p.ds_min * 10)));   // GeoAc.Solver.cpp:14
+    P.x_min = ctx->x[0]; P.x_max = ctx->x[ctx->n_nodes - 1];
+    P.ds_min = p.ds_min; P.ds_max = p.ds_max;
+    P.r_earth = p.r_earth; P.z_grnd = p.z_grnd;
+    P.ground = p.r_earth + p.z_grnd;
+    P.vert_limit = p.vert_limit; P.range_limit = p.range_limit;
+    {
+        double half = p.range_limit / (2.0 * p.r_earth);
+        if(half >= kPi / 2.0) P.range_thresh = 2.0;               // asin saturates: the range test can never fire
+        else if(half <= 0.0) P.range_thresh = -1.0;
+        else { double s = sin(half); P.range_thresh = s * s; }
+    }
+    P.src[0] = p.src[0]; P.src[1] = p.src[1]; P.src[2] = p.src[2];
+    P.freq = p.freq; P.tweak_abs = p.tweak_abs;
+    {   // SuthBass reference state: T_o, P_o at abscissa z_grnd (Atmo_State.Absorption.Global.cpp:31-32 passes the km
+        // altitude as a radius, which clamps to the lowest node; the Cartesian twin evaluates at z = z_grnd)
+        double Tg = host_spline_f(ctx->x, ctx->T, ctx->sl.data(), p.z_grnd);
+        double rg = host_spline_f(ctx->x, ctx->rho, ctx->sl.data() + 3 * (size_t)ctx->n_nodes, p.z_grnd);
+        double cg = sqrt(kGamR * Tg) * 1000.0;
+        P.T_o = cg * cg / (kRgas * kGam);
+        P.P_o = rg * (cg * cg) / kGam * 1000.0;
+    }
+    // ---- epoch size: keep the path chunk around <= 3 GiB ----
+    size_t row_bytes = (size_t)P.pathw * P.n_pad * sizeof(double);
+    long long s_rows = (long long)((3ull << 30) / row_bytes);
+    if(s_rows > 2048) s_rows = 2048;
+    if(s_rows < 64) s_rows = 64;
+    if(ctx->s_rows_override >= 8) s_rows = ctx->s_rows_override;
+    P.s_rows = (int)s_rows;
+    size_t lds_need = (size_t)P.nseg * GEOAC_SEGW * sizeof(double);
+    P.table_in_lds = (lds_need <= 160 * 1024) ? 1 : 0;
+    ctx->legs = p.bounces + 1;
+
+    HIPCHK(ctx->state.ensure(sizeof(double) * (size_t)ST_NSTATE * P.n_pad));
+    HIPCHK(ctx->path.ensure(row_bytes * (size_t)P.s_rows));
+    HIPCHK(ctx->contrib.ensure(sizeof(double) * 2 * (size_t)P.n_pad * P.s_rows));
+    HIPCHK(ctx->nrows.ensure(sizeof(int) * (size_t)P.n_pad));
+    HIPCHK(ctx->nlegend.ensure(sizeof(int) * (size_t)P.n_pad));
+    HIPCHK(ctx->legend.ensure(sizeof(int) * (size_t)P.n_pad * GEOAC_MAXLEGS));
+    HIPCHK(ctx->rec.ensure(sizeof(double) * (size_t)ctx->n_rays * ctx->legs * GEOAC_REC_STRIDE));
+    HIPCHK(ctx->counters.ensure(8 * sizeof(unsigned long long)));
+    P.seg = (const double*)ctx->seg.p; P.rho = (const double*)ctx->rhot.p;
+    P.theta_deg = (const double*)ctx->theta.p; P.phi_deg = (const double*)ctx->phi.p;
+    P.state = (double*)ctx->state.p; P.path = (double*)ctx->path.p; P.contrib = (double*)ctx->contrib.p;
+    P.nrows = (int*)ctx->nrows.p; P.legend = (int*)ctx->legend.p; P.nlegend = (int*)ctx->nlegend.p;
+    P.rec = (double*)ctx->rec.p; P.counters = (unsigned long long*)ctx->counters.p;
+
+    // RK4 workgroup shape: with the table in LDS one workgroup owns a CU, so spread the waves over the 256 CUs
+    int waves = P.n_pad / 64;
+    int wpb = (waves + 255) / 256;
+    if(wpb < 1) wpb = 1;
+    if(wpb > 16) wpb = 16;
+    int block = 64 * wpb;
+    if(!P.table_in_lds) block = 64;
+
+    hipStream_t s = ctx->stream;
+    HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 8 * sizeof(unsigned long long), s));
+    HIPCHK(hipEventRecord(ctx->ev0, s));
+    HIPCHK(geoac_launch_init(&P, s));
+    ctx->n_epochs = 0; ctx->path_bytes_w = 0; ctx->path_bytes_r = 0;
+    const long long max_epochs = (P.step_limit * (long long)ctx->legs) / (P.s_rows > 4 ? (P.s_rows - 3) : 1) + ctx->legs + 2;
+    unsigned long long live = 1;
+    while(live > 0){
+        HIPCHK(hipMemsetAsync((char*)ctx->counters.p + sizeof(unsigned long long), 0, sizeof(unsigned long long), s));
+        HIPCHK(geoac_launch_rk4(&P, block, s));
+        HIPCHK(geoac_launch_postpass(&P, P.s_rows, s));
+        HIPCHK(hipMemcpyAsync(ctx->h_counters, ctx->counters.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        live = ctx->h_counters[1];
+        ctx->n_epochs++;
+        if((long long)ctx->n_epochs > max_epochs) return fail(ctx, GEOAC_E_CAPACITY, "fan_launch: epoch bound exceeded");
+    }
+    HIPCHK(hipEventRecord(ctx->ev1, s));
+    HIPCHK(hipStreamSynchronize(s));
+    float ms = 0; hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    ctx->ms_total = ms;
+    ctx->total_steps = ctx->h_counters[0];
+    ctx->err_flags = ctx->h_counters[2];
+    // algorithmic path traffic: one PATHW-wide row per step (+ leg-start / carry rows, not counted)
+    ctx->path_bytes_w = ctx->total_steps * (unsigned long long)(P.pathw * sizeof(double));
+    ctx->path_bytes_r = 2 * ctx->path_bytes_w;
+    ctx->ran = true;
+    if(ctx->err_flags & 1ull) return fail(ctx, GEOAC_E_CAPACITY, "a ray reached step_limit (GeoAc.Solver.cpp:14) without leaving the region or reaching the ground");
+    return GEOAC_OK;
+}
+
+int geoac_fan_sync(geoac_ctx* ctx){
+    if(!ctx) return GEOAC_E_INVALID;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return GEOAC_OK;
+}
+
+int geoac_fan_records_dev(geoac_ctx* ctx, void** dev_ptr, size_t* bytes){
+    if(!ctx || !ctx->ran) return fail(ctx, GEOAC_E_INVALID, "fan_records_dev: no completed launch");
+    if(dev_ptr) *dev_ptr = ctx->rec.p;
+    if(bytes) *bytes = sizeof(double) * (size_t)ctx->n_rays * ctx->legs * GEOAC_REC_STRIDE;
+    return GEOAC_OK;
+}
+
+int geoac_fan_fetch(geoac_ctx* ctx, double* rec_host, uint64_t* total_steps){
+    if(!ctx || !ctx->ran) return fail(ctx, GEOAC_E_INVALID, "fan_fetch: no completed launch");
+    HIPCHK(hipSetDevice(ctx->device));
+    if(rec_host){
+        HIPCHK(hipMemcpyAsync(rec_host, ctx->rec.p, sizeof(double) * (size_t)ctx->n_rays * ctx->legs * GEOAC_REC_STRIDE,
+                              hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    if(total_steps) *total_steps = ctx->total_steps;
+    return GEOAC_OK;
+}
+
+int geoac_fan_sample_count(geoac_ctx* ctx, int64_t* n){ if(!ctx || !n) return GEOAC_E_INVALID; *n = 0; return GEOAC_OK; }
+int geoac_fan_fetch_samples(geoac_ctx* ctx, double*, int64_t){ return fail(ctx, GEOAC_E_UNSUPPORTED, "sample capture not implemented yet"); }
+
+int geoac_fan_run(geoac_ctx* ctx, int n_rays, const double* theta_deg, const double* phi_deg,
+                  double* rec_host, uint64_t* total_steps){
+    int rc = geoac_fan_set_angles(ctx, n_rays, theta_deg, phi_deg);
+    if(rc) return rc;
+    rc = geoac_fan_launch(ctx);
+    if(rc) return rc;
+    return geoac_fan_fetch(ctx, rec_host, total_steps);
+}
+
+int geoac_last_timing(geoac_ctx* ctx, double ms[3], uint64_t stats[3]){
+    if(!ctx || !ctx->ran) return GEOAC_E_INVALID;
+    if(ms){ ms[0] = ctx->ms_total; ms[1] = ctx->ms_rk4; ms[2] = ctx->ms_post; }
+    if(stats){ stats[0] = ctx->n_epochs; stats[1] = ctx->path_bytes_w; stats[2] = ctx->path_bytes_r; }
+    return GEOAC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+// geoac_device.h - shared host/device definitions of the MI355X ray-fan integrator.
+//
+// Data layout in HBM (all FP64 unless noted):
+//   seg table   [nseg][SEGW]            per spline segment: x0, x1, then cubic coefficients c0..c3 (in t = x - x0)
+//                                       of T, u, v.  Staged into LDS by the RK4 kernel (112 B/segment; ToyAtmo
+//                                       1399 segments = 153 KiB of the CU's 160 KiB).
+//   rho table   [nseg][4]               cubic coefficients of density (needed only at arrivals / in the post-pass)
+//   state       [NSTATE][n_pad]         per-ray persistent state, SoA (ray index fastest => coalesced)
+//   path chunk  [S_rows][PATHW][n_pad]  the state rows the post-pass needs (Global: r,lat,lon,nu_r,nu_t,nu_p),
+//                                       one row per accepted RK4 step, ray index fastest => every wave store is a
+//                                       contiguous 512 B line.  This is the reference's `double** solution`
+//                                       (Interface.cpp:53-58) re-laid-out for 64-wide coalescing and cut into epochs.
+//   contrib     [S_rows][2][n_pad]      per-segment travel-time and attenuation increments (post-pass kernel)
+//   records     [n_rays][legs][32]      one arrival record per (ray, leg), layout in include/geoac_hip.h
+#ifndef GEOAC_DEVICE_H_
+#define GEOAC_DEVICE_H_
+
+#include <stdint.h>
+
+#define GEOAC_SEGW      14      // doubles per segment in the T/u/v table
+#define GEOAC_MAXE      18
+#define GEOAC_MAXLEGS   64      // legs per ray supported by the per-epoch leg-end event list
+
+// per-ray state slots (SoA rows of the state buffer)
+enum {
+    ST_Y0     = 0,      // y[0..17]
+    ST_K      = 18,     // steps taken in the current leg (as double, exact)
+    ST_LEG    = 19,     // current leg index
+    ST_DONE   = 20,     // 1.0 when the ray is finished
+    ST_HMAX   = 21,     // running turning height
+    ST_C0     = 22,     // sound speed at the source
+    ST_NU0    = 23,     // 1/MachScalar (Global) ; c_eff_0 (2D)
+    ST_AUX0   = 24,     // eqset-specific constants (3D: nu0_xy[2], mu0_xy[2][2] => 6 values; 2D: cos/sin phi)
+    ST_SEG    = 30,     // segment hint (as double)
+    ST_TT     = 31,     // post-pass running travel time (owned by the accumulate kernel)
+    ST_AT     = 32,     // post-pass running attenuation
+    ST_PLEG   = 33,     // post-pass current leg
+    ST_LTT    = 34,     // post-pass per-leg partial sums (arrivals-only form of Q7)
+    ST_LAT    = 35,
+    ST_NSTATE = 36
+};
+
+struct GeoacDevParams {
+    // problem
+    int     eqset, calc_amp, mode, bounces;
+    int     n_rays, n_pad;          // n_pad = n_rays rounded up to 64
+    int     E, pathw;
+    int     nseg;                   // spline segments = nodes - 1
+    int     s_rows;                 // path rows per epoch chunk
+    int     table_in_lds;
+    int     pad0;
+    long long step_limit;           // GeoAc.Solver.cpp:14
+    double  x_min, x_max;           // clamp range of the spline abscissa
+    double  ds_min, ds_max;
+    double  ground;                 // Global: r_earth + z_grnd ; Cartesian: z_grnd
+    double  r_earth, z_grnd;
+    double  vert_limit, range_limit, range_thresh;   // range_thresh: sin^2(range_limit/(2 r_earth)) (Global)
+    double  src[3];                 // as in geoac_params
+    double  freq, tweak_abs;
+    double  T_o, P_o;               // SuthBass reference temperature / pressure (ground), host-evaluated from the spline
+    // buffers
+    const double* seg;              // [nseg][SEGW]
+    const double* rho;              // [nseg][4]
+    const double* theta_deg;        // [n_rays]
+    const double* phi_deg;
+    double*       state;            // [ST_NSTATE][n_pad]
+    double*       path;             // [s_rows][pathw][n_pad]
+    double*       contrib;          // [s_rows][2][n_pad]
+    int*          nrows;            // [n_pad] rows written by each ray in the current chunk
+    int*          legend;           // [GEOAC_MAXLEGS][n_pad] chunk-row index of leg-end rows in this chunk
+    int*          nlegend;          // [n_pad]
+    double*       rec;              // [n_rays][bounces+1][32]
+    unsigned long long* counters;   // [0] total steps, [1] active rays after this epoch, [2] error flags
+};
+
+#endif

@@ -1,0 +1,665 @@
+// geoac_kernels.hip - hand-written gfx950 kernels of the ray-fan integrator.
+//
+// Four kernels per epoch (an epoch advances every live ray by up to s_rows-2 RK4 steps):
+//   k_init      once per fan: launch-angle -> initial conditions            (GeoAc_SetInitialConditions)
+//   k_rk4       one ray per lane, register-resident FP64 state, spline segment table in LDS; per step:
+//               4 x {sources + RHS} (GeoAc_UpdateSources/GeoAc_EvalSrcEq fused and specialised for the
+//               stratified atmosphere), ds rule, break/ground checks, on-device bounce handling and arrival
+//               records; writes one coalesced state row per step into the path chunk   (GeoAc_Propagate_RK4 + the
+//               launch-angle / bounce loops of the mains)
+//   k_postpass  one thread per path SEGMENT: midpoint travel-time and Sutherland-Bass absorption increments
+//               (GeoAc_TravelTime / GeoAc_SB_Atten / SuthBass_Alpha) - the transcendental-heavy part, taken off the
+//               serial RK4 recurrence and run at full chip occupancy
+//   k_accum     one thread per ray: in-order summation of the increments (the reference's summation order),
+//               leg bookkeeping (Q7 forms), fills the travel-time / attenuation fields of the records
+//
+// No MFMA: there is no dense contraction anywhere on this path.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "geoac_device.h"
+#include "../../include/geoac_hip.h"
+
+#define DEVINL __device__ __forceinline__
+
+static constexpr double kPi   = 3.141592653589793238462643;   // GeoAc.Parameters.cpp:27
+static constexpr double kGam  = 1.4;
+static constexpr double kRgas = 287.05;
+static constexpr double kGamR = 0.00040187;                    // G2S_GlobalSpline1D.cpp:343
+
+// ------------------------------------------------------------------------------------------------
+// small FP64 helpers
+// ------------------------------------------------------------------------------------------------
+DEVINL double frcp(double x){ return 1.0 / x; }
+
+// sin & cos together.  Cody-Waite reduction by pi/2 (3 constants, exact products through FMA) and the
+// classic minimax kernels on [-pi/4, pi/4]; < 1 ulp for |x| < 1e5, which covers latitudes / longitudes / launch angles.
+DEVINL void fsincos(double x, double& s, double& c){
+    const double two_over_pi = 6.36619772367581382433e-01;
+    const double pio2_1  = 1.57079632673412561417e+00;
+    const double pio2_1t = 6.07710050650619224932e-11;
+    const double pio2_2t = 2.02226624879595063154e-21;
+    double fn = __builtin_rint(x * two_over_pi);
+    double r  = __builtin_fma(-fn, pio2_1, x);
+    r = __builtin_fma(-fn, pio2_1t, r);
+    r = __builtin_fma(-fn, pio2_2t, r);
+    int n = (int)fn;
+    double z = r * r;
+    // sin kernel
+    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    double sn = __builtin_fma(r * z, ps, r);
+    // cos kernel
+    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    double cs = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
+    double so = (n & 1) ? cs : sn;
+    double co = (n & 1) ? sn : cs;
+    s = (n & 2) ? -so : so;
+    c = ((n + 1) & 2) ? -co : co;
+}
+
+// ------------------------------------------------------------------------------------------------
+// spline segment table access.  Record (SEGW doubles): x0, x1, T{c0..c3}, u{c0..c3}, v{c0..c3};
+// value = c0 + t (c1 + t (c2 + t c3)), t = x - x0.  Same cubic as Eval_Spline_f (G2S_GlobalSpline1D.cpp:259-295)
+// expanded in powers of t on the host (geoac_api.cpp: build_tables).
+// ------------------------------------------------------------------------------------------------
+struct Atm9 { double T, dT, ddT, u, du, ddu, v, dv, ddv; };
+
+template <typename TabPtr>
+DEVINL int seg_find(TabPtr tab, int nseg, double x, int k){
+    // hinted walk: rays move <= 50 m per stage while nodes are ~100 m apart, so this loop almost never iterates.
+    // Stateless w.r.t. exact node ties (the spline is C2: either neighbour gives the same value to rounding, Q13).
+    k = k < 0 ? 0 : (k > nseg - 1 ? nseg - 1 : k);
+    while(k > 0 && x < tab[k * GEOAC_SEGW]) k--;
+    while(k < nseg - 1 && x > tab[k * GEOAC_SEGW + 1]) k++;
+    return k;
+}
+
+template <bool D2, typename TabPtr>
+DEVINL void seg_eval(TabPtr tab, int k, double x, Atm9& a){
+    const auto* p = tab + k * GEOAC_SEGW;
+    double t = x - p[0];
+    double c1, c2, c3;
+    c1 = p[3]; c2 = p[4]; c3 = p[5];
+    a.T  = __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, c3, c2), c1), p[2]);
+    a.dT = __builtin_fma(t, __builtin_fma(t, 3.0 * c3, 2.0 * c2), c1);
+    if(D2) a.ddT = __builtin_fma(t, 6.0 * c3, 2.0 * c2);
+    c1 = p[7]; c2 = p[8]; c3 = p[9];
+    a.u  = __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, c3, c2), c1), p[6]);
+    a.du = __builtin_fma(t, __builtin_fma(t, 3.0 * c3, 2.0 * c2), c1);
+    if(D2) a.ddu = __builtin_fma(t, 6.0 * c3, 2.0 * c2);
+    c1 = p[11]; c2 = p[12]; c3 = p[13];
+    a.v  = __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, c3, c2), c1), p[10]);
+    a.dv = __builtin_fma(t, __builtin_fma(t, 3.0 * c3, 2.0 * c2), c1);
+    if(D2) a.ddv = __builtin_fma(t, 6.0 * c3, 2.0 * c2);
+}
+
+DEVINL double clampd(double x, double lo, double hi){ double e = (hi < x) ? hi : x; return (e < lo) ? lo : e; }
+
+// first guess of the segment index for an arbitrary x (uniform-grid guess + walk)
+template <typename TabPtr>
+DEVINL int seg_guess(TabPtr tab, const GeoacDevParams& P, double x){
+    double span = P.x_max - P.x_min;
+    int k = (int)((x - P.x_min) / span * (double)P.nseg);
+    return seg_find(tab, P.nseg, x, k);
+}
+
+// density at abscissa x (global-memory table; rare / post-pass only)
+DEVINL double rho_eval(const GeoacDevParams& P, int k, double x){
+    const double* s = P.seg + (size_t)k * GEOAC_SEGW;
+    const double* q = P.rho + (size_t)k * 4;
+    double t = x - s[0];
+    return __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, q[3], q[2]), q[1]), q[0]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Global equation set: fused GeoAc_UpdateSources + GeoAc_EvalSrcEq (EquationSets.Global.cpp:222-442),
+// specialised for the stratified atmosphere (w = 0, every d/dlat, d/dlon of the medium = 0).
+// y: r, lat, lon, nu_r, nu_t, nu_p | R_lt(3), mu_lt(3) | R_lp(3), mu_lp(3)
+// sth/cth: sin/cos of y[1] supplied by the caller (reused by the range check).
+// ------------------------------------------------------------------------------------------------
+template <bool AMP, typename TabPtr>
+DEVINL void global_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const double* y, double sth, double cth, double* dy){
+    const double r = y[0];
+    const double n0 = y[3], n1 = y[4], n2 = y[5];
+    const double xe = clampd(r, P.x_min, P.x_max);
+    seg = seg_find(tab, P.nseg, xe, seg);
+    Atm9 a;
+    seg_eval<AMP>(tab, seg, xe, a);
+
+    const double c   = sqrt(kGamR * a.T);
+    const double ic  = frcp(c);
+    const double hc  = 0.5 * kGamR * ic;               // gamR / (2c)
+    const double dc  = hc * a.dT;                      // c_diff(.,0)
+    const double u = a.u, v = a.v, du = a.du, dv = a.dv;
+
+    const double ico = frcp(cth);
+    const double tn  = sth * ico;
+    const double numag = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+    const double inm = frcp(numag);
+    const double cn  = c * inm;
+    const double cg0 = cn * n0;
+    const double cg1 = __builtin_fma(cn, n1, v);
+    const double cg2 = __builtin_fma(cn, n2, u);
+    const double cgm = sqrt(cg0 * cg0 + cg1 * cg1 + cg2 * cg2);
+    const double icg = frcp(cgm);
+    const double ir  = frcp(r);
+    const double G1  = ir;
+    const double G2  = ir * ico;
+
+    const double nc12 = n1 * cg1 + n2 * cg2;
+    const double ncs  = n0 * cth + n1 * sth;
+    const double T0 = ir * nc12;
+    const double T1 = n0 * v + (n2 * cg2 * tn - n0 * cg1);
+    const double T2 = (n0 * u) * cth + (n1 * u - n2 * v) * sth - cg2 * ncs;
+
+    const double H0 = numag * dc + n1 * dv + n2 * du;
+
+    dy[0] = cg0 * icg;
+    dy[1] = G1 * cg1 * icg;
+    dy[2] = G2 * cg2 * icg;
+    dy[3] = -icg * (H0 + T0);
+    dy[4] = -G1 * icg * T1;
+    dy[5] = -G2 * icg * T2;
+
+    if(AMP){
+        const double ddc = hc * a.ddT - (0.25 * kGamR * kGamR) * (ic * ic * ic) * (a.dT * a.dT);   // c_ddiff(.,0,0)
+        const double ddu = a.ddu, ddv = a.ddv;
+        const double ir2 = ir * ir;
+        const double icg2 = icg * icg;
+        const double ico2 = ico * ico;
+        #pragma unroll
+        for(int q = 0; q < 2; q++){
+            const double R0 = y[6 + 6 * q], R1 = y[7 + 6 * q];
+            const double m0 = y[9 + 6 * q], m1 = y[10 + 6 * q], m2 = y[11 + 6 * q];
+            const double dca = R0 * dc, dva = R0 * dv, dua = R0 * du;
+            const double dnu = (n0 * m0 + n1 * m1 + n2 * m2) * inm;
+            const double qq  = cn * inm * dnu;                 // c/|nu|^2 * d|nu|
+            const double ia  = inm * dca;
+            const double dcg0 = n0 * ia + cn * m0 - n0 * qq;
+            const double dcg1 = n1 * ia + cn * m1 - n1 * qq + dva;
+            const double dcg2 = n2 * ia + cn * m2 - n2 * qq + dua;
+            const double dcgm = (cg0 * dcg0 + cg1 * dcg1 + cg2 * dcg2) * icg;
+
+            const double dG1 = -R0 * ir2;
+            const double dG2 = -R0 * ir2 * ico + sth * ir * ico2 * R1;
+
+            const double dT0 = -R0 * ir2 * nc12 + ir * (m1 * cg1 + n1 * dcg1 + m2 * cg2 + n2 * dcg2);
+            const double dT1 = (m0 * v + n0 * dva)
+                             + (-m0 * cg1 - n0 * dcg1 + (m2 * cg2 + n2 * dcg2) * tn + n2 * cg2 * R1 * ico2);
+            const double dT2 = (m0 * u + n0 * dua) * cth - (n0 * u) * R1 * sth
+                             + (m1 * u + n1 * dua - m2 * v - n2 * dva) * sth + (n1 * u - n2 * v) * R1 * cth
+                             - dcg2 * ncs - cg2 * (m0 * cth - n0 * R1 * sth + m1 * sth + n1 * R1 * cth);
+
+            dy[6 + 6 * q] = dcg0 * icg - cg0 * icg2 * dcgm;
+            dy[7 + 6 * q] = dG1 * cg1 * icg + G1 * dcg1 * icg - G1 * cg1 * icg2 * dcgm;
+            dy[8 + 6 * q] = dG2 * cg2 * icg + G2 * dcg2 * icg - G2 * cg2 * icg2 * dcgm;
+
+            dy[9 + 6 * q]  = icg2 * dcgm * H0
+                           - icg * (dnu * dc + numag * (R0 * ddc) + m1 * dv + m2 * du + n1 * (R0 * ddv) + n2 * (R0 * ddu) + dT0);
+            dy[10 + 6 * q] = -dG1 * icg * T1 - G1 * icg * dT1;
+            dy[11 + 6 * q] = -dG2 * icg * T2 - G2 * icg * dT2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// rare-path (once per leg) helpers of the Global set; medium values from the global-memory tables
+// ------------------------------------------------------------------------------------------------
+struct Medium { double c, dc, u, du, v, dv, rho; };
+DEVINL Medium medium_at(const GeoacDevParams& P, double x){
+    double xe = clampd(x, P.x_min, P.x_max);
+    int k = seg_guess(P.seg, P, xe);
+    Atm9 a; seg_eval<false>(P.seg, k, xe, a);
+    Medium m;
+    m.c = sqrt(kGamR * a.T); m.dc = kGamR / (2.0 * m.c) * a.dT;
+    m.u = a.u; m.du = a.du; m.v = a.v; m.dv = a.dv;
+    m.rho = rho_eval(P, k, xe);
+    return m;
+}
+
+// GeoAc_Jacobian: EquationSets.Global.cpp:594-607  (1/(r sin(lat)) in dp_ds: Q3)
+DEVINL double global_jacobian(const Medium& m, const double* y){
+    double r = y[0], th = y[1];
+    double nu_mag = sqrt(y[3] * y[3] + y[4] * y[4] + y[5] * y[5]);
+    double cp0 = m.c * y[3] / nu_mag, cp1 = m.c * y[4] / nu_mag + m.v, cp2 = m.c * y[5] / nu_mag + m.u;
+    double cpm = sqrt(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
+    double dr_ds = cp0 / cpm, dt_ds = 1.0 / r * cp1 / cpm, dp_ds = 1.0 / (r * sin(th)) * cp2 / cpm;
+    double dr_dlt = y[6], dt_dlt = y[7], dp_dlt = y[8];
+    double dr_dlp = y[12], dt_dlp = y[13], dp_dlp = y[14];
+    return r * r * cos(th) * (dr_ds * (dt_dlt * dp_dlp - dt_dlp * dp_dlt) - dr_dlt * (dt_ds * dp_dlp - dp_ds * dt_dlp)
+                              + dr_dlp * (dt_ds * dp_dlt - dp_ds * dt_dlt));
+}
+
+// GeoAc_Amplitude: EquationSets.Global.cpp:610-629 (c_prop0[1..2] over the ARRIVAL nu_mag: Q4)
+DEVINL double global_amplitude(const GeoacDevParams& P, const Medium& m, const Medium& m0, const double* y,
+                               double c0, double nu_mag0, double th_l, double ph_l, double D){
+    double nu0v[3] = { sin(th_l), cos(th_l) * sin(ph_l), cos(th_l) * cos(ph_l) };
+    double nu_mag = (c0 - y[4] * m.v - y[5] * m.u) / m.c;
+    double cp0 = m.c * y[3] / nu_mag, cp1 = m.c * y[4] / nu_mag + m.v, cp2 = m.c * y[5] / nu_mag + m.u;
+    double cq0 = c0 * nu0v[0] / nu_mag0, cq1 = c0 * nu0v[1] / nu_mag + m0.v, cq2 = c0 * nu0v[2] / nu_mag + m0.u;
+    double cpm = sqrt(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
+    double cqm = sqrt(cq0 * cq0 + cq1 * cq1 + cq2 * cq2);
+    double num = m.rho * nu_mag * (m.c * m.c * m.c) * cqm * cos(th_l);
+    double den = m0.rho * nu_mag0 * (m0.c * m0.c * m0.c) * cpm * D;
+    return 1.0 / (4.0 * kPi) * sqrt(fabs(num / den));
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_init: GeoAc_SetInitialConditions (EquationSets.Global.cpp:76-136) for every ray of the fan
+// ------------------------------------------------------------------------------------------------
+template <bool AMP>
+__global__ void __launch_bounds__(256) k_init_global(GeoacDevParams P){
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= P.n_pad) return;
+    double* st = P.state + i;
+    const size_t np = (size_t)P.n_pad;
+    if(i >= P.n_rays){                                   // padding lanes: finished from the start
+        for(int f = 0; f < ST_NSTATE; f++) st[f * np] = 0.0;
+        st[ST_DONE * np] = 1.0;
+        return;
+    }
+    const double th = P.theta_deg[i] * kPi / 180.0;               // GeoAcGlobal_main.cpp:244
+    const double ph = kPi / 2.0 - P.phi_deg[i] * kPi / 180.0;     // :245
+    double z_src = P.src[0] < P.z_grnd ? P.z_grnd : P.src[0];     // :165
+    double r0 = z_src + P.r_earth;
+    double lat0 = P.src[1] * kPi / 180.0, lon0 = P.src[2] * kPi / 180.0;
+    Medium m = medium_at(P, r0);
+    double c0 = m.c;
+    double Mach[3] = { 0.0, m.v / c0, m.u / c0 };
+    double sth = sin(th), cth = cos(th), sph = sin(ph), cph = cos(ph);
+    double nu0[3]  = { sth, cth * sph, cth * cph };
+    double mlt[3]  = { cth, -sth * sph, -sth * cph };
+    double mlp[3]  = { 0.0, cth * cph, -cth * sph };
+    double MS = 1.0 + (nu0[0] * Mach[0] + nu0[1] * Mach[1] + nu0[2] * Mach[2]);
+    double y[GEOAC_MAXE];
+    for(int e = 0; e < GEOAC_MAXE; e++) y[e] = 0.0;
+    y[0] = r0; y[1] = lat0; y[2] = lon0;
+    for(int e = 0; e < 3; e++) y[3 + e] = nu0[e] / MS;
+    if(AMP){
+        double dlt = mlt[0] * Mach[0] + mlt[1] * Mach[1] + mlt[2] * Mach[2];
+        double dlp = mlp[0] * Mach[0] + mlp[1] * Mach[1] + mlp[2] * Mach[2];
+        for(int e = 0; e < 3; e++){
+            y[9 + e]  = mlt[e] / MS - nu0[e] / (MS * MS) * dlt;
+            y[15 + e] = mlp[e] / MS - nu0[e] / (MS * MS) * dlp;
+        }
+    }
+    for(int e = 0; e < GEOAC_MAXE; e++) st[(ST_Y0 + e) * np] = y[e];
+    st[ST_K * np] = 0.0; st[ST_LEG * np] = 0.0; st[ST_DONE * np] = 0.0; st[ST_HMAX * np] = 0.0;
+    st[ST_C0 * np] = c0; st[ST_NU0 * np] = 1.0 / MS;
+    for(int f = ST_AUX0; f < ST_SEG; f++) st[f * np] = 0.0;
+    st[ST_SEG * np] = (double)seg_guess(P.seg, P, clampd(r0, P.x_min, P.x_max));
+    st[ST_TT * np] = 0.0; st[ST_AT * np] = 0.0; st[ST_PLEG * np] = 0.0; st[ST_LTT * np] = 0.0; st[ST_LAT * np] = 0.0;
+    // zero this ray's records
+    double* R = P.rec + (size_t)i * (P.bounces + 1) * GEOAC_REC_STRIDE;
+    for(int q = 0; q < (P.bounces + 1) * GEOAC_REC_STRIDE; q++) R[q] = 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_rk4: GeoAc_Propagate_RK4 (GeoAc.Solver.cpp:12-72) for one epoch, one ray per lane
+// ------------------------------------------------------------------------------------------------
+template <int E>
+DEVINL void write_row(const GeoacDevParams& P, int row, int slot, const double* y){
+    double* p = P.path + ((size_t)row * P.pathw) * P.n_pad + slot;
+    #pragma unroll
+    for(int c = 0; c < 6; c++) p[(size_t)c * P.n_pad] = y[c];
+}
+
+template <bool AMP, bool LDS>
+__global__ void __launch_bounds__(256, 1) k_rk4_global(GeoacDevParams P){
+    constexpr int E = AMP ? 18 : 6;
+    extern __shared__ double lds_tab[];
+    // ---- stage the segment table in LDS (coalesced 8 B/lane loads; 153 KiB for ToyAtmo) ----
+    const double* gtab = P.seg;
+    if(LDS){
+        const int total = P.nseg * GEOAC_SEGW;
+        for(int q = threadIdx.x; q < total; q += blockDim.x) lds_tab[q] = gtab[q];
+        __syncthreads();
+    }
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if(slot >= P.n_pad) return;
+    const size_t np = (size_t)P.n_pad;
+    double* st = P.state + slot;
+
+    int nr = 0, nle = 0;
+    bool done = st[ST_DONE * np] != 0.0;
+    if(done){ P.nrows[slot] = 0; P.nlegend[slot] = 0; return; }
+
+    double y[E];
+    #pragma unroll
+    for(int e = 0; e < E; e++) y[e] = st[(ST_Y0 + e) * np];
+    long long k = (long long)st[ST_K * np];
+    int leg = (int)st[ST_LEG * np];
+    double hmax = st[ST_HMAX * np];
+    const double c0 = st[ST_C0 * np];
+    const double nu_mag0 = st[ST_NU0 * np];
+    int seg = (int)st[ST_SEG * np];
+    unsigned long long steps_here = 0;
+
+    const double lat0 = P.src[1] * kPi / 180.0, lon0 = P.src[2] * kPi / 180.0;
+    double sl0, cl0; fsincos(lat0, sl0, cl0);
+
+    double sth, cth; fsincos(y[1], sth, cth);
+    write_row<E>(P, nr++, slot, y);                             // carry row: chunk row 0 = current state
+
+    while(nr + 2 <= P.s_rows && !done){
+        // running turning height: max over rows m < k of (r - r_earth)   (GeoAcGlobal_main.cpp:294)
+        { double h = y[0] - P.r_earth; hmax = (hmax < h) ? h : hmax; }
+
+        // ---- GeoAc_Set_ds (Global.cpp:210-217) ----
+        double ds = 0.05 - 0.049 * exp(-(y[0] - P.ground) / 0.75);
+        ds = (P.ds_max < ds) ? P.ds_max : ds;
+        ds = (ds < P.ds_min) ? P.ds_min : ds;
+
+        // ---- the four RK4 stages as ONE rolled loop (a single copy of the RHS keeps the live set < 256 VGPRs):
+        //      k_s = ds f(y + a_s k_{s-1}), a = {0, 1/2, 1/2, 1};  y' = y + k1/6 + k2/3 + k3/3 + k4/6  (Solver.cpp:33-54)
+        double dy[E], yt[E], yn[E];
+        #pragma unroll
+        for(int e = 0; e < E; e++){ yt[e] = y[e]; yn[e] = y[e]; }
+        double s2 = sth, c2 = cth;
+        #pragma unroll 1
+        for(int stage = 0; stage < 4; stage++){
+            if(stage > 0) fsincos(yt[1], s2, c2);
+            if(LDS) global_rhs<AMP>(lds_tab, P, seg, yt, s2, c2, dy); else global_rhs<AMP>(gtab, P, seg, yt, s2, c2, dy);
+            const double wa = (stage == 2) ? 1.0 : 0.5;
+            const double wb = (stage == 0 || stage == 3) ? (1.0 / 6.0) : (1.0 / 3.0);
+            #pragma unroll
+            for(int e = 0; e < E; e++){
+                double kk = ds * dy[e];
+                yn[e] = __builtin_fma(kk, wb, yn[e]);
+                yt[e] = __builtin_fma(kk, wa, y[e]);
+            }
+        }
+
+        k++; steps_here++;
+        write_row<E>(P, nr++, slot, yn);
+
+        // ---- GeoAc_BreakCheck / GeoAc_GroundCheck on the new row (Global.cpp:500-522) ----
+        double sn, cn; fsincos(yn[1], sn, cn);
+        double sa, ca_, sb, cb_;
+        fsincos(0.5 * (yn[1] - lat0), sa, ca_);
+        fsincos(0.5 * (yn[2] - lon0), sb, cb_);
+        double hav = sa * sa + cl0 * cn * (sb * sb);             // range = 2 R asin(sqrt(hav)) > limit  <=>  hav > sin^2(limit / 2R)
+        bool brk = (yn[0] > P.vert_limit) || (hav > P.range_thresh);
+        bool gnd = yn[0] < P.ground;
+        bool lim = (k >= P.step_limit - 1);                       // Solver.cpp loop bound; never reached on sane inputs
+
+        if(brk || gnd || lim){
+            // ---- leg end: record (GeoAcGlobal_main.cpp:293-317) ----
+            double* R = P.rec + ((size_t)slot * (P.bounces + 1) + leg) * GEOAC_REC_STRIDE;
+            R[GEOAC_REC_STEPS] = (double)k;
+            P.legend[(size_t)nle * np + slot] = nr - 1; nle++;
+            if(lim && !brk && !gnd) atomicOr(&P.counters[2], 1ull);
+            if(brk){
+                R[GEOAC_REC_BROKE] = 1.0;
+                done = true;
+            } else {
+                Medium m = medium_at(P, yn[0]);
+                double z_src = P.src[0] < P.z_grnd ? P.z_grnd : P.src[0];
+                double incl = -asin(m.c / c0 * yn[3]) * 180.0 / kPi;
+                double baz = 90.0 - atan2(-yn[4], -yn[5]) * 180.0 / kPi;
+                if(baz < -180.0) baz += 360.0;
+                if(baz > 180.0) baz -= 360.0;
+                double g1 = sin((yn[1] - lat0) / 2.0); g1 *= g1;
+                double g2 = sin((yn[2] - lon0) / 2.0); g2 = cos(lat0) * cos(yn[1]) * g2 * g2;
+                R[GEOAC_REC_VALID] = 1.0;
+                R[GEOAC_REC_TURN] = hmax;
+                R[GEOAC_REC_INCL] = incl;
+                R[GEOAC_REC_BACKAZ] = baz;
+                R[GEOAC_REC_RANGE] = 2.0 * P.r_earth * asin(sqrt(g1 + g2));
+                if(AMP){
+                    Medium m0 = medium_at(P, z_src + P.r_earth);
+                    double D = global_jacobian(m, yn);
+                    double th_l = P.theta_deg[slot] * kPi / 180.0, ph_l = kPi / 2.0 - P.phi_deg[slot] * kPi / 180.0;
+                    R[GEOAC_REC_AMP] = global_amplitude(P, m, m0, yn, c0, nu_mag0, th_l, ph_l, D);
+                    R[GEOAC_REC_JACOB] = D;
+                }
+                #pragma unroll
+                for(int e = 0; e < E; e++) R[GEOAC_REC_STATE + e] = yn[e];
+
+                if(leg >= P.bounces){
+                    done = true;
+                } else {
+                    // ---- GeoAc_ApproximateIntercept + GeoAc_SetReflectionConditions (Global.cpp:140-205);
+                    //      Q1: the quadratic term is a discarded expression in the reference -> linear intercept ----
+                    double dr_k = yn[0] - y[0];
+                    double dr_g = y[0] - P.ground;
+                    double prev[E];
+                    #pragma unroll
+                    for(int e = 0; e < E; e++) prev[e] = y[e] + (y[e] - yn[e]) / dr_k * dr_g;
+                    Medium mr = medium_at(P, prev[0]);
+                    double c_ref = mr.c;
+                    double dnu_r_ds = -1.0 / c_ref * (c0 / c_ref * mr.dc + prev[4] * mr.dv + prev[5] * mr.du
+                                                      + c_ref / prev[0] * (prev[4] * prev[4] + prev[5] * prev[5]));
+                    #pragma unroll
+                    for(int e = 0; e < E; e++) y[e] = prev[e];
+                    y[0] = P.ground;
+                    y[3] = -prev[3];
+                    if(AMP){
+                        y[6] = -prev[6]; y[12] = -prev[12];
+                        double den = c_ref / c0 * prev[3];
+                        y[9]  = -prev[9]  + 2.0 * dnu_r_ds * prev[6]  / den;
+                        y[15] = -prev[15] + 2.0 * dnu_r_ds * prev[12] / den;
+                    }
+                    leg++; k = 0;
+                    fsincos(y[1], sth, cth);
+                    write_row<E>(P, nr++, slot, y);               // leg-start row
+                }
+            }
+        } else {
+            #pragma unroll
+            for(int e = 0; e < E; e++) y[e] = yn[e];
+            sth = sn; cth = cn;
+        }
+    }
+
+    // ---- save state ----
+    #pragma unroll
+    for(int e = 0; e < E; e++) st[(ST_Y0 + e) * np] = y[e];
+    st[ST_K * np] = (double)k; st[ST_LEG * np] = (double)leg; st[ST_DONE * np] = done ? 1.0 : 0.0;
+    st[ST_HMAX * np] = hmax; st[ST_SEG * np] = (double)seg;
+    P.nrows[slot] = nr; P.nlegend[slot] = nle;
+
+    // ---- per-wave reduction of step count and live-ray count, one atomic per wave ----
+    unsigned long long s = steps_here;
+    for(int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    unsigned long long live = __popcll(__ballot(!done));
+    if((threadIdx.x & 63) == 0){
+        atomicAdd(&P.counters[0], s);
+        atomicAdd(&P.counters[1], live);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_postpass: one thread per path segment.  Travel-time segment (Global.cpp:527-589), attenuation segment
+// (Global.cpp:634-670, sin(lat) in ds: Q3) and SuthBass_Alpha (Atmo_State.Absorption.Global.cpp:12-141).
+// ------------------------------------------------------------------------------------------------
+DEVINL double suthbass_alpha(const GeoacDevParams& P, double zr, double c_snd, double rho, double freq){
+    const double mu_o = 18.192E-6, S = 117.0;
+    const double T_o = P.T_o, P_o = P.P_o;
+    double cm = c_snd * 1000.0;
+    double T_z = cm * cm / (kRgas * kGam);
+    double P_z = rho * (cm * cm) / kGam * 1000.0;
+    double mu = mu_o * sqrt(T_z / T_o) * ((1.0 + S / T_o) / (1.0 + S / T_z));
+    double nu = (8.0 * kPi * freq * mu) / (3.0 * P_z);
+
+    double z2 = zr * zr, z3 = z2 * zr, z4 = z2 * z2, z5 = z4 * zr;
+    double X0, X1, X2, X3, X4, X5, X6;
+    X0 = (zr > 90.) ? exp10(49.296 - (1.5524 * zr) + (1.8714E-2 * z2) - (1.1069E-4 * z3) + (3.199E-7 * z4) - (3.6211E-10 * z5))
+                    : 0.20947541961827458;   // 10^-0.67887
+    X1 = (zr > 76.) ? exp10((1.3972E-1) - (5.6269E-3 * zr) + (3.9407E-5 * z2) - (1.0737E-7 * z3))
+                    : 0.78083638675879660;   // 10^-0.10744
+    X2 = 0.00040003681592986493;             // 10^-3.3979
+    X3 = (zr > 80.) ? exp10(-4.234 - (3.0975E-2 * zr))
+                    : exp10(-19.027 + (1.3093 * zr) - (4.6496E-2 * z2) + (7.8543E-4 * z3) - (6.5169E-6 * z4) + (2.1343E-8 * z5));
+    X4 = (zr > 95.) ? exp10(-3.2456 + (4.6642E-2 * zr) - (2.6894E-4 * z2) + (5.264E-7 * z3))
+                    : exp10(-11.195 + (1.5408E-1 * zr) - (1.4348E-3 * z2) + (1.0166E-5 * z3));
+    X5 = exp10(-53.746 + (1.5439 * zr) - (1.8824E-2 * z2) + (1.1587E-4 * z3) - (3.5399E-7 * z4) + (4.2609E-10 * z5));
+    X6 = (zr > 30.) ? exp10(-4.2563 + (7.6245E-2 * zr) - (2.1824E-3 * z2) - (2.3010E-6 * z3) + (2.4265E-7 * z4) - (1.2500E-09 * z5))
+                    : exp10(-1.7491 + (4.4986E-2 * zr) - (6.8549E-2 * z2) + (5.4639E-3 * z3) - (1.5539E-4 * z4) + (1.5063E-06 * z5));
+    double X_ON = (X0 + X1) / 0.9903;
+
+    double rc = rcbrt(T_z);                                  // T_z^(-1/3)
+    double Zr0 = 54.1 * exp(-17.3 * rc);
+    double Zr1 = 63.3 * exp(-16.7 * rc);
+    double Z_rot_ = 1.0 / ((X1 / Zr1) + (X0 / Zr0));
+
+    const double sigma = 5.0 / 4.58257569495584000659;       // 5/sqrt(21)
+    double nn = (4.0 / 5.0) * 0.65465367070797714380 * Z_rot_;   // sqrt(3/7)
+    double chi = 3.0 * nn * nu / 4.0;
+    double cchi = 2.36 * chi;
+
+    double w0 = 2.0 * kPi * freq / c_snd;
+    double nu2 = nu * nu, sq = sqrt(1.0 + nu2);
+    double a_cl  = w0 * sqrt(0.5 * (sq - 1.0) * (1.0 + cchi * cchi) / ((1.0 + nu2) * (1.0 + (sigma * cchi) * (sigma * cchi))));
+    double a_rot = w0 * X_ON * ((sigma * sigma - 1.0) * chi / (2 * sigma)) * sqrt(0.5 * (sq + 1.0) / ((1.0 + nu2) * (1.0 + cchi * cchi)));
+    double a_diff = 0.003 * a_cl;
+
+    double Tr = cbrt(T_o / T_z) - 1.0;                       // (T_z/T_o)^(-1/3) - 1
+    double A1 = (X0 + X1) * 24.0 * exp(-9.16 * Tr);
+    double A2 = (X4 + X5) * 2400.0;
+    double B  = 40400.0 * exp(10.0 * Tr);
+    double C  = 0.02 * exp(-11.2 * Tr);
+    double D  = 0.391 * exp(8.41 * Tr);
+    double Ee = 9.0 * exp(-19.9 * Tr);
+    double F  = 60000.0;
+    double G  = 28000.0 * exp(-4.17 * Tr);
+    double H  = 22000.0 * exp(-7.68 * Tr);
+    double I  = 15100.0 * exp(-10.4 * Tr);
+    double J  = 11500.0 * exp(-9.17 * Tr);
+    double K  = (8.48E08) * exp(9.17 * Tr);
+    double L  = exp(-7.72 * Tr);
+    double ZZ = H * X2 + I * (X0 + 0.5 * X4) + J * (X1 + 0.5 * X5) + K * (X6 + X3);
+    double hu = 100.0 * (X3 + X6);
+    double pm = (P_z / P_o) * (mu_o / mu);
+    double fv[4] = { pm * (A1 + A2 + B * hu * (C + hu) * (D + hu)), pm * (Ee + F * X3 + G * X6), pm * ZZ, pm * (1.2E5) * L };
+    const double Theta[4] = { 2239.1, 3352.0, 915.0, 1037.0 };
+    const double Cp_R[4] = { 3.5, 3.5, 4.0, 4.0 }, Cv_R[4] = { 2.5, 2.5, 3.0, 3.0 };
+    double Xm[4] = { X0, X1, X2, X3 };
+    double a_vib = 0.0;
+    #pragma unroll
+    for(int m = 0; m < 4; m++){
+        double q = Theta[m] / T_z;
+        double ex = exp(-q);
+        double C_R = ((q * q) * ex) / ((1 - ex) * (1 - ex));
+        double A_max = (Xm[m] * (kPi / 2) * C_R) / (Cp_R[m] * (Cv_R[m] + C_R));
+        double fr = freq / fv[m];
+        a_vib += (A_max / c_snd) * ((2 * (freq * freq) / fv[m]) / (1 + fr * fr));
+    }
+    return (a_cl + a_rot + a_diff + a_vib) * P.tweak_abs * 8.685889;
+}
+
+__global__ void __launch_bounds__(256) k_postpass_global(GeoacDevParams P){
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;                                   // segment (row i -> row i+1)
+    if(slot >= P.n_pad) return;
+    if(i + 1 >= P.nrows[slot]) return;
+    const size_t np = (size_t)P.n_pad;
+    const double* a = P.path + ((size_t)i * P.pathw) * np + slot;
+    const double* b = a + (size_t)P.pathw * np;
+    double ar = a[0], at_ = a[np], ap = a[2 * np], an0 = a[3 * np], an1 = a[4 * np], an2 = a[5 * np];
+    double dr = b[0] - ar, dt = b[np] - at_, dp = b[2 * np] - ap;
+    double r = ar + dr / 2.0, t = at_ + dt / 2.0;
+    double st, ct; fsincos(t, st, ct);
+    double rdt = r * dt;
+    double e1 = r * ct * dp, e2 = r * st * dp;
+    double ds_tt = sqrt(dr * dr + rdt * rdt + e1 * e1);
+    double ds_at = sqrt(dr * dr + rdt * rdt + e2 * e2);
+    double n0 = an0 + (b[3 * np] - an0) / 2.0, n1 = an1 + (b[4 * np] - an1) / 2.0, n2 = an2 + (b[5 * np] - an2) / 2.0;
+    double nu_mag = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+
+    double xe = clampd(r, P.x_min, P.x_max);
+    int k = seg_guess(P.seg, P, xe);
+    Atm9 m; seg_eval<false>(P.seg, k, xe, m);
+    double c = sqrt(kGamR * m.T);
+    double rho = rho_eval(P, k, xe);
+    double cp0 = c * n0 / nu_mag, cp1 = c * n1 / nu_mag + m.v, cp2 = c * n2 / nu_mag + m.u;
+    double cpm = sqrt(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
+
+    double alpha = suthbass_alpha(P, r - P.r_earth, c, rho, P.freq);
+    double* o = P.contrib + ((size_t)i * 2) * np + slot;
+    o[0]  = ds_tt / cpm;
+    o[np] = alpha * ds_at;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_accum: in-order summation per ray, leg bookkeeping (GeoAcGlobal_main.cpp:256-291, Q7)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_accum(GeoacDevParams P){
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if(slot >= P.n_rays) return;
+    const size_t np = (size_t)P.n_pad;
+    const int nr = P.nrows[slot];
+    if(nr < 2) return;
+    double* st = P.state + slot;
+    double tt = st[ST_TT * np], at = st[ST_AT * np];           // cumulative over the ray
+    double ltt = st[ST_LTT * np], lat = st[ST_LAT * np];   // per-leg partial sums (arrivals-only form)
+    int leg = (int)st[ST_PLEG * np];
+    const int ne = P.nlegend[slot];
+    int e = 0;
+    int next_end = (e < ne) ? P.legend[(size_t)e * np + slot] : 0x7fffffff;
+    int cur_end = -1;
+    const bool rays_form = (P.mode & (GEOAC_MODE_WRITE_RAYS | GEOAC_MODE_WRITE_CAUSTICS)) != 0;
+    for(int i = 0; i + 1 < nr; i++){
+        if(i == cur_end) continue;                              // (leg-end row -> next leg's start row): not a segment
+        const double* cpt = P.contrib + ((size_t)i * 2) * np + slot;
+        const bool last = (i + 1 == next_end);
+        if(rays_form){
+            if(!last){ tt += cpt[0]; at += cpt[np]; }           // segments 0..k-2 only (GeoAcGlobal_main.cpp:264-267)
+        } else {
+            ltt += cpt[0]; lat += cpt[np];                      // GeoAc_TravelTime / GeoAc_SB_Atten start from 0 per leg
+        }
+        if(last){
+            if(!rays_form){ tt += ltt; at += lat; ltt = 0.0; lat = 0.0; }
+            double* R = P.rec + ((size_t)slot * (P.bounces + 1) + leg) * GEOAC_REC_STRIDE;
+            R[GEOAC_REC_TTIME] = tt;
+            R[GEOAC_REC_ATTEN] = at;
+            leg++; cur_end = i + 1; e++;
+            next_end = (e < ne) ? P.legend[(size_t)e * np + slot] : 0x7fffffff;
+        }
+    }
+    st[ST_TT * np] = tt; st[ST_AT * np] = at; st[ST_PLEG * np] = (double)leg;
+    st[ST_LTT * np] = ltt; st[ST_LAT * np] = lat;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-callable launchers (called from geoac_api.cpp)
+// ------------------------------------------------------------------------------------------------
+extern "C" hipError_t geoac_launch_init(const GeoacDevParams* P, hipStream_t s){
+    dim3 b(256), g((P->n_pad + 255) / 256);
+    if(P->eqset != GEOAC_EQ_GLOBAL) return hipErrorNotSupported;
+    if(P->calc_amp) hipLaunchKernelGGL(k_init_global<true>, g, b, 0, s, *P);
+    else            hipLaunchKernelGGL(k_init_global<false>, g, b, 0, s, *P);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t geoac_launch_rk4(const GeoacDevParams* P, int block, hipStream_t s){
+    if(P->eqset != GEOAC_EQ_GLOBAL) return hipErrorNotSupported;
+    dim3 b(block), g((P->n_pad + block - 1) / block);
+    size_t lds = P->table_in_lds ? (size_t)P->nseg * GEOAC_SEGW * sizeof(double) : 0;
+    hipError_t err = hipSuccess;
+    #define GEOAC_RK4_CASE(AMP, LDS) do { \
+        if(lds > 65536) err = hipFuncSetAttribute((const void*)k_rk4_global<AMP, LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if(err != hipSuccess) return err; \
+        hipLaunchKernelGGL((k_rk4_global<AMP, LDS>), g, b, lds, s, *P); } while(0)
+    if(P->calc_amp){ if(P->table_in_lds) GEOAC_RK4_CASE(true, true); else GEOAC_RK4_CASE(true, false); }
+    else           { if(P->table_in_lds) GEOAC_RK4_CASE(false, true); else GEOAC_RK4_CASE(false, false); }
+    #undef GEOAC_RK4_CASE
+    return hipGetLastError();
+}
+
+extern "C" hipError_t geoac_launch_postpass(const GeoacDevParams* P, int rows, hipStream_t s){
+    if(P->eqset != GEOAC_EQ_GLOBAL) return hipErrorNotSupported;
+    if(rows < 2) return hipSuccess;
+    dim3 b(256), g((P->n_pad + 255) / 256, rows - 1);
+    hipLaunchKernelGGL(k_postpass_global, g, b, 0, s, *P);
+    dim3 g2((P->n_rays + 255) / 256);
+    hipLaunchKernelGGL(k_accum, g2, b, 0, s, *P);
+    return hipGetLastError();
+}

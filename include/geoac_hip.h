@@ -6,7 +6,7 @@
  *
  *   int  GeoAc_Propagate_RK4(double**& solution, bool& check)        Code/GeoAc/GeoAc.Solver.h:8
  *   the 20 functions of                                              Code/GeoAc/GeoAc.EquationSets.h:6-31
- *   c,u,v,w,rho and *_diff/*_ddiff, SuthBass_Alpha                   Code/Atmo/Atmo_State.h:17-36
+ *   c,u,v,w,rho and X_diff / X_ddiff, SuthBass_Alpha                   Code/Atmo/Atmo_State.h:17-36
  *   the launch-angle double loop + bounce loop + post-pass           Code/GeoAcGlobal_main.cpp:241-325,
  *                                                                    Code/GeoAc3D_main.cpp:226-307,
  *                                                                    Code/GeoAc2D_main.cpp:170-232

@@ -1,0 +1,42 @@
+/* geoac_host.h - host-side (CPU, set-up only) helpers of libgeoac_hip.so: the pieces of GeoAc that run
+ * once per job and feed the GPU path.  They replace
+ *   file_length / Load_G2S / Spline_Single_G2S     Code/Atmo/G2S_Spline1D.cpp:55-142,293-309
+ *                                                  Code/Atmo/G2S_GlobalSpline1D.cpp:58-152,305-320
+ *   Set_Slopes                                     Code/Atmo/G2S_Spline1D.cpp:161-196
+ *   the launch-angle loop headers                  Code/GeoAcGlobal_main.cpp:241-242 (and twins)
+ * No ray is ever integrated on the host.
+ */
+#ifndef GEOAC_HOST_H_
+#define GEOAC_HOST_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* number of profile rows the reference would read from `file` (= number of '\n'), <0 on error */
+int  geoac_met_rows(const char* file);
+
+/* read a .met profile (format "zTuvdp" or "zuvwTdp").  Outputs (each `cap` >= rows doubles):
+ * x = altitude [km] (+ r_earth for eqset GEOAC_EQ_GLOBAL*), T [K], u,v [km/s] with the reference's
+ * ground taper (z_grnd = 0 at load time: the mains parse z_grnd= after loading), rho.  Returns rows. */
+int  geoac_met_load(const char* file, const char* format, int eqset, int cap,
+                    double* x, double* T, double* u, double* v, double* rho);
+
+/* the same transformation applied to columns already in memory (z [km], T [K], u,v [m/s], rho) */
+int  geoac_met_from_columns(int eqset, int n, const double* z, const double* T, const double* u_ms,
+                            const double* v_ms, const double* rho_in,
+                            double* x, double* T_out, double* u, double* v, double* rho);
+
+/* natural cubic spline node slopes (Thomas algorithm, natural end conditions) */
+void geoac_natural_spline_slopes(int n, const double* x, const double* f, double* slopes);
+
+/* enumerate `for(phi = phi_min; phi <= phi_max; phi += phi_step) for(theta = ...)` by repeated addition,
+ * phi outer.  Returns the ray count (also when cap is too small; nothing is written past cap). */
+long geoac_fan_enumerate(double theta_min, double theta_max, double theta_step,
+                         double phi_min, double phi_max, double phi_step,
+                         long cap, double* theta_out, double* phi_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
