@@ -266,6 +266,8 @@ int geoac_fan_launch(geoac_ctx* ctx){
         double cg = sqrt(kGamR * Tg) * 1000.0;
         P.T_o = cg * cg / (kRgas * kGam);
         P.P_o = rg * (cg * cg) / kGam * 1000.0;
+        P.sb_const[0] = pow(10.0, -0.67887); P.sb_const[1] = pow(10.0, -0.10744); P.sb_const[2] = pow(10, -3.3979);
+        P.sb_const[3] = 5.0 / sqrt(21.0); P.sb_const[4] = sqrt(3.0 / 7.0);
     }
     // ---- epoch size: keep the path chunk around <= 3 GiB ----
     size_t row_bytes = (size_t)P.pathw * P.n_pad * sizeof(double);

@@ -58,6 +58,7 @@ struct GeoacDevParams {
     double  src[3];                 // as in geoac_params
     double  freq, tweak_abs;
     double  T_o, P_o;               // SuthBass reference temperature / pressure (ground), host-evaluated from the spline
+    double  sb_const[5];            // 10^-0.67887, 10^-0.10744, 10^-3.3979, 5/sqrt(21), sqrt(3/7) (host libm, as the reference computes them)
     // buffers
     const double* seg;              // [nseg][SEGW]
     const double* rho;              // [nseg][4]

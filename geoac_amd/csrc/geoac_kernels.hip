@@ -466,11 +466,16 @@ __global__ void __launch_bounds__(256, 1) k_rk4_global(GeoacDevParams P){
     st[ST_HMAX * np] = hmax; st[ST_SEG * np] = (double)seg;
     P.nrows[slot] = nr; P.nlegend[slot] = nle;
 
-    // ---- per-wave reduction of step count and live-ray count, one atomic per wave ----
-    unsigned long long s = steps_here;
-    for(int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-    unsigned long long live = __popcll(__ballot(!done));
-    if((threadIdx.x & 63) == 0){
+    // ---- step count and live-ray count: lanes of finished rays have already returned, so reduce over the
+    //      lanes that are still here (ballot of the active mask), one atomic pair per wave ----
+    const unsigned long long act = __ballot(1);
+    unsigned long long s = 0;
+    for(int l = 0; l < 64; l++){
+        unsigned long long v = __shfl(steps_here, l);
+        if((act >> l) & 1ull) s += v;
+    }
+    const unsigned long long live = __popcll(__ballot(!done));
+    if((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1){
         atomicAdd(&P.counters[0], s);
         atomicAdd(&P.counters[1], live);
     }
@@ -492,10 +497,10 @@ DEVINL double suthbass_alpha(const GeoacDevParams& P, double zr, double c_snd, d
     double z2 = zr * zr, z3 = z2 * zr, z4 = z2 * z2, z5 = z4 * zr;
     double X0, X1, X2, X3, X4, X5, X6;
     X0 = (zr > 90.) ? exp10(49.296 - (1.5524 * zr) + (1.8714E-2 * z2) - (1.1069E-4 * z3) + (3.199E-7 * z4) - (3.6211E-10 * z5))
-                    : 0.20947541961827458;   // 10^-0.67887
+                    : P.sb_const[0];          // 10^-0.67887 (host pow)
     X1 = (zr > 76.) ? exp10((1.3972E-1) - (5.6269E-3 * zr) + (3.9407E-5 * z2) - (1.0737E-7 * z3))
-                    : 0.78083638675879660;   // 10^-0.10744
-    X2 = 0.00040003681592986493;             // 10^-3.3979
+                    : P.sb_const[1];          // 10^-0.10744
+    X2 = P.sb_const[2];                     // 10^-3.3979
     X3 = (zr > 80.) ? exp10(-4.234 - (3.0975E-2 * zr))
                     : exp10(-19.027 + (1.3093 * zr) - (4.6496E-2 * z2) + (7.8543E-4 * z3) - (6.5169E-6 * z4) + (2.1343E-8 * z5));
     X4 = (zr > 95.) ? exp10(-3.2456 + (4.6642E-2 * zr) - (2.6894E-4 * z2) + (5.264E-7 * z3))
@@ -510,8 +515,8 @@ DEVINL double suthbass_alpha(const GeoacDevParams& P, double zr, double c_snd, d
     double Zr1 = 63.3 * exp(-16.7 * rc);
     double Z_rot_ = 1.0 / ((X1 / Zr1) + (X0 / Zr0));
 
-    const double sigma = 5.0 / 4.58257569495584000659;       // 5/sqrt(21)
-    double nn = (4.0 / 5.0) * 0.65465367070797714380 * Z_rot_;   // sqrt(3/7)
+    const double sigma = P.sb_const[3];                      // 5/sqrt(21)
+    double nn = (4.0 / 5.0) * P.sb_const[4] * Z_rot_;         // sqrt(3/7)
     double chi = 3.0 * nn * nu / 4.0;
     double cchi = 2.36 * chi;
 
