@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""bench.py - RK4 ray-steps/sec of the GeoAcGlobal ToyAtmo launch-angle fan on MI355X.
+
+One "step" of this bench = one full pass of the hot path over the metric fan:
+    GeoAcGlobal -prop ToyAtmo.met phi_min=-180 phi_max=179 phi_step=1  (theta 0.5..45/0.5, bounces=2,
+    CalcAmp=True, WriteRays=False, lat_src=30 lon_src=0, rng_max=1500)   -> 360 az x 90 incl = 32 400 rays
+(BASELINE.json metric / SURVEY.md §8d item 3).  Profile tables and launch angles are resident in HBM before
+the timed region; the timed region covers RK4 + post-pass kernels, and for N > 1 the RCCL gather of arrivals.
+
+N > 1 (one process per GPU, torch.distributed/RCCL): weak scaling by azimuth - the fan has N x 360 azimuths
+(phi step 1/N degree), rank r integrates azimuth indices r, r+N, ...; arrival records are all-gathered over xGMI
+and the step counts all-reduced.  value = all ranks' RK4 ray-steps / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+MET = os.path.join(ROOT, "tests", "golden", "ToyAtmo.met")
+
+B_ALG_PER_STEP = 144          # 8 B x E(=18) state row per accepted RK4 step (Global, CalcAmp on)
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def cpu_baseline():
+    """the reference's own serial loop on this box's host cores: the phi = -90 slice of the metric fan
+    (90 rays, 2 057 497 steps), compiled reference if its prebuilt shim is present, else the plain-C port."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import harness as H
+    th, ph = H.fan_angles()                                   # defaults = the phi=-90 slice
+    cfg = H.make_cfg(H.EQ_GLOBAL, bounces=2, calc_amp=True, mode=0)
+    if H.ref_available(H.EQ_GLOBAL):
+        lib, kind = H.RefShim(H.EQ_GLOBAL, MET), "reference"
+    else:
+        lib, kind = H.Oracle(H.EQ_GLOBAL, MET), "port"
+    t0 = time.perf_counter()
+    steps, _, _, _ = lib.fan(cfg, th, ph)
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "RK4 ray-steps/s", "cores": 1, "kind": kind,
+            "sample": f"phi=-90 slice of the metric fan: 90 rays, {steps} steps, {dt:.1f} s "
+                      f"({'compiled reference TUs -O2 (oracle/_ref)' if kind == 'reference' else 'plain-C restatement (oracle/)'})"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--phi-step", type=float, default=1.0, help="azimuth step of the N=1 fan (metric: 1.0)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import geoac_amd as G
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    n_gpus = world
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    # ---- the fan: 360*N azimuths x 90 inclinations, this rank's azimuth shard ----
+    phi_step = args.phi_step / n_gpus
+    th_all, ph_all = G.fan_enumerate(phi_min=-180.0, phi_max=180.0 - phi_step * 0.999999, phi_step=phi_step)
+    n_theta = 90
+    n_az = len(th_all) // n_theta
+    az_idx = np.arange(rank, n_az, n_gpus)
+    sel = (az_idx[:, None] * n_theta + np.arange(n_theta)[None, :]).reshape(-1)
+    theta, phi = th_all[sel], ph_all[sel]
+
+    stream = torch.cuda.current_stream(dev)
+    ctx = G.FanContext(G.EQ_GLOBAL, device=dev.index, stream=stream.cuda_stream)
+    ctx.load_met(MET)
+    ctx.set_params(bounces=2, calc_amp=1, mode=0)
+    ctx.set_angles(theta, phi)                                 # inputs resident in HBM before timing
+    legs = 3
+    rec_local = torch.empty(len(theta) * legs * G.REC_STRIDE, dtype=torch.float64, device=dev)
+    rec_all = torch.empty(world * rec_local.numel(), dtype=torch.float64, device=dev) if world > 1 else None
+    steps_t = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def one_pass():
+        ctx.launch()
+        if world > 1:
+            ctx.copy_records_to(rec_local.data_ptr())
+            dist.all_gather_into_tensor(rec_all, rec_local)    # RCCL gather of arrivals over xGMI
+            steps_t[0] = ctx.total_steps()
+            dist.all_reduce(steps_t)
+            return int(steps_t.item())
+        return ctx.total_steps()
+
+    for _ in range(args.warmup):
+        one_pass()
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    total_steps = 0
+    rk4_ms = post_ms = 0.0
+    rk4_launches = 0
+    for _ in range(args.steps):
+        total_steps += one_pass()
+        tm = ctx.timing()
+        rk4_ms += tm["ms_rk4"]; post_ms += tm["ms_post"]; rk4_launches += tm["epochs"]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    local_steps_per_pass = ctx.total_steps()
+    if rank == 0:
+        value = total_steps / dt
+        # dominant kernel = k_rk4_global: algorithmic bytes per launch / average launch duration (HIP events on the
+        # kernel's own stream, recorded inside libgeoac_hip around every k_rk4 launch of the timed passes)
+        ach_gbs = (B_ALG_PER_STEP * local_steps_per_pass * args.steps) / (rk4_ms * 1e-3) / 1e9 if rk4_ms > 0 else 0.0
+        out = {
+            "metric": "RK4 ray-steps/sec, GeoAcGlobal 360x90 ToyAtmo fan; arrivals within 1e-6 of ref",
+            "value": value, "unit": "RK4 ray-steps/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"GeoAcGlobal -prop ToyAtmo.met, {n_az} az x {n_theta} incl = {n_az * n_theta} rays "
+                                   f"(phi step {phi_step:g} deg), bounces=2, CalcAmp=True, WriteRays=False, rng_max=1500",
+                       "rays_per_gpu": int(len(theta)), "ray_steps_per_pass": int(total_steps // args.steps),
+                       "parallelism": f"azimuth-sharded x{n_gpus}" + (", RCCL all_gather of arrivals" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_rk4_global<true,true>", "launches": rk4_launches,
+                         "avg_launch_ms": rk4_ms / max(rk4_launches, 1),
+                         "alg_bytes_per_step": B_ALG_PER_STEP,
+                         "rk4_ms_per_pass": rk4_ms / args.steps, "postpass_ms_per_pass": post_ms / args.steps},
+        }
+        if not args.no_cpu_baseline and n_gpus == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -176,6 +176,10 @@ class FanContext:
         self._chk(self.lib.geoac_fan_records_dev(self._h, ctypes.byref(ptr), ctypes.byref(nbytes)))
         return ptr.value, nbytes.value
 
+    def copy_records_to(self, dev_ptr):
+        """async D2D copy of the record table into a caller-owned device buffer (ordered on the context's stream)"""
+        self._chk(self.lib.geoac_fan_copy_records_dev(self._h, ctypes.c_void_p(dev_ptr)))
+
     def total_steps(self):
         steps = ctypes.c_uint64(0)
         self._chk(self.lib.geoac_fan_fetch(self._h, None, ctypes.byref(steps)))

@@ -39,6 +39,7 @@ struct geoac_ctx {
     int eqset = 0, device = 0;
     hipStream_t stream = nullptr; bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> evs;                  // per-epoch markers: [3e] before rk4, [3e+1] after rk4, [3e+2] after post-pass
     geoac_params prm{};
     bool have_params = false, have_atmo = false, have_angles = false, ran = false;
     // host copy of the 1-D atmosphere (for the SuthBass reference state)
@@ -163,6 +164,7 @@ int geoac_destroy(geoac_ctx* ctx){
     if(ctx->h_counters) hipHostFree(ctx->h_counters);
     if(ctx->ev0) hipEventDestroy(ctx->ev0);
     if(ctx->ev1) hipEventDestroy(ctx->ev1);
+    for(hipEvent_t e : ctx->evs) hipEventDestroy(e);
     if(ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return GEOAC_OK;
@@ -310,9 +312,14 @@ int geoac_fan_launch(geoac_ctx* ctx){
     const long long max_epochs = (P.step_limit * (long long)ctx->legs) / (P.s_rows > 4 ? (P.s_rows - 3) : 1) + ctx->legs + 2;
     unsigned long long live = 1;
     while(live > 0){
+        const size_t eb = 3 * (size_t)ctx->n_epochs;
+        while(ctx->evs.size() < eb + 3){ hipEvent_t e; HIPCHK(hipEventCreate(&e)); ctx->evs.push_back(e); }
         HIPCHK(hipMemsetAsync((char*)ctx->counters.p + sizeof(unsigned long long), 0, sizeof(unsigned long long), s));
+        HIPCHK(hipEventRecord(ctx->evs[eb], s));
         HIPCHK(geoac_launch_rk4(&P, block, s));
+        HIPCHK(hipEventRecord(ctx->evs[eb + 1], s));
         HIPCHK(geoac_launch_postpass(&P, P.s_rows, s));
+        HIPCHK(hipEventRecord(ctx->evs[eb + 2], s));
         HIPCHK(hipMemcpyAsync(ctx->h_counters, ctx->counters.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         live = ctx->h_counters[1];
@@ -323,6 +330,13 @@ int geoac_fan_launch(geoac_ctx* ctx){
     HIPCHK(hipStreamSynchronize(s));
     float ms = 0; hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->ms_total = ms;
+    ctx->ms_rk4 = 0; ctx->ms_post = 0;
+    for(size_t e = 0; e < (size_t)ctx->n_epochs; e++){
+        float a = 0, b = 0;
+        hipEventElapsedTime(&a, ctx->evs[3 * e], ctx->evs[3 * e + 1]);
+        hipEventElapsedTime(&b, ctx->evs[3 * e + 1], ctx->evs[3 * e + 2]);
+        ctx->ms_rk4 += a; ctx->ms_post += b;
+    }
     ctx->total_steps = ctx->h_counters[0];
     ctx->err_flags = ctx->h_counters[2];
     // algorithmic path traffic: one PATHW-wide row per step (+ leg-start / carry rows, not counted)
@@ -343,6 +357,14 @@ int geoac_fan_records_dev(geoac_ctx* ctx, void** dev_ptr, size_t* bytes){
     if(!ctx || !ctx->ran) return fail(ctx, GEOAC_E_INVALID, "fan_records_dev: no completed launch");
     if(dev_ptr) *dev_ptr = ctx->rec.p;
     if(bytes) *bytes = sizeof(double) * (size_t)ctx->n_rays * ctx->legs * GEOAC_REC_STRIDE;
+    return GEOAC_OK;
+}
+
+int geoac_fan_copy_records_dev(geoac_ctx* ctx, void* dst_dev){
+    if(!ctx || !ctx->ran || !dst_dev) return fail(ctx, GEOAC_E_INVALID, "fan_copy_records_dev: no completed launch / null destination");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(dst_dev, ctx->rec.p, sizeof(double) * (size_t)ctx->n_rays * ctx->legs * GEOAC_REC_STRIDE,
+                          hipMemcpyDeviceToDevice, ctx->stream));
     return GEOAC_OK;
 }
 

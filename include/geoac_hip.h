@@ -124,13 +124,17 @@ int  geoac_set_params(geoac_ctx* ctx, const geoac_params* p);
 /* launch angles in degrees, exactly the values of the reference's loop variables theta, phi */
 int  geoac_fan_set_angles(geoac_ctx* ctx, int n_rays, const double* theta_deg, const double* phi_deg);
 
-/* integrate the whole fan; asynchronous on the context's stream */
+/* integrate the whole fan.  All device work is enqueued on the context's stream; the host drives the
+ * epochs (it needs the live-ray count to stop), so the call returns when every ray has finished. */
 int  geoac_fan_launch(geoac_ctx* ctx);
 int  geoac_fan_sync(geoac_ctx* ctx);
 
 /* device pointer to the record table [n_rays][bounces+1][GEOAC_REC_STRIDE] f64 (valid after launch,
  * ordered on the context's stream) - what a multi-GPU caller hands to its gather collective */
 int  geoac_fan_records_dev(geoac_ctx* ctx, void** dev_ptr, size_t* bytes);
+/* asynchronous device-to-device copy of the record table into a caller-owned device buffer (e.g. a torch
+ * tensor that is then gathered with RCCL), ordered on the context's stream */
+int  geoac_fan_copy_records_dev(geoac_ctx* ctx, void* dst_dev);
 /* copy records (and the total step count = sum of GeoAc_Propagate_RK4 return values) to the host */
 int  geoac_fan_fetch(geoac_ctx* ctx, double* rec_host, uint64_t* total_steps);
 /* WriteRays / WriteCaustics samples: number available, then copy (ordered by ray, leg, m) */
