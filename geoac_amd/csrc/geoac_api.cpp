@@ -39,14 +39,16 @@ struct geoac_ctx {
     int eqset = 0, device = 0;
     hipStream_t stream = nullptr; bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::vector<hipEvent_t> evs;                  // per-epoch markers: [3e] before rk4, [3e+1] after rk4, [3e+2] after post-pass
+    std::vector<hipEvent_t> evs;                  // per-epoch markers: [4e], [4e+1] around k_rk4 (ctx stream); [4e+2], [4e+3] around the post-pass (pp stream)
     geoac_params prm{};
     bool have_params = false, have_atmo = false, have_angles = false, ran = false;
     // host copy of the 1-D atmosphere (for the SuthBass reference state)
     std::vector<double> x, T, u, v, rho, sl;
     int n_nodes = 0;
     // device
-    DevBuf seg, rhot, theta, phi, state, path, contrib, nrows, legend, nlegend, rec, counters;
+    DevBuf seg, rhot, theta, phi, state, rec, counters;
+    DevBuf path[2], contrib[2], nrows[2], legend[2], nlegend[2];   // double-buffered epoch chunks (RK4 of epoch e+1 overlaps the post-pass of e)
+    hipStream_t pp_stream = nullptr;                                // post-pass stream
     unsigned long long* h_counters = nullptr;     // pinned
     int n_rays = 0, n_pad = 0, legs = 0;
     // last launch
@@ -143,6 +145,7 @@ int geoac_create(geoac_ctx** out, int eqset, int device){
     ctx->eqset = eqset; ctx->device = device;
     if(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess){ delete ctx; return GEOAC_E_HIP; }
     ctx->own_stream = true;
+    if(hipStreamCreateWithFlags(&ctx->pp_stream, hipStreamNonBlocking) != hipSuccess){ delete ctx; return GEOAC_E_HIP; }
     hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
     if(hipHostMalloc((void**)&ctx->h_counters, 8 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess){
         delete ctx; return GEOAC_E_HIP;
@@ -158,13 +161,15 @@ int geoac_destroy(geoac_ctx* ctx){
     if(!ctx) return GEOAC_E_INVALID;
     hipSetDevice(ctx->device);
     if(ctx->stream) hipStreamSynchronize(ctx->stream);
-    DevBuf* bufs[] = { &ctx->seg, &ctx->rhot, &ctx->theta, &ctx->phi, &ctx->state, &ctx->path, &ctx->contrib,
-                       &ctx->nrows, &ctx->legend, &ctx->nlegend, &ctx->rec, &ctx->counters };
+    DevBuf* bufs[] = { &ctx->seg, &ctx->rhot, &ctx->theta, &ctx->phi, &ctx->state, &ctx->rec, &ctx->counters,
+                       &ctx->path[0], &ctx->path[1], &ctx->contrib[0], &ctx->contrib[1], &ctx->nrows[0], &ctx->nrows[1],
+                       &ctx->legend[0], &ctx->legend[1], &ctx->nlegend[0], &ctx->nlegend[1] };
     for(DevBuf* b : bufs) b->release();
     if(ctx->h_counters) hipHostFree(ctx->h_counters);
     if(ctx->ev0) hipEventDestroy(ctx->ev0);
     if(ctx->ev1) hipEventDestroy(ctx->ev1);
     for(hipEvent_t e : ctx->evs) hipEventDestroy(e);
+    if(ctx->pp_stream) hipStreamDestroy(ctx->pp_stream);
     if(ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return GEOAC_OK;
@@ -283,17 +288,18 @@ int geoac_fan_launch(geoac_ctx* ctx){
     ctx->legs = p.bounces + 1;
 
     HIPCHK(ctx->state.ensure(sizeof(double) * (size_t)ST_NSTATE * P.n_pad));
-    HIPCHK(ctx->path.ensure(row_bytes * (size_t)P.s_rows));
-    HIPCHK(ctx->contrib.ensure(sizeof(double) * 2 * (size_t)P.n_pad * P.s_rows));
-    HIPCHK(ctx->nrows.ensure(sizeof(int) * (size_t)P.n_pad));
-    HIPCHK(ctx->nlegend.ensure(sizeof(int) * (size_t)P.n_pad));
-    HIPCHK(ctx->legend.ensure(sizeof(int) * (size_t)P.n_pad * GEOAC_MAXLEGS));
+    for(int b = 0; b < 2; b++){
+        HIPCHK(ctx->path[b].ensure(row_bytes * (size_t)P.s_rows));
+        HIPCHK(ctx->contrib[b].ensure(sizeof(double) * 2 * (size_t)P.n_pad * P.s_rows));
+        HIPCHK(ctx->nrows[b].ensure(sizeof(int) * (size_t)P.n_pad));
+        HIPCHK(ctx->nlegend[b].ensure(sizeof(int) * (size_t)P.n_pad));
+        HIPCHK(ctx->legend[b].ensure(sizeof(int) * (size_t)P.n_pad * GEOAC_MAXLEGS));
+    }
     HIPCHK(ctx->rec.ensure(sizeof(double) * (size_t)ctx->n_rays * ctx->legs * GEOAC_REC_STRIDE));
     HIPCHK(ctx->counters.ensure(8 * sizeof(unsigned long long)));
     P.seg = (const double*)ctx->seg.p; P.rho = (const double*)ctx->rhot.p;
     P.theta_deg = (const double*)ctx->theta.p; P.phi_deg = (const double*)ctx->phi.p;
-    P.state = (double*)ctx->state.p; P.path = (double*)ctx->path.p; P.contrib = (double*)ctx->contrib.p;
-    P.nrows = (int*)ctx->nrows.p; P.legend = (int*)ctx->legend.p; P.nlegend = (int*)ctx->nlegend.p;
+    P.state = (double*)ctx->state.p;
     P.rec = (double*)ctx->rec.p; P.counters = (unsigned long long*)ctx->counters.p;
 
     // RK4 workgroup shape: with the table in LDS one workgroup owns a CU, so spread the waves over the 256 CUs
@@ -304,7 +310,10 @@ int geoac_fan_launch(geoac_ctx* ctx){
     int block = 64 * wpb;
     if(!P.table_in_lds) block = 64;
 
-    hipStream_t s = ctx->stream;
+    // ---- epoch pipeline: RK4 of epoch e on the context's stream, post-pass of epoch e on a second stream, chunk
+    //      buffers alternate, so k_rk4(e+1) runs beside k_postpass(e)/k_accum(e).  The host only waits for the
+    //      live-ray count of each RK4 launch (it must know when to stop). ----
+    hipStream_t s = ctx->stream, sp = ctx->pp_stream;
     HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 8 * sizeof(unsigned long long), s));
     HIPCHK(hipEventRecord(ctx->ev0, s));
     HIPCHK(geoac_launch_init(&P, s));
@@ -312,20 +321,28 @@ int geoac_fan_launch(geoac_ctx* ctx){
     const long long max_epochs = (P.step_limit * (long long)ctx->legs) / (P.s_rows > 4 ? (P.s_rows - 3) : 1) + ctx->legs + 2;
     unsigned long long live = 1;
     while(live > 0){
-        const size_t eb = 3 * (size_t)ctx->n_epochs;
-        while(ctx->evs.size() < eb + 3){ hipEvent_t e; HIPCHK(hipEventCreate(&e)); ctx->evs.push_back(e); }
+        const size_t e = (size_t)ctx->n_epochs, eb = 4 * e;
+        const int b = (int)(e & 1);
+        while(ctx->evs.size() < eb + 4){ hipEvent_t ev; HIPCHK(hipEventCreate(&ev)); ctx->evs.push_back(ev); }
+        GeoacDevParams Pe = P;
+        Pe.path = (double*)ctx->path[b].p; Pe.contrib = (double*)ctx->contrib[b].p;
+        Pe.nrows = (int*)ctx->nrows[b].p; Pe.legend = (int*)ctx->legend[b].p; Pe.nlegend = (int*)ctx->nlegend[b].p;
+        if(e >= 2) HIPCHK(hipStreamWaitEvent(s, ctx->evs[4 * (e - 2) + 3], 0));      // chunk b free again?
         HIPCHK(hipMemsetAsync((char*)ctx->counters.p + sizeof(unsigned long long), 0, sizeof(unsigned long long), s));
         HIPCHK(hipEventRecord(ctx->evs[eb], s));
-        HIPCHK(geoac_launch_rk4(&P, block, s));
+        HIPCHK(geoac_launch_rk4(&Pe, block, s));
         HIPCHK(hipEventRecord(ctx->evs[eb + 1], s));
-        HIPCHK(geoac_launch_postpass(&P, P.s_rows, s));
-        HIPCHK(hipEventRecord(ctx->evs[eb + 2], s));
         HIPCHK(hipMemcpyAsync(ctx->h_counters, ctx->counters.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamWaitEvent(sp, ctx->evs[eb + 1], 0));
+        HIPCHK(hipEventRecord(ctx->evs[eb + 2], sp));
+        HIPCHK(geoac_launch_postpass(&Pe, Pe.s_rows, sp));
+        HIPCHK(hipEventRecord(ctx->evs[eb + 3], sp));
         HIPCHK(hipStreamSynchronize(s));
         live = ctx->h_counters[1];
         ctx->n_epochs++;
         if((long long)ctx->n_epochs > max_epochs) return fail(ctx, GEOAC_E_CAPACITY, "fan_launch: epoch bound exceeded");
     }
+    HIPCHK(hipStreamWaitEvent(s, ctx->evs[4 * (ctx->n_epochs - 1) + 3], 0));
     HIPCHK(hipEventRecord(ctx->ev1, s));
     HIPCHK(hipStreamSynchronize(s));
     float ms = 0; hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
@@ -333,8 +350,8 @@ int geoac_fan_launch(geoac_ctx* ctx){
     ctx->ms_rk4 = 0; ctx->ms_post = 0;
     for(size_t e = 0; e < (size_t)ctx->n_epochs; e++){
         float a = 0, b = 0;
-        hipEventElapsedTime(&a, ctx->evs[3 * e], ctx->evs[3 * e + 1]);
-        hipEventElapsedTime(&b, ctx->evs[3 * e + 1], ctx->evs[3 * e + 2]);
+        hipEventElapsedTime(&a, ctx->evs[4 * e], ctx->evs[4 * e + 1]);
+        hipEventElapsedTime(&b, ctx->evs[4 * e + 2], ctx->evs[4 * e + 3]);
         ctx->ms_rk4 += a; ctx->ms_post += b;
     }
     ctx->total_steps = ctx->h_counters[0];

@@ -29,7 +29,29 @@ static constexpr double kGamR = 0.00040187;                    // G2S_GlobalSpli
 // ------------------------------------------------------------------------------------------------
 // small FP64 helpers
 // ------------------------------------------------------------------------------------------------
-DEVINL double frcp(double x){ return 1.0 / x; }
+// v_rcp_f64 / v_rsq_f64 are ~24-bit seeds on gfx950 (measured 4.6e-8 / 5.2e-8 max rel. error, tools/ubench_acc.hip);
+// two Newton steps bring both to <= 1 ulp (measured 0 / 2.6e-16) at 24 / 35 ns per wave-instruction group instead of
+// the 33 / 49+33 ns of the IEEE division / sqrt+division expansions (tools/ubench_fp64.hip, one wave per SIMD).
+DEVINL double frcp(double x){
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0); r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0); return __builtin_fma(r, e, r);
+}
+DEVINL double frsq(double x){
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double e = __builtin_fma(-h, g, 0.5); y = __builtin_fma(y, e, y);
+    g = x * y; h = 0.5 * y;
+    e = __builtin_fma(-h, g, 0.5); return __builtin_fma(y, e, y);
+}
+// rotate (sin a, cos a) by a small angle d (|d| << 1): series to d^6, error < 1e-17 for |d| < 0.03
+DEVINL void rot_small(double sa, double ca, double d, double& s, double& c){
+    double d2 = d * d;
+    double sd = d * __builtin_fma(d2 * (-1.0 / 6.0), __builtin_fma(d2, -1.0 / 20.0, 1.0), 1.0);
+    double cd = __builtin_fma(d2 * (-0.5), __builtin_fma(d2 * (-1.0 / 12.0), __builtin_fma(d2, -1.0 / 30.0, 1.0), 1.0), 1.0);
+    s = __builtin_fma(sa, cd, ca * sd);
+    c = __builtin_fma(ca, cd, -sa * sd);
+}
 
 // sin & cos together.  Cody-Waite reduction by pi/2 (3 constants, exact products through FMA) and the
 // classic minimax kernels on [-pi/4, pi/4]; < 1 ulp for |x| < 1e5, which covers latitudes / longitudes / launch angles.
@@ -132,79 +154,84 @@ DEVINL void global_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const doub
     seg = seg_find(tab, P.nseg, xe, seg);
     Atm9 a;
     seg_eval<AMP>(tab, seg, xe, a);
-
-    const double c   = sqrt(kGamR * a.T);
-    const double ic  = frcp(c);
-    const double hc  = 0.5 * kGamR * ic;               // gamR / (2c)
-    const double dc  = hc * a.dT;                      // c_diff(.,0)
     const double u = a.u, v = a.v, du = a.du, dv = a.dv;
 
-    const double ico = frcp(cth);
-    const double tn  = sth * ico;
-    const double numag = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
-    const double inm = frcp(numag);
+    // c = sqrt(gamR T), c' = gamR/(2c) T'                      (G2S_GlobalSpline1D.cpp:345-356)
+    const double qT  = kGamR * a.T;
+    const double ic  = frsq(qT);
+    const double c   = qT * ic;
+    const double hc  = (0.5 * kGamR) * ic;
+    const double dc  = hc * a.dT;
+    // |nu|, group velocity c_g = c nu/|nu| + (0, v, u), |c_g|   (Global.cpp:249-255)
+    const double nn  = __builtin_fma(n0, n0, __builtin_fma(n1, n1, n2 * n2));
+    const double inm = frsq(nn);
+    const double numag = nn * inm;
     const double cn  = c * inm;
     const double cg0 = cn * n0;
     const double cg1 = __builtin_fma(cn, n1, v);
     const double cg2 = __builtin_fma(cn, n2, u);
-    const double cgm = sqrt(cg0 * cg0 + cg1 * cg1 + cg2 * cg2);
-    const double icg = frcp(cgm);
+    const double icg = frsq(__builtin_fma(cg0, cg0, __builtin_fma(cg1, cg1, cg2 * cg2)));
     const double ir  = frcp(r);
-    const double G1  = ir;
-    const double G2  = ir * ico;
-
-    const double nc12 = n1 * cg1 + n2 * cg2;
-    const double ncs  = n0 * cth + n1 * sth;
+    const double ico = frcp(cth);
+    const double tn  = sth * ico;
+    const double u0 = cg0 * icg, u1 = cg1 * icg, u2 = cg2 * icg;       // unit group-velocity vector
+    const double G1 = ir, G2 = ir * ico;                               // GeoCoeff (Global.cpp:258-260)
+    // GeoTerms (Global.cpp:263-269) with c_g substituted; the wind terms that cancel analytically are dropped:
+    //   T1 = nu_r v - nu_r c_g1 + nu_p c_g2 tan      = -c/|nu| nu_r nu_t + nu_p c_g2 tan
+    //   T2 = (..u..)cos + (..)sin - c_g2 (nu_r cos + nu_t sin) = -nu_p (v sin + c/|nu| (nu_r cos + nu_t sin))
+    const double nc12 = __builtin_fma(n1, cg1, n2 * cg2);
+    const double ncs  = __builtin_fma(n0, cth, n1 * sth);
+    const double n2cg2 = n2 * cg2;
     const double T0 = ir * nc12;
-    const double T1 = n0 * v + (n2 * cg2 * tn - n0 * cg1);
-    const double T2 = (n0 * u) * cth + (n1 * u - n2 * v) * sth - cg2 * ncs;
+    const double T1 = __builtin_fma(n2cg2, tn, -(cn * n0) * n1);
+    const double T2 = -n2 * __builtin_fma(cn, ncs, v * sth);
+    const double H0 = __builtin_fma(numag, dc, __builtin_fma(n1, dv, n2 * du));
+    const double g1i = G1 * icg, g2i = G2 * icg;
 
-    const double H0 = numag * dc + n1 * dv + n2 * du;
-
-    dy[0] = cg0 * icg;
-    dy[1] = G1 * cg1 * icg;
-    dy[2] = G2 * cg2 * icg;
+    dy[0] = u0;
+    dy[1] = G1 * u1;
+    dy[2] = G2 * u2;
     dy[3] = -icg * (H0 + T0);
-    dy[4] = -G1 * icg * T1;
-    dy[5] = -G2 * icg * T2;
+    dy[4] = -g1i * T1;
+    dy[5] = -g2i * T2;
 
     if(AMP){
-        const double ddc = hc * a.ddT - (0.25 * kGamR * kGamR) * (ic * ic * ic) * (a.dT * a.dT);   // c_ddiff(.,0,0)
-        const double ddu = a.ddu, ddv = a.ddv;
-        const double ir2 = ir * ir;
-        const double icg2 = icg * icg;
-        const double ico2 = ico * ico;
+        const double ddc = __builtin_fma(hc, a.ddT, -(dc * dc) * ic);     // c'' = gamR/(2c) T'' - c'^2/c
+        const double K2  = __builtin_fma(numag, ddc, __builtin_fma(n1, a.ddv, n2 * a.ddu));
+        const double ir2 = ir * ir, ico2 = ico * ico;
+        const double cnn1 = cn * n1, cnn2 = cn * n2;
         #pragma unroll
         for(int q = 0; q < 2; q++){
             const double R0 = y[6 + 6 * q], R1 = y[7 + 6 * q];
             const double m0 = y[9 + 6 * q], m1 = y[10 + 6 * q], m2 = y[11 + 6 * q];
+            const double dnu = __builtin_fma(n0, m0, __builtin_fma(n1, m1, n2 * m2)) * inm;       // d|nu|
             const double dca = R0 * dc, dva = R0 * dv, dua = R0 * du;
-            const double dnu = (n0 * m0 + n1 * m1 + n2 * m2) * inm;
-            const double qq  = cn * inm * dnu;                 // c/|nu|^2 * d|nu|
-            const double ia  = inm * dca;
-            const double dcg0 = n0 * ia + cn * m0 - n0 * qq;
-            const double dcg1 = n1 * ia + cn * m1 - n1 * qq + dva;
-            const double dcg2 = n2 * ia + cn * m2 - n2 * qq + dua;
-            const double dcgm = (cg0 * dcg0 + cg1 * dcg1 + cg2 * dcg2) * icg;
-
+            const double al  = inm * __builtin_fma(-cn, dnu, dca);                               // d(c/|nu|)
+            const double a1  = __builtin_fma(n1, al, cn * m1);
+            const double a2  = __builtin_fma(n2, al, cn * m2);
+            const double dcg0 = __builtin_fma(n0, al, cn * m0);
+            const double dcg1 = a1 + dva;
+            const double dcg2 = a2 + dua;
+            const double e   = icg * __builtin_fma(u0, dcg0, __builtin_fma(u1, dcg1, u2 * dcg2)); // d|c_g| / |c_g|
+            const double w0 = __builtin_fma(icg, dcg0, -u0 * e);
+            const double w1 = __builtin_fma(icg, dcg1, -u1 * e);
+            const double w2 = __builtin_fma(icg, dcg2, -u2 * e);
             const double dG1 = -R0 * ir2;
-            const double dG2 = -R0 * ir2 * ico + sth * ir * ico2 * R1;
+            const double dG2 = G2 * __builtin_fma(tn, R1, -R0 * ir);
+            const double s22 = __builtin_fma(m2, cg2, n2 * dcg2);
+            const double dT0 = __builtin_fma(dG1, nc12, ir * __builtin_fma(m1, cg1, __builtin_fma(n1, dcg1, s22)));
+            const double dT1 = __builtin_fma(-cnn1, m0, __builtin_fma(-n0, a1, __builtin_fma(tn, s22, (n2cg2 * R1) * ico2)));
+            const double dncs = __builtin_fma(m0, cth, __builtin_fma(m1, sth, R1 * __builtin_fma(n1, cth, -n0 * sth)));
+            const double dT2 = -__builtin_fma(__builtin_fma(m2, v, n2 * dva), sth,
+                                 __builtin_fma((n2 * v) * R1, cth, __builtin_fma(a2, ncs, cnn2 * dncs)));
 
-            const double dT0 = -R0 * ir2 * nc12 + ir * (m1 * cg1 + n1 * dcg1 + m2 * cg2 + n2 * dcg2);
-            const double dT1 = (m0 * v + n0 * dva)
-                             + (-m0 * cg1 - n0 * dcg1 + (m2 * cg2 + n2 * dcg2) * tn + n2 * cg2 * R1 * ico2);
-            const double dT2 = (m0 * u + n0 * dua) * cth - (n0 * u) * R1 * sth
-                             + (m1 * u + n1 * dua - m2 * v - n2 * dva) * sth + (n1 * u - n2 * v) * R1 * cth
-                             - dcg2 * ncs - cg2 * (m0 * cth - n0 * R1 * sth + m1 * sth + n1 * R1 * cth);
-
-            dy[6 + 6 * q] = dcg0 * icg - cg0 * icg2 * dcgm;
-            dy[7 + 6 * q] = dG1 * cg1 * icg + G1 * dcg1 * icg - G1 * cg1 * icg2 * dcgm;
-            dy[8 + 6 * q] = dG2 * cg2 * icg + G2 * dcg2 * icg - G2 * cg2 * icg2 * dcgm;
-
-            dy[9 + 6 * q]  = icg2 * dcgm * H0
-                           - icg * (dnu * dc + numag * (R0 * ddc) + m1 * dv + m2 * du + n1 * (R0 * ddv) + n2 * (R0 * ddu) + dT0);
-            dy[10 + 6 * q] = -dG1 * icg * T1 - G1 * icg * dT1;
-            dy[11 + 6 * q] = -dG2 * icg * T2 - G2 * icg * dT2;
+            dy[6 + 6 * q] = w0;
+            dy[7 + 6 * q] = __builtin_fma(dG1, u1, G1 * w1);
+            dy[8 + 6 * q] = __builtin_fma(dG2, u2, G2 * w2);
+            dy[9 + 6 * q]  = icg * (__builtin_fma(e, H0, -dT0)
+                                    - __builtin_fma(dnu, dc, __builtin_fma(m1, dv, __builtin_fma(m2, du, R0 * K2))));
+            dy[10 + 6 * q] = -icg * __builtin_fma(dG1, T1, G1 * dT1);
+            dy[11 + 6 * q] = -icg * __builtin_fma(dG2, T2, G2 * dT2);
         }
     }
 }
@@ -294,6 +321,8 @@ __global__ void __launch_bounds__(256) k_init_global(GeoacDevParams P){
     st[ST_K * np] = 0.0; st[ST_LEG * np] = 0.0; st[ST_DONE * np] = 0.0; st[ST_HMAX * np] = 0.0;
     st[ST_C0 * np] = c0; st[ST_NU0 * np] = 1.0 / MS;
     for(int f = ST_AUX0; f < ST_SEG; f++) st[f * np] = 0.0;
+    { double s_, c_; fsincos(lat0, s_, c_); st[(ST_AUX0 + 0) * np] = s_; st[(ST_AUX0 + 1) * np] = c_;
+      st[(ST_AUX0 + 2) * np] = 0.0; st[(ST_AUX0 + 3) * np] = 1.0; }      // sin/cos(lat), sin/cos(lon - lon_src)
     st[ST_SEG * np] = (double)seg_guess(P.seg, P, clampd(r0, P.x_min, P.x_max));
     st[ST_TT * np] = 0.0; st[ST_AT * np] = 0.0; st[ST_PLEG * np] = 0.0; st[ST_LTT * np] = 0.0; st[ST_LAT * np] = 0.0;
     // zero this ray's records
@@ -314,6 +343,7 @@ DEVINL void write_row(const GeoacDevParams& P, int row, int slot, const double* 
 template <bool AMP, bool LDS>
 __global__ void __launch_bounds__(256, 1) k_rk4_global(GeoacDevParams P){
     constexpr int E = AMP ? 18 : 6;
+    __builtin_amdgcn_s_setprio(3);      // latency-critical serial recurrence: win VALU arbitration against co-resident post-pass waves
     extern __shared__ double lds_tab[];
     // ---- stage the segment table in LDS (coalesced 8 B/lane loads; 153 KiB for ToyAtmo) ----
     const double* gtab = P.seg;
@@ -345,7 +375,11 @@ __global__ void __launch_bounds__(256, 1) k_rk4_global(GeoacDevParams P){
     const double lat0 = P.src[1] * kPi / 180.0, lon0 = P.src[2] * kPi / 180.0;
     double sl0, cl0; fsincos(lat0, sl0, cl0);
 
-    double sth, cth; fsincos(y[1], sth, cth);
+    // sin/cos of the latitude and of (lon - lon_src) travel with the ray: exact evaluation at (re)starts and every
+    // 64 steps, small-angle rotation in between (the angles move by < 1e-5 rad per stage)
+    // (kept in the per-ray state across epochs so that results do not depend on how the path is cut into epochs)
+    double sth = st[(ST_AUX0 + 0) * np], cth = st[(ST_AUX0 + 1) * np];
+    double slo = st[(ST_AUX0 + 2) * np], clo = st[(ST_AUX0 + 3) * np];
     write_row<E>(P, nr++, slot, y);                             // carry row: chunk row 0 = current state
 
     while(nr + 2 <= P.s_rows && !done){
@@ -365,15 +399,14 @@ __global__ void __launch_bounds__(256, 1) k_rk4_global(GeoacDevParams P){
         double s2 = sth, c2 = cth;
         #pragma unroll 1
         for(int stage = 0; stage < 4; stage++){
-            if(stage > 0) fsincos(yt[1], s2, c2);
+            if(stage > 0) rot_small(sth, cth, yt[1] - y[1], s2, c2);
             if(LDS) global_rhs<AMP>(lds_tab, P, seg, yt, s2, c2, dy); else global_rhs<AMP>(gtab, P, seg, yt, s2, c2, dy);
-            const double wa = (stage == 2) ? 1.0 : 0.5;
-            const double wb = (stage == 0 || stage == 3) ? (1.0 / 6.0) : (1.0 / 3.0);
+            const double wa = ((stage == 2) ? 1.0 : 0.5) * ds;
+            const double wb = ((stage == 0 || stage == 3) ? (1.0 / 6.0) : (1.0 / 3.0)) * ds;
             #pragma unroll
             for(int e = 0; e < E; e++){
-                double kk = ds * dy[e];
-                yn[e] = __builtin_fma(kk, wb, yn[e]);
-                yt[e] = __builtin_fma(kk, wa, y[e]);
+                yn[e] = __builtin_fma(dy[e], wb, yn[e]);
+                yt[e] = __builtin_fma(dy[e], wa, y[e]);
             }
         }
 
@@ -381,11 +414,12 @@ __global__ void __launch_bounds__(256, 1) k_rk4_global(GeoacDevParams P){
         write_row<E>(P, nr++, slot, yn);
 
         // ---- GeoAc_BreakCheck / GeoAc_GroundCheck on the new row (Global.cpp:500-522) ----
-        double sn, cn; fsincos(yn[1], sn, cn);
-        double sa, ca_, sb, cb_;
-        fsincos(0.5 * (yn[1] - lat0), sa, ca_);
-        fsincos(0.5 * (yn[2] - lon0), sb, cb_);
-        double hav = sa * sa + cl0 * cn * (sb * sb);             // range = 2 R asin(sqrt(hav)) > limit  <=>  hav > sin^2(limit / 2R)
+        double sn, cn, sln, cln;
+        if((k & 63) == 0){ fsincos(yn[1], sn, cn); fsincos(yn[2] - lon0, sln, cln); }      // periodic exact re-sync (wave-uniform in practice)
+        else { rot_small(sth, cth, yn[1] - y[1], sn, cn); rot_small(slo, clo, yn[2] - y[2], sln, cln); }
+        // haversine of the great-circle range: hav = sin^2(dlat/2) + cos(lat0) cos(lat) sin^2(dlon/2), with 2 sin^2(x/2) = 1 - cos x;
+        // range = 2 R asin(sqrt(hav)) > limit  <=>  hav > sin^2(limit / 2R)
+        double hav = 0.5 * (1.0 - __builtin_fma(cn, cl0, sn * sl0)) + (cl0 * cn) * (0.5 * (1.0 - cln));
         bool brk = (yn[0] > P.vert_limit) || (hav > P.range_thresh);
         bool gnd = yn[0] < P.ground;
         bool lim = (k >= P.step_limit - 1);                       // Solver.cpp loop bound; never reached on sane inputs
@@ -449,13 +483,14 @@ __global__ void __launch_bounds__(256, 1) k_rk4_global(GeoacDevParams P){
                     }
                     leg++; k = 0;
                     fsincos(y[1], sth, cth);
+                    fsincos(y[2] - lon0, slo, clo);
                     write_row<E>(P, nr++, slot, y);               // leg-start row
                 }
             }
         } else {
             #pragma unroll
             for(int e = 0; e < E; e++) y[e] = yn[e];
-            sth = sn; cth = cn;
+            sth = sn; cth = cn; slo = sln; clo = cln;
         }
     }
 
@@ -464,6 +499,7 @@ __global__ void __launch_bounds__(256, 1) k_rk4_global(GeoacDevParams P){
     for(int e = 0; e < E; e++) st[(ST_Y0 + e) * np] = y[e];
     st[ST_K * np] = (double)k; st[ST_LEG * np] = (double)leg; st[ST_DONE * np] = done ? 1.0 : 0.0;
     st[ST_HMAX * np] = hmax; st[ST_SEG * np] = (double)seg;
+    st[(ST_AUX0 + 0) * np] = sth; st[(ST_AUX0 + 1) * np] = cth; st[(ST_AUX0 + 2) * np] = slo; st[(ST_AUX0 + 3) * np] = clo;
     P.nrows[slot] = nr; P.nlegend[slot] = nle;
 
     // ---- step count and live-ray count: lanes of finished rays have already returned, so reduce over the
