@@ -243,22 +243,27 @@ int geoac_fan_set_angles(geoac_ctx* ctx, int n_rays, const double* theta_deg, co
 int geoac_fan_launch(geoac_ctx* ctx){
     if(!ctx) return GEOAC_E_INVALID;
     if(!ctx->have_atmo || !ctx->have_angles) return fail(ctx, GEOAC_E_INVALID, "fan_launch: atmosphere and angles must be uploaded first");
-    if(ctx->eqset != GEOAC_EQ_GLOBAL) return fail(ctx, GEOAC_E_UNSUPPORTED, "only the Global stratified set is implemented on the GPU so far");
+    if(ctx->eqset != GEOAC_EQ_GLOBAL && ctx->eqset != GEOAC_EQ_3D && ctx->eqset != GEOAC_EQ_2D)
+        return fail(ctx, GEOAC_E_UNSUPPORTED, "range-dependent equation sets are not implemented on the GPU yet");
     if(ctx->prm.mode != 0) return fail(ctx, GEOAC_E_UNSUPPORTED, "WriteRays / WriteCaustics sample capture is not implemented on the GPU yet");
     HIPCHK(hipSetDevice(ctx->device));
     const geoac_params& p = ctx->prm;
     GeoacDevParams P{};
     P.eqset = ctx->eqset; P.calc_amp = p.calc_amp ? 1 : 0; P.mode = p.mode; P.bounces = p.bounces;
     P.n_rays = ctx->n_rays; P.n_pad = ctx->n_pad;
-    P.E = p.calc_amp ? 18 : 6; P.pathw = 6;
+    const bool is_global = (ctx->eqset == GEOAC_EQ_GLOBAL);
+    if(is_global){ P.E = p.calc_amp ? 18 : 6; P.pathw = 6; }
+    else if(ctx->eqset == GEOAC_EQ_3D){ P.E = p.calc_amp ? 12 : 4; P.pathw = 4; }
+    else { P.E = p.calc_amp ? 6 : 3; P.pathw = 2; }
+    P.rays_form = ((p.mode & (GEOAC_MODE_WRITE_RAYS | GEOAC_MODE_WRITE_CAUSTICS)) != 0 || ctx->eqset == GEOAC_EQ_2D) ? 1 : 0;
     P.nseg = ctx->n_nodes - 1;
     P.step_limit = (long long)(p.ray_limit * (int)(1.0 / (p.ds_min * 10)));   // GeoAc.Solver.cpp:14
     P.x_min = ctx->x[0]; P.x_max = ctx->x[ctx->n_nodes - 1];
     P.ds_min = p.ds_min; P.ds_max = p.ds_max;
-    P.r_earth = p.r_earth; P.z_grnd = p.z_grnd;
-    P.ground = p.r_earth + p.z_grnd;
+    P.r_earth = is_global ? p.r_earth : 0.0; P.z_grnd = p.z_grnd;
+    P.ground = P.r_earth + p.z_grnd;
     P.vert_limit = p.vert_limit; P.range_limit = p.range_limit;
-    {
+    if(is_global){
         double half = p.range_limit / (2.0 * p.r_earth);
         if(half >= kPi / 2.0) P.range_thresh = 2.0;               // asin saturates: the range test can never fire
         else if(half <= 0.0) P.range_thresh = -1.0;
@@ -275,6 +280,8 @@ int geoac_fan_launch(geoac_ctx* ctx){
         P.P_o = rg * (cg * cg) / kGam * 1000.0;
         P.sb_const[0] = pow(10.0, -0.67887); P.sb_const[1] = pow(10.0, -0.10744); P.sb_const[2] = pow(10, -3.3979);
         P.sb_const[3] = 5.0 / sqrt(21.0); P.sb_const[4] = sqrt(3.0 / 7.0);
+        P.c000 = sqrt(kGamR * host_spline_f(ctx->x, ctx->T, ctx->sl.data(), 0.0));       // c(0,0,0), 3DStratified.cpp:367
+        P.src_trig[0] = sin(p.src[1] * kPi / 180.0); P.src_trig[1] = cos(p.src[1] * kPi / 180.0);
     }
     // ---- epoch size: keep the path chunk around <= 3 GiB ----
     size_t row_bytes = (size_t)P.pathw * P.n_pad * sizeof(double);

@@ -37,7 +37,8 @@ enum {
     ST_PLEG   = 33,     // post-pass current leg
     ST_LTT    = 34,     // post-pass per-leg partial sums (arrivals-only form of Q7)
     ST_LAT    = 35,
-    ST_NSTATE = 36
+    ST_YM2    = 36,     // row k-2 of the current leg (Cartesian sets: quadratic ground intercept), up to 12 values
+    ST_NSTATE = 48
 };
 
 struct GeoacDevParams {
@@ -48,7 +49,7 @@ struct GeoacDevParams {
     int     nseg;                   // spline segments = nodes - 1
     int     s_rows;                 // path rows per epoch chunk
     int     table_in_lds;
-    int     pad0;
+    int     rays_form;              // post-pass sums in the WriteRays form (segments 0..k-2, cumulative): Q7
     long long step_limit;           // GeoAc.Solver.cpp:14
     double  x_min, x_max;           // clamp range of the spline abscissa
     double  ds_min, ds_max;
@@ -58,6 +59,8 @@ struct GeoacDevParams {
     double  src[3];                 // as in geoac_params
     double  freq, tweak_abs;
     double  T_o, P_o;               // SuthBass reference temperature / pressure (ground), host-evaluated from the spline
+    double  c000;                   // c(0,0,0) used by the 3-D travel-time integral (Q5)
+    double  src_trig[2];            // Global: sin, cos of the source latitude
     double  sb_const[5];            // 10^-0.67887, 10^-0.10744, 10^-3.3979, 5/sqrt(21), sqrt(3/7) (host libm, as the reference computes them)
     // buffers
     const double* seg;              // [nseg][SEGW]

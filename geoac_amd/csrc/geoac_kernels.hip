@@ -279,247 +279,7 @@ DEVINL double global_amplitude(const GeoacDevParams& P, const Medium& m, const M
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_init: GeoAc_SetInitialConditions (EquationSets.Global.cpp:76-136) for every ray of the fan
-// ------------------------------------------------------------------------------------------------
-template <bool AMP>
-__global__ void __launch_bounds__(256) k_init_global(GeoacDevParams P){
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if(i >= P.n_pad) return;
-    double* st = P.state + i;
-    const size_t np = (size_t)P.n_pad;
-    if(i >= P.n_rays){                                   // padding lanes: finished from the start
-        for(int f = 0; f < ST_NSTATE; f++) st[f * np] = 0.0;
-        st[ST_DONE * np] = 1.0;
-        return;
-    }
-    const double th = P.theta_deg[i] * kPi / 180.0;               // GeoAcGlobal_main.cpp:244
-    const double ph = kPi / 2.0 - P.phi_deg[i] * kPi / 180.0;     // :245
-    double z_src = P.src[0] < P.z_grnd ? P.z_grnd : P.src[0];     // :165
-    double r0 = z_src + P.r_earth;
-    double lat0 = P.src[1] * kPi / 180.0, lon0 = P.src[2] * kPi / 180.0;
-    Medium m = medium_at(P, r0);
-    double c0 = m.c;
-    double Mach[3] = { 0.0, m.v / c0, m.u / c0 };
-    double sth = sin(th), cth = cos(th), sph = sin(ph), cph = cos(ph);
-    double nu0[3]  = { sth, cth * sph, cth * cph };
-    double mlt[3]  = { cth, -sth * sph, -sth * cph };
-    double mlp[3]  = { 0.0, cth * cph, -cth * sph };
-    double MS = 1.0 + (nu0[0] * Mach[0] + nu0[1] * Mach[1] + nu0[2] * Mach[2]);
-    double y[GEOAC_MAXE];
-    for(int e = 0; e < GEOAC_MAXE; e++) y[e] = 0.0;
-    y[0] = r0; y[1] = lat0; y[2] = lon0;
-    for(int e = 0; e < 3; e++) y[3 + e] = nu0[e] / MS;
-    if(AMP){
-        double dlt = mlt[0] * Mach[0] + mlt[1] * Mach[1] + mlt[2] * Mach[2];
-        double dlp = mlp[0] * Mach[0] + mlp[1] * Mach[1] + mlp[2] * Mach[2];
-        for(int e = 0; e < 3; e++){
-            y[9 + e]  = mlt[e] / MS - nu0[e] / (MS * MS) * dlt;
-            y[15 + e] = mlp[e] / MS - nu0[e] / (MS * MS) * dlp;
-        }
-    }
-    for(int e = 0; e < GEOAC_MAXE; e++) st[(ST_Y0 + e) * np] = y[e];
-    st[ST_K * np] = 0.0; st[ST_LEG * np] = 0.0; st[ST_DONE * np] = 0.0; st[ST_HMAX * np] = 0.0;
-    st[ST_C0 * np] = c0; st[ST_NU0 * np] = 1.0 / MS;
-    for(int f = ST_AUX0; f < ST_SEG; f++) st[f * np] = 0.0;
-    { double s_, c_; fsincos(lat0, s_, c_); st[(ST_AUX0 + 0) * np] = s_; st[(ST_AUX0 + 1) * np] = c_;
-      st[(ST_AUX0 + 2) * np] = 0.0; st[(ST_AUX0 + 3) * np] = 1.0; }      // sin/cos(lat), sin/cos(lon - lon_src)
-    st[ST_SEG * np] = (double)seg_guess(P.seg, P, clampd(r0, P.x_min, P.x_max));
-    st[ST_TT * np] = 0.0; st[ST_AT * np] = 0.0; st[ST_PLEG * np] = 0.0; st[ST_LTT * np] = 0.0; st[ST_LAT * np] = 0.0;
-    // zero this ray's records
-    double* R = P.rec + (size_t)i * (P.bounces + 1) * GEOAC_REC_STRIDE;
-    for(int q = 0; q < (P.bounces + 1) * GEOAC_REC_STRIDE; q++) R[q] = 0.0;
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_rk4: GeoAc_Propagate_RK4 (GeoAc.Solver.cpp:12-72) for one epoch, one ray per lane
-// ------------------------------------------------------------------------------------------------
-template <int E>
-DEVINL void write_row(const GeoacDevParams& P, int row, int slot, const double* y){
-    double* p = P.path + ((size_t)row * P.pathw) * P.n_pad + slot;
-    #pragma unroll
-    for(int c = 0; c < 6; c++) p[(size_t)c * P.n_pad] = y[c];
-}
-
-template <bool AMP, bool LDS>
-__global__ void __launch_bounds__(256, 1) k_rk4_global(GeoacDevParams P){
-    constexpr int E = AMP ? 18 : 6;
-    __builtin_amdgcn_s_setprio(3);      // latency-critical serial recurrence: win VALU arbitration against co-resident post-pass waves
-    extern __shared__ double lds_tab[];
-    // ---- stage the segment table in LDS (coalesced 8 B/lane loads; 153 KiB for ToyAtmo) ----
-    const double* gtab = P.seg;
-    if(LDS){
-        const int total = P.nseg * GEOAC_SEGW;
-        for(int q = threadIdx.x; q < total; q += blockDim.x) lds_tab[q] = gtab[q];
-        __syncthreads();
-    }
-    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if(slot >= P.n_pad) return;
-    const size_t np = (size_t)P.n_pad;
-    double* st = P.state + slot;
-
-    int nr = 0, nle = 0;
-    bool done = st[ST_DONE * np] != 0.0;
-    if(done){ P.nrows[slot] = 0; P.nlegend[slot] = 0; return; }
-
-    double y[E];
-    #pragma unroll
-    for(int e = 0; e < E; e++) y[e] = st[(ST_Y0 + e) * np];
-    long long k = (long long)st[ST_K * np];
-    int leg = (int)st[ST_LEG * np];
-    double hmax = st[ST_HMAX * np];
-    const double c0 = st[ST_C0 * np];
-    const double nu_mag0 = st[ST_NU0 * np];
-    int seg = (int)st[ST_SEG * np];
-    unsigned long long steps_here = 0;
-
-    const double lat0 = P.src[1] * kPi / 180.0, lon0 = P.src[2] * kPi / 180.0;
-    double sl0, cl0; fsincos(lat0, sl0, cl0);
-
-    // sin/cos of the latitude and of (lon - lon_src) travel with the ray: exact evaluation at (re)starts and every
-    // 64 steps, small-angle rotation in between (the angles move by < 1e-5 rad per stage)
-    // (kept in the per-ray state across epochs so that results do not depend on how the path is cut into epochs)
-    double sth = st[(ST_AUX0 + 0) * np], cth = st[(ST_AUX0 + 1) * np];
-    double slo = st[(ST_AUX0 + 2) * np], clo = st[(ST_AUX0 + 3) * np];
-    write_row<E>(P, nr++, slot, y);                             // carry row: chunk row 0 = current state
-
-    while(nr + 2 <= P.s_rows && !done){
-        // running turning height: max over rows m < k of (r - r_earth)   (GeoAcGlobal_main.cpp:294)
-        { double h = y[0] - P.r_earth; hmax = (hmax < h) ? h : hmax; }
-
-        // ---- GeoAc_Set_ds (Global.cpp:210-217) ----
-        double ds = 0.05 - 0.049 * exp(-(y[0] - P.ground) / 0.75);
-        ds = (P.ds_max < ds) ? P.ds_max : ds;
-        ds = (ds < P.ds_min) ? P.ds_min : ds;
-
-        // ---- the four RK4 stages as ONE rolled loop (a single copy of the RHS keeps the live set < 256 VGPRs):
-        //      k_s = ds f(y + a_s k_{s-1}), a = {0, 1/2, 1/2, 1};  y' = y + k1/6 + k2/3 + k3/3 + k4/6  (Solver.cpp:33-54)
-        double dy[E], yt[E], yn[E];
-        #pragma unroll
-        for(int e = 0; e < E; e++){ yt[e] = y[e]; yn[e] = y[e]; }
-        double s2 = sth, c2 = cth;
-        #pragma unroll 1
-        for(int stage = 0; stage < 4; stage++){
-            if(stage > 0) rot_small(sth, cth, yt[1] - y[1], s2, c2);
-            if(LDS) global_rhs<AMP>(lds_tab, P, seg, yt, s2, c2, dy); else global_rhs<AMP>(gtab, P, seg, yt, s2, c2, dy);
-            const double wa = ((stage == 2) ? 1.0 : 0.5) * ds;
-            const double wb = ((stage == 0 || stage == 3) ? (1.0 / 6.0) : (1.0 / 3.0)) * ds;
-            #pragma unroll
-            for(int e = 0; e < E; e++){
-                yn[e] = __builtin_fma(dy[e], wb, yn[e]);
-                yt[e] = __builtin_fma(dy[e], wa, y[e]);
-            }
-        }
-
-        k++; steps_here++;
-        write_row<E>(P, nr++, slot, yn);
-
-        // ---- GeoAc_BreakCheck / GeoAc_GroundCheck on the new row (Global.cpp:500-522) ----
-        double sn, cn, sln, cln;
-        if((k & 63) == 0){ fsincos(yn[1], sn, cn); fsincos(yn[2] - lon0, sln, cln); }      // periodic exact re-sync (wave-uniform in practice)
-        else { rot_small(sth, cth, yn[1] - y[1], sn, cn); rot_small(slo, clo, yn[2] - y[2], sln, cln); }
-        // haversine of the great-circle range: hav = sin^2(dlat/2) + cos(lat0) cos(lat) sin^2(dlon/2), with 2 sin^2(x/2) = 1 - cos x;
-        // range = 2 R asin(sqrt(hav)) > limit  <=>  hav > sin^2(limit / 2R)
-        double hav = 0.5 * (1.0 - __builtin_fma(cn, cl0, sn * sl0)) + (cl0 * cn) * (0.5 * (1.0 - cln));
-        bool brk = (yn[0] > P.vert_limit) || (hav > P.range_thresh);
-        bool gnd = yn[0] < P.ground;
-        bool lim = (k >= P.step_limit - 1);                       // Solver.cpp loop bound; never reached on sane inputs
-
-        if(brk || gnd || lim){
-            // ---- leg end: record (GeoAcGlobal_main.cpp:293-317) ----
-            double* R = P.rec + ((size_t)slot * (P.bounces + 1) + leg) * GEOAC_REC_STRIDE;
-            R[GEOAC_REC_STEPS] = (double)k;
-            P.legend[(size_t)nle * np + slot] = nr - 1; nle++;
-            if(lim && !brk && !gnd) atomicOr(&P.counters[2], 1ull);
-            if(brk){
-                R[GEOAC_REC_BROKE] = 1.0;
-                done = true;
-            } else {
-                Medium m = medium_at(P, yn[0]);
-                double z_src = P.src[0] < P.z_grnd ? P.z_grnd : P.src[0];
-                double incl = -asin(m.c / c0 * yn[3]) * 180.0 / kPi;
-                double baz = 90.0 - atan2(-yn[4], -yn[5]) * 180.0 / kPi;
-                if(baz < -180.0) baz += 360.0;
-                if(baz > 180.0) baz -= 360.0;
-                double g1 = sin((yn[1] - lat0) / 2.0); g1 *= g1;
-                double g2 = sin((yn[2] - lon0) / 2.0); g2 = cos(lat0) * cos(yn[1]) * g2 * g2;
-                R[GEOAC_REC_VALID] = 1.0;
-                R[GEOAC_REC_TURN] = hmax;
-                R[GEOAC_REC_INCL] = incl;
-                R[GEOAC_REC_BACKAZ] = baz;
-                R[GEOAC_REC_RANGE] = 2.0 * P.r_earth * asin(sqrt(g1 + g2));
-                if(AMP){
-                    Medium m0 = medium_at(P, z_src + P.r_earth);
-                    double D = global_jacobian(m, yn);
-                    double th_l = P.theta_deg[slot] * kPi / 180.0, ph_l = kPi / 2.0 - P.phi_deg[slot] * kPi / 180.0;
-                    R[GEOAC_REC_AMP] = global_amplitude(P, m, m0, yn, c0, nu_mag0, th_l, ph_l, D);
-                    R[GEOAC_REC_JACOB] = D;
-                }
-                #pragma unroll
-                for(int e = 0; e < E; e++) R[GEOAC_REC_STATE + e] = yn[e];
-
-                if(leg >= P.bounces){
-                    done = true;
-                } else {
-                    // ---- GeoAc_ApproximateIntercept + GeoAc_SetReflectionConditions (Global.cpp:140-205);
-                    //      Q1: the quadratic term is a discarded expression in the reference -> linear intercept ----
-                    double dr_k = yn[0] - y[0];
-                    double dr_g = y[0] - P.ground;
-                    double prev[E];
-                    #pragma unroll
-                    for(int e = 0; e < E; e++) prev[e] = y[e] + (y[e] - yn[e]) / dr_k * dr_g;
-                    Medium mr = medium_at(P, prev[0]);
-                    double c_ref = mr.c;
-                    double dnu_r_ds = -1.0 / c_ref * (c0 / c_ref * mr.dc + prev[4] * mr.dv + prev[5] * mr.du
-                                                      + c_ref / prev[0] * (prev[4] * prev[4] + prev[5] * prev[5]));
-                    #pragma unroll
-                    for(int e = 0; e < E; e++) y[e] = prev[e];
-                    y[0] = P.ground;
-                    y[3] = -prev[3];
-                    if(AMP){
-                        y[6] = -prev[6]; y[12] = -prev[12];
-                        double den = c_ref / c0 * prev[3];
-                        y[9]  = -prev[9]  + 2.0 * dnu_r_ds * prev[6]  / den;
-                        y[15] = -prev[15] + 2.0 * dnu_r_ds * prev[12] / den;
-                    }
-                    leg++; k = 0;
-                    fsincos(y[1], sth, cth);
-                    fsincos(y[2] - lon0, slo, clo);
-                    write_row<E>(P, nr++, slot, y);               // leg-start row
-                }
-            }
-        } else {
-            #pragma unroll
-            for(int e = 0; e < E; e++) y[e] = yn[e];
-            sth = sn; cth = cn; slo = sln; clo = cln;
-        }
-    }
-
-    // ---- save state ----
-    #pragma unroll
-    for(int e = 0; e < E; e++) st[(ST_Y0 + e) * np] = y[e];
-    st[ST_K * np] = (double)k; st[ST_LEG * np] = (double)leg; st[ST_DONE * np] = done ? 1.0 : 0.0;
-    st[ST_HMAX * np] = hmax; st[ST_SEG * np] = (double)seg;
-    st[(ST_AUX0 + 0) * np] = sth; st[(ST_AUX0 + 1) * np] = cth; st[(ST_AUX0 + 2) * np] = slo; st[(ST_AUX0 + 3) * np] = clo;
-    P.nrows[slot] = nr; P.nlegend[slot] = nle;
-
-    // ---- step count and live-ray count: lanes of finished rays have already returned, so reduce over the
-    //      lanes that are still here (ballot of the active mask), one atomic pair per wave ----
-    const unsigned long long act = __ballot(1);
-    unsigned long long s = 0;
-    for(int l = 0; l < 64; l++){
-        unsigned long long v = __shfl(steps_here, l);
-        if((act >> l) & 1ull) s += v;
-    }
-    const unsigned long long live = __popcll(__ballot(!done));
-    if((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1){
-        atomicAdd(&P.counters[0], s);
-        atomicAdd(&P.counters[1], live);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_postpass: one thread per path segment.  Travel-time segment (Global.cpp:527-589), attenuation segment
-// (Global.cpp:634-670, sin(lat) in ds: Q3) and SuthBass_Alpha (Atmo_State.Absorption.Global.cpp:12-141).
+// SuthBass_Alpha (Atmo_State.Absorption.Global.cpp:12-141 / Atmo_State.Absorption.cpp:14-143); zr = altitude above sea level
 // ------------------------------------------------------------------------------------------------
 DEVINL double suthbass_alpha(const GeoacDevParams& P, double zr, double c_snd, double rho, double freq){
     const double mu_o = 18.192E-6, S = 117.0;
@@ -596,37 +356,616 @@ DEVINL double suthbass_alpha(const GeoacDevParams& P, double zr, double c_snd, d
     return (a_cl + a_rot + a_diff + a_vib) * P.tweak_abs * 8.685889;
 }
 
-__global__ void __launch_bounds__(256) k_postpass_global(GeoacDevParams P){
+
+// ------------------------------------------------------------------------------------------------
+// 3-D stratified Cartesian set: fused GeoAc_UpdateSources + GeoAc_EvalSrcEq (EquationSets.3DStratified.cpp:203-310)
+// y: x, y, z, nu_z | X_th, Y_th, Z_th, mu_z_th | X_ph, Y_ph, Z_ph, mu_z_ph ; nu_x, nu_y and their launch-angle
+// derivatives are constants of the ray (stratified medium) kept in RayCtx::a[0..5]
+// ------------------------------------------------------------------------------------------------
+struct RayCtx {
+    double c0;        // Global/3D: sound speed at the source; 2D: effective sound speed at the source
+    double nu0;       // Global: 1/MachScalar
+    double a[6];      // Global: sin/cos(lat), sin/cos(lon - lon_src) carried along the ray
+                      // 3D: nu_x, nu_y, mu_x_th, mu_y_th, mu_x_ph, mu_y_ph ; 2D: cos(phi), sin(phi), cos(theta), sin(theta)
+    double t[4];      // Global: proposed sin/cos for the row under test
+};
+
+template <bool AMP, typename TabPtr>
+DEVINL void cart3_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y, double* dy){
+    const double nz = y[3];
+    const double nx = C.a[0], ny = C.a[1];
+    const double xe = clampd(y[2], P.x_min, P.x_max);
+    seg = seg_find(tab, P.nseg, xe, seg);
+    Atm9 a;
+    seg_eval<AMP>(tab, seg, xe, a);
+    const double u = a.u, v = a.v, du = a.du, dv = a.dv;
+    const double qT = kGamR * a.T;
+    const double ic = frsq(qT);
+    const double c  = qT * ic;
+    const double hc = (0.5 * kGamR) * ic;
+    const double dc = hc * a.dT;
+    const double numag = (C.c0 - nx * u - ny * v) * ic;            // c0/c (1 - (nu.wind)/c0)     (3DStratified.cpp:214)
+    const double inm = frcp(numag);
+    const double cn  = c * inm;
+    const double cp0 = __builtin_fma(cn, nx, u), cp1 = __builtin_fma(cn, ny, v), cp2 = cn * nz;
+    const double icp = frsq(__builtin_fma(cp0, cp0, __builtin_fma(cp1, cp1, cp2 * cp2)));
+    const double u0 = cp0 * icp, u1 = cp1 * icp, u2 = cp2 * icp;
+    const double H = __builtin_fma(numag, dc, __builtin_fma(nx, du, ny * dv));
+    dy[0] = u0; dy[1] = u1; dy[2] = u2;
+    dy[3] = -icp * H;
+    if(AMP){
+        const double ddc = __builtin_fma(hc, a.ddT, -(dc * dc) * ic);
+        const double K2  = __builtin_fma(numag, ddc, __builtin_fma(nx, a.ddu, ny * a.ddv));
+        #pragma unroll
+        for(int q = 0; q < 2; q++){
+            const double mx = C.a[2 + 2 * q], my = C.a[3 + 2 * q], mz = y[7 + 4 * q], Za = y[6 + 4 * q];
+            const double dnu = __builtin_fma(nx, mx, __builtin_fma(ny, my, nz * mz)) * inm;
+            const double al  = inm * __builtin_fma(dc, Za, -cn * dnu);
+            const double dcp0 = __builtin_fma(nx, al, __builtin_fma(cn, mx, du * Za));
+            const double dcp1 = __builtin_fma(ny, al, __builtin_fma(cn, my, dv * Za));
+            const double dcp2 = __builtin_fma(nz, al, cn * mz);
+            const double e = icp * __builtin_fma(u0, dcp0, __builtin_fma(u1, dcp1, u2 * dcp2));
+            dy[4 + 4 * q] = __builtin_fma(icp, dcp0, -u0 * e);
+            dy[5 + 4 * q] = __builtin_fma(icp, dcp1, -u1 * e);
+            dy[6 + 4 * q] = __builtin_fma(icp, dcp2, -u2 * e);
+            dy[7 + 4 * q] = icp * (e * H - __builtin_fma(dnu, dc, __builtin_fma(mx, du, __builtin_fma(my, dv, K2 * Za))));
+        }
+    }
+}
+
+// 2-D effective-sound-speed set (EquationSets.2DStratified.cpp:135-181).  y: r, z, nu_z | R, Z, mu_z
+template <bool AMP, typename TabPtr>
+DEVINL void cart2_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y, double* dy){
+    const double nz = y[2];
+    const double cph = C.a[0], sph = C.a[1], cth = C.a[2], sth = C.a[3];
+    const double xe = clampd(y[1], P.x_min, P.x_max);
+    seg = seg_find(tab, P.nseg, xe, seg);
+    Atm9 a;
+    seg_eval<AMP>(tab, seg, xe, a);
+    const double qT = kGamR * a.T;
+    const double ic = frsq(qT);
+    const double c  = qT * ic;
+    const double hc = (0.5 * kGamR) * ic;
+    const double dc = hc * a.dT;
+    const double ce  = c + a.u * cph + a.v * sph;
+    const double dce = dc + a.du * cph + a.dv * sph;
+    const double ic0 = C.nu0;                                        // 1 / c_eff_0
+    const double ice = frcp(ce);
+    const double g = ce * ic0;
+    dy[0] = g * cth;
+    dy[1] = g * nz;
+    dy[2] = -C.c0 * ice * ice * dce;
+    if(AMP){
+        const double ddc  = __builtin_fma(hc, a.ddT, -(dc * dc) * ic);
+        const double ddce = ddc + a.ddu * cph + a.ddv * sph;
+        const double Zt = y[4], mz = y[5];
+        const double h = dce * Zt * ic0;
+        const double q = dce * ice;
+        dy[3] = h * cth - g * sth;
+        dy[4] = h * nz + g * mz;
+        dy[5] = (2 * (q * q) - ddce * ice) * (C.c0 * ice) * Zt;
+    }
+}
+
+// ================================================================================================
+// Equation-set policies: everything the generic kernels need to know about a set
+// ================================================================================================
+template <bool AMP_> struct EqGlobal {
+    static constexpr bool AMP = AMP_;
+    static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 0;
+    static constexpr bool KM2 = false;                              // linear intercept only (Q1)
+
+    // GeoAc_SetInitialConditions: EquationSets.Global.cpp:76-136
+    static DEVINL void init(const GeoacDevParams& P, double th, double ph, double* y, RayCtx& C){
+        double z_src = P.src[0] < P.z_grnd ? P.z_grnd : P.src[0];     // GeoAcGlobal_main.cpp:165
+        double r0 = z_src + P.r_earth;
+        double lat0 = P.src[1] * kPi / 180.0, lon0 = P.src[2] * kPi / 180.0;
+        Medium m = medium_at(P, r0);
+        double c0 = m.c;
+        double Mach[3] = { 0.0, m.v / c0, m.u / c0 };
+        double sth = sin(th), cth = cos(th), sph = sin(ph), cph = cos(ph);
+        double nu0[3]  = { sth, cth * sph, cth * cph };
+        double mlt[3]  = { cth, -sth * sph, -sth * cph };
+        double mlp[3]  = { 0.0, cth * cph, -cth * sph };
+        double MS = 1.0 + (nu0[0] * Mach[0] + nu0[1] * Mach[1] + nu0[2] * Mach[2]);
+        y[0] = r0; y[1] = lat0; y[2] = lon0;
+        for(int e = 0; e < 3; e++) y[3 + e] = nu0[e] / MS;
+        if(AMP){
+            double dlt = mlt[0] * Mach[0] + mlt[1] * Mach[1] + mlt[2] * Mach[2];
+            double dlp = mlp[0] * Mach[0] + mlp[1] * Mach[1] + mlp[2] * Mach[2];
+            for(int e = 0; e < 3; e++){
+                y[9 + e]  = mlt[e] / MS - nu0[e] / (MS * MS) * dlt;
+                y[15 + e] = mlp[e] / MS - nu0[e] / (MS * MS) * dlp;
+            }
+        }
+        C.c0 = c0; C.nu0 = 1.0 / MS;
+        fsincos(lat0, C.a[0], C.a[1]);
+        C.a[2] = 0.0; C.a[3] = 1.0; C.a[4] = 0.0; C.a[5] = 0.0;
+    }
+    static DEVINL double height(const GeoacDevParams& P, const double* y){ return y[0] - P.r_earth; }
+    static DEVINL double above_ground(const GeoacDevParams& P, const double* y){ return y[0] - P.ground; }
+
+    template <typename TabPtr>
+    static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
+        double s2 = C.a[0], c2 = C.a[1];
+        if(stage > 0) rot_small(C.a[0], C.a[1], yt[1] - y0[1], s2, c2);
+        global_rhs<AMP>(tab, P, seg, yt, s2, c2, dy);
+    }
+    // GeoAc_BreakCheck / GeoAc_GroundCheck on the new row (Global.cpp:500-522)
+    static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, long long k, bool& brk, bool& gnd){
+        const double lat0 = P.src[1] * kPi / 180.0, lon0 = P.src[2] * kPi / 180.0;
+        if((k & 63) == 0){ fsincos(yn[1], C.t[0], C.t[1]); fsincos(yn[2] - lon0, C.t[2], C.t[3]); }   // periodic exact re-sync
+        else { rot_small(C.a[0], C.a[1], yn[1] - y[1], C.t[0], C.t[1]); rot_small(C.a[2], C.a[3], yn[2] - y[2], C.t[2], C.t[3]); }
+        // haversine of the great-circle range: hav = sin^2(dlat/2) + cos(lat0) cos(lat) sin^2(dlon/2), with 2 sin^2(x/2) = 1 - cos x;
+        // range = 2 R asin(sqrt(hav)) > limit  <=>  hav > sin^2(limit / 2R)
+        const double sl0 = P.src_trig[0], cl0 = P.src_trig[1];
+        double hav = 0.5 * (1.0 - __builtin_fma(C.t[1], cl0, C.t[0] * sl0)) + (cl0 * C.t[1]) * (0.5 * (1.0 - C.t[3]));
+        brk = (yn[0] > P.vert_limit) || (hav > P.range_thresh);
+        gnd = yn[0] < P.ground;
+    }
+    static DEVINL void accept(RayCtx& C){ C.a[0] = C.t[0]; C.a[1] = C.t[1]; C.a[2] = C.t[2]; C.a[3] = C.t[3]; }
+    static DEVINL void restart(const GeoacDevParams& P, RayCtx& C, const double* y){
+        fsincos(y[1], C.a[0], C.a[1]);
+        fsincos(y[2] - P.src[2] * kPi / 180.0, C.a[2], C.a[3]);
+    }
+    // arrival row: GeoAcGlobal_main.cpp:296-317
+    static DEVINL void arrival(const GeoacDevParams& P, const RayCtx& C, int slot, const double* yn, double* R){
+        const double lat0 = P.src[1] * kPi / 180.0, lon0 = P.src[2] * kPi / 180.0;
+        Medium m = medium_at(P, yn[0]);
+        double z_src = P.src[0] < P.z_grnd ? P.z_grnd : P.src[0];
+        double incl = -asin(m.c / C.c0 * yn[3]) * 180.0 / kPi;
+        double baz = 90.0 - atan2(-yn[4], -yn[5]) * 180.0 / kPi;
+        if(baz < -180.0) baz += 360.0;
+        if(baz > 180.0) baz -= 360.0;
+        double g1 = sin((yn[1] - lat0) / 2.0); g1 *= g1;
+        double g2 = sin((yn[2] - lon0) / 2.0); g2 = cos(lat0) * cos(yn[1]) * g2 * g2;
+        R[GEOAC_REC_INCL] = incl;
+        R[GEOAC_REC_BACKAZ] = baz;
+        R[GEOAC_REC_RANGE] = 2.0 * P.r_earth * asin(sqrt(g1 + g2));
+        if(AMP){
+            Medium m0 = medium_at(P, z_src + P.r_earth);
+            double D = global_jacobian(m, yn);
+            double th_l = P.theta_deg[slot] * kPi / 180.0, ph_l = kPi / 2.0 - P.phi_deg[slot] * kPi / 180.0;
+            R[GEOAC_REC_AMP] = global_amplitude(P, m, m0, yn, C.c0, C.nu0, th_l, ph_l, D);
+            R[GEOAC_REC_JACOB] = D;
+        }
+    }
+    // GeoAc_ApproximateIntercept + GeoAc_SetReflectionConditions (Global.cpp:140-205); Q1: the quadratic term is a
+    // discarded expression in the reference -> linear intercept.  y = row k-1 in, new leg's row 0 out.
+    static DEVINL void reflect(const GeoacDevParams& P, const RayCtx& C, const double* yn, double* y, const double* ym2){
+        double dr_k = yn[0] - y[0];
+        double dr_g = y[0] - P.ground;
+        double prev[E];
+        #pragma unroll
+        for(int e = 0; e < E; e++) prev[e] = y[e] + (y[e] - yn[e]) / dr_k * dr_g;
+        Medium mr = medium_at(P, prev[0]);
+        double c_ref = mr.c;
+        double dnu_r_ds = -1.0 / c_ref * (C.c0 / c_ref * mr.dc + prev[4] * mr.dv + prev[5] * mr.du
+                                          + c_ref / prev[0] * (prev[4] * prev[4] + prev[5] * prev[5]));
+        #pragma unroll
+        for(int e = 0; e < E; e++) y[e] = prev[e];
+        y[0] = P.ground;
+        y[3] = -prev[3];
+        if(AMP){
+            y[6] = -prev[6]; y[12] = -prev[12];
+            double den = c_ref / C.c0 * prev[3];
+            y[9]  = -prev[9]  + 2.0 * dnu_r_ds * prev[6]  / den;
+            y[15] = -prev[15] + 2.0 * dnu_r_ds * prev[12] / den;
+        }
+    }
+    // one path segment: travel time (Global.cpp:527-589) and attenuation (Global.cpp:634-670, sin(lat) in ds: Q3)
+    static DEVINL void segment(const GeoacDevParams& P, const double* st, size_t np, const double* a, const double* b, double& tt, double& at){
+        double ar = a[0], at_ = a[np], ap = a[2 * np], an0 = a[3 * np], an1 = a[4 * np], an2 = a[5 * np];
+        double dr = b[0] - ar, dt = b[np] - at_, dp = b[2 * np] - ap;
+        double r = ar + dr / 2.0, t = at_ + dt / 2.0;
+        double sn, cs; fsincos(t, sn, cs);
+        double rdt = r * dt;
+        double e1 = r * cs * dp, e2 = r * sn * dp;
+        double ds_tt = sqrt(dr * dr + rdt * rdt + e1 * e1);
+        double ds_at = sqrt(dr * dr + rdt * rdt + e2 * e2);
+        double n0 = an0 + (b[3 * np] - an0) / 2.0, n1 = an1 + (b[4 * np] - an1) / 2.0, n2 = an2 + (b[5 * np] - an2) / 2.0;
+        double nu_mag = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+        double xe = clampd(r, P.x_min, P.x_max);
+        int k = seg_guess(P.seg, P, xe);
+        Atm9 m; seg_eval<false>(P.seg, k, xe, m);
+        double c = sqrt(kGamR * m.T);
+        double rho = rho_eval(P, k, xe);
+        double cp0 = c * n0 / nu_mag, cp1 = c * n1 / nu_mag + m.v, cp2 = c * n2 / nu_mag + m.u;
+        double cpm = sqrt(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
+        tt = ds_tt / cpm;
+        at = suthbass_alpha(P, r - P.r_earth, c, rho, P.freq) * ds_at;
+    }
+};
+
+template <bool AMP_> struct Eq3D {
+    static constexpr bool AMP = AMP_;
+    static constexpr int E = AMP_ ? 12 : 4, PW = 4, HIDX = 2;
+    static constexpr bool KM2 = true;                               // quadratic intercept needs row k-2
+
+    // GeoAc_SetInitialConditions: EquationSets.3DStratified.cpp:69-131
+    static DEVINL void init(const GeoacDevParams& P, double th, double ph, double* y, RayCtx& C){
+        double z0 = P.z_grnd < P.src[2] ? P.src[2] : P.z_grnd;       // GeoAc3D_main.cpp:152
+        Medium m = medium_at(P, z0);
+        double c0 = m.c;
+        double Mc[3] = { m.u / c0, m.v / c0, 0.0 };
+        double sth = sin(th), cth = cos(th), sph = sin(ph), cph = cos(ph);
+        double nu0[3] = { cth * cph, cth * sph, sth };
+        double mth[3] = { -sth * cph, -sth * sph, cth };
+        double mph[3] = { -cth * sph, cth * cph, 0.0 };
+        double M = 1.0 + (nu0[0] * Mc[0] + nu0[1] * Mc[1] + nu0[2] * Mc[2]);
+        double dMt = mth[0] * Mc[0] + mth[1] * Mc[1] + mth[2] * Mc[2];
+        double dMp = mph[0] * Mc[0] + mph[1] * Mc[1] + mph[2] * Mc[2];
+        C.c0 = c0; C.nu0 = 0.0;
+        C.a[0] = nu0[0] / M; C.a[1] = nu0[1] / M;
+        C.a[2] = mth[0] / M - nu0[0] / (M * M) * dMt;  C.a[3] = mth[1] / M - nu0[1] / (M * M) * dMt;
+        C.a[4] = mph[0] / M - nu0[0] / (M * M) * dMp;  C.a[5] = mph[1] / M - nu0[1] / (M * M) * dMp;
+        y[0] = P.src[0]; y[1] = P.src[1]; y[2] = z0; y[3] = nu0[2] / M;
+        if(AMP){
+            y[7]  = mth[2] / M - nu0[2] / (M * M) * dMt;
+            y[11] = mph[2] / M - nu0[2] / (M * M) * dMp;
+        }
+    }
+    static DEVINL double height(const GeoacDevParams& P, const double* y){ return y[2]; }
+    static DEVINL double above_ground(const GeoacDevParams& P, const double* y){ return y[2] - P.ground; }
+    template <typename TabPtr>
+    static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
+        cart3_rhs<AMP>(tab, P, seg, C, yt, dy);
+    }
+    // 3DStratified.cpp:327-343
+    static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, long long k, bool& brk, bool& gnd){
+        double r = sqrt(yn[0] * yn[0] + yn[1] * yn[1]);
+        brk = (yn[2] > P.vert_limit) || (r > P.range_limit);
+        gnd = yn[2] < P.ground;
+    }
+    static DEVINL void accept(RayCtx& C){}
+    static DEVINL void restart(const GeoacDevParams& P, RayCtx& C, const double* y){}
+    // GeoAc_Jacobian / GeoAc_Amplitude: 3DStratified.cpp:410-451 (nu_mag0 sign slip, c_prop[2] without w: Q4)
+    static DEVINL void arrival(const GeoacDevParams& P, const RayCtx& C, int slot, const double* yn, double* R){
+        double z0 = P.z_grnd < P.src[2] ? P.src[2] : P.z_grnd;
+        Medium mg = medium_at(P, P.z_grnd);
+        double incl = -asin(mg.c / C.c0 * yn[3]) * 180.0 / kPi;            // GeoAc3D_main.cpp:281-284
+        double baz = P.phi_deg[slot] + 180.0;
+        while(baz > 180.0) baz -= 360.0;
+        while(baz < -180.0) baz += 360.0;
+        R[GEOAC_REC_INCL] = incl;
+        R[GEOAC_REC_BACKAZ] = baz;
+        R[GEOAC_REC_RANGE] = sqrt(yn[0] * yn[0] + yn[1] * yn[1]);
+        if(AMP){
+            Medium m = medium_at(P, yn[2]);
+            Medium m0 = medium_at(P, z0);
+            double nx = C.a[0], ny = C.a[1], nz = yn[3];
+            double nu_mag  = (m0.c - nx * m.u - ny * m.v) / m.c;
+            double nu_mag0 = 1.0 - (nx * m0.u - ny * m0.v) / m0.c;
+            double cp0 = m.c * nx / nu_mag + m.u, cp1 = m.c * ny / nu_mag + m.v, cp2 = m.c * nz / nu_mag;
+            double cq0 = m0.c * nx / nu_mag0 + m0.u, cq1 = m0.c * ny / nu_mag0 + m0.v;
+            double qx = nx / nu_mag0, qy = ny / nu_mag0;
+            double cq2 = m0.c * sqrt(1.0 - qx * qx - qy * qy);
+            double cpm = sqrt(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
+            double cqm = sqrt(cq0 * cq0 + cq1 * cq1 + cq2 * cq2);
+            double dxds = cp0 / cpm, dyds = cp1 / cpm, dzds = cp2 / cpm;
+            double D = dxds * (yn[5] * yn[10] - yn[9] * yn[6]) - yn[4] * (dyds * yn[10] - dzds * yn[9]) + yn[8] * (dyds * yn[6] - dzds * yn[5]);
+            double th_l = P.theta_deg[slot] * kPi / 180.0;
+            double num = m.rho * nu_mag * (m.c * m.c * m.c) * cqm * cos(th_l);
+            double den = m0.rho * nu_mag0 * (m0.c * m0.c * m0.c) * cpm * D;
+            R[GEOAC_REC_AMP] = 1.0 / (4.0 * kPi) * sqrt(fabs(num / den));
+            R[GEOAC_REC_JACOB] = D;
+        }
+    }
+    // ApproximateIntercept + SetReflectionConditions: 3DStratified.cpp:136-186 (quadratic term kept)
+    static DEVINL void reflect(const GeoacDevParams& P, const RayCtx& C, const double* yn, double* y, const double* ym2){
+        double dz_k = yn[2] - y[2];
+        double dz_g = y[2] - P.ground;
+        double prev[E];
+        #pragma unroll
+        for(int e = 0; e < E; e++)
+            prev[e] = y[e] + (y[e] - yn[e]) / dz_k * dz_g + 1.0 / 2.0 * (yn[e] + ym2[e] - 2.0 * y[e]) / (dz_k * dz_k) * (dz_g * dz_g);
+        Medium mg = medium_at(P, P.z_grnd);
+        double dnuz_ds = -1.0 / mg.c * (C.c0 / mg.c * mg.dc + C.a[0] * mg.du + C.a[1] * mg.dv);
+        #pragma unroll
+        for(int e = 0; e < E; e++) y[e] = prev[e];
+        y[3] = -prev[3];
+        if(AMP){
+            y[6] = -prev[6]; y[10] = -prev[10];
+            double den = mg.c / C.c0 * prev[3];
+            y[7]  = -prev[7]  + 2.0 * dnuz_ds * prev[6]  / den;
+            y[11] = -prev[11] + 2.0 * dnuz_ds * prev[10] / den;
+        }
+    }
+    // 3DStratified.cpp:348-405 (c(0,0,0) instead of c0, w ignored: Q5) and :456-490
+    static DEVINL void segment(const GeoacDevParams& P, const double* st, size_t np, const double* a, const double* b, double& tt, double& at){
+        double nx = st[(ST_AUX0 + 0) * np], ny = st[(ST_AUX0 + 1) * np];
+        double ax = a[0], ay = a[np], az = a[2 * np], anz = a[3 * np];
+        double dx = b[0] - ax, dy = b[np] - ay, dz = b[2 * np] - az;
+        double ds = sqrt(dx * dx + dy * dy + dz * dz);
+        double z = az + dz / 2.0;
+        double nz = anz + (b[3 * np] - anz) / 2.0;
+        double xe = clampd(z, P.x_min, P.x_max);
+        int k = seg_guess(P.seg, P, xe);
+        Atm9 m; seg_eval<false>(P.seg, k, xe, m);
+        double c = sqrt(kGamR * m.T);
+        double rho = rho_eval(P, k, xe);
+        double nu_mag = (P.c000 - nx * m.u - ny * m.v) / c;
+        double cp0 = c * nx / nu_mag + m.u, cp1 = c * ny / nu_mag + m.v, cp2 = c * nz / nu_mag;
+        double cpm = sqrt(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
+        tt = ds / cpm;
+        at = suthbass_alpha(P, z, c, rho, P.freq) * ds;
+    }
+};
+
+template <bool AMP_> struct Eq2D {
+    static constexpr bool AMP = AMP_;
+    static constexpr int E = AMP_ ? 6 : 3, PW = 2, HIDX = 1;
+    static constexpr bool KM2 = true;
+
+    // GeoAc_SetInitialConditions: EquationSets.2DStratified.cpp:38-68
+    static DEVINL void init(const GeoacDevParams& P, double th, double ph, double* y, RayCtx& C){
+        double z0 = P.src[0] < P.z_grnd ? P.z_grnd : P.src[0];       // GeoAc2D_main.cpp:104
+        Medium m = medium_at(P, z0);
+        C.a[0] = cos(ph); C.a[1] = sin(ph); C.a[2] = cos(th); C.a[3] = sin(th); C.a[4] = 0.0; C.a[5] = 0.0;
+        C.c0 = m.c + m.u * C.a[0] + m.v * C.a[1];
+        C.nu0 = 1.0 / C.c0;
+        y[0] = 0.0; y[1] = z0; y[2] = C.a[3];
+        if(AMP) y[5] = C.a[2];
+    }
+    static DEVINL double height(const GeoacDevParams& P, const double* y){ return y[1]; }
+    static DEVINL double above_ground(const GeoacDevParams& P, const double* y){ return y[1] - P.ground; }
+    template <typename TabPtr>
+    static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
+        cart2_rhs<AMP>(tab, P, seg, C, yt, dy);
+    }
+    // 2DStratified.cpp:194-212
+    static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, long long k, bool& brk, bool& gnd){
+        brk = (yn[1] > P.vert_limit) || (yn[0] > P.range_limit);
+        gnd = yn[1] < P.ground;
+    }
+    static DEVINL void accept(RayCtx& C){}
+    static DEVINL void restart(const GeoacDevParams& P, RayCtx& C, const double* y){}
+    // GeoAc2D_main.cpp:216-226; Jacobian / Amplitude: 2DStratified.cpp:291-313
+    static DEVINL void arrival(const GeoacDevParams& P, const RayCtx& C, int slot, const double* yn, double* R){
+        R[GEOAC_REC_INCL] = -P.theta_deg[slot];
+        R[GEOAC_REC_BACKAZ] = 0.0;
+        R[GEOAC_REC_RANGE] = yn[0];
+        if(AMP){
+            Medium m = medium_at(P, yn[1]);
+            Medium mg = medium_at(P, P.z_grnd);
+            double drds = m.c / C.c0 * C.a[2];
+            double dzds = m.c / C.c0 * yn[2];
+            double D = yn[0] * (drds * yn[4] - dzds * yn[3]);
+            double num = m.rho * m.c * C.a[2];
+            double den = mg.rho * C.c0 * D;
+            R[GEOAC_REC_AMP] = 1.0 / (4.0 * kPi) * sqrt(fabs(num / den));
+            R[GEOAC_REC_JACOB] = D;
+        }
+    }
+    // 2DStratified.cpp:74-117
+    static DEVINL void reflect(const GeoacDevParams& P, const RayCtx& C, const double* yn, double* y, const double* ym2){
+        double dz_k = yn[1] - y[1];
+        double dz_g = y[1] - P.ground;
+        double prev[E];
+        #pragma unroll
+        for(int e = 0; e < E; e++)
+            prev[e] = y[e] + (y[e] - yn[e]) / dz_k * dz_g + 1.0 / 2.0 * (yn[e] + ym2[e] - 2.0 * y[e]) / (dz_k * dz_k) * (dz_g * dz_g);
+        Medium mg = medium_at(P, P.z_grnd);
+        double ced = mg.dc + mg.du * C.a[0] + mg.dv * C.a[1];
+        double dnuz_ds = -C.c0 / (mg.c * mg.c) * ced;
+        y[0] = prev[0]; y[1] = P.ground; y[2] = -prev[2];
+        if(AMP){
+            y[3] = prev[3]; y[4] = -prev[4];
+            y[5] = -prev[5] + 2.0 * dnuz_ds * prev[4] / (mg.c / C.c0 * prev[2]);
+        }
+    }
+    // 2DStratified.cpp:217-286
+    static DEVINL void segment(const GeoacDevParams& P, const double* st, size_t np, const double* a, const double* b, double& tt, double& at){
+        double cph = st[(ST_AUX0 + 0) * np], sph = st[(ST_AUX0 + 1) * np];
+        double ar = a[0], az = a[np];
+        double dr = b[0] - ar, dz = b[np] - az;
+        double z = az + dz / 2.0;
+        double ds = sqrt(dr * dr + dz * dz);
+        double xe = clampd(z, P.x_min, P.x_max);
+        int k = seg_guess(P.seg, P, xe);
+        Atm9 m; seg_eval<false>(P.seg, k, xe, m);
+        double c = sqrt(kGamR * m.T);
+        double rho = rho_eval(P, k, xe);
+        tt = ds / (c + m.u * cph + m.v * sph);
+        at = suthbass_alpha(P, z, c, rho, P.freq) * ds;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// k_init: launch angles -> initial conditions + per-ray state
+// ------------------------------------------------------------------------------------------------
+template <class EQ>
+__global__ void __launch_bounds__(256) k_init(GeoacDevParams P){
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= P.n_pad) return;
+    double* st = P.state + i;
+    const size_t np = (size_t)P.n_pad;
+    for(int f = 0; f < ST_NSTATE; f++) st[f * np] = 0.0;
+    if(i >= P.n_rays){ st[ST_DONE * np] = 1.0; return; }          // padding lanes: finished from the start
+    const double th = P.theta_deg[i] * kPi / 180.0;               // GeoAcGlobal_main.cpp:244
+    const double ph = kPi / 2.0 - P.phi_deg[i] * kPi / 180.0;     // :245
+    double y[GEOAC_MAXE];
+    for(int e = 0; e < GEOAC_MAXE; e++) y[e] = 0.0;
+    RayCtx C;
+    EQ::init(P, th, ph, y, C);
+    for(int e = 0; e < GEOAC_MAXE; e++) st[(ST_Y0 + e) * np] = y[e];
+    st[ST_C0 * np] = C.c0; st[ST_NU0 * np] = C.nu0;
+    for(int q = 0; q < 6; q++) st[(ST_AUX0 + q) * np] = C.a[q];
+    st[ST_SEG * np] = (double)seg_guess(P.seg, P, clampd(y[EQ::HIDX], P.x_min, P.x_max));
+    double* R = P.rec + (size_t)i * (P.bounces + 1) * GEOAC_REC_STRIDE;
+    for(int q = 0; q < (P.bounces + 1) * GEOAC_REC_STRIDE; q++) R[q] = 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_rk4: GeoAc_Propagate_RK4 (GeoAc.Solver.cpp:12-72) for one epoch, one ray per lane
+// ------------------------------------------------------------------------------------------------
+template <class EQ>
+DEVINL void write_row(const GeoacDevParams& P, int row, int slot, const double* y){
+    double* p = P.path + ((size_t)row * EQ::PW) * P.n_pad + slot;
+    if(EQ::PW == 6){                       // Global: r, lat, lon, nu_r, nu_t, nu_p
+        #pragma unroll
+        for(int c = 0; c < 6; c++) p[(size_t)c * P.n_pad] = y[c];
+    } else if(EQ::PW == 4){                // 3D: x, y, z, nu_z
+        #pragma unroll
+        for(int c = 0; c < 4; c++) p[(size_t)c * P.n_pad] = y[c];
+    } else {                               // 2D: r, z
+        p[0] = y[0]; p[P.n_pad] = y[1];
+    }
+}
+
+template <class EQ, bool LDS>
+__global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
+    constexpr int E = EQ::E;
+    __builtin_amdgcn_s_setprio(3);      // latency-critical serial recurrence: win VALU arbitration against co-resident post-pass waves
+    extern __shared__ double lds_tab[];
+    // ---- stage the segment table in LDS (coalesced 8 B/lane loads; 153 KiB for ToyAtmo) ----
+    const double* gtab = P.seg;
+    if(LDS){
+        const int total = P.nseg * GEOAC_SEGW;
+        for(int q = threadIdx.x; q < total; q += blockDim.x) lds_tab[q] = gtab[q];
+        __syncthreads();
+    }
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = blockIdx.y;                                   // segment (row i -> row i+1)
+    if(slot >= P.n_pad) return;
+    const size_t np = (size_t)P.n_pad;
+    double* st = P.state + slot;
+
+    int nr = 0, nle = 0;
+    bool done = st[ST_DONE * np] != 0.0;
+    if(done){ P.nrows[slot] = 0; P.nlegend[slot] = 0; return; }
+
+    double y[E], ym2[EQ::KM2 ? E : 1];
+    #pragma unroll
+    for(int e = 0; e < E; e++) y[e] = st[(ST_Y0 + e) * np];
+    if(EQ::KM2){
+        #pragma unroll
+        for(int e = 0; e < E; e++) ym2[e] = st[(ST_YM2 + e) * np];
+    }
+    long long k = (long long)st[ST_K * np];
+    int leg = (int)st[ST_LEG * np];
+    double hmax = st[ST_HMAX * np];
+    RayCtx C;
+    C.c0 = st[ST_C0 * np]; C.nu0 = st[ST_NU0 * np];
+    #pragma unroll
+    for(int q = 0; q < 6; q++) C.a[q] = st[(ST_AUX0 + q) * np];
+    int seg = (int)st[ST_SEG * np];
+    unsigned long long steps_here = 0;
+
+    write_row<EQ>(P, nr++, slot, y);                            // carry row: chunk row 0 = current state
+
+    while(nr + 2 <= P.s_rows && !done){
+        // running turning height: max over rows m < k of the height component   (GeoAcGlobal_main.cpp:294)
+        { double h = EQ::height(P, y); hmax = (hmax < h) ? h : hmax; }
+
+        // ---- GeoAc_Set_ds (Global.cpp:210-217 and twins) ----
+        double ds = 0.05 - 0.049 * exp(-EQ::above_ground(P, y) / 0.75);
+        ds = (P.ds_max < ds) ? P.ds_max : ds;
+        ds = (ds < P.ds_min) ? P.ds_min : ds;
+
+        // ---- the four RK4 stages as ONE rolled loop (a single copy of the RHS keeps the live set < 256 VGPRs):
+        //      k_s = ds f(y + a_s k_{s-1}), a = {0, 1/2, 1/2, 1};  y' = y + k1/6 + k2/3 + k3/3 + k4/6  (Solver.cpp:33-54)
+        double dy[E], yt[E], yn[E];
+        #pragma unroll
+        for(int e = 0; e < E; e++){ yt[e] = y[e]; yn[e] = y[e]; }
+        #pragma unroll 1
+        for(int stage = 0; stage < 4; stage++){
+            if(LDS) EQ::rhs(lds_tab, P, seg, C, y, yt, stage, dy); else EQ::rhs(gtab, P, seg, C, y, yt, stage, dy);
+            const double wa = ((stage == 2) ? 1.0 : 0.5) * ds;
+            const double wb = ((stage == 0 || stage == 3) ? (1.0 / 6.0) : (1.0 / 3.0)) * ds;
+            #pragma unroll
+            for(int e = 0; e < E; e++){
+                yn[e] = __builtin_fma(dy[e], wb, yn[e]);
+                yt[e] = __builtin_fma(dy[e], wa, y[e]);
+            }
+        }
+
+        k++; steps_here++;
+        write_row<EQ>(P, nr++, slot, yn);
+
+        bool brk, gnd;
+        EQ::checks(P, C, y, yn, k, brk, gnd);
+        bool lim = (k >= P.step_limit - 1);                       // Solver.cpp loop bound; never reached on sane inputs
+
+        if(brk || gnd || lim){
+            // ---- leg end: record (GeoAcGlobal_main.cpp:293-317 and twins) ----
+            double* R = P.rec + ((size_t)slot * (P.bounces + 1) + leg) * GEOAC_REC_STRIDE;
+            R[GEOAC_REC_STEPS] = (double)k;
+            P.legend[(size_t)nle * np + slot] = nr - 1; nle++;
+            if(lim && !brk && !gnd) atomicOr(&P.counters[2], 1ull);
+            if(brk){
+                R[GEOAC_REC_BROKE] = 1.0;
+                done = true;
+            } else {
+                R[GEOAC_REC_VALID] = 1.0;
+                R[GEOAC_REC_TURN] = hmax;
+                EQ::arrival(P, C, slot, yn, R);
+                #pragma unroll
+                for(int e = 0; e < E; e++) R[GEOAC_REC_STATE + e] = yn[e];
+                if(leg >= P.bounces){
+                    done = true;
+                } else {
+                    EQ::reflect(P, C, yn, y, ym2);
+                    leg++; k = 0;
+                    EQ::restart(P, C, y);
+                    write_row<EQ>(P, nr++, slot, y);              // leg-start row
+                }
+            }
+        } else {
+            if(EQ::KM2){
+                #pragma unroll
+                for(int e = 0; e < E; e++) ym2[e] = y[e];
+            }
+            #pragma unroll
+            for(int e = 0; e < E; e++) y[e] = yn[e];
+            EQ::accept(C);
+        }
+    }
+
+    // ---- save state ----
+    #pragma unroll
+    for(int e = 0; e < E; e++) st[(ST_Y0 + e) * np] = y[e];
+    if(EQ::KM2){
+        #pragma unroll
+        for(int e = 0; e < E; e++) st[(ST_YM2 + e) * np] = ym2[e];
+    }
+    st[ST_K * np] = (double)k; st[ST_LEG * np] = (double)leg; st[ST_DONE * np] = done ? 1.0 : 0.0;
+    st[ST_HMAX * np] = hmax; st[ST_SEG * np] = (double)seg;
+    #pragma unroll
+    for(int q = 0; q < 4; q++) st[(ST_AUX0 + q) * np] = C.a[q];
+    P.nrows[slot] = nr; P.nlegend[slot] = nle;
+
+    // ---- step count and live-ray count: lanes of finished rays have already returned, so reduce over the
+    //      lanes that are still here (ballot of the active mask), one atomic pair per wave ----
+    const unsigned long long act = __ballot(1);
+    unsigned long long s = 0;
+    for(int l = 0; l < 64; l++){
+        unsigned long long v = __shfl(steps_here, l);
+        if((act >> l) & 1ull) s += v;
+    }
+    const unsigned long long live = __popcll(__ballot(!done));
+    if((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1){
+        atomicAdd(&P.counters[0], s);
+        atomicAdd(&P.counters[1], live);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_postpass: one thread per path segment (row i -> row i+1 of one ray)
+// ------------------------------------------------------------------------------------------------
+template <class EQ>
+__global__ void __launch_bounds__(256) k_postpass(GeoacDevParams P){
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
     if(slot >= P.n_pad) return;
     if(i + 1 >= P.nrows[slot]) return;
     const size_t np = (size_t)P.n_pad;
-    const double* a = P.path + ((size_t)i * P.pathw) * np + slot;
-    const double* b = a + (size_t)P.pathw * np;
-    double ar = a[0], at_ = a[np], ap = a[2 * np], an0 = a[3 * np], an1 = a[4 * np], an2 = a[5 * np];
-    double dr = b[0] - ar, dt = b[np] - at_, dp = b[2 * np] - ap;
-    double r = ar + dr / 2.0, t = at_ + dt / 2.0;
-    double st, ct; fsincos(t, st, ct);
-    double rdt = r * dt;
-    double e1 = r * ct * dp, e2 = r * st * dp;
-    double ds_tt = sqrt(dr * dr + rdt * rdt + e1 * e1);
-    double ds_at = sqrt(dr * dr + rdt * rdt + e2 * e2);
-    double n0 = an0 + (b[3 * np] - an0) / 2.0, n1 = an1 + (b[4 * np] - an1) / 2.0, n2 = an2 + (b[5 * np] - an2) / 2.0;
-    double nu_mag = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
-
-    double xe = clampd(r, P.x_min, P.x_max);
-    int k = seg_guess(P.seg, P, xe);
-    Atm9 m; seg_eval<false>(P.seg, k, xe, m);
-    double c = sqrt(kGamR * m.T);
-    double rho = rho_eval(P, k, xe);
-    double cp0 = c * n0 / nu_mag, cp1 = c * n1 / nu_mag + m.v, cp2 = c * n2 / nu_mag + m.u;
-    double cpm = sqrt(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
-
-    double alpha = suthbass_alpha(P, r - P.r_earth, c, rho, P.freq);
+    const double* a = P.path + ((size_t)i * EQ::PW) * np + slot;
+    const double* b = a + (size_t)EQ::PW * np;
+    double tt, at;
+    EQ::segment(P, P.state + slot, np, a, b, tt, at);
     double* o = P.contrib + ((size_t)i * 2) * np + slot;
-    o[0]  = ds_tt / cpm;
-    o[np] = alpha * ds_at;
+    o[0]  = tt;
+    o[np] = at;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -646,7 +985,7 @@ __global__ void __launch_bounds__(256) k_accum(GeoacDevParams P){
     int e = 0;
     int next_end = (e < ne) ? P.legend[(size_t)e * np + slot] : 0x7fffffff;
     int cur_end = -1;
-    const bool rays_form = (P.mode & (GEOAC_MODE_WRITE_RAYS | GEOAC_MODE_WRITE_CAUSTICS)) != 0;
+    const bool rays_form = P.rays_form != 0;      // WriteRays/WriteCaustics form of Q7; GeoAc2D always uses it (GeoAc2D_main.cpp:190-192)
     for(int i = 0; i + 1 < nr; i++){
         if(i == cur_end) continue;                              // (leg-end row -> next leg's start row): not a segment
         const double* cpt = P.contrib + ((size_t)i * 2) * np + slot;
@@ -672,34 +1011,47 @@ __global__ void __launch_bounds__(256) k_accum(GeoacDevParams P){
 // ------------------------------------------------------------------------------------------------
 // host-callable launchers (called from geoac_api.cpp)
 // ------------------------------------------------------------------------------------------------
+#define GEOAC_DISPATCH_EQ(P, CALL) \
+    switch((P)->eqset * 2 + ((P)->calc_amp ? 1 : 0)){ \
+        case GEOAC_EQ_GLOBAL * 2 + 1: { using EQ = EqGlobal<true>;  CALL; } break; \
+        case GEOAC_EQ_GLOBAL * 2 + 0: { using EQ = EqGlobal<false>; CALL; } break; \
+        case GEOAC_EQ_3D * 2 + 1:     { using EQ = Eq3D<true>;      CALL; } break; \
+        case GEOAC_EQ_3D * 2 + 0:     { using EQ = Eq3D<false>;     CALL; } break; \
+        case GEOAC_EQ_2D * 2 + 1:     { using EQ = Eq2D<true>;      CALL; } break; \
+        case GEOAC_EQ_2D * 2 + 0:     { using EQ = Eq2D<false>;     CALL; } break; \
+        default: return hipErrorNotSupported; }
+
 extern "C" hipError_t geoac_launch_init(const GeoacDevParams* P, hipStream_t s){
     dim3 b(256), g((P->n_pad + 255) / 256);
-    if(P->eqset != GEOAC_EQ_GLOBAL) return hipErrorNotSupported;
-    if(P->calc_amp) hipLaunchKernelGGL(k_init_global<true>, g, b, 0, s, *P);
-    else            hipLaunchKernelGGL(k_init_global<false>, g, b, 0, s, *P);
+    GEOAC_DISPATCH_EQ(P, hipLaunchKernelGGL(k_init<EQ>, g, b, 0, s, *P));
+    return hipGetLastError();
+}
+
+template <class EQ>
+static hipError_t launch_rk4_t(const GeoacDevParams* P, int block, hipStream_t s){
+    dim3 b(block), g((P->n_pad + block - 1) / block);
+    size_t lds = P->table_in_lds ? (size_t)P->nseg * GEOAC_SEGW * sizeof(double) : 0;
+    if(P->table_in_lds){
+        if(lds > 65536){
+            hipError_t err = hipFuncSetAttribute((const void*)k_rk4<EQ, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if(err != hipSuccess) return err;
+        }
+        hipLaunchKernelGGL((k_rk4<EQ, true>), g, b, lds, s, *P);
+    } else {
+        hipLaunchKernelGGL((k_rk4<EQ, false>), g, b, 0, s, *P);
+    }
     return hipGetLastError();
 }
 
 extern "C" hipError_t geoac_launch_rk4(const GeoacDevParams* P, int block, hipStream_t s){
-    if(P->eqset != GEOAC_EQ_GLOBAL) return hipErrorNotSupported;
-    dim3 b(block), g((P->n_pad + block - 1) / block);
-    size_t lds = P->table_in_lds ? (size_t)P->nseg * GEOAC_SEGW * sizeof(double) : 0;
-    hipError_t err = hipSuccess;
-    #define GEOAC_RK4_CASE(AMP, LDS) do { \
-        if(lds > 65536) err = hipFuncSetAttribute((const void*)k_rk4_global<AMP, LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        if(err != hipSuccess) return err; \
-        hipLaunchKernelGGL((k_rk4_global<AMP, LDS>), g, b, lds, s, *P); } while(0)
-    if(P->calc_amp){ if(P->table_in_lds) GEOAC_RK4_CASE(true, true); else GEOAC_RK4_CASE(true, false); }
-    else           { if(P->table_in_lds) GEOAC_RK4_CASE(false, true); else GEOAC_RK4_CASE(false, false); }
-    #undef GEOAC_RK4_CASE
-    return hipGetLastError();
+    GEOAC_DISPATCH_EQ(P, return launch_rk4_t<EQ>(P, block, s));
+    return hipErrorNotSupported;
 }
 
 extern "C" hipError_t geoac_launch_postpass(const GeoacDevParams* P, int rows, hipStream_t s){
-    if(P->eqset != GEOAC_EQ_GLOBAL) return hipErrorNotSupported;
     if(rows < 2) return hipSuccess;
     dim3 b(256), g((P->n_pad + 255) / 256, rows - 1);
-    hipLaunchKernelGGL(k_postpass_global, g, b, 0, s, *P);
+    GEOAC_DISPATCH_EQ(P, hipLaunchKernelGGL(k_postpass<EQ>, g, b, 0, s, *P));
     dim3 g2((P->n_rays + 255) / 256);
     hipLaunchKernelGGL(k_accum, g2, b, 0, s, *P);
     return hipGetLastError();

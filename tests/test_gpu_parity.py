@@ -23,26 +23,32 @@ def _ctx(G, eq, **params):
     return ctx
 
 
+ESIZE = {H.EQ_GLOBAL: (6, 18), H.EQ_3D: (4, 12), H.EQ_2D: (3, 6)}
+HIDX = {H.EQ_GLOBAL: None, H.EQ_3D: 2, H.EQ_2D: 1}
+
+
+@pytest.mark.parametrize("eq", [H.EQ_GLOBAL, H.EQ_3D, H.EQ_2D])
 @pytest.mark.parametrize("amp", [1, 0])
-def test_global_small_fan_vs_golden(G, golden, amp):
-    g = golden(H.EQ_GLOBAL)
-    ctx = _ctx(G, G.EQ_GLOBAL, bounces=2, calc_amp=amp, mode=0)
+def test_small_fan_vs_golden(G, golden, eq, amp):
+    g = golden(eq)
+    ctx = _ctx(G, eq, bounces=2, calc_amp=amp, mode=0)
     rec, steps = ctx.run(g["theta"], g["phi"])
     want = g[f"rec_amp{amp}_mode0"]
-    print(max_rel_errors(rec, want, 18 if amp else 6))
+    print(H.EQ_NAMES[eq], amp, max_rel_errors(rec, want, ESIZE[eq][amp], HIDX[eq]))
     assert steps == int(g[f"steps_amp{amp}_mode0"])
-    compare_records(rec, want, E=18 if amp else 6)
+    compare_records(rec, want, E=ESIZE[eq][amp], hidx=HIDX[eq])
 
 
-def test_global_alt_config_vs_golden(G, golden):
-    g = golden(H.EQ_GLOBAL)
-    ctx = _ctx(G, G.EQ_GLOBAL, bounces=int(g["altcfg_bounces"]), calc_amp=1, mode=0, src=tuple(g["altcfg_src"]),
+@pytest.mark.parametrize("eq", [H.EQ_GLOBAL, H.EQ_3D, H.EQ_2D])
+def test_alt_config_vs_golden(G, golden, eq):
+    g = golden(eq)
+    ctx = _ctx(G, eq, bounces=int(g["altcfg_bounces"]), calc_amp=1, mode=0, src=tuple(g["altcfg_src"]),
                z_grnd=float(g["altcfg_z_grnd"]), tweak_abs=float(g["altcfg_tweak_abs"]), freq=float(g["altcfg_freq"]),
                range_limit=float(g["altcfg_range_limit"]))
     rec, steps = ctx.run(g["theta"], g["phi"])
-    print(max_rel_errors(rec, g["rec_alt"], 18))
+    print(H.EQ_NAMES[eq], max_rel_errors(rec, g["rec_alt"], ESIZE[eq][1], HIDX[eq]))
     assert steps == int(g["steps_alt"])
-    compare_records(rec, g["rec_alt"], E=18)
+    compare_records(rec, g["rec_alt"], E=ESIZE[eq][1], hidx=HIDX[eq])
 
 
 def test_global_slice_vs_oracle(G):
@@ -57,13 +63,14 @@ def test_global_slice_vs_oracle(G):
     compare_records(rec, ro, E=18)
 
 
-def test_epoch_size_invariance(G, golden, monkeypatch):
+@pytest.mark.parametrize("eq", [H.EQ_GLOBAL, H.EQ_3D, H.EQ_2D])
+def test_epoch_size_invariance(G, golden, monkeypatch, eq):
     """results must not depend on how the path is cut into epochs"""
-    g = golden(H.EQ_GLOBAL)
+    g = golden(eq)
     recs = []
     for s_rows in ("64", "777"):
         monkeypatch.setenv("GEOAC_S_ROWS", s_rows)
-        ctx = _ctx(G, G.EQ_GLOBAL, bounces=2, calc_amp=1, mode=0)
+        ctx = _ctx(G, eq, bounces=2, calc_amp=1, mode=0)
         recs.append(ctx.run(g["theta"], g["phi"]))
         ctx.close()
     assert recs[0][1] == recs[1][1]
