@@ -171,6 +171,15 @@ class FanContext:
         self._chk(self.lib.geoac_fan_fetch(self._h, _p(rec), ctypes.byref(steps)))
         return rec, int(steps.value)
 
+    def fetch_samples(self):
+        """WriteRays / WriteCaustics rows, ordered by (ray, leg, m): [n][10] (GEOAC_SMP_* layout)"""
+        n = ctypes.c_int64(0)
+        self._chk(self.lib.geoac_fan_sample_count(self._h, ctypes.byref(n)))
+        smp = np.zeros((max(n.value, 1), 10))
+        if n.value:
+            self._chk(self.lib.geoac_fan_fetch_samples(self._h, _p(smp), ctypes.c_int64(n.value)))
+        return smp[:n.value]
+
     def records_dev(self):
         ptr = ctypes.c_void_p(); nbytes = ctypes.c_size_t()
         self._chk(self.lib.geoac_fan_records_dev(self._h, ctypes.byref(ptr), ctypes.byref(nbytes)))

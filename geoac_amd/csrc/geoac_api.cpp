@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -49,6 +50,9 @@ struct geoac_ctx {
     DevBuf seg, rhot, theta, phi, state, rec, counters;
     DevBuf path[2], contrib[2], nrows[2], legend[2], nlegend[2];   // double-buffered epoch chunks (RK4 of epoch e+1 overlaps the post-pass of e)
     hipStream_t pp_stream = nullptr;                                // post-pass stream
+    DevBuf ev_row[2], ev_m[2], ev_amp[2], nev[2], smp_out;          // WriteRays / WriteCaustics events and the sample list
+    long long smp_cap = 4ll << 20;                                  // sample records the device list can hold (GEOAC_SMP_CAP)
+    unsigned long long n_samples = 0;
     unsigned long long* h_counters = nullptr;     // pinned
     int n_rays = 0, n_pad = 0, legs = 0;
     // last launch
@@ -147,12 +151,14 @@ int geoac_create(geoac_ctx** out, int eqset, int device){
     ctx->own_stream = true;
     if(hipStreamCreateWithFlags(&ctx->pp_stream, hipStreamNonBlocking) != hipSuccess){ delete ctx; return GEOAC_E_HIP; }
     hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
-    if(hipHostMalloc((void**)&ctx->h_counters, 8 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess){
+    if(hipHostMalloc((void**)&ctx->h_counters, 16 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess){
         delete ctx; return GEOAC_E_HIP;
     }
     geoac_default_params(eqset, &ctx->prm);
     const char* sr = getenv("GEOAC_S_ROWS");
     if(sr) ctx->s_rows_override = atoi(sr);
+    const char* sc = getenv("GEOAC_SMP_CAP");
+    if(sc && atoll(sc) > 0) ctx->smp_cap = atoll(sc);
     *out = ctx;
     return GEOAC_OK;
 }
@@ -163,7 +169,9 @@ int geoac_destroy(geoac_ctx* ctx){
     if(ctx->stream) hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = { &ctx->seg, &ctx->rhot, &ctx->theta, &ctx->phi, &ctx->state, &ctx->rec, &ctx->counters,
                        &ctx->path[0], &ctx->path[1], &ctx->contrib[0], &ctx->contrib[1], &ctx->nrows[0], &ctx->nrows[1],
-                       &ctx->legend[0], &ctx->legend[1], &ctx->nlegend[0], &ctx->nlegend[1] };
+                       &ctx->legend[0], &ctx->legend[1], &ctx->nlegend[0], &ctx->nlegend[1],
+                       &ctx->ev_row[0], &ctx->ev_row[1], &ctx->ev_m[0], &ctx->ev_m[1], &ctx->ev_amp[0], &ctx->ev_amp[1],
+                       &ctx->nev[0], &ctx->nev[1], &ctx->smp_out };
     for(DevBuf* b : bufs) b->release();
     if(ctx->h_counters) hipHostFree(ctx->h_counters);
     if(ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -245,7 +253,6 @@ int geoac_fan_launch(geoac_ctx* ctx){
     if(!ctx->have_atmo || !ctx->have_angles) return fail(ctx, GEOAC_E_INVALID, "fan_launch: atmosphere and angles must be uploaded first");
     if(ctx->eqset != GEOAC_EQ_GLOBAL && ctx->eqset != GEOAC_EQ_3D && ctx->eqset != GEOAC_EQ_2D)
         return fail(ctx, GEOAC_E_UNSUPPORTED, "range-dependent equation sets are not implemented on the GPU yet");
-    if(ctx->prm.mode != 0) return fail(ctx, GEOAC_E_UNSUPPORTED, "WriteRays / WriteCaustics sample capture is not implemented on the GPU yet");
     HIPCHK(hipSetDevice(ctx->device));
     const geoac_params& p = ctx->prm;
     GeoacDevParams P{};
@@ -295,6 +302,20 @@ int geoac_fan_launch(geoac_ctx* ctx){
     ctx->legs = p.bounces + 1;
 
     HIPCHK(ctx->state.ensure(sizeof(double) * (size_t)ST_NSTATE * P.n_pad));
+    const bool sampling = (p.mode & (GEOAC_MODE_WRITE_RAYS | GEOAC_MODE_WRITE_CAUSTICS)) != 0;
+    P.smp_stride = p.sample_stride > 0 ? p.sample_stride : 25;
+    P.ev_cap = sampling ? (P.s_rows / P.smp_stride + 72) : 0;
+    P.smp_cap = sampling ? ctx->smp_cap : 0;
+    if(sampling){
+        HIPCHK(ctx->smp_out.ensure(sizeof(double) * GEOAC_SMP_STRIDE * (size_t)P.smp_cap));
+        for(int b = 0; b < 2; b++){
+            HIPCHK(ctx->ev_row[b].ensure(sizeof(int) * (size_t)P.ev_cap * P.n_pad));
+            HIPCHK(ctx->ev_m[b].ensure(sizeof(int) * (size_t)P.ev_cap * P.n_pad));
+            HIPCHK(ctx->ev_amp[b].ensure(sizeof(double) * (size_t)P.ev_cap * P.n_pad));
+            HIPCHK(ctx->nev[b].ensure(sizeof(int) * (size_t)P.n_pad));
+        }
+        P.smp_out = (double*)ctx->smp_out.p;
+    }
     for(int b = 0; b < 2; b++){
         HIPCHK(ctx->path[b].ensure(row_bytes * (size_t)P.s_rows));
         HIPCHK(ctx->contrib[b].ensure(sizeof(double) * 2 * (size_t)P.n_pad * P.s_rows));
@@ -334,6 +355,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
         GeoacDevParams Pe = P;
         Pe.path = (double*)ctx->path[b].p; Pe.contrib = (double*)ctx->contrib[b].p;
         Pe.nrows = (int*)ctx->nrows[b].p; Pe.legend = (int*)ctx->legend[b].p; Pe.nlegend = (int*)ctx->nlegend[b].p;
+        if(sampling){ Pe.ev_row = (int*)ctx->ev_row[b].p; Pe.ev_m = (int*)ctx->ev_m[b].p; Pe.ev_amp = (double*)ctx->ev_amp[b].p; Pe.nev = (int*)ctx->nev[b].p; }
         if(e >= 2) HIPCHK(hipStreamWaitEvent(s, ctx->evs[4 * (e - 2) + 3], 0));      // chunk b free again?
         HIPCHK(hipMemsetAsync((char*)ctx->counters.p + sizeof(unsigned long long), 0, sizeof(unsigned long long), s));
         HIPCHK(hipEventRecord(ctx->evs[eb], s));
@@ -351,7 +373,9 @@ int geoac_fan_launch(geoac_ctx* ctx){
     }
     HIPCHK(hipStreamWaitEvent(s, ctx->evs[4 * (ctx->n_epochs - 1) + 3], 0));
     HIPCHK(hipEventRecord(ctx->ev1, s));
+    HIPCHK(hipMemcpyAsync(ctx->h_counters + 4, ctx->counters.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    ctx->n_samples = ctx->h_counters[4 + 3];
     float ms = 0; hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->ms_total = ms;
     ctx->ms_rk4 = 0; ctx->ms_post = 0;
@@ -367,6 +391,9 @@ int geoac_fan_launch(geoac_ctx* ctx){
     ctx->path_bytes_w = ctx->total_steps * (unsigned long long)(P.pathw * sizeof(double));
     ctx->path_bytes_r = 2 * ctx->path_bytes_w;
     ctx->ran = true;
+    if(ctx->err_flags & 2ull) return fail(ctx, GEOAC_E_CAPACITY, "per-epoch sample/caustic event list overflowed");
+    if(sampling && ctx->n_samples > (unsigned long long)P.smp_cap)
+        return fail(ctx, GEOAC_E_CAPACITY, "sample list overflowed: raise GEOAC_SMP_CAP (needed " + std::to_string(ctx->n_samples) + ")");
     if(ctx->err_flags & 1ull) return fail(ctx, GEOAC_E_CAPACITY, "a ray reached step_limit (GeoAc.Solver.cpp:14) without leaving the region or reaching the ground");
     return GEOAC_OK;
 }
@@ -404,8 +431,34 @@ int geoac_fan_fetch(geoac_ctx* ctx, double* rec_host, uint64_t* total_steps){
     return GEOAC_OK;
 }
 
-int geoac_fan_sample_count(geoac_ctx* ctx, int64_t* n){ if(!ctx || !n) return GEOAC_E_INVALID; *n = 0; return GEOAC_OK; }
-int geoac_fan_fetch_samples(geoac_ctx* ctx, double*, int64_t){ return fail(ctx, GEOAC_E_UNSUPPORTED, "sample capture not implemented yet"); }
+int geoac_fan_sample_count(geoac_ctx* ctx, int64_t* n){
+    if(!ctx || !n || !ctx->ran) return GEOAC_E_INVALID;
+    *n = (int64_t)ctx->n_samples;
+    return GEOAC_OK;
+}
+
+int geoac_fan_fetch_samples(geoac_ctx* ctx, double* smp_host, int64_t cap){
+    if(!ctx || !ctx->ran || !smp_host) return fail(ctx, GEOAC_E_INVALID, "fan_fetch_samples: no completed launch / null buffer");
+    int64_t n = (int64_t)ctx->n_samples;
+    if(n > ctx->smp_cap) n = ctx->smp_cap;
+    if(cap < n) return fail(ctx, GEOAC_E_CAPACITY, "fan_fetch_samples: buffer too small");
+    if(n == 0) return GEOAC_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<double> tmp((size_t)n * GEOAC_SMP_STRIDE);
+    HIPCHK(hipMemcpyAsync(tmp.data(), ctx->smp_out.p, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    // the device list is in completion order; the files are in (ray, leg, m) order, raypath rows before caustic rows
+    std::vector<int64_t> idx((size_t)n);
+    for(int64_t i = 0; i < n; i++) idx[(size_t)i] = i;
+    const double* t = tmp.data();
+    std::sort(idx.begin(), idx.end(), [t](int64_t a, int64_t b){
+        const double* A = t + a * GEOAC_SMP_STRIDE; const double* B = t + b * GEOAC_SMP_STRIDE;
+        for(int q = 0; q < 4; q++){ if(A[q] != B[q]) return A[q] < B[q]; }
+        return a < b;
+    });
+    for(int64_t i = 0; i < n; i++) memcpy(smp_host + i * GEOAC_SMP_STRIDE, t + idx[(size_t)i] * GEOAC_SMP_STRIDE, sizeof(double) * GEOAC_SMP_STRIDE);
+    return GEOAC_OK;
+}
 
 int geoac_fan_run(geoac_ctx* ctx, int n_rays, const double* theta_deg, const double* phi_deg,
                   double* rec_host, uint64_t* total_steps){

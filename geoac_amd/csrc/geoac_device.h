@@ -38,7 +38,8 @@ enum {
     ST_LTT    = 34,     // post-pass per-leg partial sums (arrivals-only form of Q7)
     ST_LAT    = 35,
     ST_YM2    = 36,     // row k-2 of the current leg (Cartesian sets: quadratic ground intercept), up to 12 values
-    ST_NSTATE = 48
+    ST_DPREV  = 48,     // Jacobian of the previous row (WriteCaustics)
+    ST_NSTATE = 49
 };
 
 struct GeoacDevParams {
@@ -73,8 +74,16 @@ struct GeoacDevParams {
     int*          nrows;            // [n_pad] rows written by each ray in the current chunk
     int*          legend;           // [GEOAC_MAXLEGS][n_pad] chunk-row index of leg-end rows in this chunk
     int*          nlegend;          // [n_pad]
+    // WriteRays / WriteCaustics events of the current chunk (k_rk4 -> k_accum) and the sample output list
+    int           smp_stride, ev_cap;
+    int*          ev_row;           // [ev_cap][n_pad] chunk-row index of the event
+    int*          ev_m;             // [ev_cap][n_pad] row index m within the leg | kind << 30
+    double*       ev_amp;           // [ev_cap][n_pad] GeoAc_Amplitude at the row (raypath rows)
+    int*          nev;              // [n_pad]
+    double*       smp_out;          // [smp_cap][GEOAC_SMP_STRIDE]
+    long long     smp_cap;
     double*       rec;              // [n_rays][bounces+1][32]
-    unsigned long long* counters;   // [0] total steps, [1] active rays after this epoch, [2] error flags
+    unsigned long long* counters;   // [0] total steps, [1] active rays after this epoch, [2] error flags, [3] samples emitted
 };
 
 #endif

@@ -523,12 +523,20 @@ template <bool AMP_> struct EqGlobal {
         R[GEOAC_REC_BACKAZ] = baz;
         R[GEOAC_REC_RANGE] = 2.0 * P.r_earth * asin(sqrt(g1 + g2));
         if(AMP){
-            Medium m0 = medium_at(P, z_src + P.r_earth);
-            double D = global_jacobian(m, yn);
-            double th_l = P.theta_deg[slot] * kPi / 180.0, ph_l = kPi / 2.0 - P.phi_deg[slot] * kPi / 180.0;
-            R[GEOAC_REC_AMP] = global_amplitude(P, m, m0, yn, C.c0, C.nu0, th_l, ph_l, D);
+            double amp, D;
+            amp_jac(P, C, slot, yn, amp, D);
+            R[GEOAC_REC_AMP] = amp;
             R[GEOAC_REC_JACOB] = D;
         }
+    }
+    // GeoAc_Amplitude / GeoAc_Jacobian of an arbitrary row (arrival rows, raypath samples, caustic detection)
+    static DEVINL void amp_jac(const GeoacDevParams& P, const RayCtx& C, int slot, const double* yr, double& amp, double& D){
+        double z_src = P.src[0] < P.z_grnd ? P.z_grnd : P.src[0];
+        Medium m = medium_at(P, yr[0]);
+        Medium m0 = medium_at(P, z_src + P.r_earth);
+        D = global_jacobian(m, yr);
+        double th_l = P.theta_deg[slot] * kPi / 180.0, ph_l = kPi / 2.0 - P.phi_deg[slot] * kPi / 180.0;
+        amp = global_amplitude(P, m, m0, yr, C.c0, C.nu0, th_l, ph_l, D);
     }
     // GeoAc_ApproximateIntercept + GeoAc_SetReflectionConditions (Global.cpp:140-205); Q1: the quadratic term is a
     // discarded expression in the reference -> linear intercept.  y = row k-1 in, new leg's row 0 out.
@@ -631,25 +639,31 @@ template <bool AMP_> struct Eq3D {
         R[GEOAC_REC_BACKAZ] = baz;
         R[GEOAC_REC_RANGE] = sqrt(yn[0] * yn[0] + yn[1] * yn[1]);
         if(AMP){
-            Medium m = medium_at(P, yn[2]);
-            Medium m0 = medium_at(P, z0);
-            double nx = C.a[0], ny = C.a[1], nz = yn[3];
-            double nu_mag  = (m0.c - nx * m.u - ny * m.v) / m.c;
-            double nu_mag0 = 1.0 - (nx * m0.u - ny * m0.v) / m0.c;
-            double cp0 = m.c * nx / nu_mag + m.u, cp1 = m.c * ny / nu_mag + m.v, cp2 = m.c * nz / nu_mag;
-            double cq0 = m0.c * nx / nu_mag0 + m0.u, cq1 = m0.c * ny / nu_mag0 + m0.v;
-            double qx = nx / nu_mag0, qy = ny / nu_mag0;
-            double cq2 = m0.c * sqrt(1.0 - qx * qx - qy * qy);
-            double cpm = sqrt(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
-            double cqm = sqrt(cq0 * cq0 + cq1 * cq1 + cq2 * cq2);
-            double dxds = cp0 / cpm, dyds = cp1 / cpm, dzds = cp2 / cpm;
-            double D = dxds * (yn[5] * yn[10] - yn[9] * yn[6]) - yn[4] * (dyds * yn[10] - dzds * yn[9]) + yn[8] * (dyds * yn[6] - dzds * yn[5]);
-            double th_l = P.theta_deg[slot] * kPi / 180.0;
-            double num = m.rho * nu_mag * (m.c * m.c * m.c) * cqm * cos(th_l);
-            double den = m0.rho * nu_mag0 * (m0.c * m0.c * m0.c) * cpm * D;
-            R[GEOAC_REC_AMP] = 1.0 / (4.0 * kPi) * sqrt(fabs(num / den));
+            double amp, D;
+            amp_jac(P, C, slot, yn, amp, D);
+            R[GEOAC_REC_AMP] = amp;
             R[GEOAC_REC_JACOB] = D;
         }
+    }
+    static DEVINL void amp_jac(const GeoacDevParams& P, const RayCtx& C, int slot, const double* yn, double& amp, double& D){
+        double z0 = P.z_grnd < P.src[2] ? P.src[2] : P.z_grnd;
+        Medium m = medium_at(P, yn[2]);
+        Medium m0 = medium_at(P, z0);
+        double nx = C.a[0], ny = C.a[1], nz = yn[3];
+        double nu_mag  = (m0.c - nx * m.u - ny * m.v) / m.c;
+        double nu_mag0 = 1.0 - (nx * m0.u - ny * m0.v) / m0.c;
+        double cp0 = m.c * nx / nu_mag + m.u, cp1 = m.c * ny / nu_mag + m.v, cp2 = m.c * nz / nu_mag;
+        double cq0 = m0.c * nx / nu_mag0 + m0.u, cq1 = m0.c * ny / nu_mag0 + m0.v;
+        double qx = nx / nu_mag0, qy = ny / nu_mag0;
+        double cq2 = m0.c * sqrt(1.0 - qx * qx - qy * qy);
+        double cpm = sqrt(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
+        double cqm = sqrt(cq0 * cq0 + cq1 * cq1 + cq2 * cq2);
+        double dxds = cp0 / cpm, dyds = cp1 / cpm, dzds = cp2 / cpm;
+        D = dxds * (yn[5] * yn[10] - yn[9] * yn[6]) - yn[4] * (dyds * yn[10] - dzds * yn[9]) + yn[8] * (dyds * yn[6] - dzds * yn[5]);
+        double th_l = P.theta_deg[slot] * kPi / 180.0;
+        double num = m.rho * nu_mag * (m.c * m.c * m.c) * cqm * cos(th_l);
+        double den = m0.rho * nu_mag0 * (m0.c * m0.c * m0.c) * cpm * D;
+        amp = 1.0 / (4.0 * kPi) * sqrt(fabs(num / den));
     }
     // ApproximateIntercept + SetReflectionConditions: 3DStratified.cpp:136-186 (quadratic term kept)
     static DEVINL void reflect(const GeoacDevParams& P, const RayCtx& C, const double* yn, double* y, const double* ym2){
@@ -726,16 +740,21 @@ template <bool AMP_> struct Eq2D {
         R[GEOAC_REC_BACKAZ] = 0.0;
         R[GEOAC_REC_RANGE] = yn[0];
         if(AMP){
-            Medium m = medium_at(P, yn[1]);
-            Medium mg = medium_at(P, P.z_grnd);
-            double drds = m.c / C.c0 * C.a[2];
-            double dzds = m.c / C.c0 * yn[2];
-            double D = yn[0] * (drds * yn[4] - dzds * yn[3]);
-            double num = m.rho * m.c * C.a[2];
-            double den = mg.rho * C.c0 * D;
-            R[GEOAC_REC_AMP] = 1.0 / (4.0 * kPi) * sqrt(fabs(num / den));
+            double amp, D;
+            amp_jac(P, C, slot, yn, amp, D);
+            R[GEOAC_REC_AMP] = amp;
             R[GEOAC_REC_JACOB] = D;
         }
+    }
+    static DEVINL void amp_jac(const GeoacDevParams& P, const RayCtx& C, int slot, const double* yn, double& amp, double& D){
+        Medium m = medium_at(P, yn[1]);
+        Medium mg = medium_at(P, P.z_grnd);
+        double drds = m.c / C.c0 * C.a[2];
+        double dzds = m.c / C.c0 * yn[2];
+        D = yn[0] * (drds * yn[4] - dzds * yn[3]);
+        double num = m.rho * m.c * C.a[2];
+        double den = mg.rho * C.c0 * D;
+        amp = 1.0 / (4.0 * kPi) * sqrt(fabs(num / den));
     }
     // 2DStratified.cpp:74-117
     static DEVINL void reflect(const GeoacDevParams& P, const RayCtx& C, const double* yn, double* y, const double* ym2){
@@ -813,7 +832,7 @@ DEVINL void write_row(const GeoacDevParams& P, int row, int slot, const double* 
     }
 }
 
-template <class EQ, bool LDS>
+template <class EQ, bool LDS, bool SMP>
 __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
     constexpr int E = EQ::E;
     __builtin_amdgcn_s_setprio(3);      // latency-critical serial recurrence: win VALU arbitration against co-resident post-pass waves
@@ -832,7 +851,7 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
 
     int nr = 0, nle = 0;
     bool done = st[ST_DONE * np] != 0.0;
-    if(done){ P.nrows[slot] = 0; P.nlegend[slot] = 0; return; }
+    if(done){ P.nrows[slot] = 0; P.nlegend[slot] = 0; if(SMP) P.nev[slot] = 0; return; }
 
     double y[E], ym2[EQ::KM2 ? E : 1];
     #pragma unroll
@@ -850,12 +869,36 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
     for(int q = 0; q < 6; q++) C.a[q] = st[(ST_AUX0 + q) * np];
     int seg = (int)st[ST_SEG * np];
     unsigned long long steps_here = 0;
+    int nev = 0;                                                // WriteRays / WriteCaustics events of this chunk
+    double dprev = SMP ? st[ST_DPREV * np] : 0.0;               // Jacobian of the previous row (caustic detection)
+    const bool want_rays = SMP && (P.mode & GEOAC_MODE_WRITE_RAYS), want_caus = SMP && EQ::AMP && (P.mode & GEOAC_MODE_WRITE_CAUSTICS);
 
     write_row<EQ>(P, nr++, slot, y);                            // carry row: chunk row 0 = current state
 
     while(nr + 2 <= P.s_rows && !done){
         // running turning height: max over rows m < k of the height component   (GeoAcGlobal_main.cpp:294)
         { double h = EQ::height(P, y); hmax = (hmax < h) ? h : hmax; }
+
+        if(SMP && k >= 1){
+            // y is row m = k (1 <= m < k_final) at chunk row nr-1: the rows the reference's post-pass loop visits
+            // (GeoAcGlobal_main.cpp:264-286).  Raypath sample every sample_stride-th row; caustic where the Jacobian changes sign.
+            const bool smp_row = want_rays && (k % P.smp_stride == 0);
+            if(smp_row || want_caus){
+                double amp = 0.0, D = 0.0;
+                if(EQ::AMP) EQ::amp_jac(P, C, slot, y, amp, D);
+                if(smp_row){
+                    if(nev < P.ev_cap){ P.ev_row[(size_t)nev * np + slot] = nr - 1; P.ev_m[(size_t)nev * np + slot] = (int)k; P.ev_amp[(size_t)nev * np + slot] = amp; }
+                    nev++;
+                }
+                if(want_caus){
+                    if(k > 1 && D * dprev < 0.0){
+                        if(nev < P.ev_cap){ P.ev_row[(size_t)nev * np + slot] = nr - 1; P.ev_m[(size_t)nev * np + slot] = (int)k | (1 << 30); P.ev_amp[(size_t)nev * np + slot] = 0.0; }
+                        nev++;
+                    }
+                    dprev = D;
+                }
+            }
+        }
 
         // ---- GeoAc_Set_ds (Global.cpp:210-217 and twins) ----
         double ds = 0.05 - 0.049 * exp(-EQ::above_ground(P, y) / 0.75);
@@ -933,6 +976,11 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
     #pragma unroll
     for(int q = 0; q < 4; q++) st[(ST_AUX0 + q) * np] = C.a[q];
     P.nrows[slot] = nr; P.nlegend[slot] = nle;
+    if(SMP){
+        st[ST_DPREV * np] = dprev;
+        P.nev[slot] = nev < P.ev_cap ? nev : P.ev_cap;
+        if(nev > P.ev_cap) atomicOr(&P.counters[2], 2ull);
+    }
 
     // ---- step count and live-ray count: lanes of finished rays have already returned, so reduce over the
     //      lanes that are still here (ballot of the active mask), one atomic pair per wave ----
@@ -986,6 +1034,33 @@ __global__ void __launch_bounds__(256) k_accum(GeoacDevParams P){
     int next_end = (e < ne) ? P.legend[(size_t)e * np + slot] : 0x7fffffff;
     int cur_end = -1;
     const bool rays_form = P.rays_form != 0;      // WriteRays/WriteCaustics form of Q7; GeoAc2D always uses it (GeoAc2D_main.cpp:190-192)
+    const int nev = P.ev_cap > 0 ? P.nev[slot] : 0;
+    int ev = 0;
+    auto emit_events = [&](int crow){
+        while(ev < nev && P.ev_row[(size_t)ev * np + slot] == crow){
+        const int mm = P.ev_m[(size_t)ev * np + slot];
+        const int kind = (mm >> 30) & 1, m = mm & 0x3fffffff;
+        unsigned long long o = atomicAdd(&P.counters[3], 1ull);
+        if(o < (unsigned long long)P.smp_cap){
+            double* S = P.smp_out + o * GEOAC_SMP_STRIDE;
+            const double* row = P.path + ((size_t)crow * P.pathw) * np + slot;
+            S[GEOAC_SMP_RAY] = (double)slot; S[GEOAC_SMP_LEG] = (double)leg; S[GEOAC_SMP_M] = (double)m; S[GEOAC_SMP_KIND] = (double)kind;
+            double amp = P.ev_amp[(size_t)ev * np + slot];
+            double amp_db = P.calc_amp ? 20.0 * log10(amp) : 0.0;
+            double v[6] = {0, 0, 0, 0, 0, 0};
+            int np3;                                                   // number of position columns
+            if(P.eqset == GEOAC_EQ_GLOBAL){ v[0] = row[0] - P.r_earth; v[1] = row[np] * 180.0 / kPi; v[2] = row[2 * np] * 180.0 / kPi; np3 = 3; }
+            else if(P.eqset == GEOAC_EQ_3D){ v[0] = row[0]; v[1] = row[np]; double z = row[2 * np]; v[2] = (z < 0.0 ? 0.0 : z); np3 = 3; }   // max(z, 0) in both files (GeoAc3D_main.cpp:257,267)
+            else { v[0] = row[0]; double z = row[np]; v[1] = (kind == 0) ? (z < 0.0 ? 0.0 : z) : z; np3 = 2; }
+            if(kind == 0){ v[np3] = amp_db; v[np3 + 1] = -at; v[np3 + 2] = tt; }
+            else { v[np3] = tt; }
+            #pragma unroll
+            for(int q = 0; q < 6; q++) S[GEOAC_SMP_V0 + q] = v[q];
+        }
+        ev++;
+    }
+    };
+    emit_events(0);             // events on the carry row (the row a previous epoch ended on)
     for(int i = 0; i + 1 < nr; i++){
         if(i == cur_end) continue;                              // (leg-end row -> next leg's start row): not a segment
         const double* cpt = P.contrib + ((size_t)i * 2) * np + slot;
@@ -995,6 +1070,7 @@ __global__ void __launch_bounds__(256) k_accum(GeoacDevParams P){
         } else {
             ltt += cpt[0]; lat += cpt[np];                      // GeoAc_TravelTime / GeoAc_SB_Atten start from 0 per leg
         }
+        emit_events(i + 1);     // raypath / caustic rows at chunk row i+1: the sums now include segment (m-1, m) (GeoAcGlobal_main.cpp:266-284)
         if(last){
             if(!rays_form){ tt += ltt; at += lat; ltt = 0.0; lat = 0.0; }
             double* R = P.rec + ((size_t)slot * (P.bounces + 1) + leg) * GEOAC_REC_STRIDE;
@@ -1031,15 +1107,16 @@ template <class EQ>
 static hipError_t launch_rk4_t(const GeoacDevParams* P, int block, hipStream_t s){
     dim3 b(block), g((P->n_pad + block - 1) / block);
     size_t lds = P->table_in_lds ? (size_t)P->nseg * GEOAC_SEGW * sizeof(double) : 0;
-    if(P->table_in_lds){
-        if(lds > 65536){
-            hipError_t err = hipFuncSetAttribute((const void*)k_rk4<EQ, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if(err != hipSuccess) return err;
-        }
-        hipLaunchKernelGGL((k_rk4<EQ, true>), g, b, lds, s, *P);
-    } else {
-        hipLaunchKernelGGL((k_rk4<EQ, false>), g, b, 0, s, *P);
-    }
+    const bool smp = (P->mode & (GEOAC_MODE_WRITE_RAYS | GEOAC_MODE_WRITE_CAUSTICS)) != 0;
+    #define GEOAC_RK4_LAUNCH(LDSF, SMPF) do { \
+        if(lds > 65536){ \
+            hipError_t err = hipFuncSetAttribute((const void*)k_rk4<EQ, LDSF, SMPF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if(err != hipSuccess) return err; \
+        } \
+        hipLaunchKernelGGL((k_rk4<EQ, LDSF, SMPF>), g, b, lds, s, *P); } while(0)
+    if(P->table_in_lds){ if(smp) GEOAC_RK4_LAUNCH(true, true); else GEOAC_RK4_LAUNCH(true, false); }
+    else               { if(smp) GEOAC_RK4_LAUNCH(false, true); else GEOAC_RK4_LAUNCH(false, false); }
+    #undef GEOAC_RK4_LAUNCH
     return hipGetLastError();
 }
 

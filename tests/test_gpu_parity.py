@@ -51,6 +51,36 @@ def test_alt_config_vs_golden(G, golden, eq):
     compare_records(rec, g["rec_alt"], E=ESIZE[eq][1], hidx=HIDX[eq])
 
 
+@pytest.mark.parametrize("eq", [H.EQ_GLOBAL, H.EQ_3D, H.EQ_2D])
+@pytest.mark.parametrize("amp,mode", [(1, 1), (1, 3), (0, 1)])
+def test_write_rays_and_caustics_modes_vs_golden(G, golden, eq, amp, mode):
+    """WriteRays / WriteCaustics: the Q7 form of the sums, every 25th-row raypath sample and the caustic rows"""
+    g = golden(eq)
+    ctx = _ctx(G, eq, bounces=2, calc_amp=amp, mode=mode)
+    rec, steps = ctx.run(g["theta"], g["phi"])
+    tag = f"amp{amp}_mode{mode}"
+    want = g[f"rec_{tag}"]
+    print(H.EQ_NAMES[eq], tag, max_rel_errors(rec, want, ESIZE[eq][amp], HIDX[eq]))
+    assert steps == int(g[f"steps_{tag}"])
+    compare_records(rec, want, E=ESIZE[eq][amp], hidx=HIDX[eq])
+    smp = ctx.fetch_samples()
+    assert len(smp) == int(g[f"nsmp_{tag}"])                      # same number of raypath + caustic rows
+    if f"smp_{tag}" in g.files:
+        ws = g[f"smp_{tag}"]
+        gs = smp[g[f"smp_idx_{tag}"]]
+        assert np.array_equal(gs[:, :4], ws[:, :4])               # ray, leg, m, kind: exact
+        ray_rows = ws[:, 3] == 0
+        for col in range(4, 10):
+            d = np.abs(gs[:, col] - ws[:, col])
+            scale = np.maximum(np.abs(ws[:, col]), 1e-3 * max(np.abs(ws[:, col]).max(), 1e-30))
+            if col == 7 and eq != H.EQ_2D or (col == 6 and eq == H.EQ_2D):
+                # amplitude column [dB] of raypath rows: 1e-6 relative on the amplitude = 8.7e-6 dB absolute
+                assert (d[ray_rows] <= 8.7e-6 + 1e-6 * np.abs(ws[ray_rows, col])).all(), col
+                assert (d[~ray_rows] / scale[~ray_rows] <= 1e-6).all(), col
+            else:
+                assert (d / scale).max() <= 1e-6, (col, (d / scale).max())
+
+
 def test_global_slice_vs_oracle(G):
     """the phi = -90 slice of the metric fan (90 rays, 2 057 497 steps) against the oracle"""
     th, ph = H.fan_angles()
