@@ -1,0 +1,316 @@
+// geoac_cli.cpp - host drivers `GeoAc2D`, `GeoAc3D`, `GeoAcGlobal` (built three times with -DGEOAC_CLI_SET=0/1/2):
+// the reference's `-prop` command line, .met input and `_results.dat` / `_raypaths.dat` / `_caustics-path#.dat` /
+// `atmo.dat` outputs, with the launch-angle fan integrated by libgeoac_hip.so on the GPU.
+//
+// Surface kept (grammar, defaults, ordering side effects, number formatting):
+//   GeoAcGlobal_RunProp  Code/GeoAcGlobal_main.cpp:116-332      GeoAc3D_RunProp  Code/GeoAc3D_main.cpp:106-313
+//   GeoAc2D_RunProp      Code/GeoAc2D_main.cpp:66-237           GeoAc_WriteProfile  Code/GeoAc/GeoAc.Interface{,.Global}.cpp:78-98
+// Not provided here (out of the accelerated path): -interactive, -eig_search, -eig_direct.
+#include <strings.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../../../include/geoac_hip.h"
+#include "../../../include/geoac_host.h"
+
+#ifndef GEOAC_CLI_SET
+#define GEOAC_CLI_SET 2
+#endif
+
+using namespace std;
+
+static const double Pi = 3.141592653589793238462643;
+static const double kGamR = 0.00040187, kR = 287.05, kGam = 1.4;
+static const char* kName = (GEOAC_CLI_SET == 0) ? "GeoAc2D" : (GEOAC_CLI_SET == 1) ? "GeoAc3D" : "GeoAcGlobal";
+static const int kEq = (GEOAC_CLI_SET == 0) ? GEOAC_EQ_2D : (GEOAC_CLI_SET == 1) ? GEOAC_EQ_3D : GEOAC_EQ_GLOBAL;
+
+static bool string2bool(const string& v){          // GeoAc.Interface.cpp:125-128
+    return !v.empty() && (strcasecmp(v.c_str(), "true") == 0 || atoi(v.c_str()) != 0);
+}
+
+static void usage(){
+    cout << '\n' << "Usage: " << kName << " -prop profile.met [parameter=value ...]" << '\n'
+         << "  GPU (MI355X) build of the " << kName << " launch-angle fan; parameters, defaults and output files follow" << '\n'
+         << "  LANL-Seismoacoustics/GeoAc (see GeoAc_Manual.pdf).  Only the -prop option is provided by this build." << '\n' << '\n';
+}
+
+// host evaluation of the profile splines for atmo.dat only (set-up / reporting code, not the ray path)
+struct Profile {
+    int n = 0;
+    vector<double> x, T, u, v, rho, sl;
+    double eval(const vector<double>& f, const double* s, double xq) const {
+        if(xq > x[n - 1]) xq = x[n - 1];
+        if(xq < x[0]) xq = x[0];
+        int k = 0;
+        while(k < n - 2 && xq > x[k + 1]) k++;
+        double h = x[k + 1] - x[k], X = (xq - x[k]) / h, df = f[k + 1] - f[k];
+        double A = s[k] * h - df, B = -s[k + 1] * h + df;
+        return (1.0 - X) * f[k] + X * f[k + 1] + X * (1.0 - X) * (A * (1.0 - X) + B * X);
+    }
+    double c(double xq) const { return sqrt(kGamR * eval(T, &sl[0], xq)); }
+    double uu(double xq) const { return eval(u, &sl[n], xq); }
+    double vv(double xq) const { return eval(v, &sl[2 * (size_t)n], xq); }
+    double rr(double xq) const { return eval(rho, &sl[3 * (size_t)n], xq); }
+};
+
+// GeoAc_WriteProfile(file, azimuth): Interface.cpp:78-98 / Interface.Global.cpp:78-97
+static void write_profile(const Profile& p, const char* file_name, double azimuth){
+    ofstream file_out; file_out.open(file_name);
+    if(!file_out.is_open()){ cout << "Error opening file, check file name." << '\n'; return; }
+    for(int m = 0; m < 1400; m++){
+        double x0 = (kEq == GEOAC_EQ_GLOBAL ? 6370.0 : 0.0) + m / 10.0;
+        double c = p.c(x0), u = p.uu(x0), v = p.vv(x0), rho = p.rr(x0);
+        file_out << x0 << '\t';
+        file_out << pow(c * 1000.0, 2) / (kR * kGam) << '\t';
+        file_out << u * 1000.0 << '\t';
+        file_out << v * 1000.0 << '\t';
+        file_out << rho << '\t';
+        file_out << rho * pow(c * 1000.0, 2) / kGam * 10.0 << '\t';
+        file_out << c << '\t';
+        file_out << c + cos(azimuth * Pi / 180.0) * u + sin(azimuth * Pi / 180.0) * v;
+        if(kEq != GEOAC_EQ_GLOBAL) file_out << '\t';            // the Cartesian writer ends the row with a tab (Interface.cpp:93-94)
+        file_out << '\n';
+    }
+    file_out.close();
+}
+
+static int run_prop(char* inputs[], int count){
+    double theta_min = 0.5, theta_max = 45.0, theta_step = 0.5;
+    double phi_min = -90.0, phi_max = -90.0, phi_step = 1.0;
+    int bounces = 2;
+    double src_a = 0.0, src_b = 0.0, z_src = 0.0;                 // Global: lat_src, lon_src; (3D x_src, y_src are not settable in -prop)
+    if(kEq == GEOAC_EQ_GLOBAL){ src_a = 30.0; src_b = 0.0; }
+    bool CalcAmp = true, WriteAtmo = false, WriteRays = true, WriteCaustics = false;
+    double freq = 0.1;
+    const char* ProfileFormat = "zTuvdp";
+    double z_grnd = 0.0, tweak_abs = 0.3;
+    char input_check;
+
+    for(int i = 3; i < count; i++) if(strncmp(inputs[i], "profile_format=", 15) == 0) ProfileFormat = inputs[i] + 15;
+
+    // ---- load the profile BEFORE parsing the rest (z_grnd= therefore never reaches the wind taper: Q9) ----
+    Profile prof;
+    prof.n = geoac_met_rows(inputs[2]);
+    if(prof.n < 3){ cout << "Error opening file, check file name" << '\n'; return 1; }
+    prof.x.resize(prof.n); prof.T.resize(prof.n); prof.u.resize(prof.n); prof.v.resize(prof.n); prof.rho.resize(prof.n);
+    prof.sl.resize(4 * (size_t)prof.n);
+    if(geoac_met_load(inputs[2], ProfileFormat, kEq, prof.n, prof.x.data(), prof.T.data(), prof.u.data(), prof.v.data(), prof.rho.data()) != prof.n){
+        cout << "Unrecognized profile option: " << ProfileFormat << ".  Valid options are: zTuvdp and zuvwTdp" << '\n';
+        return 1;
+    }
+    geoac_natural_spline_slopes(prof.n, prof.x.data(), prof.T.data(),   &prof.sl[0]);
+    geoac_natural_spline_slopes(prof.n, prof.x.data(), prof.u.data(),   &prof.sl[prof.n]);
+    geoac_natural_spline_slopes(prof.n, prof.x.data(), prof.v.data(),   &prof.sl[2 * (size_t)prof.n]);
+    geoac_natural_spline_slopes(prof.n, prof.x.data(), prof.rho.data(), &prof.sl[3 * (size_t)prof.n]);
+
+    geoac_params P;
+    geoac_default_params(kEq, &P);
+    P.vert_limit = prof.x[prof.n - 1];                             // GeoAc_SetPropRegion
+
+    for(int i = 3; i < count; i++){
+        const char* a = inputs[i];
+        if(strncmp(a, "theta_min=", 10) == 0){ theta_min = atof(a + 10); }
+        else if(strncmp(a, "theta_max=", 10) == 0){ theta_max = atof(a + 10); }
+        else if(strncmp(a, "theta_step=", 11) == 0){ theta_step = atof(a + 11); }
+        else if(kEq != GEOAC_EQ_2D && strncmp(a, "phi_min=", 8) == 0){ phi_min = atof(a + 8); }
+        else if(kEq != GEOAC_EQ_2D && strncmp(a, "phi_max=", 8) == 0){ phi_max = atof(a + 8); }
+        else if(kEq != GEOAC_EQ_2D && strncmp(a, "phi_step=", 9) == 0){ phi_step = atof(a + 9); }
+        else if(strncmp(a, "azimuth=", 8) == 0){ phi_min = atof(a + 8); phi_max = atof(a + 8); phi_step = 1.0; }
+        else if(strncmp(a, "bounces=", 8) == 0){ bounces = atoi(a + 8); }
+        else if(kEq == GEOAC_EQ_GLOBAL && strncmp(a, "lat_src=", 8) == 0){ src_a = atof(a + 8); }
+        else if(kEq == GEOAC_EQ_GLOBAL && strncmp(a, "lon_src=", 8) == 0){ src_b = atof(a + 8); }
+        else if(strncmp(a, "z_src=", 6) == 0){ z_src = atof(a + 6); }
+        else if(strncmp(a, "z_grnd=", 7) == 0){ z_grnd = atof(a + 7); }
+        else if(kEq != GEOAC_EQ_2D && strncmp(a, "WriteAtmo=", 10) == 0){ WriteAtmo = string2bool(a + 10); }
+        else if(kEq != GEOAC_EQ_2D && strncmp(a, "WriteRays=", 10) == 0){ WriteRays = string2bool(a + 10); }
+        else if(strncmp(a, "freq=", 5) == 0){ freq = atof(a + 5); }
+        else if(strncmp(a, "abs_coeff=", 10) == 0){ tweak_abs = max(0.0, atof(a + 10)); }
+        else if(strncmp(a, "profile_format=", 15) == 0){ ProfileFormat = a + 15; }
+        else if(strncmp(a, "WriteCaustics=", 14) == 0){ WriteCaustics = string2bool(a + 14); }
+        else if(strncmp(a, "CalcAmp=", 8) == 0){ CalcAmp = string2bool(a + 8); }
+        else if(strncmp(a, "alt_max=", 8) == 0){ P.vert_limit = atof(a + 8); }     // Global: a km altitude compared with a radius (Q9)
+        else if(strncmp(a, "rng_max=", 8) == 0){ P.range_limit = atof(a + 8); }
+        else {
+            cout << "***WARNING*** Unrecognized parameter entry: " << a << '\n';
+            cout << "Continue? (y/n):"; cin >> input_check;
+            if(input_check != 'y' && input_check != 'Y') return 0;
+        }
+    }
+    if(kEq == GEOAC_EQ_2D){ WriteRays = true; WriteAtmo = true; }     // GeoAc2D always writes raypaths and atmo.dat
+    if(WriteCaustics) CalcAmp = true;
+
+    // output prefix = input path up to the first '.' (GeoAcGlobal_main.cpp:170-177)
+    char file_title[64];
+    { int m = 0; for(; m < 50 && inputs[2][m] != '\0' && inputs[2][m] != '.'; m++) file_title[m] = inputs[2][m]; file_title[m] = '\0'; }
+    char output_buffer[96];
+
+    if(WriteAtmo) write_profile(prof, "atmo.dat", 90.0 - phi_min);
+
+    // ---- the fan on the GPU ----
+    geoac_ctx* ctx = nullptr;
+    int rc = geoac_create(&ctx, kEq, 0);
+    if(rc){ cout << kName << ": " << geoac_strerror(rc) << '\n'; return 2; }
+    rc = geoac_upload_atmo_1d(ctx, prof.n, prof.x.data(), prof.T.data(), prof.u.data(), prof.v.data(), prof.rho.data(), prof.sl.data());
+    if(rc){ cout << kName << ": " << geoac_last_error(ctx) << '\n'; return 2; }
+    P.z_grnd = z_grnd; P.tweak_abs = tweak_abs; P.freq = freq; P.bounces = bounces; P.calc_amp = CalcAmp ? 1 : 0;
+    P.mode = (WriteRays ? GEOAC_MODE_WRITE_RAYS : 0) | (WriteCaustics ? GEOAC_MODE_WRITE_CAUSTICS : 0);
+    if(kEq == GEOAC_EQ_GLOBAL){ P.src[0] = z_src; P.src[1] = src_a; P.src[2] = src_b; }
+    else if(kEq == GEOAC_EQ_3D){ P.src[0] = 0.0; P.src[1] = 0.0; P.src[2] = z_src; }
+    else { P.src[0] = z_src; P.src[1] = 0.0; P.src[2] = 0.0; }
+    rc = geoac_set_params(ctx, &P);
+    if(rc){ cout << kName << ": " << geoac_last_error(ctx) << '\n'; return 2; }
+
+    long nr;
+    if(kEq == GEOAC_EQ_2D) nr = geoac_fan_enumerate(theta_min, theta_max, theta_step, phi_min, phi_min, 1.0, 0, nullptr, nullptr);
+    else nr = geoac_fan_enumerate(theta_min, theta_max, theta_step, phi_min, phi_max, phi_step, 0, nullptr, nullptr);
+    if(nr < 0) nr = 0;
+    vector<double> th((size_t)max(nr, 1L)), ph((size_t)max(nr, 1L));
+    if(kEq == GEOAC_EQ_2D) geoac_fan_enumerate(theta_min, theta_max, theta_step, phi_min, phi_min, 1.0, nr, th.data(), ph.data());
+    else geoac_fan_enumerate(theta_min, theta_max, theta_step, phi_min, phi_max, phi_step, nr, th.data(), ph.data());
+    const int legs = bounces + 1;
+    vector<double> rec((size_t)max(nr, 1L) * legs * GEOAC_REC_STRIDE, 0.0);
+    vector<double> smp;
+    uint64_t steps = 0;
+    if(nr > 0){
+        rc = geoac_fan_run(ctx, (int)nr, th.data(), ph.data(), rec.data(), &steps);
+        if(rc){ cout << kName << ": " << geoac_last_error(ctx) << '\n'; geoac_destroy(ctx); return 2; }
+        int64_t ns = 0;
+        geoac_fan_sample_count(ctx, &ns);
+        smp.resize((size_t)max<int64_t>(ns, 1) * GEOAC_SMP_STRIDE);
+        if(ns > 0 && geoac_fan_fetch_samples(ctx, smp.data(), ns)){ cout << kName << ": " << geoac_last_error(ctx) << '\n'; geoac_destroy(ctx); return 2; }
+        smp.resize((size_t)ns * GEOAC_SMP_STRIDE);
+    }
+    geoac_destroy(ctx);
+
+    // ---- files, in the reference's formats ----
+    ofstream results, raypath;
+    sprintf(output_buffer, "%s_results.dat", file_title);
+    results.open(output_buffer);
+    if(kEq == GEOAC_EQ_GLOBAL){
+        results << "# theta [deg]" << '\t' << "phi [deg]" << '\t' << "n_b" << '\t' << "lat_0 [deg]" << '\t' << "lon_0 [deg]" << '\t' << "Travel Time [s]"
+                << '\t' << "Celerity [km/s]" << '\t' << "Turning Height [km]" << '\t' << "Inclination [deg]" << '\t' << "Back Azimuth [deg]"
+                << '\t' << "Geo. Atten. [dB]" << '\t' << "Atmo. Atten. [dB]" << '\n';
+    } else if(kEq == GEOAC_EQ_3D){
+        results << "# theta [deg]" << '\t' << "phi [deg]" << '\t' << "n_b" << '\t' << "x_0 [km]" << '\t' << "y_0 [km]" << '\t' << "Travel Time [s]"
+                << '\t' << "Turning Height [km]" << '\t' << "Inclination [deg]" << '\t' << "Back Azimuth [deg]"
+                << '\t' << "Geo. Atten. [dB]" << '\t' << "Atmo. Atten. [dB]" << '\n';
+    } else {
+        results << "# theta [deg]" << '\t' << "phi [deg]" << '\t' << "n_b" << '\t' << "r_0 [km]" << '\t' << "Travel Time [s]"
+                << '\t' << "Turning Height [km]" << '\t' << "Inclination [deg]" << '\t' << "Geo. Atten. [dB]" << '\t' << "Atmo. Atten. [dB]" << '\n';
+    }
+    if(WriteRays){
+        sprintf(output_buffer, "%s_raypaths.dat", file_title);
+        raypath.open(output_buffer);
+        if(kEq == GEOAC_EQ_GLOBAL)  raypath << "# z [km]" << '\t' << "Lat [deg]" << '\t' << "Long [deg]";
+        else if(kEq == GEOAC_EQ_3D) raypath << "# x [km]" << '\t' << "y [km]" << '\t' << "z [km]";
+        else                        raypath << "# r [km]" << '\t' << "z [km]";
+        raypath << '\t' << "Geo. Atten. [dB]" << '\t' << "Atmo. Atten. [dB]" << '\t' << "Travel Time [s]" << '\n';
+    }
+    vector<ofstream> caustics;
+    if(WriteCaustics){
+        caustics.resize((size_t)legs);
+        for(int bnc = 0; bnc <= bounces; bnc++){
+            sprintf(output_buffer, "%s_caustics-path%i.dat", file_title, bnc);
+            caustics[(size_t)bnc].open(output_buffer);
+            if(kEq == GEOAC_EQ_GLOBAL)  caustics[(size_t)bnc] << "# z [km]" << '\t' << "Lat [deg]" << '\t' << "Long [deg]";
+            else if(kEq == GEOAC_EQ_3D) caustics[(size_t)bnc] << "# x [km]" << '\t' << "y [km]" << '\t' << "z [km]";
+            else                        caustics[(size_t)bnc] << "# r [km]" << '\t' << "z [km]";
+            caustics[(size_t)bnc] << '\t' << "Travel Time [s]" << '\n';
+        }
+    }
+
+    size_t sp = 0;
+    const size_t nsmp = smp.size() / GEOAC_SMP_STRIDE;
+    for(long i = 0; i < nr; i++){
+        cout << "Plotting ray path w/ theta = " << th[(size_t)i] << ", phi = " << ph[(size_t)i] << '\n';
+        // raypath / caustic rows of this ray (sorted by ray, leg, m)
+        while(sp < nsmp && (long)smp[sp * GEOAC_SMP_STRIDE + GEOAC_SMP_RAY] == i){
+            const double* S = &smp[sp * GEOAC_SMP_STRIDE];
+            const int leg = (int)S[GEOAC_SMP_LEG], kind = (int)S[GEOAC_SMP_KIND];
+            const double* v = S + GEOAC_SMP_V0;
+            if(kind == 0 && WriteRays){
+                if(kEq == GEOAC_EQ_GLOBAL){
+                    raypath << v[0];
+                    raypath << '\t' << setprecision(8) << v[1];
+                    raypath << '\t' << setprecision(8) << v[2];
+                    raypath << '\t' << v[3] << '\t' << v[4] << '\t' << v[5] << '\n';
+                } else if(kEq == GEOAC_EQ_3D){
+                    raypath << v[0] << '\t' << v[1] << '\t' << v[2] << '\t' << v[3] << '\t' << v[4] << '\t' << v[5] << '\n';
+                } else {
+                    raypath << v[0] << '\t' << v[1] << '\t' << v[2] << '\t' << v[3] << '\t' << v[4] << '\n';
+                }
+            } else if(kind == 1 && WriteCaustics && leg < legs){
+                ofstream& c = caustics[(size_t)leg];
+                if(kEq == GEOAC_EQ_GLOBAL){
+                    c << v[0];
+                    c << '\t' << setprecision(8) << v[1];
+                    c << '\t' << setprecision(8) << v[2];
+                    c << '\t' << v[3] << '\n';
+                } else if(kEq == GEOAC_EQ_3D){
+                    c << v[0] << '\t' << v[1] << '\t' << v[2] << '\t' << v[3] << '\n';
+                } else {
+                    c << v[0] << '\t' << v[1] << '\t' << v[2] << '\n';
+                }
+            }
+            sp++;
+        }
+        for(int b = 0; b < legs; b++){
+            const double* R = &rec[((size_t)i * legs + b) * GEOAC_REC_STRIDE];
+            if(R[GEOAC_REC_VALID] == 0.0) break;                    // BreakCheck: no row for this and later legs
+            results << th[(size_t)i];
+            results << '\t' << ph[(size_t)i];
+            results << '\t' << b;
+            if(kEq == GEOAC_EQ_GLOBAL){
+                results << '\t' << setprecision(8) << R[GEOAC_REC_STATE + 1] * 180.0 / Pi;
+                results << '\t' << setprecision(8) << R[GEOAC_REC_STATE + 2] * 180.0 / Pi;
+                results << '\t' << R[GEOAC_REC_TTIME];
+                results << '\t' << R[GEOAC_REC_RANGE] / R[GEOAC_REC_TTIME];
+                results << '\t' << R[GEOAC_REC_TURN];
+                results << '\t' << R[GEOAC_REC_INCL];
+                results << '\t' << R[GEOAC_REC_BACKAZ];
+            } else if(kEq == GEOAC_EQ_3D){
+                results << '\t' << R[GEOAC_REC_STATE + 0];
+                results << '\t' << R[GEOAC_REC_STATE + 1];
+                results << '\t' << R[GEOAC_REC_TTIME];
+                results << '\t' << R[GEOAC_REC_TURN];
+                results << '\t' << R[GEOAC_REC_INCL];
+                results << '\t' << R[GEOAC_REC_BACKAZ];
+            } else {
+                results << '\t' << R[GEOAC_REC_STATE + 0];
+                results << '\t' << R[GEOAC_REC_TTIME];
+                results << '\t' << R[GEOAC_REC_TURN];
+                results << '\t' << R[GEOAC_REC_INCL];
+            }
+            if(CalcAmp) results << '\t' << 20.0 * log10(R[GEOAC_REC_AMP]);
+            else        results << '\t' << 0.0;
+            results << '\t' << -R[GEOAC_REC_ATTEN];
+            results << '\n';
+        }
+        if(WriteRays) raypath << '\n';                              // blank line after each ray
+        // blank line after each azimuth in results (not in GeoAc2D)
+        if(kEq != GEOAC_EQ_2D && (i + 1 == nr || ph[(size_t)i + 1] != ph[(size_t)i])) results << '\n';
+    }
+    if(WriteRays) raypath.close();
+    results.close();
+    for(auto& c : caustics) c.close();
+    cerr << kName << ": " << nr << " rays, " << steps << " RK4 ray-steps on the GPU" << '\n';
+    return 0;
+}
+
+int main(int argc, char* argv[]){
+    if(argc < 3){ usage(); return 0; }
+    if(strncmp(argv[1], "-prop", 5) == 0) return run_prop(argv, argc);
+    if(strncmp(argv[1], "-interactive", 12) == 0 || strncmp(argv[1], "-eig_search", 11) == 0 || strncmp(argv[1], "-eig_direct", 11) == 0){
+        cout << kName << ": option " << argv[1] << " is not part of the GPU build (only -prop is accelerated)." << '\n';
+        return 3;
+    }
+    cout << "Unrecognized option." << '\n';
+    return 0;
+}

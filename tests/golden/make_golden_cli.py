@@ -1,0 +1,41 @@
+"""Runs the reference's own CLI binaries (oracle/_ref/GeoAc*, compiled from /root/reference by oracle/Makefile)
+on small fans and stores their output FILES (data) under tests/golden/cli/<set>/.  Run here only."""
+import os
+import shutil
+import subprocess
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+CASES = {
+    "global": ("GeoAcGlobal", ["theta_min=15", "theta_max=35", "theta_step=20", "phi_min=-90", "phi_max=-45", "phi_step=45",
+                               "bounces=1", "WriteCaustics=True", "WriteAtmo=True"]),
+    "3d": ("GeoAc3D", ["theta_min=15", "theta_max=35", "theta_step=20", "phi_min=-90", "phi_max=-45", "phi_step=45",
+                       "bounces=1", "WriteCaustics=True", "WriteAtmo=True"]),
+    "2d": ("GeoAc2D", ["theta_min=5", "theta_max=35", "theta_step=15", "azimuth=-80", "bounces=1", "WriteCaustics=True"]),
+    "global_norays": ("GeoAcGlobal", ["theta_min=5", "theta_max=45", "theta_step=8", "azimuth=37", "WriteRays=False", "CalcAmp=False",
+                                      "lat_src=41.131", "lon_src=-112.896", "z_src=1.0", "freq=0.5", "rng_max=900"]),
+}
+
+
+def main():
+    for name, (binary, args) in CASES.items():
+        out = os.path.join(HERE, "cli", name)
+        shutil.rmtree(out, ignore_errors=True)
+        os.makedirs(out)
+        with tempfile.TemporaryDirectory() as td:
+            shutil.copy(os.path.join(HERE, "ToyAtmo.met"), os.path.join(td, "ToyAtmo.met"))
+            subprocess.run([os.path.join(REF, binary), "-prop", "ToyAtmo.met"] + args, cwd=td, check=True,
+                           stdout=subprocess.DEVNULL)
+            for f in sorted(os.listdir(td)):
+                if f.endswith(".dat"):
+                    shutil.copy(os.path.join(td, f), os.path.join(out, f))
+        with open(os.path.join(out, "ARGS"), "w") as fh:
+            fh.write(binary + "\n" + "\n".join(args) + "\n")
+        print(name, sorted(os.listdir(out)), sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()
