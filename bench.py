@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phi-step", type=float, default=1.0, help="azimuth step of the N=1 fan (metric: 1.0)")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured path) or gloo (rehearsal of the N>1 flow on fewer GPUs than ranks)")
     args = ap.parse_args()
 
     import numpy as np
@@ -64,24 +65,28 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev_index = min(local_rank, torch.cuda.device_count() - 1) if world > 1 else 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=args.backend)
     else:
         torch.cuda.set_device(0)
     n_gpus = world
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
+    coll_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     # ---- the fan: 360*N azimuths x 90 inclinations, this rank's azimuth shard ----
     phi_step = args.phi_step / n_gpus
     th_all, ph_all = G.fan_enumerate(phi_min=-180.0, phi_max=180.0 - phi_step * 0.999999, phi_step=phi_step)
     n_theta = 90
     n_az = len(th_all) // n_theta
-    az_idx = np.arange(rank, n_az, n_gpus)
-    sel = (az_idx[:, None] * n_theta + np.arange(n_theta)[None, :]).reshape(-1)
-    theta, phi = th_all[sel], ph_all[sel]
+    from geoac_amd.sharding import gather_records, shard_by_azimuth
+    theta, phi, _ = shard_by_azimuth(th_all, ph_all, n_theta, rank, n_gpus)
 
     stream = torch.cuda.current_stream(dev)
     ctx = G.FanContext(G.EQ_GLOBAL, device=dev.index, stream=stream.cuda_stream)
@@ -89,15 +94,16 @@ def main():
     ctx.set_params(bounces=2, calc_amp=1, mode=0)
     ctx.set_angles(theta, phi)                                 # inputs resident in HBM before timing
     legs = 3
-    rec_local = torch.empty(len(theta) * legs * G.REC_STRIDE, dtype=torch.float64, device=dev)
-    rec_all = torch.empty(world * rec_local.numel(), dtype=torch.float64, device=dev) if world > 1 else None
-    steps_t = torch.zeros(1, dtype=torch.int64, device=dev)
+    rec_local = torch.empty((len(theta), legs, G.REC_STRIDE), dtype=torch.float64, device=dev)
+    steps_t = torch.zeros(1, dtype=torch.int64, device=coll_dev)
+    gathered = {}
 
     def one_pass():
         ctx.launch()
         if world > 1:
-            ctx.copy_records_to(rec_local.data_ptr())
-            dist.all_gather_into_tensor(rec_all, rec_local)    # RCCL gather of arrivals over xGMI
+            ctx.copy_records_to(rec_local.data_ptr())          # D2D on the context's (= torch's current) stream
+            # gather of the arrival records of the whole fan: RCCL all_gather over xGMI (gloo: host rehearsal)
+            gathered["rec"] = gather_records(rec_local if coll_dev == dev else rec_local.cpu(), n_az, n_theta)
             steps_t[0] = ctx.total_steps()
             dist.all_reduce(steps_t)
             return int(steps_t.item())
@@ -122,9 +128,11 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # every leg that produced a row somewhere must be present in the gathered table
+        assert gathered["rec"].shape[0] == n_az * n_theta
 
     local_steps_per_pass = ctx.total_steps()
     if rank == 0:
@@ -140,7 +148,7 @@ def main():
             "config": {"workload": f"GeoAcGlobal -prop ToyAtmo.met, {n_az} az x {n_theta} incl = {n_az * n_theta} rays "
                                    f"(phi step {phi_step:g} deg), bounces=2, CalcAmp=True, WriteRays=False, rng_max=1500",
                        "rays_per_gpu": int(len(theta)), "ray_steps_per_pass": int(total_steps // args.steps),
-                       "parallelism": f"azimuth-sharded x{n_gpus}" + (", RCCL all_gather of arrivals" if world > 1 else "")},
+                       "parallelism": f"azimuth-sharded x{n_gpus}" + (f", {'RCCL' if args.backend == 'nccl' else args.backend} all_gather of arrivals" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "k_rk4_global<true,true>", "launches": rk4_launches,

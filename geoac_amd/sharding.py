@@ -1,0 +1,43 @@
+"""Azimuth sharding of a launch-angle fan over ranks (one process per GPU) and the gather of arrival records.
+
+The fan shards with no data-path exchange (rays are independent); the only collective is the gather of the
+fixed-stride record tables at the end (RCCL over xGMI when the tensors live on GPUs, gloo on CPU for tests)."""
+import numpy as np
+
+
+def shard_by_azimuth(theta, phi, n_theta, rank, world):
+    """rank r takes azimuth indices r, r+world, ... of a phi-major fan with n_theta inclinations per azimuth.
+    Returns (theta_local, phi_local, global_ray_index_local)."""
+    n = len(theta)
+    assert n % n_theta == 0, "fan is not phi-major with a fixed inclination count"
+    n_az = n // n_theta
+    az = np.arange(rank, n_az, world)
+    idx = (az[:, None] * n_theta + np.arange(n_theta)[None, :]).reshape(-1)
+    return theta[idx], phi[idx], idx
+
+
+def shard_sizes(n_az, n_theta, world):
+    return [len(range(r, n_az, world)) * n_theta for r in range(world)]
+
+
+def gather_records(rec_local, n_az, n_theta, group=None):
+    """all-gather per-rank record tables [n_local][legs][stride] (torch tensors, same device on every rank) and
+    return the table of the whole fan in the reference's ray order.  Ranks may hold different ray counts
+    (n_az not divisible by world): tables are padded to the largest shard for the collective."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    sizes = shard_sizes(n_az, n_theta, world)
+    legs, stride = rec_local.shape[1], rec_local.shape[2]
+    nmax = max(sizes)
+    pad = torch.zeros((nmax, legs, stride), dtype=rec_local.dtype, device=rec_local.device)
+    pad[: rec_local.shape[0]] = rec_local
+    out = torch.empty((world * nmax, legs, stride), dtype=rec_local.dtype, device=rec_local.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    out = out.view(world, nmax, legs, stride)
+    full = torch.empty((n_az * n_theta, legs, stride), dtype=rec_local.dtype, device=rec_local.device)
+    for r in range(world):
+        az = torch.arange(r, n_az, world, device=rec_local.device)
+        idx = (az[:, None] * n_theta + torch.arange(n_theta, device=rec_local.device)[None, :]).reshape(-1)
+        full[idx] = out[r, : sizes[r]]
+    return full
