@@ -28,6 +28,20 @@ B_ALG_PER_STEP = 144          # 8 B x E(=18) state row per accept
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
+def pmc_traffic_per_step():
+    """HBM bytes per ray-step of the dominant kernel from the newest committed rocprofv3 PMC summary
+    (profiles/rNN_*_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes of this same command); None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as fh:
+            return float(json.load(fh)["k_rk4_hbm_bytes_per_ray_step"]), os.path.basename(files[-1])
+    except Exception:
+        return None, None
+
+
 def cpu_baseline():
     """the reference's own serial loop on this box's host cores: the phi = -90 slice of the metric fan
     (90 rays, 2 057 497 steps), compiled reference if its prebuilt shim is present, else the plain-C port."""
@@ -140,6 +154,8 @@ def main():
         # dominant kernel = k_rk4_global: algorithmic bytes per launch / average launch duration (HIP events on the
         # kernel's own stream, recorded inside libgeoac_hip around every k_rk4 launch of the timed passes)
         ach_gbs = (B_ALG_PER_STEP * local_steps_per_pass * args.steps) / (rk4_ms * 1e-3) / 1e9 if rk4_ms > 0 else 0.0
+        bps, pmc_src = pmc_traffic_per_step()
+        steps_per_launch = local_steps_per_pass * args.steps / max(rk4_launches, 1)
         out = {
             "metric": "RK4 ray-steps/sec, GeoAcGlobal 360x90 ToyAtmo fan; arrivals within 1e-6 of ref",
             "value": value, "unit": "RK4 ray-steps/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -150,7 +166,9 @@ def main():
                        "rays_per_gpu": int(len(theta)), "ray_steps_per_pass": int(total_steps // args.steps),
                        "parallelism": f"azimuth-sharded x{n_gpus}" + (f", {'RCCL' if args.backend == 'nccl' else args.backend} all_gather of arrivals" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach_gbs / HBM_PEAK_GBS,
+                         "traffic": (bps * steps_per_launch) if bps else None, "traffic_unit": "bytes per launch",
+                         "traffic_source": pmc_src, "achieved_bytes_per_launch": B_ALG_PER_STEP * steps_per_launch,
                          "kernel": "k_rk4_global<true,true>", "launches": rk4_launches,
                          "avg_launch_ms": rk4_ms / max(rk4_launches, 1),
                          "alg_bytes_per_step": B_ALG_PER_STEP,
