@@ -59,6 +59,11 @@ struct geoac_ctx {
     double ms_total = 0, ms_rk4 = 0, ms_post = 0;
     unsigned long long n_epochs = 0, path_bytes_w = 0, path_bytes_r = 0, total_steps = 0, err_flags = 0;
     int s_rows_override = 0;
+    bool no_overlap = false;                      // GEOAC_NO_OVERLAP=1: post-pass on the RK4 stream (diagnostics)
+    int pp_blocks = 0;                            // GEOAC_PP_BLOCKS: post-pass grid (256-thread blocks); 0 = one block per 256 segments.
+                                                  // Measured: a short full-occupancy burst disturbs k_rk4 LESS than a long thin sweep
+                                                  // (avg k_rk4 launch 10.9 ms vs 11.7-12.8 ms at 8192-256 blocks).
+    bool no_pair = false;                         // GEOAC_NO_PAIR=1: force one lane per ray (A/B measurements)
     std::string err;
 };
 
@@ -157,6 +162,12 @@ int geoac_create(geoac_ctx** out, int eqset, int device){
     geoac_default_params(eqset, &ctx->prm);
     const char* sr = getenv("GEOAC_S_ROWS");
     if(sr) ctx->s_rows_override = atoi(sr);
+    const char* nov = getenv("GEOAC_NO_OVERLAP");
+    if(nov && atoi(nov) != 0) ctx->no_overlap = true;
+    const char* ppb = getenv("GEOAC_PP_BLOCKS");
+    if(ppb && atoi(ppb) > 0) ctx->pp_blocks = atoi(ppb);
+    const char* npr = getenv("GEOAC_NO_PAIR");
+    if(npr && atoi(npr) != 0) ctx->no_pair = true;
     const char* sc = getenv("GEOAC_SMP_CAP");
     if(sc && atoll(sc) > 0) ctx->smp_cap = atoll(sc);
     *out = ctx;
@@ -330,8 +341,11 @@ int geoac_fan_launch(geoac_ctx* ctx){
     P.state = (double*)ctx->state.p;
     P.rec = (double*)ctx->rec.p; P.counters = (unsigned long long*)ctx->counters.p;
 
+    // two lanes per ray (EqGlobalPair) for the Global set with amplitudes when no sample capture is requested
+    P.pp_blocks = ctx->pp_blocks;
+    P.lanes_per_ray = (is_global && p.calc_amp && !sampling && !ctx->no_pair) ? 2 : 1;
     // RK4 workgroup shape: with the table in LDS one workgroup owns a CU, so spread the waves over the 256 CUs
-    int waves = P.n_pad / 64;
+    int waves = P.n_pad * P.lanes_per_ray / 64;
     int wpb = (waves + 255) / 256;
     if(wpb < 1) wpb = 1;
     if(wpb > 16) wpb = 16;
@@ -341,7 +355,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
     // ---- epoch pipeline: RK4 of epoch e on the context's stream, post-pass of epoch e on a second stream, chunk
     //      buffers alternate, so k_rk4(e+1) runs beside k_postpass(e)/k_accum(e).  The host only waits for the
     //      live-ray count of each RK4 launch (it must know when to stop). ----
-    hipStream_t s = ctx->stream, sp = ctx->pp_stream;
+    hipStream_t s = ctx->stream, sp = ctx->no_overlap ? ctx->stream : ctx->pp_stream;
     HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 8 * sizeof(unsigned long long), s));
     HIPCHK(hipEventRecord(ctx->ev0, s));
     HIPCHK(geoac_launch_init(&P, s));

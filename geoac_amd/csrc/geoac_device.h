@@ -50,6 +50,8 @@ struct GeoacDevParams {
     int     nseg;                   // spline segments = nodes - 1
     int     s_rows;                 // path rows per epoch chunk
     int     table_in_lds;
+    int     lanes_per_ray;          // 2: Global + CalcAmp without sample capture runs the two-lanes-per-ray kernel
+    int     pp_blocks;              // grid size of the persistent post-pass kernel
     int     rays_form;              // post-pass sums in the WriteRays form (segments 0..k-2, cumulative): Q7
     long long step_limit;           // GeoAc.Solver.cpp:14
     double  x_min, x_max;           // clamp range of the spline abscissa

@@ -103,6 +103,21 @@ DEVINL int seg_find(TabPtr tab, int nseg, double x, int k){
     return k;
 }
 
+// hinted segment step for the RK4 stages: rays move <= 50 m per stage while nodes are ~100 m apart, so the segment index
+// changes by at most one.  Branch-free +-1 move (two dependent LDS round trips, ~10 instructions) with a walk as the
+// never-taken fallback for pathological (very short) segments.
+template <typename TabPtr>
+DEVINL int seg_step(TabPtr tab, int nseg, double x, int k){
+    const auto* p = tab + k * GEOAC_SEGW;
+    const double x0 = p[0], x1 = p[1];
+    int kn = k + ((x > x1 && k < nseg - 1) ? 1 : 0) - ((x < x0 && k > 0) ? 1 : 0);
+    if(kn != k){
+        const auto* q = tab + kn * GEOAC_SEGW;
+        if((x < q[0] && kn > 0) || (x > q[1] && kn < nseg - 1)) kn = seg_find(tab, nseg, x, kn);
+    }
+    return kn;
+}
+
 template <bool D2, typename TabPtr>
 DEVINL void seg_eval(TabPtr tab, int k, double x, Atm9& a){
     const auto* p = tab + k * GEOAC_SEGW;
@@ -146,12 +161,14 @@ DEVINL double rho_eval(const GeoacDevParams& P, int k, double x){
 // y: r, lat, lon, nu_r, nu_t, nu_p | R_lt(3), mu_lt(3) | R_lp(3), mu_lp(3)
 // sth/cth: sin/cos of y[1] supplied by the caller (reused by the range check).
 // ------------------------------------------------------------------------------------------------
-template <bool AMP, typename TabPtr>
+// NQ = number of launch-angle derivative systems carried in y after the 6 base components: 2 = the reference layout
+// (theta then phi), 1 = the two-lanes-per-ray kernel where each lane of a pair carries the base ray and ONE of the two systems.
+template <bool AMP, int NQ, typename TabPtr>
 DEVINL void global_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const double* y, double sth, double cth, double* dy){
     const double r = y[0];
     const double n0 = y[3], n1 = y[4], n2 = y[5];
     const double xe = clampd(r, P.x_min, P.x_max);
-    seg = seg_find(tab, P.nseg, xe, seg);
+    seg = seg_step(tab, P.nseg, xe, seg);
     Atm9 a;
     seg_eval<AMP>(tab, seg, xe, a);
     const double u = a.u, v = a.v, du = a.du, dv = a.dv;
@@ -201,7 +218,7 @@ DEVINL void global_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const doub
         const double ir2 = ir * ir, ico2 = ico * ico;
         const double cnn1 = cn * n1, cnn2 = cn * n2;
         #pragma unroll
-        for(int q = 0; q < 2; q++){
+        for(int q = 0; q < NQ; q++){
             const double R0 = y[6 + 6 * q], R1 = y[7 + 6 * q];
             const double m0 = y[9 + 6 * q], m1 = y[10 + 6 * q], m2 = y[11 + 6 * q];
             const double dnu = __builtin_fma(n0, m0, __builtin_fma(n1, m1, n2 * m2)) * inm;       // d|nu|
@@ -375,7 +392,7 @@ DEVINL void cart3_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCt
     const double nz = y[3];
     const double nx = C.a[0], ny = C.a[1];
     const double xe = clampd(y[2], P.x_min, P.x_max);
-    seg = seg_find(tab, P.nseg, xe, seg);
+    seg = seg_step(tab, P.nseg, xe, seg);
     Atm9 a;
     seg_eval<AMP>(tab, seg, xe, a);
     const double u = a.u, v = a.v, du = a.du, dv = a.dv;
@@ -419,7 +436,7 @@ DEVINL void cart2_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCt
     const double nz = y[2];
     const double cph = C.a[0], sph = C.a[1], cth = C.a[2], sth = C.a[3];
     const double xe = clampd(y[1], P.x_min, P.x_max);
-    seg = seg_find(tab, P.nseg, xe, seg);
+    seg = seg_step(tab, P.nseg, xe, seg);
     Atm9 a;
     seg_eval<AMP>(tab, seg, xe, a);
     const double qT = kGamR * a.T;
@@ -452,7 +469,7 @@ DEVINL void cart2_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCt
 // ================================================================================================
 template <bool AMP_> struct EqGlobal {
     static constexpr bool AMP = AMP_;
-    static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 0;
+    static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 0, LANES = 1;
     static constexpr bool KM2 = false;                              // linear intercept only (Q1)
 
     // GeoAc_SetInitialConditions: EquationSets.Global.cpp:76-136
@@ -489,7 +506,7 @@ template <bool AMP_> struct EqGlobal {
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
         double s2 = C.a[0], c2 = C.a[1];
         if(stage > 0) rot_small(C.a[0], C.a[1], yt[1] - y0[1], s2, c2);
-        global_rhs<AMP>(tab, P, seg, yt, s2, c2, dy);
+        global_rhs<AMP, 2>(tab, P, seg, yt, s2, c2, dy);
     }
     // GeoAc_BreakCheck / GeoAc_GroundCheck on the new row (Global.cpp:500-522)
     static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, long long k, bool& brk, bool& gnd){
@@ -585,9 +602,43 @@ template <bool AMP_> struct EqGlobal {
     }
 };
 
+
+// Two lanes per ray for the Global set with amplitudes: lanes 2j and 2j+1 both carry the base ray j (identical
+// instructions on identical data, so every decision is taken identically) and ONE of the two launch-angle derivative
+// systems each (lane parity 0: d/d(inclination), 1: d/d(azimuth)) - the two systems are the same code on different
+// data (Global.cpp:273-367 is written twice, once per angle).  Halves the auxiliary work on the serial chain and puts
+// a wave on every SIMD for the 32 400-ray metric fan.  Lanes exchange values only at leg ends (arrival record).
+struct EqGlobalPair : EqGlobal<true> {
+    static constexpr int E = 12, LANES = 2;
+    template <typename TabPtr>
+    static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
+        double s2 = C.a[0], c2 = C.a[1];
+        if(stage > 0) rot_small(C.a[0], C.a[1], yt[1] - y0[1], s2, c2);
+        global_rhs<true, 1>(tab, P, seg, yt, s2, c2, dy);
+    }
+    // reflection of the base ray and of this lane's derivative system (Global.cpp:140-205, Q1 linear intercept)
+    static DEVINL void reflect(const GeoacDevParams& P, const RayCtx& C, const double* yn, double* y, const double* ym2){
+        double dr_k = yn[0] - y[0];
+        double dr_g = y[0] - P.ground;
+        double prev[E];
+        #pragma unroll
+        for(int e = 0; e < E; e++) prev[e] = y[e] + (y[e] - yn[e]) / dr_k * dr_g;
+        Medium mr = medium_at(P, prev[0]);
+        double c_ref = mr.c;
+        double dnu_r_ds = -1.0 / c_ref * (C.c0 / c_ref * mr.dc + prev[4] * mr.dv + prev[5] * mr.du
+                                          + c_ref / prev[0] * (prev[4] * prev[4] + prev[5] * prev[5]));
+        #pragma unroll
+        for(int e = 0; e < E; e++) y[e] = prev[e];
+        y[0] = P.ground;
+        y[3] = -prev[3];
+        y[6] = -prev[6];
+        y[9] = -prev[9] + 2.0 * dnu_r_ds * prev[6] / (c_ref / C.c0 * prev[3]);
+    }
+};
+
 template <bool AMP_> struct Eq3D {
     static constexpr bool AMP = AMP_;
-    static constexpr int E = AMP_ ? 12 : 4, PW = 4, HIDX = 2;
+    static constexpr int E = AMP_ ? 12 : 4, PW = 4, HIDX = 2, LANES = 1;
     static constexpr bool KM2 = true;                               // quadratic intercept needs row k-2
 
     // GeoAc_SetInitialConditions: EquationSets.3DStratified.cpp:69-131
@@ -708,7 +759,7 @@ template <bool AMP_> struct Eq3D {
 
 template <bool AMP_> struct Eq2D {
     static constexpr bool AMP = AMP_;
-    static constexpr int E = AMP_ ? 6 : 3, PW = 2, HIDX = 1;
+    static constexpr int E = AMP_ ? 6 : 3, PW = 2, HIDX = 1, LANES = 1;
     static constexpr bool KM2 = true;
 
     // GeoAc_SetInitialConditions: EquationSets.2DStratified.cpp:38-68
@@ -819,9 +870,13 @@ __global__ void __launch_bounds__(256) k_init(GeoacDevParams P){
 // k_rk4: GeoAc_Propagate_RK4 (GeoAc.Solver.cpp:12-72) for one epoch, one ray per lane
 // ------------------------------------------------------------------------------------------------
 template <class EQ>
-DEVINL void write_row(const GeoacDevParams& P, int row, int slot, const double* y){
+DEVINL void write_row(const GeoacDevParams& P, int row, int slot, int q, const double* y){
     double* p = P.path + ((size_t)row * EQ::PW) * P.n_pad + slot;
-    if(EQ::PW == 6){                       // Global: r, lat, lon, nu_r, nu_t, nu_p
+    if(EQ::LANES == 2){                    // pair kernel: lane parity 0 stores r, lat, lon; parity 1 stores nu_r, nu_t, nu_p
+        p += (size_t)(3 * q) * P.n_pad;
+        #pragma unroll
+        for(int c = 0; c < 3; c++) p[(size_t)c * P.n_pad] = q ? y[c + 3] : y[c];
+    } else if(EQ::PW == 6){                // Global: r, lat, lon, nu_r, nu_t, nu_p
         #pragma unroll
         for(int c = 0; c < 6; c++) p[(size_t)c * P.n_pad] = y[c];
     } else if(EQ::PW == 4){                // 3D: x, y, z, nu_z
@@ -844,7 +899,9 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
         for(int q = threadIdx.x; q < total; q += blockDim.x) lds_tab[q] = gtab[q];
         __syncthreads();
     }
-    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int slot = (EQ::LANES == 2) ? (tid >> 1) : tid;       // ray slot
+    const int q = (EQ::LANES == 2) ? (tid & 1) : 0;             // which derivative system this lane carries (pair kernel)
     if(slot >= P.n_pad) return;
     const size_t np = (size_t)P.n_pad;
     double* st = P.state + slot;
@@ -855,7 +912,7 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
 
     double y[E], ym2[EQ::KM2 ? E : 1];
     #pragma unroll
-    for(int e = 0; e < E; e++) y[e] = st[(ST_Y0 + e) * np];
+    for(int e = 0; e < E; e++) y[e] = st[(ST_Y0 + ((EQ::LANES == 2 && e >= 6) ? e + 6 * q : e)) * np];
     if(EQ::KM2){
         #pragma unroll
         for(int e = 0; e < E; e++) ym2[e] = st[(ST_YM2 + e) * np];
@@ -873,7 +930,7 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
     double dprev = SMP ? st[ST_DPREV * np] : 0.0;               // Jacobian of the previous row (caustic detection)
     const bool want_rays = SMP && (P.mode & GEOAC_MODE_WRITE_RAYS), want_caus = SMP && EQ::AMP && (P.mode & GEOAC_MODE_WRITE_CAUSTICS);
 
-    write_row<EQ>(P, nr++, slot, y);                            // carry row: chunk row 0 = current state
+    write_row<EQ>(P, nr++, slot, q, y);                            // carry row: chunk row 0 = current state
 
     while(nr + 2 <= P.s_rows && !done){
         // running turning height: max over rows m < k of the height component   (GeoAcGlobal_main.cpp:294)
@@ -923,7 +980,7 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
         }
 
         k++; steps_here++;
-        write_row<EQ>(P, nr++, slot, yn);
+        write_row<EQ>(P, nr++, slot, q, yn);
 
         bool brk, gnd;
         EQ::checks(P, C, y, yn, k, brk, gnd);
@@ -941,16 +998,32 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
             } else {
                 R[GEOAC_REC_VALID] = 1.0;
                 R[GEOAC_REC_TURN] = hmax;
-                EQ::arrival(P, C, slot, yn, R);
-                #pragma unroll
-                for(int e = 0; e < E; e++) R[GEOAC_REC_STATE + e] = yn[e];
+                if(EQ::LANES == 2){
+                    // assemble the reference's 18-component row from the lane pair (both lanes end up with the same row
+                    // and store the same record)
+                    double yf[18];
+                    #pragma unroll
+                    for(int e = 0; e < 6; e++){
+                        yf[e] = yn[e];
+                        double mine = yn[6 + e], other = __shfl_xor(mine, 1);
+                        yf[6 + e]  = q ? other : mine;
+                        yf[12 + e] = q ? mine : other;
+                    }
+                    EqGlobal<true>::arrival(P, C, slot, yf, R);
+                    #pragma unroll
+                    for(int e = 0; e < 18; e++) R[GEOAC_REC_STATE + e] = yf[e];
+                } else {
+                    EQ::arrival(P, C, slot, yn, R);
+                    #pragma unroll
+                    for(int e = 0; e < E; e++) R[GEOAC_REC_STATE + e] = yn[e];
+                }
                 if(leg >= P.bounces){
                     done = true;
                 } else {
                     EQ::reflect(P, C, yn, y, ym2);
                     leg++; k = 0;
                     EQ::restart(P, C, y);
-                    write_row<EQ>(P, nr++, slot, y);              // leg-start row
+                    write_row<EQ>(P, nr++, slot, q, y);              // leg-start row
                 }
             }
         } else {
@@ -964,9 +1037,9 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
         }
     }
 
-    // ---- save state ----
+    // ---- save state (pair kernel: both lanes store the identical base ray; each stores its own derivative system) ----
     #pragma unroll
-    for(int e = 0; e < E; e++) st[(ST_Y0 + e) * np] = y[e];
+    for(int e = 0; e < E; e++) st[(ST_Y0 + ((EQ::LANES == 2 && e >= 6) ? e + 6 * q : e)) * np] = y[e];
     if(EQ::KM2){
         #pragma unroll
         for(int e = 0; e < E; e++) st[(ST_YM2 + e) * np] = ym2[e];
@@ -984,13 +1057,14 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
 
     // ---- step count and live-ray count: lanes of finished rays have already returned, so reduce over the
     //      lanes that are still here (ballot of the active mask), one atomic pair per wave ----
+    if(q != 0) steps_here = 0;                                   // pair kernel: count each ray once
     const unsigned long long act = __ballot(1);
     unsigned long long s = 0;
     for(int l = 0; l < 64; l++){
         unsigned long long v = __shfl(steps_here, l);
         if((act >> l) & 1ull) s += v;
     }
-    const unsigned long long live = __popcll(__ballot(!done));
+    const unsigned long long live = __popcll(__ballot(!done && q == 0));
     if((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1){
         atomicAdd(&P.counters[0], s);
         atomicAdd(&P.counters[1], live);
@@ -1001,19 +1075,24 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
 // k_postpass: one thread per path segment (row i -> row i+1 of one ray)
 // ------------------------------------------------------------------------------------------------
 template <class EQ>
-__global__ void __launch_bounds__(256) k_postpass(GeoacDevParams P){
-    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = blockIdx.y;
-    if(slot >= P.n_pad) return;
-    if(i + 1 >= P.nrows[slot]) return;
+__global__ void __launch_bounds__(256) k_postpass(GeoacDevParams P, int rows){
+    // grid-stride sweep over (segment row i, ray slot); by default the grid covers the sweep in one pass
     const size_t np = (size_t)P.n_pad;
-    const double* a = P.path + ((size_t)i * EQ::PW) * np + slot;
-    const double* b = a + (size_t)EQ::PW * np;
-    double tt, at;
-    EQ::segment(P, P.state + slot, np, a, b, tt, at);
-    double* o = P.contrib + ((size_t)i * 2) * np + slot;
-    o[0]  = tt;
-    o[np] = at;
+    const int bx = (P.n_pad + 255) / 256;                       // slot-blocks per row
+    const long long total = (long long)bx * (rows - 1);
+    for(long long w = blockIdx.x; w < total; w += gridDim.x){
+        const int i = (int)(w / bx);
+        const int slot = (int)(w % bx) * 256 + threadIdx.x;
+        if(slot >= P.n_pad) continue;
+        if(i + 1 >= P.nrows[slot]) continue;
+        const double* a = P.path + ((size_t)i * EQ::PW) * np + slot;
+        const double* b = a + (size_t)EQ::PW * np;
+        double tt, at;
+        EQ::segment(P, P.state + slot, np, a, b, tt, at);
+        double* o = P.contrib + ((size_t)i * 2) * np + slot;
+        o[0]  = tt;
+        o[np] = at;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1105,7 +1184,8 @@ extern "C" hipError_t geoac_launch_init(const GeoacDevParams* P, hipStream_t s){
 
 template <class EQ>
 static hipError_t launch_rk4_t(const GeoacDevParams* P, int block, hipStream_t s){
-    dim3 b(block), g((P->n_pad + block - 1) / block);
+    const int lanes = P->n_pad * EQ::LANES;
+    dim3 b(block), g((lanes + block - 1) / block);
     size_t lds = P->table_in_lds ? (size_t)P->nseg * GEOAC_SEGW * sizeof(double) : 0;
     const bool smp = (P->mode & (GEOAC_MODE_WRITE_RAYS | GEOAC_MODE_WRITE_CAUSTICS)) != 0;
     #define GEOAC_RK4_LAUNCH(LDSF, SMPF) do { \
@@ -1121,14 +1201,20 @@ static hipError_t launch_rk4_t(const GeoacDevParams* P, int block, hipStream_t s
 }
 
 extern "C" hipError_t geoac_launch_rk4(const GeoacDevParams* P, int block, hipStream_t s){
+    if(P->lanes_per_ray == 2) return launch_rk4_t<EqGlobalPair>(P, block, s);
     GEOAC_DISPATCH_EQ(P, return launch_rk4_t<EQ>(P, block, s));
     return hipErrorNotSupported;
 }
 
 extern "C" hipError_t geoac_launch_postpass(const GeoacDevParams* P, int rows, hipStream_t s){
     if(rows < 2) return hipSuccess;
-    dim3 b(256), g((P->n_pad + 255) / 256, rows - 1);
-    GEOAC_DISPATCH_EQ(P, hipLaunchKernelGGL(k_postpass<EQ>, g, b, 0, s, *P));
+    long long total = (long long)((P->n_pad + 255) / 256) * (rows - 1);
+    long long nbl = P->pp_blocks > 0 ? P->pp_blocks : total;
+    if(total < nbl) nbl = total;
+    if(nbl > 0x7fffffffLL) nbl = 0x7fffffffLL;
+    int nb = (int)nbl;
+    dim3 b(256), g(nb);
+    GEOAC_DISPATCH_EQ(P, hipLaunchKernelGGL(k_postpass<EQ>, g, b, 0, s, *P, rows));
     dim3 g2((P->n_rays + 255) / 256);
     hipLaunchKernelGGL(k_accum, g2, b, 0, s, *P);
     return hipGetLastError();
