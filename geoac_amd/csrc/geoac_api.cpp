@@ -91,14 +91,16 @@ double host_spline_f(const std::vector<double>& xv, const std::vector<double>& f
 
 // cubic of Eval_Spline_f (G2S_Spline1D.cpp:245-281) expanded in powers of t = x - x_k:
 //   f = f_k + s_k t + (B - 2A)/h^2 t^2 + (A - B)/h^3 t^3,  A = s_k h - df,  B = -s_{k+1} h + df
-void seg_coeffs(double x0, double x1, double f0, double f1, double s0, double s1, double* c){
+// `deriv_form`: store (c0, c1, 2 c2, 6 c3) - the layout the kernels' cubic3() evaluates (value + two derivatives in 6 FMAs)
+void seg_coeffs(double x0, double x1, double f0, double f1, double s0, double s1, double* c, bool deriv_form){
     long double h = (long double)x1 - (long double)x0;
     long double df = (long double)f1 - (long double)f0;
     long double A = (long double)s0 * h - df, B = -(long double)s1 * h + df;
+    long double c2 = (B - 2.0L * A) / (h * h), c3 = (A - B) / (h * h * h);
     c[0] = f0;
     c[1] = s0;
-    c[2] = (double)((B - 2.0L * A) / (h * h));
-    c[3] = (double)((A - B) / (h * h * h));
+    c[2] = (double)(deriv_form ? 2.0L * c2 : c2);
+    c[3] = (double)(deriv_form ? 6.0L * c3 : c3);
 }
 
 }  // namespace
@@ -217,10 +219,10 @@ int geoac_upload_atmo_1d(geoac_ctx* ctx, int n, const double* x, const double* T
     for(int k = 0; k < nseg; k++){
         double* s = &seg[(size_t)k * GEOAC_SEGW];
         s[0] = x[k]; s[1] = x[k + 1];
-        seg_coeffs(x[k], x[k + 1], T[k], T[k + 1], sT[k], sT[k + 1], s + 2);
-        seg_coeffs(x[k], x[k + 1], u[k], u[k + 1], su[k], su[k + 1], s + 6);
-        seg_coeffs(x[k], x[k + 1], v[k], v[k + 1], sv[k], sv[k + 1], s + 10);
-        seg_coeffs(x[k], x[k + 1], rho[k], rho[k + 1], sr[k], sr[k + 1], &rt[(size_t)k * 4]);
+        seg_coeffs(x[k], x[k + 1], T[k], T[k + 1], sT[k], sT[k + 1], s + 2, true);
+        seg_coeffs(x[k], x[k + 1], u[k], u[k + 1], su[k], su[k + 1], s + 6, true);
+        seg_coeffs(x[k], x[k + 1], v[k], v[k + 1], sv[k], sv[k + 1], s + 10, true);
+        seg_coeffs(x[k], x[k + 1], rho[k], rho[k + 1], sr[k], sr[k + 1], &rt[(size_t)k * 4], false);
     }
     HIPCHK(ctx->seg.ensure(seg.size() * sizeof(double)));
     HIPCHK(ctx->rhot.ensure(rt.size() * sizeof(double)));
@@ -342,6 +344,12 @@ int geoac_fan_launch(geoac_ctx* ctx){
     P.rec = (double*)ctx->rec.p; P.counters = (unsigned long long*)ctx->counters.p;
 
     // two lanes per ray (EqGlobalPair) for the Global set with amplitudes when no sample capture is requested
+    {   // largest displacement of one RK4 step: ds = max(min(0.05 - ..., ds_max), ds_min)  (GeoAc_Set_ds)
+        double ds_bound = std::max(std::min(0.05, p.ds_max), p.ds_min);
+        double hmin = 1e300;
+        for(int i = 1; i < ctx->n_nodes; i++) hmin = std::min(hmin, ctx->x[i] - ctx->x[i - 1]);
+        P.seg_safe = (hmin >= 1.001 * ds_bound) ? 1 : 0;
+    }
     P.pp_blocks = ctx->pp_blocks;
     P.lanes_per_ray = (is_global && p.calc_amp && !sampling && !ctx->no_pair) ? 2 : 1;
     // RK4 workgroup shape: with the table in LDS one workgroup owns a CU, so spread the waves over the 256 CUs

@@ -1,8 +1,8 @@
 // geoac_device.h - shared host/device definitions of the MI355X ray-fan integrator.
 //
 // Data layout in HBM (all FP64 unless noted):
-//   seg table   [nseg][SEGW]            per spline segment: x0, x1, then cubic coefficients c0..c3 (in t = x - x0)
-//                                       of T, u, v.  Staged into LDS by the RK4 kernel (112 B/segment; ToyAtmo
+//   seg table   [nseg][SEGW]            per spline segment: x0, x1, then the cubic of T, u, v in t = x - x0 as
+//                                       (c0, c1, 2 c2, 6 c3).  Staged into LDS by the RK4 kernel (112 B/segment; ToyAtmo
 //                                       1399 segments = 153 KiB of the CU's 160 KiB).
 //   rho table   [nseg][4]               cubic coefficients of density (needed only at arrivals / in the post-pass)
 //   state       [NSTATE][n_pad]         per-ray persistent state, SoA (ray index fastest => coalesced)
@@ -51,6 +51,7 @@ struct GeoacDevParams {
     int     s_rows;                 // path rows per epoch chunk
     int     table_in_lds;
     int     lanes_per_ray;          // 2: Global + CalcAmp without sample capture runs the two-lanes-per-ray kernel
+    int     seg_safe;               // 1: every spline segment is longer than the largest RK4 step => the +-1 segment move is exact
     int     pp_blocks;              // grid size of the persistent post-pass kernel
     int     rays_form;              // post-pass sums in the WriteRays form (segments 0..k-2, cumulative): Q7
     long long step_limit;           // GeoAc.Solver.cpp:14

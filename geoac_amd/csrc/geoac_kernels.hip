@@ -103,38 +103,44 @@ DEVINL int seg_find(TabPtr tab, int nseg, double x, int k){
     return k;
 }
 
-// hinted segment step for the RK4 stages: rays move <= 50 m per stage while nodes are ~100 m apart, so the segment index
-// changes by at most one.  Branch-free +-1 move (two dependent LDS round trips, ~10 instructions) with a walk as the
-// never-taken fallback for pathological (very short) segments.
+// cubic in the derivative-friendly form (c0, c1, d2 = 2 c2, e3 = 6 c3): f'' = d2 + e3 t, f' = c1 + t/2 (d2 + f''),
+// f = c0 + t (c1 + t/6 (2 d2 + f'')) - 6 FMA-class operations per function for value + both derivatives
+DEVINL void cubic3(double c0, double c1, double d2, double e3, double t, double th, double t6, double& f, double& f1, double& f2){
+    f2 = __builtin_fma(t, e3, d2);
+    const double s2 = d2 + f2;
+    f1 = __builtin_fma(th, s2, c1);
+    f  = __builtin_fma(t, __builtin_fma(t6, d2 + s2, c1), c0);
+}
+
 template <typename TabPtr>
-DEVINL int seg_step(TabPtr tab, int nseg, double x, int k){
-    const auto* p = tab + k * GEOAC_SEGW;
-    const double x0 = p[0], x1 = p[1];
-    int kn = k + ((x > x1 && k < nseg - 1) ? 1 : 0) - ((x < x0 && k > 0) ? 1 : 0);
-    if(kn != k){
-        const auto* q = tab + kn * GEOAC_SEGW;
-        if((x < q[0] && kn > 0) || (x > q[1] && kn < nseg - 1)) kn = seg_find(tab, nseg, x, kn);
-    }
-    return kn;
+DEVINL void seg_eval_at(TabPtr p, double x, Atm9& a){
+    const double t = x - p[0];
+    const double th = 0.5 * t, t6 = t * (1.0 / 6.0);
+    cubic3(p[2],  p[3],  p[4],  p[5],  t, th, t6, a.T, a.dT, a.ddT);
+    cubic3(p[6],  p[7],  p[8],  p[9],  t, th, t6, a.u, a.du, a.ddu);
+    cubic3(p[10], p[11], p[12], p[13], t, th, t6, a.v, a.dv, a.ddv);
 }
 
 template <bool D2, typename TabPtr>
-DEVINL void seg_eval(TabPtr tab, int k, double x, Atm9& a){
-    const auto* p = tab + k * GEOAC_SEGW;
-    double t = x - p[0];
-    double c1, c2, c3;
-    c1 = p[3]; c2 = p[4]; c3 = p[5];
-    a.T  = __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, c3, c2), c1), p[2]);
-    a.dT = __builtin_fma(t, __builtin_fma(t, 3.0 * c3, 2.0 * c2), c1);
-    if(D2) a.ddT = __builtin_fma(t, 6.0 * c3, 2.0 * c2);
-    c1 = p[7]; c2 = p[8]; c3 = p[9];
-    a.u  = __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, c3, c2), c1), p[6]);
-    a.du = __builtin_fma(t, __builtin_fma(t, 3.0 * c3, 2.0 * c2), c1);
-    if(D2) a.ddu = __builtin_fma(t, 6.0 * c3, 2.0 * c2);
-    c1 = p[11]; c2 = p[12]; c3 = p[13];
-    a.v  = __builtin_fma(t, __builtin_fma(t, __builtin_fma(t, c3, c2), c1), p[10]);
-    a.dv = __builtin_fma(t, __builtin_fma(t, 3.0 * c3, 2.0 * c2), c1);
-    if(D2) a.ddv = __builtin_fma(t, 6.0 * c3, 2.0 * c2);
+DEVINL void seg_eval(TabPtr tab, int k, double x, Atm9& a){ seg_eval_at(tab + k * GEOAC_SEGW, x, a); }
+
+// RK4-stage lookup: `off` = element offset (segment index * SEGW) of the segment used by the previous stage.  Rays move
+// <= 50 m per stage while nodes are ~100 m apart, so one branch-free +-1 move (two dependent LDS round trips) finds the
+// segment; the walk is the never-taken fallback for pathological (very short) segments.
+template <typename TabPtr>
+DEVINL void seg_step_eval(TabPtr tab, const GeoacDevParams& P, double x, int& off, Atm9& a){
+    const int last = (P.nseg - 1) * GEOAC_SEGW;
+    {
+        const auto* p = tab + off;
+        const double x0 = p[0], x1 = p[1];
+        off += (((x > x1) & (off < last)) ? GEOAC_SEGW : 0) - (((x < x0) & (off > 0)) ? GEOAC_SEGW : 0);
+    }
+    if(!P.seg_safe){                                             // wave-uniform: only for profiles with nodes closer than one step
+        const auto* p = tab + off;
+        const double x0 = p[0], x1 = p[1];
+        if(((x < x0) & (off > 0)) | ((x > x1) & (off < last))) off = seg_find(tab, P.nseg, x, off / GEOAC_SEGW) * GEOAC_SEGW;
+    }
+    seg_eval_at(tab + off, x, a);
 }
 
 DEVINL double clampd(double x, double lo, double hi){ double e = (hi < x) ? hi : x; return (e < lo) ? lo : e; }
@@ -168,9 +174,8 @@ DEVINL void global_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const doub
     const double r = y[0];
     const double n0 = y[3], n1 = y[4], n2 = y[5];
     const double xe = clampd(r, P.x_min, P.x_max);
-    seg = seg_step(tab, P.nseg, xe, seg);
     Atm9 a;
-    seg_eval<AMP>(tab, seg, xe, a);
+    seg_step_eval(tab, P, xe, seg, a);
     const double u = a.u, v = a.v, du = a.du, dv = a.dv;
 
     // c = sqrt(gamR T), c' = gamR/(2c) T'                      (G2S_GlobalSpline1D.cpp:345-356)
@@ -392,9 +397,8 @@ DEVINL void cart3_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCt
     const double nz = y[3];
     const double nx = C.a[0], ny = C.a[1];
     const double xe = clampd(y[2], P.x_min, P.x_max);
-    seg = seg_step(tab, P.nseg, xe, seg);
     Atm9 a;
-    seg_eval<AMP>(tab, seg, xe, a);
+    seg_step_eval(tab, P, xe, seg, a);
     const double u = a.u, v = a.v, du = a.du, dv = a.dv;
     const double qT = kGamR * a.T;
     const double ic = frsq(qT);
@@ -436,9 +440,8 @@ DEVINL void cart2_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCt
     const double nz = y[2];
     const double cph = C.a[0], sph = C.a[1], cth = C.a[2], sth = C.a[3];
     const double xe = clampd(y[1], P.x_min, P.x_max);
-    seg = seg_step(tab, P.nseg, xe, seg);
     Atm9 a;
-    seg_eval<AMP>(tab, seg, xe, a);
+    seg_step_eval(tab, P, xe, seg, a);
     const double qT = kGamR * a.T;
     const double ic = frsq(qT);
     const double c  = qT * ic;
@@ -504,8 +507,8 @@ template <bool AMP_> struct EqGlobal {
 
     template <typename TabPtr>
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
-        double s2 = C.a[0], c2 = C.a[1];
-        if(stage > 0) rot_small(C.a[0], C.a[1], yt[1] - y0[1], s2, c2);
+        double s2, c2;
+        rot_small(C.a[0], C.a[1], yt[1] - y0[1], s2, c2);          // stage 0: zero angle, exact identity
         global_rhs<AMP, 2>(tab, P, seg, yt, s2, c2, dy);
     }
     // GeoAc_BreakCheck / GeoAc_GroundCheck on the new row (Global.cpp:500-522)
@@ -612,8 +615,8 @@ struct EqGlobalPair : EqGlobal<true> {
     static constexpr int E = 12, LANES = 2;
     template <typename TabPtr>
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
-        double s2 = C.a[0], c2 = C.a[1];
-        if(stage > 0) rot_small(C.a[0], C.a[1], yt[1] - y0[1], s2, c2);
+        double s2, c2;
+        rot_small(C.a[0], C.a[1], yt[1] - y0[1], s2, c2);          // stage 0: zero angle, exact identity
         global_rhs<true, 1>(tab, P, seg, yt, s2, c2, dy);
     }
     // reflection of the base ray and of this lane's derivative system (Global.cpp:140-205, Q1 linear intercept)
@@ -924,7 +927,7 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
     C.c0 = st[ST_C0 * np]; C.nu0 = st[ST_NU0 * np];
     #pragma unroll
     for(int q = 0; q < 6; q++) C.a[q] = st[(ST_AUX0 + q) * np];
-    int seg = (int)st[ST_SEG * np];
+    int seg = (int)st[ST_SEG * np] * GEOAC_SEGW;                // element offset of the current spline segment
     unsigned long long steps_here = 0;
     int nev = 0;                                                // WriteRays / WriteCaustics events of this chunk
     double dprev = SMP ? st[ST_DPREV * np] : 0.0;               // Jacobian of the previous row (caustic detection)
@@ -1045,7 +1048,7 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
         for(int e = 0; e < E; e++) st[(ST_YM2 + e) * np] = ym2[e];
     }
     st[ST_K * np] = (double)k; st[ST_LEG * np] = (double)leg; st[ST_DONE * np] = done ? 1.0 : 0.0;
-    st[ST_HMAX * np] = hmax; st[ST_SEG * np] = (double)seg;
+    st[ST_HMAX * np] = hmax; st[ST_SEG * np] = (double)(seg / GEOAC_SEGW);
     #pragma unroll
     for(int q = 0; q < 4; q++) st[(ST_AUX0 + q) * np] = C.a[q];
     P.nrows[slot] = nr; P.nlegend[slot] = nle;
