@@ -81,6 +81,42 @@ def test_write_rays_and_caustics_modes_vs_golden(G, golden, eq, amp, mode):
                 assert (d / scale).max() <= 1e-6, (col, (d / scale).max())
 
 
+def _irregular_profile(n, seed, zmax=150.0, tiny=True):
+    """raw .met-like columns on an irregular grid (some segments much shorter than an RK4 step)"""
+    raw = np.loadtxt(H.TOYATMO)
+    rng = np.random.default_rng(seed)
+    w = rng.uniform(0.2, 1.8, n - 1)
+    if tiny:
+        w[rng.integers(0, n - 1, n // 20)] = 0.02            # ~3-10 m segments
+    z = np.concatenate([[0.0], np.cumsum(w)])
+    z *= zmax / z[-1]
+    zz = np.minimum(z, raw[-1, 0])
+    cols = [np.interp(zz, raw[:, 0], raw[:, c]) for c in (1, 2, 3, 4)]
+    return z, cols[0], cols[1], cols[2], cols[3]
+
+
+@pytest.mark.parametrize("eq", [H.EQ_GLOBAL, H.EQ_3D])
+@pytest.mark.parametrize("n,lds", [(700, True), (1800, False)])
+def test_irregular_profiles_vs_oracle(G, eq, n, lds):
+    """non-ToyAtmo input: irregular node spacing with segments shorter than a step (segment walk fallback),
+    and a profile too large for LDS (table read through L2)"""
+    z, T, u, v, rho = _irregular_profile(n, seed=n + eq)
+    O = H.Oracle(eq, met=None)
+    O.load_arrays(z, T, u, v, rho)
+    th = np.array([3.0, 12.0, 24.0, 33.0, 41.0]); ph = np.array([-90.0, -30.0, 10.0, 77.0, 140.0])
+    cfg = H.make_cfg(eq, bounces=1, calc_amp=True, mode=0)
+    so, ro, _, _ = O.fan(cfg, th, ph)
+    ctx = G.FanContext(eq, device=0)
+    x = z + (6370.0 if eq == H.EQ_GLOBAL else 0.0)
+    taper = (2.0 / (1.0 + np.exp(-(z - 0.0) / 0.2)) - 1.0) / 1000.0
+    ctx.upload_atmo_1d(x, T, u * taper, v * taper, rho)
+    ctx.set_params(bounces=1, calc_amp=1, mode=0)
+    rec, steps = ctx.run(th, ph)
+    print(H.EQ_NAMES[eq], n, max_rel_errors(rec, ro, ESIZE[eq][1], HIDX[eq]))
+    assert steps == so
+    compare_records(rec, ro, E=ESIZE[eq][1], hidx=HIDX[eq])
+
+
 def test_global_slice_vs_oracle(G):
     """the phi = -90 slice of the metric fan (90 rays, 2 057 497 steps) against the oracle"""
     th, ph = H.fan_angles()
