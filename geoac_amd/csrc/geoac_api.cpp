@@ -356,7 +356,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
     int waves = P.n_pad * P.lanes_per_ray / 64;
     int wpb = (waves + 255) / 256;
     if(wpb < 1) wpb = 1;
-    if(wpb > 16) wpb = 16;
+    if(wpb > 4) wpb = 4;                       // k_rk4 is compiled with __launch_bounds__(256): never launch a larger workgroup
     int block = 64 * wpb;
     if(!P.table_in_lds) block = 64;
 

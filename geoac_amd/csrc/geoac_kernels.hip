@@ -1187,6 +1187,7 @@ extern "C" hipError_t geoac_launch_init(const GeoacDevParams* P, hipStream_t s){
 
 template <class EQ>
 static hipError_t launch_rk4_t(const GeoacDevParams* P, int block, hipStream_t s){
+    if(block < 64 || block > 256 || (block % 64) != 0) return hipErrorInvalidValue;   // k_rk4 carries __launch_bounds__(256)
     const int lanes = P->n_pad * EQ::LANES;
     dim3 b(block), g((lanes + block - 1) / block);
     size_t lds = P->table_in_lds ? (size_t)P->nseg * GEOAC_SEGW * sizeof(double) : 0;
