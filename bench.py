@@ -43,11 +43,11 @@ def pmc_traffic_per_step():
 
 
 def cpu_baseline():
-    """the reference's own serial loop on this box's host cores: the phi = -90 slice of the metric fan
-    (90 rays, 2 057 497 steps), compiled reference if its prebuilt shim is present, else the plain-C port."""
+    """the reference's own serial loop on this box's host cores: three azimuth slices of the metric fan
+    (270 rays, ~6e6 steps, 10-20 s), compiled reference if its prebuilt shim is present, else the plain-C port."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import harness as H
-    th, ph = H.fan_angles()                                   # defaults = the phi=-90 slice
+    th, ph = H.fan_angles(phi_min=-90.0, phi_max=90.0, phi_step=90.0)     # three azimuth slices (-90, 0, 90) of the metric fan
     cfg = H.make_cfg(H.EQ_GLOBAL, bounces=2, calc_amp=True, mode=0)
     if H.ref_available(H.EQ_GLOBAL):
         lib, kind = H.RefShim(H.EQ_GLOBAL, MET), "reference"
@@ -57,7 +57,7 @@ def cpu_baseline():
     steps, _, _, _ = lib.fan(cfg, th, ph)
     dt = time.perf_counter() - t0
     return {"value": steps / dt, "unit": "RK4 ray-steps/s", "cores": 1, "kind": kind,
-            "sample": f"phi=-90 slice of the metric fan: 90 rays, {steps} steps, {dt:.1f} s "
+            "sample": f"phi = -90, 0, 90 slices of the metric fan: {len(th)} rays, {steps} steps, {dt:.1f} s "
                       f"({'compiled reference TUs -O2 (oracle/_ref)' if kind == 'reference' else 'plain-C restatement (oracle/)'})"}
 
 
@@ -151,7 +151,7 @@ def main():
     local_steps_per_pass = ctx.total_steps()
     if rank == 0:
         value = total_steps / dt
-        # dominant kernel = k_rk4_global: algorithmic bytes per launch / average launch duration (HIP events on the
+        # dominant kernel = k_rk4<EqGlobalPair,...>: algorithmic bytes per launch / average launch duration (HIP events on the
         # kernel's own stream, recorded inside libgeoac_hip around every k_rk4 launch of the timed passes)
         ach_gbs = (B_ALG_PER_STEP * local_steps_per_pass * args.steps) / (rk4_ms * 1e-3) / 1e9 if rk4_ms > 0 else 0.0
         bps, pmc_src = pmc_traffic_per_step()
@@ -169,7 +169,7 @@ def main():
                          "frac": ach_gbs / HBM_PEAK_GBS,
                          "traffic": (bps * steps_per_launch) if bps else None, "traffic_unit": "bytes per launch",
                          "traffic_source": pmc_src, "achieved_bytes_per_launch": B_ALG_PER_STEP * steps_per_launch,
-                         "kernel": "k_rk4_global<true,true>", "launches": rk4_launches,
+                         "kernel": "k_rk4<EqGlobalPair,true,false>", "launches": rk4_launches,
                          "avg_launch_ms": rk4_ms / max(rk4_launches, 1),
                          "alg_bytes_per_step": B_ALG_PER_STEP,
                          "rk4_ms_per_pass": rk4_ms / args.steps, "postpass_ms_per_pass": post_ms / args.steps},
