@@ -153,6 +153,18 @@ typedef struct {          /* EquationSets.3DStratified.cpp:23-54 */
     double c_prop[3], c_prop_mag, dc_prop[3][2], dc_prop_mag[2];
 } src_3d;
 
+typedef struct {          /* EquationSets.3DRngDep.cpp:25-55 */
+    double src_loc[3], c0;
+    double c, dc[5], ddc[3][2];
+    double u, du[5], ddu[3][2];
+    double v, dv[5], ddv[3][2];
+    double w, dw[5], ddw[3][2];
+    double nu0, nu_mag, dnu_mag[2];
+    double c_gr[3], c_gr_mag, dc_gr[3][2], dc_gr_mag[2];
+} src_rd;
+
+struct grid3d;
+
 typedef struct {          /* EquationSets.2DStratified.cpp:24-30 */
     double c_eff, c_eff_0, c_eff_diff, c_eff_ddiff;
 } src_2d;
@@ -171,7 +183,10 @@ struct orc_ctx {
     int    EqCnt, CalcAmp;
     double ds_min, ds_max, ray_limit, vert_limit, range_limit;
     /* sources */
-    src_global G; src_3d S3; src_2d S2;
+    src_global G; src_3d S3; src_2d S2; src_rd RD;
+    /* range-dependent sets: grid atmosphere + lateral limits (GeoAc.Parameters.RngDep.cpp:24-28) */
+    struct grid3d* G3;
+    double x_min_limit, x_max_limit, y_min_limit, y_max_limit;
     /* solution array, rows of EqCnt doubles (Interface.cpp:53-58), kept contiguous with stride 18 */
     double* sol; int64_t sol_rows;
 };
@@ -179,12 +194,13 @@ struct orc_ctx {
 #define ROW(ctx,k) ((ctx)->sol + (size_t)(k) * SOLSTRIDE)
 
 orc_ctx* orc_create(int eqset){
-    if(eqset != GEOAC_EQ_2D && eqset != GEOAC_EQ_3D && eqset != GEOAC_EQ_GLOBAL) return NULL;
+    if(eqset != GEOAC_EQ_2D && eqset != GEOAC_EQ_3D && eqset != GEOAC_EQ_GLOBAL && eqset != GEOAC_EQ_3D_RNGDEP) return NULL;
     orc_ctx* c = (orc_ctx*)calloc(1, sizeof(orc_ctx));
     c->eqset = eqset;
     c->ds_min = 0.001; c->ds_max = 0.5;                       /* Parameters.cpp:19-20 */
     if(eqset == GEOAC_EQ_GLOBAL){ c->ray_limit = 10000.0; c->r_earth = 6370.0; }   /* Parameters.Global.cpp:23 */
     else { c->ray_limit = 5000.0; c->vert_limit = 200.0; c->range_limit = 2000.0; c->r_earth = 0.0; }  /* Parameters.cpp:23-25 */
+    if(eqset == GEOAC_EQ_3D_RNGDEP){ c->vert_limit = 160.0; c->x_min_limit = -500.0; c->x_max_limit = 500.0; c->y_min_limit = -500.0; c->y_max_limit = 500.0; }  /* Parameters.RngDep.cpp:24-28 */
     c->tweak_abs = 0.3; c->z_grnd = 0.0;
     return c;
 }
@@ -194,7 +210,8 @@ static void free_atmo(orc_ctx* c){
     free(c->sT); free(c->su); free(c->sv); free(c->srho);
     c->x = c->T = c->u = c->v = c->rho = c->sT = c->su = c->sv = c->srho = NULL; c->n = 0;
 }
-void orc_destroy(orc_ctx* c){ if(!c) return; free_atmo(c); free(c->sol); free(c); }
+static void g3_free(struct grid3d* G);
+void orc_destroy(orc_ctx* c){ if(!c) return; free_atmo(c); g3_free(c->G3); free(c->sol); free(c); }
 
 static void alloc_atmo(orc_ctx* c, int n){
     free_atmo(c); c->n = n;
@@ -297,27 +314,26 @@ static double atm_v_ddiff(orc_ctx* c, double x){ return eval_ddf(clampx(c, x), &
  * `x` is the spline abscissa (z or geocentric r); zr = altitude above sea level used by the gas-fraction fits.
  * Global quirk kept: the reference temperature/pressure are taken at abscissa z_grnd (a km altitude passed
  * as a radius, so it clamps to the lowest node), Absorption.Global.cpp:31-32. */
-static double suthbass_alpha(orc_ctx* c, double x, double freq){
+static double suthbass_core(orc_ctx* c, double zr, double c_grnd, double rho_grnd, double c_pt, double rho_pt, double freq){
     double T_o, P_o, S, X[7], X_ON, Z_rot[2], Z_rot_;
     double sigma, nn, chi, cchi, mu, nu, mu_o;
     double a_cl, a_rot, a_diff, a_vib;
     double T_z, P_z, c_snd_z;
     double A1, A2, B, C, D, E, F, G, H, I, J, K, L, ZZ, hu;
     double f_vib[4], a_vib_c[4], Cp_R[4], Cv_R[4], Theta[4], C_R, A_max, Tr;
-    double zr = x - c->r_earth;          /* Cartesian: z; Global: (r - r_earth) */
 
     mu_o  = 18.192E-6;
-    T_o   = pow(atm_c(c, c->z_grnd)*1000.0,2)/(Rgas*gam);
-    P_o   = atm_rho(c, c->z_grnd)*pow(atm_c(c, c->z_grnd)*1000.0,2)/gam*1000.0;
+    T_o   = pow(c_grnd*1000.0,2)/(Rgas*gam);
+    P_o   = rho_grnd*pow(c_grnd*1000.0,2)/gam*1000.0;
     S     = 117.0;
 
     Cv_R[0] = 5.0/2.0; Cv_R[1] = 5.0/2.0; Cv_R[2] = 3.0; Cv_R[3] = 3.0;
     Cp_R[0] = 7.0/2.0; Cp_R[1] = 7.0/2.0; Cp_R[2] = 4.0; Cp_R[3] = 4.0;
     Theta[0]= 2239.1;  Theta[1]= 3352.0;  Theta[2]= 915.0; Theta[3]= 1037.0;
 
-    T_z     = pow(atm_c(c, x)*1000.0,2)/(Rgas*gam);
-    P_z     = atm_rho(c, x)*pow(atm_c(c, x)*1000.0,2)/gam * 1000.0;
-    c_snd_z = atm_c(c, x);
+    T_z     = pow(c_pt*1000.0,2)/(Rgas*gam);
+    P_z     = rho_pt*pow(c_pt*1000.0,2)/gam * 1000.0;
+    c_snd_z = c_pt;
 
     mu      = mu_o*sqrt(T_z/T_o)*((1.0+S/T_o)/(1.0+S/T_z));
     nu      = (8.0*Pi*freq*mu)/(3.0*P_z);
@@ -380,6 +396,13 @@ static double suthbass_alpha(orc_ctx* c, double x, double freq){
         a_vib        += a_vib_c[m];
     }
     return (a_cl + a_rot + a_diff + a_vib) * c->tweak_abs * 8.685889;
+}
+
+/* 1-D atmosphere wrapper: the medium values SuthBass_Alpha looks up, in its call order (ground state first) */
+static double suthbass_alpha(orc_ctx* c, double x, double freq){
+    double c_g = atm_c(c, c->z_grnd), rho_g = atm_rho(c, c->z_grnd);
+    double c_z = atm_c(c, x), rho_z = atm_rho(c, x);
+    return suthbass_core(c, x - c->r_earth, c_g, rho_g, c_z, rho_z, freq);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -899,57 +922,68 @@ static void s2_reflect(orc_ctx* c, int k){
     }
 }
 
+#include "geoac_oracle_rngdep.inc.c"
+
 /* ------------------------------------------------------------------------------------------ */
 /* dispatch by equation set                                                                     */
 /* ------------------------------------------------------------------------------------------ */
 static void update_sources(orc_ctx* c, const double* y){
     if(c->eqset == GEOAC_EQ_GLOBAL) g_update_sources(c, y);
     else if(c->eqset == GEOAC_EQ_3D) s3_update_sources(c, y);
+    else if(c->eqset == GEOAC_EQ_3D_RNGDEP) rd_update_sources(c, y);
     else s2_update_sources(c, y);
 }
 static double eval_src_eq(const orc_ctx* c, const double* y, int q){
     if(c->eqset == GEOAC_EQ_GLOBAL) return g_eval_src_eq(c, y, q);
     if(c->eqset == GEOAC_EQ_3D) return s3_eval_src_eq(c, y, q);
+    if(c->eqset == GEOAC_EQ_3D_RNGDEP) return rd_eval_src_eq(c, y, q);
     return s2_eval_src_eq(c, y, q);
 }
 static double step_ds(const orc_ctx* c, const double* y){
     if(c->eqset == GEOAC_EQ_GLOBAL) return set_ds(c, y[0] - (c->r_earth + c->z_grnd));
-    if(c->eqset == GEOAC_EQ_3D) return set_ds(c, y[2] - c->z_grnd);
+    if(c->eqset == GEOAC_EQ_3D || c->eqset == GEOAC_EQ_3D_RNGDEP) return set_ds(c, y[2] - c->z_grnd);
     return set_ds(c, y[1] - c->z_grnd);
 }
 static int break_check(const orc_ctx* c, int k){
     if(c->eqset == GEOAC_EQ_GLOBAL) return g_break_check(c, k);
     if(c->eqset == GEOAC_EQ_3D) return s3_break_check(c, k);
+    if(c->eqset == GEOAC_EQ_3D_RNGDEP) return rd_break_check(c, k);
     return s2_break_check(c, k);
 }
 static int ground_check(const orc_ctx* c, int k){
     if(c->eqset == GEOAC_EQ_GLOBAL) return g_ground_check(c, k);
     if(c->eqset == GEOAC_EQ_3D) return s3_ground_check(c, k);
+    if(c->eqset == GEOAC_EQ_3D_RNGDEP) return rd_ground_check(c, k);
     return s2_ground_check(c, k);
 }
 static double tt_seg(orc_ctx* c, int n){
     if(c->eqset == GEOAC_EQ_GLOBAL) return g_tt_seg(c, n);
     if(c->eqset == GEOAC_EQ_3D) return s3_tt_seg(c, n);
+    if(c->eqset == GEOAC_EQ_3D_RNGDEP) return rd_tt_seg(c, n);
     return s2_tt_seg(c, n);
 }
 static double att_seg(orc_ctx* c, int n, double f){
     if(c->eqset == GEOAC_EQ_GLOBAL) return g_att_seg(c, n, f);
     if(c->eqset == GEOAC_EQ_3D) return s3_att_seg(c, n, f);
+    if(c->eqset == GEOAC_EQ_3D_RNGDEP) return rd_att_seg(c, n, f);
     return s2_att_seg(c, n, f);
 }
 static double jacobian(orc_ctx* c, int k){
     if(c->eqset == GEOAC_EQ_GLOBAL) return g_jacobian(c, k);
     if(c->eqset == GEOAC_EQ_3D) return s3_jacobian(c, k);
+    if(c->eqset == GEOAC_EQ_3D_RNGDEP) return rd_jacobian(c, k);
     return s2_jacobian(c, k);
 }
 static double amplitude(orc_ctx* c, int k){
     if(c->eqset == GEOAC_EQ_GLOBAL) return g_amplitude(c, k);
     if(c->eqset == GEOAC_EQ_3D) return s3_amplitude(c, k);
+    if(c->eqset == GEOAC_EQ_3D_RNGDEP) return rd_amplitude(c, k);
     return s2_amplitude(c, k);
 }
 static void reflect(orc_ctx* c, int k){
     if(c->eqset == GEOAC_EQ_GLOBAL) g_reflect(c, k);
     else if(c->eqset == GEOAC_EQ_3D) s3_reflect(c, k);
+    else if(c->eqset == GEOAC_EQ_3D_RNGDEP) rd_reflect(c, k);
     else s2_reflect(c, k);
 }
 
@@ -959,7 +993,7 @@ static void configure(orc_ctx* c, int calc_amp){
     c->CalcAmp = calc_amp ? 1 : 0;
     if(c->eqset == GEOAC_EQ_2D) c->EqCnt = calc_amp ? 6 : 3;
     else if(c->eqset == GEOAC_EQ_3D) c->EqCnt = calc_amp ? 12 : 4;
-    else c->EqCnt = calc_amp ? 18 : 6;
+    else c->EqCnt = calc_amp ? 18 : 6;                          /* Global and the RngDep sets: dim 3, not stratified */
 }
 
 static int64_t step_limit(const orc_ctx* c){ return (int64_t)(c->ray_limit * (int)(1.0/(c->ds_min*10))); }   /* Solver.cpp:14 */
@@ -1007,6 +1041,10 @@ static void apply_cfg(orc_ctx* c, const ref_fan_cfg* cfg){
     c->tweak_abs = cfg->tweak_abs;
     if(cfg->vert_limit == cfg->vert_limit)   c->vert_limit  = cfg->vert_limit;
     if(cfg->range_limit == cfg->range_limit) c->range_limit = cfg->range_limit;
+    if(cfg->xy_limits[0] == cfg->xy_limits[0]) c->x_min_limit = cfg->xy_limits[0];
+    if(cfg->xy_limits[1] == cfg->xy_limits[1]) c->x_max_limit = cfg->xy_limits[1];
+    if(cfg->xy_limits[2] == cfg->xy_limits[2]) c->y_min_limit = cfg->xy_limits[2];
+    if(cfg->xy_limits[3] == cfg->xy_limits[3]) c->y_max_limit = cfg->xy_limits[3];
     int calc = cfg->calc_amp != 0;
     if(cfg->mode & GEOAC_MODE_WRITE_CAUSTICS) calc = 1;
     configure(c, calc);
@@ -1025,6 +1063,9 @@ static void set_ic(orc_ctx* c, const ref_fan_cfg* cfg){
     } else if(c->eqset == GEOAC_EQ_3D){
         double z_src = DMAX(c->z_grnd, cfg->src[2]);
         s3_set_ic(c, cfg->src[0], cfg->src[1], z_src);
+    } else if(c->eqset == GEOAC_EQ_3D_RNGDEP){
+        double z_src = DMAX(c->z_grnd, cfg->src[2]);          /* GeoAc3D.RngDep_main.cpp:165 */
+        rd_set_ic(c, cfg->src[0], cfg->src[1], z_src);
     } else {
         double z_src = DMAX(cfg->src[0], c->z_grnd);
         s2_set_ic(c, 0.0, z_src);
@@ -1036,7 +1077,7 @@ int64_t orc_fan(orc_ctx* c, const ref_fan_cfg* cfg, int n, const double* theta_d
                 double* rec, double* smp, int64_t smp_cap, int64_t* n_smp){
     apply_cfg(c, cfg);
     const int CalcAmp = c->CalcAmp;
-    const int is2d = (c->eqset == GEOAC_EQ_2D), is3d = (c->eqset == GEOAC_EQ_3D);
+    const int is2d = (c->eqset == GEOAC_EQ_2D), isrd = (c->eqset == GEOAC_EQ_3D_RNGDEP), is3d = (c->eqset == GEOAC_EQ_3D) || isrd;
     const int WriteRays = is2d ? 1 : ((cfg->mode & GEOAC_MODE_WRITE_RAYS) != 0);   /* GeoAc2D always writes raypaths */
     const int WriteCaustics = (cfg->mode & GEOAC_MODE_WRITE_CAUSTICS) != 0;
     const int bounces = cfg->bounces;
@@ -1085,9 +1126,10 @@ int64_t orc_fan(orc_ctx* c, const ref_fan_cfg* cfg, int n, const double* theta_d
                             double* S = smp + ns * GEOAC_SMP_STRIDE;
                             S[GEOAC_SMP_RAY] = i; S[GEOAC_SMP_LEG] = bnc_cnt; S[GEOAC_SMP_M] = m; S[GEOAC_SMP_KIND] = 1;
                             if(is2d){        S[4] = y[0]; S[5] = y[1]; S[6] = travel_time_sum; S[7] = 0; }
+                            else if(isrd){   S[4] = y[0]; S[5] = y[1]; S[6] = y[2]; S[7] = 0.0; S[8] = travel_time_sum; S[9] = 0; }   /* GeoAc3D.RngDep_main.cpp:279-284: raw z, a 0.0 column */
                             else if(is3d){   S[4] = y[0]; S[5] = y[1]; S[6] = DMAX(y[2], 0.0); S[7] = travel_time_sum; }
                             else {           S[4] = y[0] - c->r_earth; S[5] = y[1]*180.0/Pi; S[6] = y[2]*180.0/Pi; S[7] = travel_time_sum; }
-                            S[8] = 0; S[9] = 0;
+                            if(!isrd){ S[8] = 0; S[9] = 0; }
                         }
                         ns++;
                     }
@@ -1104,6 +1146,7 @@ int64_t orc_fan(orc_ctx* c, const ref_fan_cfg* cfg, int n, const double* theta_d
             R[GEOAC_REC_ATTEN] = attenuation;
 
             if(BreakCheck) break;
+            if(isrd) h_max = 0.0;                                           /* turning height per leg in the RngDep mains (Q8) */
             for(int m = 0; m < k; m++) h_max = DMAX(h_max, ROW(c, m)[hidx] - hoff);
 
             const double* yk = ROW(c, k);
@@ -1120,6 +1163,14 @@ int64_t orc_fan(orc_ctx* c, const ref_fan_cfg* cfg, int n, const double* theta_d
                 if(back_az >  180.0) back_az -= 360.0;
                 R[GEOAC_REC_INCL] = inclination; R[GEOAC_REC_BACKAZ] = back_az;
                 R[GEOAC_REC_RANGE] = 2.0 * c->r_earth * asin(sqrt(GC_Dist1+GC_Dist2));
+            } else if(isrd){                                                /* GeoAc3D.RngDep_main.cpp:298-301 */
+                double z_src = DMAX(c->z_grnd, cfg->src[2]);
+                double inclination = - asin(g3_c(c->G3, yk[0], yk[1], c->z_grnd) / g3_c(c->G3, cfg->src[0], cfg->src[1], z_src) * yk[5]) * 180.0 / Pi;
+                double back_az = 90.0 - atan2(-yk[4], -yk[3]) * 180.0 / Pi;
+                while(back_az < -180.0) back_az += 360.0;
+                while(back_az >  180.0) back_az -= 360.0;
+                R[GEOAC_REC_INCL] = inclination; R[GEOAC_REC_BACKAZ] = back_az;
+                R[GEOAC_REC_RANGE] = sqrt(yk[0]*yk[0] + yk[1]*yk[1]);
             } else if(is3d){                                                /* GeoAc3D_main.cpp:281-284 */
                 double z_src = DMAX(c->z_grnd, cfg->src[2]);
                 double back_az = phi + 180.0;
@@ -1184,4 +1235,34 @@ int orc_trace_leg0(orc_ctx* c, const ref_fan_cfg* cfg, double theta_deg, double 
         for(int e = 0; e < c->EqCnt; e++) out[(size_t)m*c->EqCnt + e] = ROW(c, m)[e];
     for(int m = 0; m < k; m++) memset(ROW(c, m), 0, sizeof(double) * (size_t)c->EqCnt);
     return chk ? -k : k;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* range-dependent API                                                                          */
+/* ------------------------------------------------------------------------------------------ */
+int orc_load_grid(orc_ctx* c, const char* prefix, const char* locx, const char* locy, const char* format, double z_grnd_at_load){
+    if(c->eqset != GEOAC_EQ_3D_RNGDEP) return -10;
+    g3_free(c->G3);
+    c->G3 = g3_load(prefix, locx, locy, format, z_grnd_at_load);
+    if(!c->G3) return -1;
+    /* GeoAc_SetPropRegion: G2S_MultiDimSpline3D.cpp:25-33 */
+    c->vert_limit = c->G3->z_max;
+    c->x_min_limit = c->G3->x_min; c->x_max_limit = c->G3->x_max;
+    c->y_min_limit = c->G3->y_min; c->y_max_limit = c->G3->y_max;
+    return c->G3->nz;
+}
+void orc_grid_dims(orc_ctx* c, int* nx, int* ny, int* nz){ *nx = c->G3->nx; *ny = c->G3->ny; *nz = c->G3->nz; }
+
+/* out30[i]: AllOrder2 of T, u, v (10 each); api8[i]: c, rho, u, v, c_diff(z), u_diff(z), v_diff(z), c_diff(x) scalar API values */
+void orc_grid_probe(orc_ctx* c, int n, const double* x, const double* y, const double* z, double* out30, double* api8){
+    struct grid3d* G = c->G3;
+    for(int i = 0; i < n; i++){
+        g3_eval_all(G, x[i], y[i], z[i], &G->Temp, 1, out30 + 30*i);
+        g3_eval_all(G, x[i], y[i], z[i], &G->Windu, 1, out30 + 30*i + 10);
+        g3_eval_all(G, x[i], y[i], z[i], &G->Windv, 1, out30 + 30*i + 20);
+        double* a = api8 + 8*i;
+        a[0] = g3_c(G, x[i], y[i], z[i]); a[1] = g3_rho(G, x[i], y[i], z[i]); a[2] = g3_u(G, x[i], y[i], z[i]); a[3] = g3_v(G, x[i], y[i], z[i]);
+        a[4] = g3_c_diff(G, x[i], y[i], z[i], 2); a[5] = g3_u_diff(G, x[i], y[i], z[i], 2); a[6] = g3_v_diff(G, x[i], y[i], z[i], 2);
+        a[7] = g3_c_diff(G, x[i], y[i], z[i], 0);
+    }
 }

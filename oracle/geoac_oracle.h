@@ -40,6 +40,11 @@ int      orc_tables(orc_ctx*, int cap, double* x, double* T, double* u, double* 
                     double* sT, double* su, double* sv, double* srho);
 int      orc_trace_leg0(orc_ctx*, const ref_fan_cfg* cfg, double theta_deg, double phi_deg, int max_rows, double* out, int* E);
 
+/* range-dependent Cartesian set (GEOAC_EQ_3D_RNGDEP): grid of profiles <prefix><n>.met, n = ix*ny + iy */
+int      orc_load_grid(orc_ctx*, const char* prefix, const char* locx, const char* locy, const char* format, double z_grnd_at_load);
+void     orc_grid_dims(orc_ctx*, int* nx, int* ny, int* nz);
+void     orc_grid_probe(orc_ctx*, int n, const double* x, const double* y, const double* z, double* out30, double* api8);
+
 /* limits chosen by GeoAc_SetPropRegion for the loaded profile */
 void     orc_limits(orc_ctx*, double* vert_limit, double* range_limit);
 

@@ -31,6 +31,8 @@ typedef struct {
     int    bounces;
     int    calc_amp;
     int    mode;
+    int    pad_;
+    double xy_limits[4];  /* RngDep sets: x_min, x_max, y_min, y_max limits; NaN = keep what GeoAc_SetPropRegion chose */
 } ref_fan_cfg;
 
 /* Spline_Single_G2S(file, format); returns number of profile rows */
@@ -50,6 +52,10 @@ void    ref_absorption_probe(int n, const double* x, const double* f, double z_g
 /* spline tables as the reference built them: fills x,T,u,v,rho and the four slope arrays (each n doubles) */
 int     ref_tables(int cap, double* x, double* T, double* u, double* v, double* rho,
                    double* sT, double* su, double* sv, double* srho);
+/* range-dependent sets only: Spline_Multi_G2S(prefix, locx, locy, format) after setting z_grnd (the RngDep mains parse
+ * z_grnd= before loading); and probes of the grid interpolant (layout as orc_grid_probe) */
+int     ref_load_grid(const char* prefix, const char* locx, const char* locy, const char* format, double z_grnd_at_load);
+void    ref_grid_probe(int n, const double* x, const double* y, const double* z, double* out30, double* api8);
 /* full state row dump of one leg-0 propagation (for stepper-level tests): out rows*(E) doubles, returns k */
 int     ref_trace_leg0(const ref_fan_cfg* cfg, double theta_deg, double phi_deg, int max_rows, double* out, int* E);
 

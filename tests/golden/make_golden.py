@@ -93,5 +93,44 @@ def main():
         print(name, "->", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def main_rngdep():
+    """3D.RngDep: synthetic 5x5 grid (tests/rngdep_data.py), compiled reference libref_3drd.so"""
+    import tempfile
+    import rngdep_data as RD
+    RD.save_grid_npz()
+    grid = RD.write_grid(os.path.join(tempfile.gettempdir(), "gd"))
+    eq = H.EQ_3D_RNGDEP
+    R = H.RefShim(eq, grid=grid)
+    out = {}
+    rng = np.random.default_rng(2024)
+    n = 400
+    x = rng.uniform(-1100, 1100, n); y = rng.uniform(-900, 900, n); z = rng.uniform(-1, 141, n)
+    x[:6] = [-1000, 1000, 0, 500, -500, 250]; y[:6] = [-800, 800, 0, -400, 400, 0]; z[:6] = [0, 139.6, 10, 0.4, 70, 0.0]
+    o30, a8 = R.grid_probe(x, y, z)
+    out.update(probe_x=x, probe_y=y, probe_z=z, probe_out30=o30, probe_api8=a8)
+    th = np.array([3.0, 9.0, 16.0, 24.0, 31.0, 40.0]); ph = np.array([-90.0, -35.0, 20.0, 75.0, 130.0, -160.0])
+    out.update(theta=th, phi=ph)
+    for amp in (1, 0):
+        for mode in (0, 3):
+            cfg = H.make_cfg(eq, bounces=1, calc_amp=bool(amp), mode=mode, src=(0.0, 0.0, 0.0))
+            steps, rec, smp, nsmp = R.fan(cfg, th, ph, smp_cap=40000)
+            tag = f"amp{amp}_mode{mode}"
+            out[f"rec_{tag}"] = rec; out[f"steps_{tag}"] = np.int64(steps); out[f"nsmp_{tag}"] = np.int64(nsmp)
+            if amp == 1 and mode == 3:
+                sel = np.arange(0, len(smp), 4)
+                out[f"smp_idx_{tag}"] = sel; out[f"smp_{tag}"] = smp[sel]
+    # off-centre source, raised ground (enters the wind taper in this main), tighter box
+    cfg = H.make_cfg(eq, bounces=2, calc_amp=True, mode=0, src=(120.0, -60.0, 1.0), freq=0.4, tweak_abs=0.6,
+                     xy_limits=(-700.0, 900.0, -600.0, 700.0))
+    steps, rec, _, _ = R.fan(cfg, th, ph)
+    out["rec_alt"] = rec; out["steps_alt"] = np.int64(steps)
+    path = os.path.join(OUT, "3drd_small.npz")
+    np.savez_compressed(path, **out)
+    print("3drd ->", path, os.path.getsize(path) // 1024, "KiB;", os.path.getsize(RD.GRID_NPZ) // 1024, "KiB grid")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "rngdep":
+        main_rngdep()
+    else:
+        main()

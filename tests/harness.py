@@ -11,8 +11,8 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 TOYATMO = os.path.join(GOLDEN_DIR, "ToyAtmo.met")
 
-EQ_2D, EQ_3D, EQ_GLOBAL = 0, 1, 2
-EQ_NAMES = {EQ_2D: "2d", EQ_3D: "3d", EQ_GLOBAL: "global"}
+EQ_2D, EQ_3D, EQ_GLOBAL, EQ_3D_RNGDEP = 0, 1, 2, 3
+EQ_NAMES = {EQ_2D: "2d", EQ_3D: "3d", EQ_GLOBAL: "global", EQ_3D_RNGDEP: "3drd"}
 REC_STRIDE = 32
 SMP_STRIDE = 10
 REC = dict(VALID=0, STEPS=1, BROKE=2, TTIME=3, ATTEN=4, TURN=5, INCL=6, BACKAZ=7, AMP=8, RANGE=9, JACOB=10, STATE=12)
@@ -25,15 +25,17 @@ class FanCfg(ctypes.Structure):
     _fields_ = [("z_grnd", ctypes.c_double), ("tweak_abs", ctypes.c_double), ("freq", ctypes.c_double),
                 ("vert_limit", ctypes.c_double), ("range_limit", ctypes.c_double),
                 ("src", ctypes.c_double * 3), ("bounces", ctypes.c_int), ("calc_amp", ctypes.c_int),
-                ("mode", ctypes.c_int)]
+                ("mode", ctypes.c_int), ("pad_", ctypes.c_int), ("xy_limits", ctypes.c_double * 4)]
 
 
 def make_cfg(eqset, bounces=2, calc_amp=True, mode=0, src=None, z_grnd=0.0, tweak_abs=0.3, freq=0.1,
-             vert_limit=float("nan"), range_limit=float("nan")):
+             vert_limit=float("nan"), range_limit=float("nan"), xy_limits=None):
     if src is None:
         src = (0.0, 30.0, 0.0) if eqset == EQ_GLOBAL else (0.0, 0.0, 0.0)
+    if xy_limits is None:
+        xy_limits = (float("nan"),) * 4
     return FanCfg(z_grnd, tweak_abs, freq, vert_limit, range_limit, (ctypes.c_double * 3)(*src),
-                  bounces, 1 if calc_amp else 0, mode)
+                  bounces, 1 if calc_amp else 0, mode, 0, (ctypes.c_double * 4)(*xy_limits))
 
 
 def _p(a):
@@ -87,7 +89,7 @@ class Oracle(_FanLib):
         L.orc_create.argtypes = [ctypes.c_int]
         L.orc_fan.restype = ctypes.c_int64
         for f in (L.orc_destroy, L.orc_load, L.orc_load_arrays, L.orc_fan, L.orc_atmo_probe,
-                  L.orc_absorption_probe, L.orc_tables, L.orc_trace_leg0, L.orc_limits):
+                  L.orc_absorption_probe, L.orc_tables, L.orc_trace_leg0, L.orc_limits, L.orc_load_grid, L.orc_grid_probe):
             f.argtypes = None
         self.eqset = eqset
         self.ctx = ctypes.c_void_p(L.orc_create(eqset))
@@ -96,6 +98,17 @@ class Oracle(_FanLib):
             n = L.orc_load(self.ctx, met.encode(), fmt.encode())
             assert n > 0, f"orc_load({met}) -> {n}"
             self.n = n
+
+    def load_grid(self, prefix, locx, locy, fmt="zTuvdp", z_grnd=0.0):
+        n = self.lib.orc_load_grid(self.ctx, prefix.encode(), locx.encode(), locy.encode(), fmt.encode(), ctypes.c_double(z_grnd))
+        assert n > 0, f"orc_load_grid -> {n}"
+        self.n = n
+
+    def grid_probe(self, x, y, z):
+        x, y, z = (np.ascontiguousarray(a, dtype=np.float64) for a in (x, y, z))
+        o = np.zeros((len(x), 30)); a = np.zeros((len(x), 8))
+        self.lib.orc_grid_probe(self.ctx, len(x), _p(x), _p(y), _p(z), _p(o), _p(a))
+        return o, a
 
     def load_arrays(self, z, T, u, v, rho):
         arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (z, T, u, v, rho)]
@@ -152,15 +165,19 @@ class RefShim(_FanLib):
     One instance per equation set per process (the reference keeps its state in globals)."""
     _loaded = {}
 
-    def __init__(self, eqset, met=TOYATMO, fmt="zTuvdp"):
+    def __init__(self, eqset, met=TOYATMO, fmt="zTuvdp", grid=None, z_grnd=0.0):
+        """grid = (prefix, locx, locy) for the range-dependent sets"""
         path = os.path.join(ORACLE_DIR, "_ref", f"libref_{EQ_NAMES[eqset]}.so")
-        key = (eqset, met, fmt)
+        key = (eqset, met if grid is None else tuple(grid) + (z_grnd,), fmt)
         if eqset in RefShim._loaded and RefShim._loaded[eqset][0] != key:
             raise RuntimeError("reference shim already loaded with another profile in this process")
         if eqset not in RefShim._loaded:
             lib = ctypes.CDLL(path)
             lib.ref_fan.restype = ctypes.c_int64
-            n = lib.ref_load(met.encode(), fmt.encode())
+            if grid is None:
+                n = lib.ref_load(met.encode(), fmt.encode())
+            else:
+                n = lib.ref_load_grid(grid[0].encode(), grid[1].encode(), grid[2].encode(), fmt.encode(), ctypes.c_double(z_grnd))
             assert n > 0
             RefShim._loaded[eqset] = (key, lib, n)
         _, self.lib, self.n = RefShim._loaded[eqset]
@@ -180,6 +197,12 @@ class RefShim(_FanLib):
         o = np.zeros(len(x))
         self.lib.ref_absorption_probe(len(x), _p(x), _p(f), ctypes.c_double(z_grnd), ctypes.c_double(tweak), _p(o))
         return o
+
+    def grid_probe(self, x, y, z):
+        x, y, z = (np.ascontiguousarray(a, dtype=np.float64) for a in (x, y, z))
+        o = np.zeros((len(x), 30)); a = np.zeros((len(x), 8))
+        self.lib.ref_grid_probe(len(x), _p(x), _p(y), _p(z), _p(o), _p(a))
+        return o, a
 
     def tables(self):
         n = self.n

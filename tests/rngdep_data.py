@@ -1,0 +1,64 @@
+"""Deterministic synthetic range-dependent atmosphere for the 3D.RngDep tests: a grid of perturbed, vertically thinned
+copies of ToyAtmo.met written as <prefix><n>.met (n = ix*ny + iy, the reference's file index, G2S_MultiDimSpline3D.cpp:154)
+plus loc_x.dat / loc_y.dat.  Non-square cells (dx != dy) so that quirk Q11 matters."""
+import os
+
+import numpy as np
+
+import harness as H
+
+X_NODES = np.array([-1000.0, -500.0, 0.0, 500.0, 1000.0])
+Y_NODES = np.array([-800.0, -400.0, 0.0, 400.0, 800.0])
+THIN = 4                      # keep every 4th ToyAtmo row: 350 nodes, dz = 0.4 km
+
+
+def grid_columns():
+    """returns z [nz], and T, u, v, rho as [nx][ny][nz] (raw .met units: K, m/s, m/s, g/cm^3)"""
+    raw = np.loadtxt(H.TOYATMO)[::THIN]
+    z = raw[:, 0]
+    nx, ny = len(X_NODES), len(Y_NODES)
+    T = np.zeros((nx, ny, len(z))); u = np.zeros_like(T); v = np.zeros_like(T); rho = np.zeros_like(T)
+    for i, x in enumerate(X_NODES):
+        for j, y in enumerate(Y_NODES):
+            bump = np.exp(-((z - 45.0) / 25.0) ** 2)
+            T[i, j] = raw[:, 1] * (1.0 + 0.015 * np.sin(x / 700.0 + y / 900.0) * bump + 0.004 * np.cos(x / 450.0) * np.sin(y / 380.0))
+            u[i, j] = raw[:, 2] + 12.0 * (x / 1000.0) * bump + 3.0 * np.sin(y / 500.0)
+            v[i, j] = raw[:, 3] + 8.0 * (y / 800.0) * bump - 2.5 * np.cos(x / 600.0) * np.exp(-z / 60.0)
+            rho[i, j] = raw[:, 4] * (1.0 + 0.01 * np.cos(x / 800.0 - y / 650.0))
+    return z, T, u, v, rho, raw[:, 5]
+
+
+GRID_NPZ = os.path.join(H.GOLDEN_DIR, "rngdep_grid.npz")
+
+
+def save_grid_npz():
+    """(make_golden.py) evaluates the analytic perturbation once and stores the columns, so that the files written at
+    test time are the same bytes on every machine"""
+    z, T, u, v, rho, p = grid_columns()
+    np.savez_compressed(GRID_NPZ, z=z, T=T, u=u, v=v, rho=rho, p=p, x=X_NODES, y=Y_NODES)
+
+
+def load_grid_columns():
+    g = np.load(GRID_NPZ)
+    return g["z"], g["T"], g["u"], g["v"], g["rho"], g["p"]
+
+
+def write_grid(dirpath):
+    """writes the files; returns (prefix, locx, locy).  Paths must stay short: the reference formats file names into a
+    50-byte buffer (G2S_MultiDimSpline3D.cpp:112,154)."""
+    os.makedirs(dirpath, exist_ok=True)
+    z, T, u, v, rho, p = load_grid_columns()
+    prefix = os.path.join(dirpath, "p")
+    assert len(prefix) < 40
+    for i in range(len(X_NODES)):
+        for j in range(len(Y_NODES)):
+            n = i * len(Y_NODES) + j
+            with open(f"{prefix}{n}.met", "w") as fh:
+                for k in range(len(z)):
+                    fh.write(f"{z[k]:.10g} {T[i, j, k]:.12g} {u[i, j, k]:.12g} {v[i, j, k]:.12g} {rho[i, j, k]:.12g} {p[k]:.10g}\n")
+    locx, locy = os.path.join(dirpath, "loc_x.dat"), os.path.join(dirpath, "loc_y.dat")
+    with open(locx, "w") as fh:
+        fh.write("".join(f"{x:.10g}\n" for x in X_NODES))
+    with open(locy, "w") as fh:
+        fh.write("".join(f"{y:.10g}\n" for y in Y_NODES))
+    return prefix, locx, locy
