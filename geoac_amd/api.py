@@ -24,7 +24,7 @@ class Params(ctypes.Structure):
                 ("vert_limit", ctypes.c_double), ("range_limit", ctypes.c_double), ("z_grnd", ctypes.c_double),
                 ("r_earth", ctypes.c_double), ("tweak_abs", ctypes.c_double), ("freq", ctypes.c_double),
                 ("src", ctypes.c_double * 3), ("bounces", ctypes.c_int), ("calc_amp", ctypes.c_int),
-                ("mode", ctypes.c_int), ("sample_stride", ctypes.c_int)]
+                ("mode", ctypes.c_int), ("sample_stride", ctypes.c_int), ("xy_limits", ctypes.c_double * 4)]
 
 
 def library_path():
@@ -48,6 +48,7 @@ def load_library():
     lib.geoac_last_error.restype = ctypes.c_char_p
     lib.geoac_last_error.argtypes = [ctypes.c_void_p]
     lib.geoac_version.restype = ctypes.c_char_p
+    lib.geoac_grid_load.argtypes = None
     lib.geoac_fan_enumerate.restype = ctypes.c_long
     lib.geoac_fan_enumerate.argtypes = [ctypes.c_double] * 6 + [ctypes.c_long, _dp, _dp]
     _lib = lib
@@ -142,6 +143,26 @@ class FanContext:
         slopes4 = _arr(slopes4)
         self._chk(self.lib.geoac_upload_atmo_1d(self._h, len(x), _p(x), _p(T), _p(u), _p(v), _p(rho), _p(slopes4)))
 
+    def upload_atmo_3d(self, x, y, z, T, u, v, rho):
+        """grid of profiles: fields [nx][ny][nz] (winds already tapered, km/s)"""
+        x, y, z, T, u, v, rho = (_arr(a) for a in (x, y, z, T, u, v, rho))
+        self._chk(self.lib.geoac_upload_atmo_3d(self._h, len(x), len(y), len(z), _p(x), _p(y), _p(z), _p(T), _p(u), _p(v), _p(rho)))
+
+    def load_grid(self, prefix, locx, locy, fmt="zTuvdp", z_grnd=0.0):
+        """Spline_Multi_G2S equivalent: <prefix><n>.met files + loc_x / loc_y node files"""
+        nx, ny, nz = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        if self.lib.geoac_grid_dims(prefix.encode(), locx.encode(), locy.encode(), ctypes.byref(nx), ctypes.byref(ny), ctypes.byref(nz)):
+            raise GeoAcError(f"cannot read grid {prefix}")
+        nx, ny, nz = nx.value, ny.value, nz.value
+        x, y, z = np.zeros(nx), np.zeros(ny), np.zeros(nz)
+        F = [np.zeros((nx, ny, nz)) for _ in range(4)]
+        rc = self.lib.geoac_grid_load(prefix.encode(), locx.encode(), locy.encode(), fmt.encode(), ctypes.c_double(z_grnd),
+                                      nx, ny, nz, _p(x), _p(y), _p(z), *[_p(f) for f in F])
+        if rc:
+            raise GeoAcError(f"geoac_grid_load -> {rc}")
+        self.upload_atmo_3d(x, y, z, *F)
+        return dict(x=x, y=y, z=z, T=F[0], u=F[1], v=F[2], rho=F[3])
+
     def load_met(self, path, fmt="zTuvdp"):
         a = met_load(path, self.eqset, fmt)
         self.upload_atmo_1d(a["x"], a["T"], a["u"], a["v"], a["rho"])
@@ -151,6 +172,8 @@ class FanContext:
         for k, val in kw.items():
             if k == "src":
                 self.params.src = (ctypes.c_double * 3)(*val)
+            elif k == "xy_limits":
+                self.params.xy_limits = (ctypes.c_double * 4)(*val)
             else:
                 setattr(self.params, k, val)
         self._chk(self.lib.geoac_set_params(self._h, ctypes.byref(self.params)))

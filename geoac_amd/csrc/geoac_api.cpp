@@ -13,6 +13,7 @@
 #include "../../include/geoac_hip.h"
 #include "geoac_device.h"
 
+extern "C" void geoac_natural_spline_slopes(int n, const double* x, const double* f, double* slopes);
 extern "C" hipError_t geoac_launch_init(const GeoacDevParams* P, hipStream_t s);
 extern "C" hipError_t geoac_launch_rk4(const GeoacDevParams* P, int block, hipStream_t s);
 extern "C" hipError_t geoac_launch_postpass(const GeoacDevParams* P, int rows, hipStream_t s);
@@ -46,6 +47,11 @@ struct geoac_ctx {
     // host copy of the 1-D atmosphere (for the SuthBass reference state)
     std::vector<double> x, T, u, v, rho, sl;
     int n_nodes = 0;
+    // range-dependent grid
+    int gnx = 0, gny = 0;
+    std::vector<double> gx, gy;
+    DevBuf d_gx, d_gy, d_gz, d_gtab, d_consts;
+    bool have_grid = false;
     // device
     DevBuf seg, rhot, theta, phi, state, rec, counters;
     DevBuf path[2], contrib[2], nrows[2], legend[2], nlegend[2];   // double-buffered epoch chunks (RK4 of epoch e+1 overlaps the post-pass of e)
@@ -141,6 +147,7 @@ int geoac_default_params(int eqset, geoac_params* p){
     p->vert_limit = NAN;                                        // = top of the profile, set at upload (GeoAc_SetPropRegion)
     p->z_grnd = 0.0; p->tweak_abs = 0.3; p->freq = 0.1;
     p->bounces = 2; p->calc_amp = 1; p->mode = 0; p->sample_stride = 25;
+    for(int q = 0; q < 4; q++) p->xy_limits[q] = NAN;           // RngDep: grid extents at upload (GeoAc_SetPropRegion)
     return GEOAC_OK;
 }
 
@@ -184,7 +191,8 @@ int geoac_destroy(geoac_ctx* ctx){
                        &ctx->path[0], &ctx->path[1], &ctx->contrib[0], &ctx->contrib[1], &ctx->nrows[0], &ctx->nrows[1],
                        &ctx->legend[0], &ctx->legend[1], &ctx->nlegend[0], &ctx->nlegend[1],
                        &ctx->ev_row[0], &ctx->ev_row[1], &ctx->ev_m[0], &ctx->ev_m[1], &ctx->ev_amp[0], &ctx->ev_amp[1],
-                       &ctx->nev[0], &ctx->nev[1], &ctx->smp_out };
+                       &ctx->nev[0], &ctx->nev[1], &ctx->smp_out,
+                       &ctx->d_gx, &ctx->d_gy, &ctx->d_gz, &ctx->d_gtab, &ctx->d_consts };
     for(DevBuf* b : bufs) b->release();
     if(ctx->h_counters) hipHostFree(ctx->h_counters);
     if(ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -235,12 +243,72 @@ int geoac_upload_atmo_1d(geoac_ctx* ctx, int n, const double* x, const double* T
     return GEOAC_OK;
 }
 
+// one cubic of a vertical spline segment in the derivative-friendly form
+static void col_coeffs(const double* z, const double* f, const double* sl, int k, double* c){
+    seg_coeffs(z[k], z[k + 1], f[k], f[k + 1], sl[k], sl[k + 1], c, true);
+}
+
+int geoac_upload_atmo_3d(geoac_ctx* ctx, int nx, int ny, int nz, const double* x, const double* y, const double* z,
+                         const double* T, const double* u, const double* v, const double* rho){
+    if(!ctx || nx < 2 || ny < 2 || nz < 3 || !x || !y || !z || !T || !u || !v || !rho) return fail(ctx, GEOAC_E_INVALID, "upload_atmo_3d: bad arguments");
+    if(ctx->eqset != GEOAC_EQ_3D_RNGDEP) return fail(ctx, GEOAC_E_UNSUPPORTED, "grid atmosphere needs the range-dependent Cartesian equation set");
+    for(int i = 1; i < nx; i++) if(!(x[i] > x[i - 1])) return fail(ctx, GEOAC_E_INVALID, "upload_atmo_3d: x not strictly increasing");
+    for(int i = 1; i < ny; i++) if(!(y[i] > y[i - 1])) return fail(ctx, GEOAC_E_INVALID, "upload_atmo_3d: y not strictly increasing");
+    for(int i = 1; i < nz; i++) if(!(z[i] > z[i - 1])) return fail(ctx, GEOAC_E_INVALID, "upload_atmo_3d: z not strictly increasing");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int nseg = nz - 1, nn = nx * ny;
+    const double* F[4] = { T, u, v, rho };
+    std::vector<double> tab((size_t)4 * nseg * nn * 12);
+    std::vector<double> dcol((size_t)nz), sl((size_t)nz);
+    for(int f = 0; f < 4; f++){
+        for(int i = 0; i < nx; i++) for(int j = 0; j < ny; j++){
+            const double* col = F[f] + ((size_t)i * ny + j) * nz;
+            const int node = i * ny + j;
+            // S_f: vertical natural spline of the values (Set_Slopes_Multi :313-343)
+            geoac_natural_spline_slopes(nz, z, col, sl.data());
+            for(int k = 0; k < nseg; k++) col_coeffs(z, col, sl.data(), k, &tab[((((size_t)f * nseg + k) * nn) + node) * 12 + 0]);
+            // S_fx: spline of the centred (one-sided at the edges) x-difference (:346-391)
+            int iu = std::min(i + 1, nx - 1), id = std::max(i - 1, 0);
+            const double* cu = F[f] + ((size_t)iu * ny + j) * nz; const double* cd = F[f] + ((size_t)id * ny + j) * nz;
+            for(int k = 0; k < nz; k++) dcol[k] = (cu[k] - cd[k]) / (x[iu] - x[id]);
+            geoac_natural_spline_slopes(nz, z, dcol.data(), sl.data());
+            for(int k = 0; k < nseg; k++) col_coeffs(z, dcol.data(), sl.data(), k, &tab[((((size_t)f * nseg + k) * nn) + node) * 12 + 4]);
+            // S_fy (:394-424)
+            int ju = std::min(j + 1, ny - 1), jd = std::max(j - 1, 0);
+            const double* du = F[f] + ((size_t)i * ny + ju) * nz; const double* dd = F[f] + ((size_t)i * ny + jd) * nz;
+            for(int k = 0; k < nz; k++) dcol[k] = (du[k] - dd[k]) / (y[ju] - y[jd]);
+            geoac_natural_spline_slopes(nz, z, dcol.data(), sl.data());
+            for(int k = 0; k < nseg; k++) col_coeffs(z, dcol.data(), sl.data(), k, &tab[((((size_t)f * nseg + k) * nn) + node) * 12 + 8]);
+        }
+    }
+    HIPCHK(ctx->d_gx.ensure(sizeof(double) * nx)); HIPCHK(ctx->d_gy.ensure(sizeof(double) * ny)); HIPCHK(ctx->d_gz.ensure(sizeof(double) * nz));
+    HIPCHK(ctx->d_gtab.ensure(sizeof(double) * tab.size()));
+    HIPCHK(ctx->d_consts.ensure(sizeof(double) * 8));
+    HIPCHK(hipMemcpyAsync(ctx->d_gx.p, x, sizeof(double) * nx, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_gy.p, y, sizeof(double) * ny, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_gz.p, z, sizeof(double) * nz, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_gtab.p, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->gnx = nx; ctx->gny = ny; ctx->n_nodes = nz;
+    ctx->gx.assign(x, x + nx); ctx->gy.assign(y, y + ny); ctx->x.assign(z, z + nz);
+    // GeoAc_SetPropRegion (G2S_MultiDimSpline3D.cpp:25-33)
+    if(!(ctx->prm.vert_limit == ctx->prm.vert_limit)) ctx->prm.vert_limit = z[nz - 1];
+    const double ext[4] = { x[0], x[nx - 1], y[0], y[ny - 1] };
+    for(int q = 0; q < 4; q++) if(!(ctx->prm.xy_limits[q] == ctx->prm.xy_limits[q])) ctx->prm.xy_limits[q] = ext[q];
+    ctx->have_grid = true; ctx->have_atmo = true;
+    return GEOAC_OK;
+}
+
 int geoac_set_params(geoac_ctx* ctx, const geoac_params* p){
     if(!ctx || !p) return GEOAC_E_INVALID;
     if(p->bounces < 0 || p->bounces + 1 > GEOAC_MAXLEGS) return fail(ctx, GEOAC_E_INVALID, "bounces out of range (0..63)");
     if(!(p->ds_min > 0) || !(p->ds_max >= p->ds_min)) return fail(ctx, GEOAC_E_INVALID, "ds_min/ds_max");
     ctx->prm = *p;
     if(!(ctx->prm.vert_limit == ctx->prm.vert_limit) && ctx->have_atmo) ctx->prm.vert_limit = ctx->x[ctx->n_nodes - 1];
+    if(ctx->have_grid){
+        const double ext[4] = { ctx->gx.front(), ctx->gx.back(), ctx->gy.front(), ctx->gy.back() };
+        for(int q = 0; q < 4; q++) if(!(ctx->prm.xy_limits[q] == ctx->prm.xy_limits[q])) ctx->prm.xy_limits[q] = ext[q];
+    }
     if(ctx->prm.mode & GEOAC_MODE_WRITE_CAUSTICS) ctx->prm.calc_amp = 1;      // GeoAcGlobal_main.cpp:166
     if(ctx->prm.sample_stride <= 0) ctx->prm.sample_stride = 25;
     ctx->have_params = true;
@@ -264,8 +332,10 @@ int geoac_fan_set_angles(geoac_ctx* ctx, int n_rays, const double* theta_deg, co
 int geoac_fan_launch(geoac_ctx* ctx){
     if(!ctx) return GEOAC_E_INVALID;
     if(!ctx->have_atmo || !ctx->have_angles) return fail(ctx, GEOAC_E_INVALID, "fan_launch: atmosphere and angles must be uploaded first");
-    if(ctx->eqset != GEOAC_EQ_GLOBAL && ctx->eqset != GEOAC_EQ_3D && ctx->eqset != GEOAC_EQ_2D)
-        return fail(ctx, GEOAC_E_UNSUPPORTED, "range-dependent equation sets are not implemented on the GPU yet");
+    if(ctx->eqset == GEOAC_EQ_GLOBAL_RNGDEP)
+        return fail(ctx, GEOAC_E_UNSUPPORTED, "the spherical range-dependent equation set is not implemented on the GPU yet");
+    const bool is_grid = (ctx->eqset == GEOAC_EQ_3D_RNGDEP);
+    if(is_grid != ctx->have_grid) return fail(ctx, GEOAC_E_INVALID, "fan_launch: atmosphere kind does not match the equation set");
     HIPCHK(hipSetDevice(ctx->device));
     const geoac_params& p = ctx->prm;
     GeoacDevParams P{};
@@ -274,6 +344,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
     const bool is_global = (ctx->eqset == GEOAC_EQ_GLOBAL);
     if(is_global){ P.E = p.calc_amp ? 18 : 6; P.pathw = 6; }
     else if(ctx->eqset == GEOAC_EQ_3D){ P.E = p.calc_amp ? 12 : 4; P.pathw = 4; }
+    else if(is_grid){ P.E = p.calc_amp ? 18 : 6; P.pathw = 6; }
     else { P.E = p.calc_amp ? 6 : 3; P.pathw = 2; }
     P.rays_form = ((p.mode & (GEOAC_MODE_WRITE_RAYS | GEOAC_MODE_WRITE_CAUSTICS)) != 0 || ctx->eqset == GEOAC_EQ_2D) ? 1 : 0;
     P.nseg = ctx->n_nodes - 1;
@@ -293,14 +364,16 @@ int geoac_fan_launch(geoac_ctx* ctx){
     P.freq = p.freq; P.tweak_abs = p.tweak_abs;
     {   // SuthBass reference state: T_o, P_o at abscissa z_grnd (Atmo_State.Absorption.Global.cpp:31-32 passes the km
         // altitude as a radius, which clamps to the lowest node; the Cartesian twin evaluates at z = z_grnd)
+        P.sb_const[0] = pow(10.0, -0.67887); P.sb_const[1] = pow(10.0, -0.10744); P.sb_const[2] = pow(10, -3.3979);
+        P.sb_const[3] = 5.0 / sqrt(21.0); P.sb_const[4] = sqrt(3.0 / 7.0);
+        if(is_grid){ P.T_o = P.P_o = 0.0; P.c000 = 0.0; } else {
         double Tg = host_spline_f(ctx->x, ctx->T, ctx->sl.data(), p.z_grnd);
         double rg = host_spline_f(ctx->x, ctx->rho, ctx->sl.data() + 3 * (size_t)ctx->n_nodes, p.z_grnd);
         double cg = sqrt(kGamR * Tg) * 1000.0;
         P.T_o = cg * cg / (kRgas * kGam);
         P.P_o = rg * (cg * cg) / kGam * 1000.0;
-        P.sb_const[0] = pow(10.0, -0.67887); P.sb_const[1] = pow(10.0, -0.10744); P.sb_const[2] = pow(10, -3.3979);
-        P.sb_const[3] = 5.0 / sqrt(21.0); P.sb_const[4] = sqrt(3.0 / 7.0);
         P.c000 = sqrt(kGamR * host_spline_f(ctx->x, ctx->T, ctx->sl.data(), 0.0));       // c(0,0,0), 3DStratified.cpp:367
+        }
         P.src_trig[0] = sin(p.src[1] * kPi / 180.0); P.src_trig[1] = cos(p.src[1] * kPi / 180.0);
     }
     // ---- epoch size: keep the path chunk around <= 3 GiB ----
@@ -311,7 +384,13 @@ int geoac_fan_launch(geoac_ctx* ctx){
     if(ctx->s_rows_override >= 8) s_rows = ctx->s_rows_override;
     P.s_rows = (int)s_rows;
     size_t lds_need = (size_t)P.nseg * GEOAC_SEGW * sizeof(double);
-    P.table_in_lds = (lds_need <= 160 * 1024) ? 1 : 0;
+    P.table_in_lds = (!is_grid && lds_need <= 160 * 1024) ? 1 : 0;
+    if(is_grid){
+        P.gnx = ctx->gnx; P.gny = ctx->gny;
+        P.gx = (const double*)ctx->d_gx.p; P.gy = (const double*)ctx->d_gy.p; P.gz = (const double*)ctx->d_gz.p;
+        P.gtab = (const double*)ctx->d_gtab.p; P.dev_consts = (double*)ctx->d_consts.p;
+        for(int q = 0; q < 4; q++) P.xy_lim[q] = p.xy_limits[q];
+    }
     ctx->legs = p.bounces + 1;
 
     HIPCHK(ctx->state.ensure(sizeof(double) * (size_t)ST_NSTATE * P.n_pad));

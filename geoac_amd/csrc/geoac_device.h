@@ -69,6 +69,14 @@ struct GeoacDevParams {
     // buffers
     const double* seg;              // [nseg][SEGW]
     const double* rho;              // [nseg][4]
+    // range-dependent sets: grid of profiles
+    int           gnx, gny;         // horizontal node counts
+    const double* gx;               // [gnx] node x
+    const double* gy;               // [gny] node y
+    const double* gz;               // [nseg+1] node z (x_min / x_max hold the z range)
+    const double* gtab;             // [4 fields][nseg][gnx*gny][12]: cubics of f, df/dx, df/dy per node and vertical segment
+    double        xy_lim[4];        // x_min, x_max, y_min, y_max break limits (GeoAc.Parameters.RngDep.cpp:24-28)
+    double*       dev_consts;       // [0] T_o, [1] P_o of SuthBass evaluated on the device (RngDep: medium at (0, 0, z_grnd))
     const double* theta_deg;        // [n_rays]
     const double* phi_deg;
     double*       state;            // [ST_NSTATE][n_pad]

@@ -2,6 +2,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <string>
 #include <vector>
 
 #include "../../include/geoac_hip.h"
@@ -67,6 +68,46 @@ int geoac_met_load(const char* file, const char* format, int eqset, int cap,
     }
     fclose(fp);
     return geoac_met_from_columns(eqset, rows, z.data(), Tc.data(), uc.data(), vc.data(), rc.data(), x, T, u, v, rho);
+}
+
+int geoac_grid_dims(const char* prefix, const char* locx, const char* locy, int* nx, int* ny, int* nz){
+    std::string first = std::string(prefix) + "0.met";
+    *nx = geoac_met_rows(locx); *ny = geoac_met_rows(locy); *nz = geoac_met_rows(first.c_str());
+    return (*nx >= 2 && *ny >= 2 && *nz >= 3) ? 0 : -1;
+}
+
+int geoac_grid_load(const char* prefix, const char* locx, const char* locy, const char* format, double z_grnd,
+                    int nx, int ny, int nz, double* x, double* y, double* z,
+                    double* T, double* u, double* v, double* rho){
+    int fmt;
+    if(strncmp(format, "zTuvdp", 6) == 0) fmt = 0;
+    else if(strncmp(format, "zuvwTdp", 7) == 0) fmt = 1;
+    else return -2;
+    FILE* fp = fopen(locx, "r"); if(!fp) return -1;
+    for(int i = 0; i < nx; i++) if(fscanf(fp, "%lf", &x[i]) != 1) x[i] = 0.0;
+    fclose(fp);
+    fp = fopen(locy, "r"); if(!fp) return -1;
+    for(int j = 0; j < ny; j++) if(fscanf(fp, "%lf", &y[j]) != 1) y[j] = 0.0;
+    fclose(fp);
+    const int ncol = fmt ? 7 : 6;
+    for(int i = 0; i < nx; i++) for(int j = 0; j < ny; j++){
+        std::string name = std::string(prefix) + std::to_string(i * ny + j) + ".met";
+        fp = fopen(name.c_str(), "r");
+        if(!fp) return -1;
+        for(int k = 0; k < nz; k++){
+            double t[7] = {0, 0, 0, 0, 0, 0, 0};
+            for(int q = 0; q < ncol; q++) if(fscanf(fp, "%lf", &t[q]) != 1) t[q] = 0.0;
+            double zz, TT, uu, vv, rr;
+            if(fmt == 0){ zz = t[0]; TT = t[1]; uu = t[2]; vv = t[3]; rr = t[4]; }
+            else        { zz = t[0]; uu = t[1]; vv = t[2]; TT = t[4]; rr = t[5]; }
+            z[k] = zz;
+            double w = (2.0 / (1.0 + exp(-(zz - z_grnd) / 0.05)) - 1.0) / 1000.0;      // G2S_MultiDimSpline3D.cpp:167-168
+            size_t o = ((size_t)i * ny + j) * nz + k;
+            T[o] = TT; u[o] = uu * w; v[o] = vv * w; rho[o] = rr;
+        }
+        fclose(fp);
+    }
+    return 0;
 }
 
 void geoac_natural_spline_slopes(int n, const double* x, const double* f, double* slopes){

@@ -303,9 +303,8 @@ DEVINL double global_amplitude(const GeoacDevParams& P, const Medium& m, const M
 // ------------------------------------------------------------------------------------------------
 // SuthBass_Alpha (Atmo_State.Absorption.Global.cpp:12-141 / Atmo_State.Absorption.cpp:14-143); zr = altitude above sea level
 // ------------------------------------------------------------------------------------------------
-DEVINL double suthbass_alpha(const GeoacDevParams& P, double zr, double c_snd, double rho, double freq){
+DEVINL double suthbass_alpha(const GeoacDevParams& P, double zr, double c_snd, double rho, double freq, double T_o, double P_o){
     const double mu_o = 18.192E-6, S = 117.0;
-    const double T_o = P.T_o, P_o = P.P_o;
     double cm = c_snd * 1000.0;
     double T_z = cm * cm / (kRgas * kGam);
     double P_z = rho * (cm * cm) / kGam * 1000.0;
@@ -473,7 +472,7 @@ DEVINL void cart2_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCt
 template <bool AMP_> struct EqGlobal {
     static constexpr bool AMP = AMP_;
     static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 0, LANES = 1;
-    static constexpr bool KM2 = false;                              // linear intercept only (Q1)
+    static constexpr bool KM2 = false, HMAX_PER_LEG = false;        // linear intercept only (Q1); turning height accumulates over legs
 
     // GeoAc_SetInitialConditions: EquationSets.Global.cpp:76-136
     static DEVINL void init(const GeoacDevParams& P, double th, double ph, double* y, RayCtx& C){
@@ -502,6 +501,7 @@ template <bool AMP_> struct EqGlobal {
         fsincos(lat0, C.a[0], C.a[1]);
         C.a[2] = 0.0; C.a[3] = 1.0; C.a[4] = 0.0; C.a[5] = 0.0;
     }
+    static DEVINL void fan_init(const GeoacDevParams& P){}
     static DEVINL double height(const GeoacDevParams& P, const double* y){ return y[0] - P.r_earth; }
     static DEVINL double above_ground(const GeoacDevParams& P, const double* y){ return y[0] - P.ground; }
 
@@ -601,7 +601,7 @@ template <bool AMP_> struct EqGlobal {
         double cp0 = c * n0 / nu_mag, cp1 = c * n1 / nu_mag + m.v, cp2 = c * n2 / nu_mag + m.u;
         double cpm = sqrt(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
         tt = ds_tt / cpm;
-        at = suthbass_alpha(P, r - P.r_earth, c, rho, P.freq) * ds_at;
+        at = suthbass_alpha(P, r - P.r_earth, c, rho, P.freq, P.T_o, P.P_o) * ds_at;
     }
 };
 
@@ -639,10 +639,140 @@ struct EqGlobalPair : EqGlobal<true> {
     }
 };
 
+#include "geoac_rngdep.h"
+
+// Range-dependent Cartesian set (GeoAc3D.RngDep): EquationSets.3DRngDep.cpp + G2S_MultiDimSpline3D.cpp
+template <bool AMP_> struct Eq3DRngDep {
+    static constexpr bool AMP = AMP_;
+    static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 2, LANES = 1;
+    static constexpr bool KM2 = true, HMAX_PER_LEG = true;          // quadratic intercept; turning height per leg (Q8)
+
+    // SuthBass reference state at (0, 0, z_grnd) (Atmo_State.Absorption.cpp:31-33), once per fan
+    static DEVINL void fan_init(const GeoacDevParams& P){
+        Medium3 g = medium3_at<true, false>(P, 0.0, 0.0, P.z_grnd);
+        double cm = g.c * 1000.0;
+        P.dev_consts[0] = cm * cm / (kRgas * kGam);
+        P.dev_consts[1] = g.rho * (cm * cm) / kGam * 1000.0;
+    }
+    // GeoAc_SetInitialConditions: 3DRngDep.cpp:70-136
+    static DEVINL void init(const GeoacDevParams& P, double th, double ph, double* y, RayCtx& C){
+        double z0 = P.z_grnd < P.src[2] ? P.src[2] : P.z_grnd;       // GeoAc3D.RngDep_main.cpp:165
+        Medium3 m = medium3_at<false, false>(P, P.src[0], P.src[1], z0);
+        double c0 = m.c;
+        double Mc[3] = { m.u / c0, m.v / c0, 0.0 };
+        double sth = sin(th), cth = cos(th), sph = sin(ph), cph = cos(ph);
+        double nu0[3] = { cth * cph, cth * sph, sth };
+        double mth[3] = { -sth * cph, -sth * sph, cth };
+        double mph[3] = { -cth * sph, cth * cph, 0.0 };
+        double MS = 1.0 + (nu0[0] * Mc[0] + nu0[1] * Mc[1] + nu0[2] * Mc[2]);
+        C.c0 = c0; C.nu0 = 1.0 / MS;
+        for(int q = 0; q < 6; q++) C.a[q] = 0.0;
+        y[0] = P.src[0]; y[1] = P.src[1]; y[2] = z0;
+        for(int e = 0; e < 3; e++) y[3 + e] = nu0[e] / MS;
+        if(AMP){
+            double dt = mth[0] * Mc[0] + mth[1] * Mc[1] + mth[2] * Mc[2];
+            double dp = mph[0] * Mc[0] + mph[1] * Mc[1] + mph[2] * Mc[2];
+            for(int e = 0; e < 3; e++){
+                y[9 + e]  = mth[e] / MS - nu0[e] / (MS * MS) * dt;
+                y[15 + e] = mph[e] / MS - nu0[e] / (MS * MS) * dp;
+            }
+        }
+    }
+    static DEVINL double height(const GeoacDevParams& P, const double* y){ return y[2]; }
+    static DEVINL double above_ground(const GeoacDevParams& P, const double* y){ return y[2] - P.ground; }
+    template <typename TabPtr>
+    static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
+        rngdep_rhs<AMP>(P, seg, yt, dy);
+    }
+    // 3DRngDep.cpp:451-472
+    static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, long long k, bool& brk, bool& gnd){
+        brk = (yn[0] > P.xy_lim[1]) || (yn[0] < P.xy_lim[0]) || (yn[1] > P.xy_lim[3]) || (yn[1] < P.xy_lim[2]) || (yn[2] > P.vert_limit);
+        gnd = yn[2] < P.ground;
+    }
+    static DEVINL void accept(RayCtx& C){}
+    static DEVINL void restart(const GeoacDevParams& P, RayCtx& C, const double* y){}
+    // GeoAc3D.RngDep_main.cpp:298-301
+    static DEVINL void arrival(const GeoacDevParams& P, const RayCtx& C, int slot, const double* yn, double* R){
+        Medium3 mg = medium3_at<false, false>(P, yn[0], yn[1], P.z_grnd);
+        double incl = -asin(mg.c / C.c0 * yn[5]) * 180.0 / kPi;
+        double baz = 90.0 - atan2(-yn[4], -yn[3]) * 180.0 / kPi;
+        while(baz < -180.0) baz += 360.0;
+        while(baz > 180.0) baz -= 360.0;
+        R[GEOAC_REC_INCL] = incl;
+        R[GEOAC_REC_BACKAZ] = baz;
+        R[GEOAC_REC_RANGE] = sqrt(yn[0] * yn[0] + yn[1] * yn[1]);
+        if(AMP){
+            double amp, D;
+            amp_jac(P, C, slot, yn, amp, D);
+            R[GEOAC_REC_AMP] = amp;
+            R[GEOAC_REC_JACOB] = D;
+        }
+    }
+    // GeoAc_Jacobian / GeoAc_Amplitude: 3DRngDep.cpp:547-592
+    static DEVINL void amp_jac(const GeoacDevParams& P, const RayCtx& C, int slot, const double* yn, double& amp, double& D){
+        double z0 = P.z_grnd < P.src[2] ? P.src[2] : P.z_grnd;
+        Medium3 m = medium3_at<true, false>(P, yn[0], yn[1], yn[2]);
+        Medium3 m0 = medium3_at<true, false>(P, P.src[0], P.src[1], z0);
+        double n0 = yn[3], n1 = yn[4], n2 = yn[5];
+        double nmag = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+        double cp0 = m.c * n0 / nmag + m.u, cp1 = m.c * n1 / nmag + m.v, cp2 = m.c * n2 / nmag;
+        double cpm = sqrt(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
+        double dxds = cp0 / cpm, dyds = cp1 / cpm, dzds = cp2 / cpm;
+        D = dxds * (yn[7] * yn[14] - yn[13] * yn[8]) - yn[6] * (dyds * yn[14] - dzds * yn[13]) + yn[12] * (dyds * yn[8] - dzds * yn[7]);
+        double th_l = P.theta_deg[slot] * kPi / 180.0, ph_l = kPi / 2.0 - P.phi_deg[slot] * kPi / 180.0;
+        double c0 = C.c0;
+        double nu_mag = (c0 - n0 * m.u - n1 * m.v) / m.c;
+        double nu_mag0 = 1.0 - n0 * m0.u / c0 - n1 * m0.v / c0;
+        double ap0 = m.c * n0 / nu_mag + m.u, ap1 = m.c * n1 / nu_mag + m.v, ap2 = m.c * n2 / nu_mag;
+        double aq0 = c0 * cos(th_l) * cos(ph_l) + m0.u, aq1 = c0 * cos(th_l) * sin(ph_l) + m0.v, aq2 = c0 * sin(th_l);
+        double apm = sqrt(ap0 * ap0 + ap1 * ap1 + ap2 * ap2);
+        double aqm = sqrt(aq0 * aq0 + aq1 * aq1 + aq2 * aq2);
+        double num = m.rho * nu_mag * (m.c * m.c * m.c) * aqm * cos(th_l);
+        double den = m0.rho * nu_mag0 * (c0 * c0 * c0) * apm * D;
+        amp = 1.0 / (4.0 * kPi) * sqrt(fabs(num / den));
+    }
+    // ApproximateIntercept + SetReflectionConditions: 3DRngDep.cpp:142-201
+    static DEVINL void reflect(const GeoacDevParams& P, const RayCtx& C, const double* yn, double* y, const double* ym2){
+        double dz_k = yn[2] - y[2];
+        double dz_g = y[2] - P.ground;
+        double prev[E];
+        #pragma unroll
+        for(int e = 0; e < E; e++)
+            prev[e] = y[e] + (y[e] - yn[e]) / dz_k * dz_g + 1.0 / 2.0 * (yn[e] + ym2[e] - 2.0 * y[e]) / (dz_k * dz_k) * (dz_g * dz_g);
+        Medium3 mg = medium3_at<false, true>(P, prev[0], prev[1], P.z_grnd);
+        double dnuz_ds = -1.0 / mg.c * (C.c0 / mg.c * mg.dcz + prev[3] * mg.duz + prev[4] * mg.dvz);
+        #pragma unroll
+        for(int e = 0; e < E; e++) y[e] = prev[e];
+        y[2] = P.ground;
+        y[5] = -prev[5];
+        if(AMP){
+            y[8] = -prev[8]; y[14] = -prev[14];
+            double den = mg.c / C.c0 * prev[5];
+            y[11] = -prev[11] + 2.0 * dnuz_ds * prev[8]  / den;
+            y[17] = -prev[17] + 2.0 * dnuz_ds * prev[14] / den;
+        }
+    }
+    // 3DRngDep.cpp:478-542, 598-634
+    static DEVINL void segment(const GeoacDevParams& P, const double* st, size_t np, const double* a, const double* b, double& tt, double& at){
+        double ax = a[0], ay = a[np], az = a[2 * np], an0 = a[3 * np], an1 = a[4 * np], an2 = a[5 * np];
+        double dx = b[0] - ax, dy = b[np] - ay, dz = b[2 * np] - az;
+        double ds = sqrt(dx * dx + dy * dy + dz * dz);
+        double x = ax + dx / 2.0, y = ay + dy / 2.0, z = az + dz / 2.0;
+        double n0 = an0 + (b[3 * np] - an0) / 2.0, n1 = an1 + (b[4 * np] - an1) / 2.0, n2 = an2 + (b[5 * np] - an2) / 2.0;
+        double nmag = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+        Medium3 m = medium3_at<true, false>(P, x, y, z);
+        double cp0 = m.c * n0 / nmag + m.u, cp1 = m.c * n1 / nmag + m.v, cp2 = m.c * n2 / nmag;
+        double cpm = sqrt(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
+        tt = ds / cpm;
+        at = suthbass_alpha(P, z, m.c, m.rho, P.freq, P.dev_consts[0], P.dev_consts[1]) * ds;
+    }
+};
+
+
 template <bool AMP_> struct Eq3D {
     static constexpr bool AMP = AMP_;
     static constexpr int E = AMP_ ? 12 : 4, PW = 4, HIDX = 2, LANES = 1;
-    static constexpr bool KM2 = true;                               // quadratic intercept needs row k-2
+    static constexpr bool KM2 = true, HMAX_PER_LEG = false;                               // quadratic intercept needs row k-2
 
     // GeoAc_SetInitialConditions: EquationSets.3DStratified.cpp:69-131
     static DEVINL void init(const GeoacDevParams& P, double th, double ph, double* y, RayCtx& C){
@@ -667,6 +797,7 @@ template <bool AMP_> struct Eq3D {
             y[11] = mph[2] / M - nu0[2] / (M * M) * dMp;
         }
     }
+    static DEVINL void fan_init(const GeoacDevParams& P){}
     static DEVINL double height(const GeoacDevParams& P, const double* y){ return y[2]; }
     static DEVINL double above_ground(const GeoacDevParams& P, const double* y){ return y[2] - P.ground; }
     template <typename TabPtr>
@@ -756,14 +887,14 @@ template <bool AMP_> struct Eq3D {
         double cp0 = c * nx / nu_mag + m.u, cp1 = c * ny / nu_mag + m.v, cp2 = c * nz / nu_mag;
         double cpm = sqrt(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
         tt = ds / cpm;
-        at = suthbass_alpha(P, z, c, rho, P.freq) * ds;
+        at = suthbass_alpha(P, z, c, rho, P.freq, P.T_o, P.P_o) * ds;
     }
 };
 
 template <bool AMP_> struct Eq2D {
     static constexpr bool AMP = AMP_;
     static constexpr int E = AMP_ ? 6 : 3, PW = 2, HIDX = 1, LANES = 1;
-    static constexpr bool KM2 = true;
+    static constexpr bool KM2 = true, HMAX_PER_LEG = false;
 
     // GeoAc_SetInitialConditions: EquationSets.2DStratified.cpp:38-68
     static DEVINL void init(const GeoacDevParams& P, double th, double ph, double* y, RayCtx& C){
@@ -775,6 +906,7 @@ template <bool AMP_> struct Eq2D {
         y[0] = 0.0; y[1] = z0; y[2] = C.a[3];
         if(AMP) y[5] = C.a[2];
     }
+    static DEVINL void fan_init(const GeoacDevParams& P){}
     static DEVINL double height(const GeoacDevParams& P, const double* y){ return y[1]; }
     static DEVINL double above_ground(const GeoacDevParams& P, const double* y){ return y[1] - P.ground; }
     template <typename TabPtr>
@@ -840,7 +972,7 @@ template <bool AMP_> struct Eq2D {
         double c = sqrt(kGamR * m.T);
         double rho = rho_eval(P, k, xe);
         tt = ds / (c + m.u * cph + m.v * sph);
-        at = suthbass_alpha(P, z, c, rho, P.freq) * ds;
+        at = suthbass_alpha(P, z, c, rho, P.freq, P.T_o, P.P_o) * ds;
     }
 };
 
@@ -851,6 +983,7 @@ template <class EQ>
 __global__ void __launch_bounds__(256) k_init(GeoacDevParams P){
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if(i >= P.n_pad) return;
+    if(i == 0) EQ::fan_init(P);
     double* st = P.state + i;
     const size_t np = (size_t)P.n_pad;
     for(int f = 0; f < ST_NSTATE; f++) st[f * np] = 0.0;
@@ -864,7 +997,7 @@ __global__ void __launch_bounds__(256) k_init(GeoacDevParams P){
     for(int e = 0; e < GEOAC_MAXE; e++) st[(ST_Y0 + e) * np] = y[e];
     st[ST_C0 * np] = C.c0; st[ST_NU0 * np] = C.nu0;
     for(int q = 0; q < 6; q++) st[(ST_AUX0 + q) * np] = C.a[q];
-    st[ST_SEG * np] = (double)seg_guess(P.seg, P, clampd(y[EQ::HIDX], P.x_min, P.x_max));
+    st[ST_SEG * np] = P.gtab ? -1.0 : (double)seg_guess(P.seg, P, clampd(y[EQ::HIDX], P.x_min, P.x_max));   // grid sets: search from scratch
     double* R = P.rec + (size_t)i * (P.bounces + 1) * GEOAC_REC_STRIDE;
     for(int q = 0; q < (P.bounces + 1) * GEOAC_REC_STRIDE; q++) R[q] = 0.0;
 }
@@ -927,7 +1060,7 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
     C.c0 = st[ST_C0 * np]; C.nu0 = st[ST_NU0 * np];
     #pragma unroll
     for(int q = 0; q < 6; q++) C.a[q] = st[(ST_AUX0 + q) * np];
-    int seg = (int)st[ST_SEG * np] * GEOAC_SEGW;                // element offset of the current spline segment
+    int seg = P.gtab ? (int)st[ST_SEG * np] : (int)st[ST_SEG * np] * GEOAC_SEGW;   // 1-D sets: element offset of the current spline segment; grid sets: vertical segment index
     unsigned long long steps_here = 0;
     int nev = 0;                                                // WriteRays / WriteCaustics events of this chunk
     double dprev = SMP ? st[ST_DPREV * np] : 0.0;               // Jacobian of the previous row (caustic detection)
@@ -937,7 +1070,7 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
 
     while(nr + 2 <= P.s_rows && !done){
         // running turning height: max over rows m < k of the height component   (GeoAcGlobal_main.cpp:294)
-        { double h = EQ::height(P, y); hmax = (hmax < h) ? h : hmax; }
+        { double h = EQ::height(P, y); if(EQ::HMAX_PER_LEG && k == 0) hmax = 0.0; hmax = (hmax < h) ? h : hmax; }
 
         if(SMP && k >= 1){
             // y is row m = k (1 <= m < k_final) at chunk row nr-1: the rows the reference's post-pass loop visits
@@ -1048,7 +1181,7 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
         for(int e = 0; e < E; e++) st[(ST_YM2 + e) * np] = ym2[e];
     }
     st[ST_K * np] = (double)k; st[ST_LEG * np] = (double)leg; st[ST_DONE * np] = done ? 1.0 : 0.0;
-    st[ST_HMAX * np] = hmax; st[ST_SEG * np] = (double)(seg / GEOAC_SEGW);
+    st[ST_HMAX * np] = hmax; st[ST_SEG * np] = P.gtab ? (double)seg : (double)(seg / GEOAC_SEGW);
     #pragma unroll
     for(int q = 0; q < 4; q++) st[(ST_AUX0 + q) * np] = C.a[q];
     P.nrows[slot] = nr; P.nlegend[slot] = nle;
@@ -1133,6 +1266,8 @@ __global__ void __launch_bounds__(256) k_accum(GeoacDevParams P){
             int np3;                                                   // number of position columns
             if(P.eqset == GEOAC_EQ_GLOBAL){ v[0] = row[0] - P.r_earth; v[1] = row[np] * 180.0 / kPi; v[2] = row[2 * np] * 180.0 / kPi; np3 = 3; }
             else if(P.eqset == GEOAC_EQ_3D){ v[0] = row[0]; v[1] = row[np]; double z = row[2 * np]; v[2] = (z < 0.0 ? 0.0 : z); np3 = 3; }   // max(z, 0) in both files (GeoAc3D_main.cpp:257,267)
+            else if(P.eqset == GEOAC_EQ_3D_RNGDEP){ v[0] = row[0]; v[1] = row[np]; double z = row[2 * np]; v[2] = (kind == 0) ? (z < 0.0 ? 0.0 : z) : z; np3 = 3;
+                                                    if(kind == 1){ v[3] = 0.0; np3 = 4; } }                 // caustic rows: raw z and a 0.0 column (GeoAc3D.RngDep_main.cpp:279-284)
             else { v[0] = row[0]; double z = row[np]; v[1] = (kind == 0) ? (z < 0.0 ? 0.0 : z) : z; np3 = 2; }
             if(kind == 0){ v[np3] = amp_db; v[np3 + 1] = -at; v[np3 + 2] = tt; }
             else { v[np3] = tt; }
@@ -1177,6 +1312,8 @@ __global__ void __launch_bounds__(256) k_accum(GeoacDevParams P){
         case GEOAC_EQ_3D * 2 + 0:     { using EQ = Eq3D<false>;     CALL; } break; \
         case GEOAC_EQ_2D * 2 + 1:     { using EQ = Eq2D<true>;      CALL; } break; \
         case GEOAC_EQ_2D * 2 + 0:     { using EQ = Eq2D<false>;     CALL; } break; \
+        case GEOAC_EQ_3D_RNGDEP * 2 + 1: { using EQ = Eq3DRngDep<true>;  CALL; } break; \
+        case GEOAC_EQ_3D_RNGDEP * 2 + 0: { using EQ = Eq3DRngDep<false>; CALL; } break; \
         default: return hipErrorNotSupported; }
 
 extern "C" hipError_t geoac_launch_init(const GeoacDevParams* P, hipStream_t s){

@@ -38,7 +38,7 @@ enum {
     GEOAC_EQ_2D            = 0,   /* GeoAc.EquationSets.2DStratified.cpp   E = 3 / 6   */
     GEOAC_EQ_3D            = 1,   /* GeoAc.EquationSets.3DStratified.cpp   E = 4 / 12  */
     GEOAC_EQ_GLOBAL        = 2,   /* GeoAc.EquationSets.Global.cpp         E = 6 / 18  */
-    GEOAC_EQ_3D_RNGDEP     = 3,   /* GeoAc.EquationSets.3DRngDep.cpp       (not yet implemented) */
+    GEOAC_EQ_3D_RNGDEP     = 3,   /* GeoAc.EquationSets.3DRngDep.cpp       E = 6 / 18  */
     GEOAC_EQ_GLOBAL_RNGDEP = 4    /* GeoAc.EquationSets.GlobalRngDep.cpp   (not yet implemented) */
 };
 
@@ -98,6 +98,7 @@ typedef struct {
     int    calc_amp;      /* CalcAmp                                                */
     int    mode;          /* GEOAC_MODE_* bits                                      */
     int    sample_stride; /* 25 (GeoAcGlobal_main.cpp:269)                          */
+    double xy_limits[4];  /* RngDep sets: GeoAc_x_min/x_max/y_min/y_max_limit; NaN = grid extents (GeoAc_SetPropRegion) */
 } geoac_params;
 
 typedef struct geoac_ctx geoac_ctx;   /* opaque: owns device buffers, stream, events */
@@ -118,6 +119,12 @@ int  geoac_set_stream(geoac_ctx* ctx, void* hip_stream);
  * coefficient tables and uploads them.  */
 int  geoac_upload_atmo_1d(geoac_ctx* ctx, int n, const double* x, const double* T, const double* u,
                           const double* v, const double* rho, const double* slopes4);
+
+/* range-dependent Cartesian atmosphere (GEOAC_EQ_3D_RNGDEP): nx x ny profiles of nz nodes on common z nodes;
+ * fields are [nx][ny][nz] row-major (T [K], u,v [km/s, tapered], rho).  Replaces Spline_Multi_G2S + Set_Slopes_Multi
+ * (G2S_MultiDimSpline3D.cpp:306-425, 1603-1621): vertical natural splines of f, df/dx, df/dy per node are built here. */
+int  geoac_upload_atmo_3d(geoac_ctx* ctx, int nx, int ny, int nz, const double* x, const double* y, const double* z,
+                          const double* T, const double* u, const double* v, const double* rho);
 
 int  geoac_set_params(geoac_ctx* ctx, const geoac_params* p);
 

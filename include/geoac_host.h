@@ -27,6 +27,15 @@ int  geoac_met_from_columns(int eqset, int n, const double* z, const double* T, 
                             const double* v_ms, const double* rho_in,
                             double* x, double* T_out, double* u, double* v, double* rho);
 
+/* range-dependent grid of profiles <prefix><n>.met (n = ix*ny + iy, G2S_MultiDimSpline3D.cpp:154) with node coordinates in
+ * locx / locy (one value per line).  geoac_grid_dims returns the counts the reference would use (newline counts);
+ * geoac_grid_load fills x[nx], y[ny], z[nz] and the fields [nx][ny][nz] with the reference's taper (width 0.05 km around
+ * z_grnd: the RngDep mains parse z_grnd= BEFORE loading, :167-168) and m/s -> km/s. */
+int  geoac_grid_dims(const char* prefix, const char* locx, const char* locy, int* nx, int* ny, int* nz);
+int  geoac_grid_load(const char* prefix, const char* locx, const char* locy, const char* format, double z_grnd,
+                     int nx, int ny, int nz, double* x, double* y, double* z,
+                     double* T, double* u, double* v, double* rho);
+
 /* natural cubic spline node slopes (Thomas algorithm, natural end conditions) */
 void geoac_natural_spline_slopes(int n, const double* x, const double* f, double* slopes);
 

@@ -1,0 +1,69 @@
+"""GPU parity of the range-dependent Cartesian set (GeoAc3D.RngDep) against golden vectors from the compiled reference:
+synthetic 5x5 grid of perturbed profiles with non-square cells (tests/rngdep_data.py)."""
+import numpy as np
+import pytest
+
+import harness as H
+import rngdep_data as RD
+from parity import compare_records, max_rel_errors
+
+pytestmark = pytest.mark.gpu
+EQ = H.EQ_3D_RNGDEP
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(f"{H.GOLDEN_DIR}/3drd_small.npz")
+
+
+@pytest.fixture(scope="module")
+def grid(tmp_path_factory):
+    return RD.write_grid(str(tmp_path_factory.mktemp("gd")))
+
+
+def _ctx(grid, **params):
+    import geoac_amd as G
+    z_grnd = params.get("z_grnd", 0.0)
+    ctx = G.FanContext(G.EQ_3D_RNGDEP, device=0)
+    ctx.load_grid(*grid, z_grnd=z_grnd)
+    ctx.set_params(**params)
+    return ctx
+
+
+@pytest.mark.parametrize("amp", [1, 0])
+def test_rngdep_fan_vs_golden(gold, grid, amp):
+    ctx = _ctx(grid, bounces=1, calc_amp=amp, mode=0, src=(0.0, 0.0, 0.0))
+    rec, steps = ctx.run(gold["theta"], gold["phi"])
+    want = gold[f"rec_amp{amp}_mode0"]
+    E = 18 if amp else 6
+    print("3drd", amp, max_rel_errors(rec, want, E, 2))
+    assert steps == int(gold[f"steps_amp{amp}_mode0"])
+    compare_records(rec, want, E=E, hidx=2)
+
+
+def test_rngdep_alt_config_vs_golden(gold, grid):
+    ctx = _ctx(grid, bounces=2, calc_amp=1, mode=0, src=(120.0, -60.0, 1.0), freq=0.4, tweak_abs=0.6,
+               xy_limits=(-700.0, 900.0, -600.0, 700.0))
+    rec, steps = ctx.run(gold["theta"], gold["phi"])
+    print("3drd alt", max_rel_errors(rec, gold["rec_alt"], 18, 2))
+    assert steps == int(gold["steps_alt"])
+    compare_records(rec, gold["rec_alt"], E=18, hidx=2)
+
+
+def test_rngdep_write_rays_caustics_vs_golden(gold, grid):
+    ctx = _ctx(grid, bounces=1, calc_amp=1, mode=3, src=(0.0, 0.0, 0.0))
+    rec, steps = ctx.run(gold["theta"], gold["phi"])
+    compare_records(rec, gold["rec_amp1_mode3"], E=18, hidx=2)
+    smp = ctx.fetch_samples()
+    assert len(smp) == int(gold["nsmp_amp1_mode3"])
+    gs = smp[gold["smp_idx_amp1_mode3"]]; ws = gold["smp_amp1_mode3"]
+    assert np.array_equal(gs[:, :4], ws[:, :4])
+    ray_rows = ws[:, 3] == 0
+    for col in range(4, 10):
+        d = np.abs(gs[:, col] - ws[:, col])
+        scale = np.maximum(np.abs(ws[:, col]), 1e-3 * max(np.abs(ws[:, col]).max(), 1e-30))
+        if col == 7:
+            assert (d[ray_rows] <= 8.7e-6 + 1e-6 * np.abs(ws[ray_rows, col])).all()
+            assert (d[~ray_rows] / scale[~ray_rows] <= 1e-6).all()
+        else:
+            assert (d / scale).max() <= 1e-6, (col, (d / scale).max())
