@@ -258,27 +258,50 @@ int geoac_upload_atmo_3d(geoac_ctx* ctx, int nx, int ny, int nz, const double* x
     HIPCHK(hipSetDevice(ctx->device));
     const int nseg = nz - 1, nn = nx * ny;
     const double* F[4] = { T, u, v, rho };
-    std::vector<double> tab((size_t)4 * nseg * nn * 12);
+    // device table (geoac_rngdep.h): per (field, kz, node) the vertical cubics F, DxF, DyF, DxyF, Vx, DxVx, DxyVx, Vy, DyVy, DxyVy
+    // (T, u, v: 40 doubles) or F, DxF, DyF, DxyF (rho: 16 doubles).  V0 = S_f, Vx = S_fx, Vy = S_fy are the reference's three
+    // vertical splines per node; D* are its evaluation-time finite differences (BiCubic_Deriv_*, :568-800), which are linear in
+    // the coefficients and centred at the node, taken here once on the coefficients.
+    const size_t rho_off = (size_t)3 * nseg * nn * 40;
+    std::vector<double> tab(rho_off + (size_t)nseg * nn * 16);
+    std::vector<double> V0((size_t)nseg * nn * 4), Vx((size_t)nseg * nn * 4), Vy((size_t)nseg * nn * 4);
     std::vector<double> dcol((size_t)nz), sl((size_t)nz);
+    auto at = [&](std::vector<double>& V, int k, int i, int j) -> double* { return &V[(((size_t)k * nn) + (size_t)i * ny + j) * 4]; };
     for(int f = 0; f < 4; f++){
         for(int i = 0; i < nx; i++) for(int j = 0; j < ny; j++){
             const double* col = F[f] + ((size_t)i * ny + j) * nz;
-            const int node = i * ny + j;
             // S_f: vertical natural spline of the values (Set_Slopes_Multi :313-343)
             geoac_natural_spline_slopes(nz, z, col, sl.data());
-            for(int k = 0; k < nseg; k++) col_coeffs(z, col, sl.data(), k, &tab[((((size_t)f * nseg + k) * nn) + node) * 12 + 0]);
+            for(int k = 0; k < nseg; k++) col_coeffs(z, col, sl.data(), k, at(V0, k, i, j));
+            if(f == 3) continue;                                   // rho is only ever evaluated through Eval_Spline_f
             // S_fx: spline of the centred (one-sided at the edges) x-difference (:346-391)
             int iu = std::min(i + 1, nx - 1), id = std::max(i - 1, 0);
             const double* cu = F[f] + ((size_t)iu * ny + j) * nz; const double* cd = F[f] + ((size_t)id * ny + j) * nz;
             for(int k = 0; k < nz; k++) dcol[k] = (cu[k] - cd[k]) / (x[iu] - x[id]);
             geoac_natural_spline_slopes(nz, z, dcol.data(), sl.data());
-            for(int k = 0; k < nseg; k++) col_coeffs(z, dcol.data(), sl.data(), k, &tab[((((size_t)f * nseg + k) * nn) + node) * 12 + 4]);
+            for(int k = 0; k < nseg; k++) col_coeffs(z, dcol.data(), sl.data(), k, at(Vx, k, i, j));
             // S_fy (:394-424)
             int ju = std::min(j + 1, ny - 1), jd = std::max(j - 1, 0);
             const double* du = F[f] + ((size_t)i * ny + ju) * nz; const double* dd = F[f] + ((size_t)i * ny + jd) * nz;
             for(int k = 0; k < nz; k++) dcol[k] = (du[k] - dd[k]) / (y[ju] - y[jd]);
             geoac_natural_spline_slopes(nz, z, dcol.data(), sl.data());
-            for(int k = 0; k < nseg; k++) col_coeffs(z, dcol.data(), sl.data(), k, &tab[((((size_t)f * nseg + k) * nn) + node) * 12 + 8]);
+            for(int k = 0; k < nseg; k++) col_coeffs(z, dcol.data(), sl.data(), k, at(Vy, k, i, j));
+        }
+        for(int k = 0; k < nseg; k++) for(int i = 0; i < nx; i++) for(int j = 0; j < ny; j++){
+            const int iu = std::min(i + 1, nx - 1), id = std::max(i - 1, 0), ju = std::min(j + 1, ny - 1), jd = std::max(j - 1, 0);
+            const double ix = 1.0 / (x[iu] - x[id]), iy = 1.0 / (y[ju] - y[jd]);
+            double* r = (f < 3) ? &tab[((((size_t)f * nseg + k) * nn) + (size_t)i * ny + j) * 40]
+                                : &tab[rho_off + (((size_t)k * nn) + (size_t)i * ny + j) * 16];
+            auto dx  = [&](std::vector<double>& V, int c){ return (at(V, k, iu, j)[c] - at(V, k, id, j)[c]) * ix; };
+            auto dy  = [&](std::vector<double>& V, int c){ return (at(V, k, i, ju)[c] - at(V, k, i, jd)[c]) * iy; };
+            auto dxy = [&](std::vector<double>& V, int c){ return (at(V, k, iu, ju)[c] - at(V, k, iu, jd)[c] - at(V, k, id, ju)[c] + at(V, k, id, jd)[c]) * (ix * iy); };
+            for(int c = 0; c < 4; c++){
+                r[0 + c] = at(V0, k, i, j)[c]; r[4 + c] = dx(V0, c); r[8 + c] = dy(V0, c); r[12 + c] = dxy(V0, c);
+                if(f < 3){
+                    r[16 + c] = at(Vx, k, i, j)[c]; r[20 + c] = dx(Vx, c); r[24 + c] = dxy(Vx, c);
+                    r[28 + c] = at(Vy, k, i, j)[c]; r[32 + c] = dy(Vy, c); r[36 + c] = dxy(Vy, c);
+                }
+            }
         }
     }
     HIPCHK(ctx->d_gx.ensure(sizeof(double) * nx)); HIPCHK(ctx->d_gy.ensure(sizeof(double) * ny)); HIPCHK(ctx->d_gz.ensure(sizeof(double) * nz));

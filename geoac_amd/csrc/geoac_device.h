@@ -37,9 +37,9 @@ enum {
     ST_PLEG   = 33,     // post-pass current leg
     ST_LTT    = 34,     // post-pass per-leg partial sums (arrivals-only form of Q7)
     ST_LAT    = 35,
-    ST_YM2    = 36,     // row k-2 of the current leg (Cartesian sets: quadratic ground intercept), up to 12 values
-    ST_DPREV  = 48,     // Jacobian of the previous row (WriteCaustics)
-    ST_NSTATE = 49
+    ST_YM2    = 36,     // row k-2 of the current leg (Cartesian sets: quadratic ground intercept), up to 18 values (3D.RngDep)
+    ST_DPREV  = 54,     // Jacobian of the previous row (WriteCaustics)
+    ST_NSTATE = 55
 };
 
 struct GeoacDevParams {

@@ -1046,6 +1046,8 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
     bool done = st[ST_DONE * np] != 0.0;
     if(done){ P.nrows[slot] = 0; P.nlegend[slot] = 0; if(SMP) P.nev[slot] = 0; return; }
 
+    static_assert(E <= ST_K - ST_Y0, "state block: y[] overruns ST_K");
+    static_assert(!EQ::KM2 || ST_YM2 + E <= ST_DPREV, "state block: ym2[] overruns ST_DPREV");
     double y[E], ym2[EQ::KM2 ? E : 1];
     #pragma unroll
     for(int e = 0; e < E; e++) y[e] = st[(ST_Y0 + ((EQ::LANES == 2 && e >= 6) ? e + 6 * q : e)) * np];

@@ -4,29 +4,36 @@
 // cubic splines in z of f, of the centred-difference df/dx and of df/dy, and evaluates a field at (x, y, z) as a bicubic
 // Hermite patch over the cell whose corner data (f, f_x, f_y, f_xy) are vertical-spline values and horizontal finite
 // differences of vertical-spline values; every derivative the equation set needs is again its own bicubic patch of
-// differentiated data (Eval_Spline_AllOrder1/2, :1156-1593).  Here:
-//   * table  gtab[field][kz][ix][iy][12] : per node and vertical segment the three cubics (f, df/dx, df/dy) in the
-//     derivative-friendly form (c0, c1, 2c2, 6c3); all 16 nodes of a 4x4 neighbourhood at one kz are within 96*nx*ny bytes;
-//   * one pass per vertical quantity over the 4x4 neighbourhood -> corner values and finite differences,
-//   * the 16x16 matrix product + power sums of the reference are evaluated as the equivalent tensor Hermite form.
-// Quirk Q11 kept: the scalar evaluators and the d2f/dz2 patch scale the y-derivative rows by the x cell size.
+// differentiated data (Eval_Spline_AllOrder1/2, :1156-1593).
+//
+// The finite differences the reference takes at evaluation time (BiCubic_Deriv_*, :568-800) are centred at a NODE (clamped
+// to one-sided at the grid edge) and linear in the vertical-spline coefficients, and all nodes share the z grid.  So the
+// host differences the COEFFICIENTS once (geoac_upload_atmo_3d) and the device table holds, per (field, kz, node), ten
+// vertical cubics  F, DxF, DyF, DxyF, Vx, DxVx, DxyVx, Vy, DyVy, DxyVy  (V0 = S_f, Vx = S_fx, Vy = S_fy of the reference)
+// in the derivative-friendly form (c0, c1, 2c2, 6c3): one evaluation touches the FOUR cell corners only, 320 contiguous
+// bytes each, instead of a 4x4 neighbourhood of scattered records - the path is bound by divergent table gathers.
+// The 16x16 matrix product + power sums of the reference are evaluated as the equivalent tensor Hermite form, accumulated
+// corner by corner.  Quirk Q11 kept: the scalar evaluators and the d2f/dz2 patch scale the y-derivative rows by the x cell size.
 #ifndef GEOAC_RNGDEP_H_
 #define GEOAC_RNGDEP_H_
 
+#define GEOAC_GREC 40        // doubles per (field, kz, node) record of T, u, v: ten cubics
+#define GEOAC_GREC_RHO 16    // rho: F, DxF, DyF, DxyF only (scalar evaluator)
+enum { GC_F = 0, GC_DXF, GC_DYF, GC_DXYF, GC_VX, GC_DXVX, GC_DXYVX, GC_VY, GC_DYVY, GC_DXYVY };
+
 struct GridLoc {
     int kz;                 // vertical segment
-    int nb[4][4];           // node index (ix*ny + iy) of the clamped 4x4 neighbourhood, [p][q], p <-> x, q <-> y
+    int nb[2][2];           // node index (ix*ny + iy) of the cell corners, [a][b], a <-> x edge, b <-> y edge
     double t;               // z - z0[kz]
     double xs, ys;          // position inside the cell, scaled to [0, 1]
     double dxs, dys;        // cell sizes (dx_scalar, dy_scalar)
-    double idx[2], idy[2];  // 1 / (X[a+2] - X[a]), 1 / (Y[b+2] - Y[b]) : spans of the finite differences at the cell corners
 };
 
-// locate (x, y, z) (already clamped to the grid): cell, neighbourhood, vertical segment.  kz_hint < 0: search from scratch.
+// locate (x, y, z) (already clamped to the grid): cell, corners, vertical segment.  kz_hint < 0: search from scratch.
 DEVINL void grid_locate(const GeoacDevParams& P, double x, double y, double z, int kz_hint, GridLoc& L){
     const int nx = P.gnx, ny = P.gny;
     int kx = 0, ky = 0;
-    for(int i = 1; i < nx - 1; i++) kx += (x >= P.gx[i]) ? 1 : 0;       // last i with x >= X[i], capped at nx-2 (5-ish nodes: branch-free scan)
+    for(int i = 1; i < nx - 1; i++) kx += (x >= P.gx[i]) ? 1 : 0;       // last i with x >= X[i], capped at nx-2 (branch-free scan)
     for(int j = 1; j < ny - 1; j++) ky += (y >= P.gy[j]) ? 1 : 0;
     int kz;
     if(kz_hint < 0){
@@ -38,213 +45,155 @@ DEVINL void grid_locate(const GeoacDevParams& P, double x, double y, double z, i
     while(kz < P.nseg - 1 && z > P.gz[kz + 1]) kz++;
     L.kz = kz;
     L.t = z - P.gz[kz];
-    int ix[4] = { kx > 0 ? kx - 1 : 0, kx, kx + 1, kx + 2 < nx ? kx + 2 : nx - 1 };
-    int iy[4] = { ky > 0 ? ky - 1 : 0, ky, ky + 1, ky + 2 < ny ? ky + 2 : ny - 1 };
-    #pragma unroll
-    for(int p = 0; p < 4; p++){
-        #pragma unroll
-        for(int q = 0; q < 4; q++) L.nb[p][q] = ix[p] * ny + iy[q];
-    }
+    L.nb[0][0] = kx * ny + ky;       L.nb[0][1] = kx * ny + ky + 1;
+    L.nb[1][0] = (kx + 1) * ny + ky; L.nb[1][1] = (kx + 1) * ny + ky + 1;
     const double X1 = P.gx[kx], X2 = P.gx[kx + 1], Y1 = P.gy[ky], Y2 = P.gy[ky + 1];
     L.dxs = X2 - X1; L.dys = Y2 - Y1;
     L.xs = (x - X1) / L.dxs; L.ys = (y - Y1) / L.dys;
-    L.idx[0] = 1.0 / (X2 - P.gx[ix[0]]); L.idx[1] = 1.0 / (P.gx[ix[3]] - X1);
-    L.idy[0] = 1.0 / (Y2 - P.gy[iy[0]]); L.idy[1] = 1.0 / (P.gy[iy[3]] - Y1);
 }
 
-// Hermite basis on [0,1] and its derivative: value weights h0, h1 and slope weights g0, g1 of the two cell edges
-struct Herm { double h0, h1, g0, g1, dh0, dh1, dg0, dg1; };
+// Hermite basis on [0,1] and its derivative: value weights h[0], h[1] and slope weights g[0], g[1] of the two cell edges
+struct Herm { double h[2], g[2], dh[2], dg[2]; };
 DEVINL Herm hermite(double s){
     Herm H; double s2 = s * s, s3 = s2 * s;
-    H.h1 = 3.0 * s2 - 2.0 * s3; H.h0 = 1.0 - H.h1;
-    H.g0 = s - 2.0 * s2 + s3;   H.g1 = s3 - s2;
-    H.dh1 = 6.0 * (s - s2);     H.dh0 = -H.dh1;
-    H.dg0 = 1.0 - 4.0 * s + 3.0 * s2; H.dg1 = 3.0 * s2 - 2.0 * s;
+    H.h[1] = 3.0 * s2 - 2.0 * s3; H.h[0] = 1.0 - H.h[1];
+    H.g[0] = s - 2.0 * s2 + s3;   H.g[1] = s3 - s2;
+    H.dh[1] = 6.0 * (s - s2);     H.dh[0] = -H.dh[1];
+    H.dg[0] = 1.0 - 4.0 * s + 3.0 * s2; H.dg[1] = 3.0 * s2 - 2.0 * s;
     return H;
 }
 
-// corner data of one bicubic patch: F, FX (already times dx), FY (times dy), FXY (times dx dy), [a][b] = corner (x edge a, y edge b)
-struct Patch { double F[2][2], FX[2][2], FY[2][2], FXY[2][2]; };
-
-// value and (optionally) the two first derivatives in SCALED coordinates of the patch
-template <bool WANT_DX, bool WANT_DY>
-DEVINL void patch_eval(const Patch& B, const Herm& hx, const Herm& hy, double& val, double& dsx, double& dsy){
-    double U[2], W[2], Ud[2], Wd[2];
-    #pragma unroll
-    for(int a = 0; a < 2; a++){
-        U[a] = B.F[a][0] * hy.h0 + B.F[a][1] * hy.h1 + B.FY[a][0] * hy.g0 + B.FY[a][1] * hy.g1;
-        W[a] = B.FX[a][0] * hy.h0 + B.FX[a][1] * hy.h1 + B.FXY[a][0] * hy.g0 + B.FXY[a][1] * hy.g1;
-        if(WANT_DY){
-            Ud[a] = B.F[a][0] * hy.dh0 + B.F[a][1] * hy.dh1 + B.FY[a][0] * hy.dg0 + B.FY[a][1] * hy.dg1;
-            Wd[a] = B.FX[a][0] * hy.dh0 + B.FX[a][1] * hy.dh1 + B.FXY[a][0] * hy.dg0 + B.FXY[a][1] * hy.dg1;
-        }
-    }
-    val = U[0] * hx.h0 + U[1] * hx.h1 + W[0] * hx.g0 + W[1] * hx.g1;
-    if(WANT_DX) dsx = U[0] * hx.dh0 + U[1] * hx.dh1 + W[0] * hx.dg0 + W[1] * hx.dg1;
-    if(WANT_DY) dsy = Ud[0] * hx.h0 + Ud[1] * hx.h1 + Wd[0] * hx.g0 + Wd[1] * hx.g1;
+// one vertical cubic (c0, c1, 2 c2, 6 c3), 32-byte aligned: two 16-byte loads
+struct Cub { double c0, c1, d2, e3; };
+DEVINL Cub load_cubic(const double* __restrict__ c){
+    const double2* q = (const double2*)__builtin_assume_aligned(c, 16);
+    const double2 lo = q[0], hi = q[1];
+    return Cub{ lo.x, lo.y, hi.x, hi.y };
 }
+DEVINL double cub_val(const Cub& c, double t, double t6){ return __builtin_fma(t, __builtin_fma(t6, __builtin_fma(t, c.e3, 3.0 * c.d2), c.c1), c.c0); }
+DEVINL double cub_d1(const Cub& c, double t, double th){ return __builtin_fma(th, __builtin_fma(t, c.e3, 2.0 * c.d2), c.c1); }
+DEVINL double cub_d2(const Cub& c, double t){ return __builtin_fma(t, c.e3, c.d2); }
 
-// node record of field f at (kz, node): 12 doubles {S_f, S_fx, S_fy} x (c0, c1, 2c2, 6c3)
 DEVINL const double* grid_rec(const GeoacDevParams& P, int field, int kz, int node){
-    return P.gtab + (((size_t)field * P.nseg + kz) * (size_t)(P.gnx * P.gny) + node) * 12;
-}
-DEVINL double cubic_val(const double* c, double t, double t6){     // c0 + t (c1 + t/6 (3 d2 + e3 t))
-    return __builtin_fma(t, __builtin_fma(t6, __builtin_fma(t, c[3], 3.0 * c[2]), c[1]), c[0]);
-}
-DEVINL double cubic_d1(const double* c, double t, double th){      // c1 + t/2 (2 d2 + e3 t)
-    return __builtin_fma(th, __builtin_fma(t, c[3], 2.0 * c[2]), c[1]);
-}
-DEVINL double cubic_d2(const double* c, double t){ return __builtin_fma(t, c[3], c[2]); }
-
-// finite differences at the four cell corners from values g[p][q] on the 4x4 neighbourhood (BiCubic_Deriv_*, :568-800)
-DEVINL void fd_x(const double g[4][4], const GridLoc& L, double o[2][2]){
-    #pragma unroll
-    for(int a = 0; a < 2; a++){
-        #pragma unroll
-        for(int b = 0; b < 2; b++) o[a][b] = (g[a + 2][b + 1] - g[a][b + 1]) * L.idx[a];
-    }
-}
-DEVINL void fd_y(const double g[4][4], const GridLoc& L, double o[2][2]){
-    #pragma unroll
-    for(int a = 0; a < 2; a++){
-        #pragma unroll
-        for(int b = 0; b < 2; b++) o[a][b] = (g[a + 1][b + 2] - g[a + 1][b]) * L.idy[b];
-    }
-}
-DEVINL void fd_xy(const double g[4][4], const GridLoc& L, double o[2][2]){
-    #pragma unroll
-    for(int a = 0; a < 2; a++){
-        #pragma unroll
-        for(int b = 0; b < 2; b++) o[a][b] = (g[a + 2][b + 2] - g[a + 2][b] - g[a][b + 2] + g[a][b]) * (L.idx[a] * L.idy[b]);
-    }
-}
-DEVINL void corners(const double g[4][4], double o[2][2]){
-    #pragma unroll
-    for(int a = 0; a < 2; a++){
-        #pragma unroll
-        for(int b = 0; b < 2; b++) o[a][b] = g[a + 1][b + 1];
-    }
-}
-DEVINL void scale22(double o[2][2], double s){
-    #pragma unroll
-    for(int a = 0; a < 2; a++){
-        #pragma unroll
-        for(int b = 0; b < 2; b++) o[a][b] *= s;
-    }
-}
-DEVINL void copy22(const double i[2][2], double o[2][2], double s){
-    #pragma unroll
-    for(int a = 0; a < 2; a++){
-        #pragma unroll
-        for(int b = 0; b < 2; b++) o[a][b] = i[a][b] * s;
-    }
+    const size_t nn = (size_t)(P.gnx * P.gny);
+    if(field < 3) return P.gtab + (((size_t)field * P.nseg + kz) * nn + node) * GEOAC_GREC;
+    return P.gtab + (size_t)3 * P.nseg * nn * GEOAC_GREC + ((size_t)kz * nn + node) * GEOAC_GREC_RHO;
 }
 
-// which of the three vertical cubics of a node record, and which z-derivative of it
-template <int WHICH, int ZDER>
-DEVINL void nbhd(const GeoacDevParams& P, int field, const GridLoc& L, double g[4][4]){
-    const double t = L.t, th = 0.5 * t, t6 = t * (1.0 / 6.0);
-    #pragma unroll
-    for(int p = 0; p < 4; p++){
-        #pragma unroll
-        for(int q = 0; q < 4; q++){
-            const double* c = grid_rec(P, field, L.kz, L.nb[p][q]) + 4 * WHICH;
-            g[p][q] = (ZDER == 0) ? cubic_val(c, t, t6) : (ZDER == 1) ? cubic_d1(c, t, th) : cubic_d2(c, t);
-        }
-    }
+// tensor Hermite weights of corner (a, b): value (W), d/dxs (D), d/dys (E); index hh, gh, hg, gg <-> F, FX, FY, FXY
+struct CornerW { double W[4], D[4], E[4]; };
+template <bool WANT_D, bool WANT_E>
+DEVINL CornerW corner_weights(const Herm& hx, const Herm& hy, int a, int b){
+    // (a, b) are loop variables of a ROLLED corner loop (one corner's loads in flight at a time keeps the live set in
+    // registers): pick the edge with selects so that nothing is indexed dynamically
+    const double xh = a ? hx.h[1] : hx.h[0], xg = a ? hx.g[1] : hx.g[0], xdh = a ? hx.dh[1] : hx.dh[0], xdg = a ? hx.dg[1] : hx.dg[0];
+    const double yh = b ? hy.h[1] : hy.h[0], yg = b ? hy.g[1] : hy.g[0], ydh = b ? hy.dh[1] : hy.dh[0], ydg = b ? hy.dg[1] : hy.dg[0];
+    CornerW w;
+    w.W[0] = xh * yh; w.W[1] = xg * yh; w.W[2] = xh * yg; w.W[3] = xg * yg;
+    if(WANT_D){ w.D[0] = xdh * yh; w.D[1] = xdg * yh; w.D[2] = xdh * yg; w.D[3] = xdg * yg; }
+    if(WANT_E){ w.E[0] = xh * ydh; w.E[1] = xg * ydh; w.E[2] = xh * ydg; w.E[3] = xg * ydg; }
+    return w;
 }
-template <int WHICH, int ZDER>
-DEVINL void nbhd_corners(const GeoacDevParams& P, int field, const GridLoc& L, double o[2][2]){
-    const double t = L.t, th = 0.5 * t, t6 = t * (1.0 / 6.0);
-    #pragma unroll
-    for(int a = 0; a < 2; a++){
-        #pragma unroll
-        for(int b = 0; b < 2; b++){
-            const double* c = grid_rec(P, field, L.kz, L.nb[a + 1][b + 1]) + 4 * WHICH;
-            o[a][b] = (ZDER == 0) ? cubic_val(c, t, t6) : (ZDER == 1) ? cubic_d1(c, t, th) : cubic_d2(c, t);
-        }
-    }
+DEVINL int corner_node(const GridLoc& L, int a, int b){ return a ? (b ? L.nb[1][1] : L.nb[1][0]) : (b ? L.nb[0][1] : L.nb[0][0]); }
+DEVINL double dot4(const double* w, double F, double FX, double FY, double FXY, double acc){
+    return __builtin_fma(w[0], F, __builtin_fma(w[1], FX, __builtin_fma(w[2], FY, __builtin_fma(w[3], FXY, acc))));
 }
 
 // Eval_Spline_AllOrder1 (ORDER2 = false, :1156-1339) / AllOrder2 (:1341-1593):
 // out = f, f_x, f_y, f_z [, f_xx, f_yy, f_zz, f_xy, f_xz, f_yz]
+//   patch f    : F = V0,     FX = Dx V0 dx,    FY = Dy V0 dy,        FXY = Dxy V0 dx dy
+//   patch f_x  : F = Dx V0,  FX = Dx Vx dx,    FY = Dxy V0 dy,       FXY = Dxy Vx dx dy     (its d/dx, d/dy: f_xx, f_xy)
+//   patch f_y  : F = Dy V0,  FX = Dxy V0 dx,   FY = Dy Vy dy,        FXY = Dxy Vy dx dy     (its d/dy: f_yy)
+//   patch f_z  : F = V0',    FX = Vx' dx,      FY = Vy' dy,          FXY = Dxy V0' dx dy    (its d/dx, d/dy: f_xz, f_yz)
+//   patch f_zz : F = V0'',   FX = Dx V0'' dx,  FY = Dy V0'' dx (Q11, :1568-1571), FXY = Dxy V0'' dx dy
 template <bool ORDER2>
 DEVINL void grid_eval_all(const GeoacDevParams& P, int field, const GridLoc& L, double* out){
     const Herm hx = hermite(L.xs), hy = hermite(L.ys);
     const double dxs = L.dxs, dys = L.dys, dxy = dxs * dys;
-    const double idxs = 1.0 / dxs, idys = 1.0 / dys;
-    double g[4][4];
-    double DxV0[2][2], DyV0[2][2], DxyV0[2][2];
-    Patch B; double v, sx, sy;
-
-    nbhd<0, 0>(P, field, L, g);                                   // V0 = S_f(z) on the neighbourhood
-    fd_x(g, L, DxV0); fd_y(g, L, DyV0); fd_xy(g, L, DxyV0);
-    // patch 1: f
-    corners(g, B.F); copy22(DxV0, B.FX, dxs); copy22(DyV0, B.FY, dys); copy22(DxyV0, B.FXY, dxy);
-    patch_eval<false, false>(B, hx, hy, v, sx, sy);
-    out[0] = v;
-
-    // patch 2: df/dx  (F = Dx V0, FX = Dx Vx dx, FY = Dxy V0 dy, FXY = Dxy Vx dx dy)
-    nbhd<1, 0>(P, field, L, g);                                   // Vx = S_fx(z)
-    copy22(DxV0, B.F, 1.0); copy22(DxyV0, B.FY, dys);
-    fd_x(g, L, B.FX); scale22(B.FX, dxs);
-    fd_xy(g, L, B.FXY); scale22(B.FXY, dxy);
-    patch_eval<ORDER2, ORDER2>(B, hx, hy, v, sx, sy);
-    out[1] = v;
-    if(ORDER2){ out[4] = sx * idxs; out[7] = sy * idys; }
-
-    // patch 3: df/dy  (F = Dy V0, FX = Dxy V0 dx, FY = Dy Vy dy, FXY = Dxy Vy dx dy)
-    nbhd<2, 0>(P, field, L, g);                                   // Vy = S_fy(z)
-    copy22(DyV0, B.F, 1.0); copy22(DxyV0, B.FX, dxs);
-    fd_y(g, L, B.FY); scale22(B.FY, dys);
-    fd_xy(g, L, B.FXY); scale22(B.FXY, dxy);
-    patch_eval<false, ORDER2>(B, hx, hy, v, sx, sy);
-    out[2] = v;
-    if(ORDER2) out[5] = sy * idys;
-
-    // patch 4: df/dz  (F = V0z, FX = Vxz dx, FY = Vyz dy, FXY = Dxy V0z dx dy)
-    nbhd<0, 1>(P, field, L, g);                                   // V0z = S_f'(z)
-    corners(g, B.F);
-    fd_xy(g, L, B.FXY); scale22(B.FXY, dxy);
-    nbhd_corners<1, 1>(P, field, L, B.FX); scale22(B.FX, dxs);
-    nbhd_corners<2, 1>(P, field, L, B.FY); scale22(B.FY, dys);
-    patch_eval<ORDER2, ORDER2>(B, hx, hy, v, sx, sy);
-    out[3] = v;
-    if(ORDER2){
-        out[8] = sx * idxs; out[9] = sy * idys;
-        // patch 5: d2f/dz2 (F = V0zz, FX = Dx V0zz dx, FY = Dy V0zz * DX (Q11, :1568-1571), FXY = Dxy V0zz dx dy)
-        nbhd<0, 2>(P, field, L, g);
-        corners(g, B.F);
-        fd_x(g, L, B.FX); scale22(B.FX, dxs);
-        fd_y(g, L, B.FY); scale22(B.FY, dxs);
-        fd_xy(g, L, B.FXY); scale22(B.FXY, dxy);
-        patch_eval<false, false>(B, hx, hy, v, sx, sy);
-        out[6] = v;
+    const double t = L.t, th = 0.5 * t, t6 = t * (1.0 / 6.0);
+    const double* __restrict__ base = grid_rec(P, field, L.kz, 0);
+    double o[10];
+    #pragma unroll
+    for(int i = 0; i < 10; i++) o[i] = 0.0;
+    #pragma unroll 1
+    for(int cn = 0; cn < 4; cn++){
+        {
+            const int a = cn >> 1, b = cn & 1;
+            const double* __restrict__ r = base + (size_t)corner_node(L, a, b) * GEOAC_GREC;
+            Cub c[10];                                             // all 20 loads of the corner in flight before the first use
+            #pragma unroll
+            for(int i = 0; i < 10; i++) c[i] = load_cubic(r + 4 * i);
+            CornerW w = corner_weights<ORDER2, ORDER2>(hx, hy, a, b);
+            // fold the cell-size factors of the FX / FY / FXY rows into the weights
+            const double Wq = w.W[2] * dxs;                        // Q11 row of the f_zz patch
+            w.W[1] *= dxs; w.W[2] *= dys; w.W[3] *= dxy;
+            if(ORDER2){ w.D[1] *= dxs; w.D[2] *= dys; w.D[3] *= dxy; w.E[1] *= dxs; w.E[2] *= dys; w.E[3] *= dxy; }
+            const double F = cub_val(c[GC_F], t, t6), DxF = cub_val(c[GC_DXF], t, t6), DyF = cub_val(c[GC_DYF], t, t6), DxyF = cub_val(c[GC_DXYF], t, t6);
+            const double DxVx = cub_val(c[GC_DXVX], t, t6), DxyVx = cub_val(c[GC_DXYVX], t, t6);
+            const double DyVy = cub_val(c[GC_DYVY], t, t6), DxyVy = cub_val(c[GC_DXYVY], t, t6);
+            const double Fz = cub_d1(c[GC_F], t, th), Vxz = cub_d1(c[GC_VX], t, th), Vyz = cub_d1(c[GC_VY], t, th), DxyFz = cub_d1(c[GC_DXYF], t, th);
+            o[0] = dot4(w.W, F, DxF, DyF, DxyF, o[0]);
+            o[1] = dot4(w.W, DxF, DxVx, DxyF, DxyVx, o[1]);
+            o[2] = dot4(w.W, DyF, DxyF, DyVy, DxyVy, o[2]);
+            o[3] = dot4(w.W, Fz, Vxz, Vyz, DxyFz, o[3]);
+            if(ORDER2){
+                o[4] = dot4(w.D, DxF, DxVx, DxyF, DxyVx, o[4]);    // d/dxs of the f_x patch
+                o[7] = dot4(w.E, DxF, DxVx, DxyF, DxyVx, o[7]);    // d/dys of the f_x patch
+                o[5] = dot4(w.E, DyF, DxyF, DyVy, DxyVy, o[5]);    // d/dys of the f_y patch
+                o[8] = dot4(w.D, Fz, Vxz, Vyz, DxyFz, o[8]);       // d/dxs of the f_z patch
+                o[9] = dot4(w.E, Fz, Vxz, Vyz, DxyFz, o[9]);       // d/dys of the f_z patch
+                const double Fzz = cub_d2(c[GC_F], t), DxFzz = cub_d2(c[GC_DXF], t), DyFzz = cub_d2(c[GC_DYF], t), DxyFzz = cub_d2(c[GC_DXYF], t);
+                o[6] = __builtin_fma(w.W[0], Fzz, __builtin_fma(w.W[1], DxFzz, __builtin_fma(Wq, DyFzz, __builtin_fma(w.W[3], DxyFzz, o[6]))));
+            }
+        }
     }
+    if(ORDER2){
+        const double idxs = 1.0 / dxs, idys = 1.0 / dys;
+        o[4] *= idxs; o[8] *= idxs; o[7] *= idys; o[5] *= idys; o[9] *= idys;
+    }
+    #pragma unroll
+    for(int i = 0; i < (ORDER2 ? 10 : 4); i++) out[i] = o[i];
 }
 
 // Eval_Spline_f (:806-863): scalar value, y rows scaled by dx_scalar (Q11)
 DEVINL double grid_eval_f(const GeoacDevParams& P, int field, const GridLoc& L){
     const Herm hx = hermite(L.xs), hy = hermite(L.ys);
-    double g[4][4]; Patch B; double v, sx, sy;
-    nbhd<0, 0>(P, field, L, g);
-    corners(g, B.F);
-    fd_x(g, L, B.FX); scale22(B.FX, L.dxs);
-    fd_y(g, L, B.FY); scale22(B.FY, L.dxs);
-    fd_xy(g, L, B.FXY); scale22(B.FXY, L.dxs * L.dys);
-    patch_eval<false, false>(B, hx, hy, v, sx, sy);
+    const double t = L.t, t6 = t * (1.0 / 6.0);
+    const double* __restrict__ base = grid_rec(P, field, L.kz, 0);
+    const int stride = field < 3 ? GEOAC_GREC : GEOAC_GREC_RHO;
+    double v = 0.0;
+    #pragma unroll 1
+    for(int cn = 0; cn < 4; cn++){
+        {
+            const int a = cn >> 1, b = cn & 1;
+            const double* __restrict__ r = base + (size_t)corner_node(L, a, b) * stride;
+            Cub c[4];
+            #pragma unroll
+            for(int i = 0; i < 4; i++) c[i] = load_cubic(r + 4 * i);
+            CornerW w = corner_weights<false, false>(hx, hy, a, b);
+            w.W[1] *= L.dxs; w.W[2] *= L.dxs; w.W[3] *= L.dxs * L.dys;
+            v = dot4(w.W, cub_val(c[GC_F], t, t6), cub_val(c[GC_DXF], t, t6), cub_val(c[GC_DYF], t, t6), cub_val(c[GC_DXYF], t, t6), v);
+        }
+    }
     return v;
 }
-// Eval_Spline_df(.., index = 2, ..) (:920-939): df/dz patch, y rows scaled by dx_scalar (Q11)
+// Eval_Spline_df(.., index = 2, ..) (:920-939): df/dz patch, y rows scaled by dx_scalar (Q11); T, u, v only
 DEVINL double grid_eval_dfdz(const GeoacDevParams& P, int field, const GridLoc& L){
     const Herm hx = hermite(L.xs), hy = hermite(L.ys);
-    double g[4][4]; Patch B; double v, sx, sy;
-    nbhd<0, 1>(P, field, L, g);
-    corners(g, B.F);
-    fd_xy(g, L, B.FXY); scale22(B.FXY, L.dxs * L.dys);
-    nbhd_corners<1, 1>(P, field, L, B.FX); scale22(B.FX, L.dxs);
-    nbhd_corners<2, 1>(P, field, L, B.FY); scale22(B.FY, L.dxs);
-    patch_eval<false, false>(B, hx, hy, v, sx, sy);
+    const double t = L.t, th = 0.5 * t;
+    const double* __restrict__ base = grid_rec(P, field, L.kz, 0);
+    double v = 0.0;
+    #pragma unroll 1
+    for(int cn = 0; cn < 4; cn++){
+        {
+            const int a = cn >> 1, b = cn & 1;
+            const double* __restrict__ r = base + (size_t)corner_node(L, a, b) * GEOAC_GREC;
+            const Cub cF = load_cubic(r + 4 * GC_F), cXY = load_cubic(r + 4 * GC_DXYF), cX = load_cubic(r + 4 * GC_VX), cY = load_cubic(r + 4 * GC_VY);
+            CornerW w = corner_weights<false, false>(hx, hy, a, b);
+            w.W[1] *= L.dxs; w.W[2] *= L.dxs; w.W[3] *= L.dxs * L.dys;
+            v = dot4(w.W, cub_d1(cF, t, th), cub_d1(cX, t, th), cub_d1(cY, t, th), cub_d1(cXY, t, th), v);
+        }
+    }
     return v;
 }
 
@@ -274,10 +223,10 @@ DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double
     const double xe = clampd(y[0], P.gx[0], P.gx[P.gnx - 1]), ye = clampd(y[1], P.gy[0], P.gy[P.gny - 1]), ze = clampd(y[2], P.x_min, P.x_max);
     GridLoc L; grid_locate(P, xe, ye, ze, kz, L);
     kz = L.kz;
-    double T[10], U[10], V[10];
-    grid_eval_all<AMP>(P, 0, L, T);
-    grid_eval_all<AMP>(P, 1, L, U);
-    grid_eval_all<AMP>(P, 2, L, V);
+    double M[3][10];                                               // T, u, v and their derivatives; one (non-inlined) evaluator call per field
+    #pragma unroll 1
+    for(int f = 0; f < 3; f++) grid_eval_all<AMP>(P, f, L, M[f]);
+    const double* T = M[0]; const double* U = M[1]; const double* V = M[2];
     const double n0 = y[3], n1 = y[4], n2 = y[5];
     const double qT = kGamR * T[0];
     const double ic = frsq(qT);
