@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/geoac_hip.h"
+#include "../../include/geoac_host.h"
 #include "geoac_device.h"
 
 extern "C" void geoac_natural_spline_slopes(int n, const double* x, const double* f, double* slopes);
@@ -95,18 +96,9 @@ double host_spline_f(const std::vector<double>& xv, const std::vector<double>& f
     return (1.0 - X) * fv[k] + X * fv[k + 1] + X * (1.0 - X) * (A * (1.0 - X) + B * X);
 }
 
-// cubic of Eval_Spline_f (G2S_Spline1D.cpp:245-281) expanded in powers of t = x - x_k:
-//   f = f_k + s_k t + (B - 2A)/h^2 t^2 + (A - B)/h^3 t^3,  A = s_k h - df,  B = -s_{k+1} h + df
-// `deriv_form`: store (c0, c1, 2 c2, 6 c3) - the layout the kernels' cubic3() evaluates (value + two derivatives in 6 FMAs)
-void seg_coeffs(double x0, double x1, double f0, double f1, double s0, double s1, double* c, bool deriv_form){
-    long double h = (long double)x1 - (long double)x0;
-    long double df = (long double)f1 - (long double)f0;
-    long double A = (long double)s0 * h - df, B = -(long double)s1 * h + df;
-    long double c2 = (B - 2.0L * A) / (h * h), c3 = (A - B) / (h * h * h);
-    c[0] = f0;
-    c[1] = s0;
-    c[2] = (double)(deriv_form ? 2.0L * c2 : c2);
-    c[3] = (double)(deriv_form ? 6.0L * c3 : c3);
+// cubic of one spline segment in powers of t = x - x_k: geoac_spline_segment_cubic (geoac_host.cpp)
+static inline void seg_coeffs(double x0, double x1, double f0, double f1, double s0, double s1, double* c, bool deriv_form){
+    geoac_spline_segment_cubic(x0, x1, f0, f1, s0, s1, c, deriv_form ? 1 : 0);
 }
 
 }  // namespace
@@ -243,11 +235,6 @@ int geoac_upload_atmo_1d(geoac_ctx* ctx, int n, const double* x, const double* T
     return GEOAC_OK;
 }
 
-// one cubic of a vertical spline segment in the derivative-friendly form
-static void col_coeffs(const double* z, const double* f, const double* sl, int k, double* c){
-    seg_coeffs(z[k], z[k + 1], f[k], f[k + 1], sl[k], sl[k + 1], c, true);
-}
-
 int geoac_upload_atmo_3d(geoac_ctx* ctx, int nx, int ny, int nz, const double* x, const double* y, const double* z,
                          const double* T, const double* u, const double* v, const double* rho){
     if(!ctx || nx < 2 || ny < 2 || nz < 3 || !x || !y || !z || !T || !u || !v || !rho) return fail(ctx, GEOAC_E_INVALID, "upload_atmo_3d: bad arguments");
@@ -256,54 +243,9 @@ int geoac_upload_atmo_3d(geoac_ctx* ctx, int nx, int ny, int nz, const double* x
     for(int i = 1; i < ny; i++) if(!(y[i] > y[i - 1])) return fail(ctx, GEOAC_E_INVALID, "upload_atmo_3d: y not strictly increasing");
     for(int i = 1; i < nz; i++) if(!(z[i] > z[i - 1])) return fail(ctx, GEOAC_E_INVALID, "upload_atmo_3d: z not strictly increasing");
     HIPCHK(hipSetDevice(ctx->device));
-    const int nseg = nz - 1, nn = nx * ny;
-    const double* F[4] = { T, u, v, rho };
-    // device table (geoac_rngdep.h): per (field, kz, node) the vertical cubics F, DxF, DyF, DxyF, Vx, DxVx, DxyVx, Vy, DyVy, DxyVy
-    // (T, u, v: 40 doubles) or F, DxF, DyF, DxyF (rho: 16 doubles).  V0 = S_f, Vx = S_fx, Vy = S_fy are the reference's three
-    // vertical splines per node; D* are its evaluation-time finite differences (BiCubic_Deriv_*, :568-800), which are linear in
-    // the coefficients and centred at the node, taken here once on the coefficients.
-    const size_t rho_off = (size_t)3 * nseg * nn * 40;
-    std::vector<double> tab(rho_off + (size_t)nseg * nn * 16);
-    std::vector<double> V0((size_t)nseg * nn * 4), Vx((size_t)nseg * nn * 4), Vy((size_t)nseg * nn * 4);
-    std::vector<double> dcol((size_t)nz), sl((size_t)nz);
-    auto at = [&](std::vector<double>& V, int k, int i, int j) -> double* { return &V[(((size_t)k * nn) + (size_t)i * ny + j) * 4]; };
-    for(int f = 0; f < 4; f++){
-        for(int i = 0; i < nx; i++) for(int j = 0; j < ny; j++){
-            const double* col = F[f] + ((size_t)i * ny + j) * nz;
-            // S_f: vertical natural spline of the values (Set_Slopes_Multi :313-343)
-            geoac_natural_spline_slopes(nz, z, col, sl.data());
-            for(int k = 0; k < nseg; k++) col_coeffs(z, col, sl.data(), k, at(V0, k, i, j));
-            if(f == 3) continue;                                   // rho is only ever evaluated through Eval_Spline_f
-            // S_fx: spline of the centred (one-sided at the edges) x-difference (:346-391)
-            int iu = std::min(i + 1, nx - 1), id = std::max(i - 1, 0);
-            const double* cu = F[f] + ((size_t)iu * ny + j) * nz; const double* cd = F[f] + ((size_t)id * ny + j) * nz;
-            for(int k = 0; k < nz; k++) dcol[k] = (cu[k] - cd[k]) / (x[iu] - x[id]);
-            geoac_natural_spline_slopes(nz, z, dcol.data(), sl.data());
-            for(int k = 0; k < nseg; k++) col_coeffs(z, dcol.data(), sl.data(), k, at(Vx, k, i, j));
-            // S_fy (:394-424)
-            int ju = std::min(j + 1, ny - 1), jd = std::max(j - 1, 0);
-            const double* du = F[f] + ((size_t)i * ny + ju) * nz; const double* dd = F[f] + ((size_t)i * ny + jd) * nz;
-            for(int k = 0; k < nz; k++) dcol[k] = (du[k] - dd[k]) / (y[ju] - y[jd]);
-            geoac_natural_spline_slopes(nz, z, dcol.data(), sl.data());
-            for(int k = 0; k < nseg; k++) col_coeffs(z, dcol.data(), sl.data(), k, at(Vy, k, i, j));
-        }
-        for(int k = 0; k < nseg; k++) for(int i = 0; i < nx; i++) for(int j = 0; j < ny; j++){
-            const int iu = std::min(i + 1, nx - 1), id = std::max(i - 1, 0), ju = std::min(j + 1, ny - 1), jd = std::max(j - 1, 0);
-            const double ix = 1.0 / (x[iu] - x[id]), iy = 1.0 / (y[ju] - y[jd]);
-            double* r = (f < 3) ? &tab[((((size_t)f * nseg + k) * nn) + (size_t)i * ny + j) * 40]
-                                : &tab[rho_off + (((size_t)k * nn) + (size_t)i * ny + j) * 16];
-            auto dx  = [&](std::vector<double>& V, int c){ return (at(V, k, iu, j)[c] - at(V, k, id, j)[c]) * ix; };
-            auto dy  = [&](std::vector<double>& V, int c){ return (at(V, k, i, ju)[c] - at(V, k, i, jd)[c]) * iy; };
-            auto dxy = [&](std::vector<double>& V, int c){ return (at(V, k, iu, ju)[c] - at(V, k, iu, jd)[c] - at(V, k, id, ju)[c] + at(V, k, id, jd)[c]) * (ix * iy); };
-            for(int c = 0; c < 4; c++){
-                r[0 + c] = at(V0, k, i, j)[c]; r[4 + c] = dx(V0, c); r[8 + c] = dy(V0, c); r[12 + c] = dxy(V0, c);
-                if(f < 3){
-                    r[16 + c] = at(Vx, k, i, j)[c]; r[20 + c] = dx(Vx, c); r[24 + c] = dxy(Vx, c);
-                    r[28 + c] = at(Vy, k, i, j)[c]; r[32 + c] = dy(Vy, c); r[36 + c] = dxy(Vy, c);
-                }
-            }
-        }
-    }
+    // device table (geoac_rngdep.h) built on the host: vertical cubics of the node values and of the node-centred differences
+    std::vector<double> tab(geoac_grid_table_size(nx, ny, nz));
+    geoac_grid_table(nx, ny, nz, x, y, z, T, u, v, rho, tab.data());
     HIPCHK(ctx->d_gx.ensure(sizeof(double) * nx)); HIPCHK(ctx->d_gy.ensure(sizeof(double) * ny)); HIPCHK(ctx->d_gz.ensure(sizeof(double) * nz));
     HIPCHK(ctx->d_gtab.ensure(sizeof(double) * tab.size()));
     HIPCHK(ctx->d_consts.ensure(sizeof(double) * 8));

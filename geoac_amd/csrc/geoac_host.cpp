@@ -2,6 +2,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -108,6 +109,98 @@ int geoac_grid_load(const char* prefix, const char* locx, const char* locy, cons
         fclose(fp);
     }
     return 0;
+}
+
+// cubic of Eval_Spline_f (G2S_Spline1D.cpp:245-281) expanded in powers of t = x - x_k:
+//   f = f_k + s_k t + (B - 2A)/h^2 t^2 + (A - B)/h^3 t^3,  A = s_k h - df,  B = -s_{k+1} h + df
+// `deriv_form`: store (c0, c1, 2 c2, 6 c3) - the layout the kernels evaluate (value + two derivatives in 6 FMAs)
+void geoac_spline_segment_cubic(double x0, double x1, double f0, double f1, double s0, double s1, double* c, int deriv_form){
+    long double h = (long double)x1 - (long double)x0;
+    long double df = (long double)f1 - (long double)f0;
+    long double A = (long double)s0 * h - df, B = -(long double)s1 * h + df;
+    long double c2 = (B - 2.0L * A) / (h * h), c3 = (A - B) / (h * h * h);
+    c[0] = f0;
+    c[1] = s0;
+    c[2] = (double)(deriv_form ? 2.0L * c2 : c2);
+    c[3] = (double)(deriv_form ? 6.0L * c3 : c3);
+}
+
+size_t geoac_grid_table_size(int nx, int ny, int nz){
+    const size_t nseg = (size_t)(nz - 1), nn = (size_t)nx * ny;
+    return 3 * nseg * nn * 40 + nseg * nn * 16;
+}
+
+int geoac_grid_table(int nx, int ny, int nz, const double* x, const double* y, const double* z,
+                     const double* T, const double* u, const double* v, const double* rho, double* tab){
+    if(nx < 2 || ny < 2 || nz < 3 || !tab) return -1;
+    const int nseg = nz - 1, nn = nx * ny;
+    const double* F[4] = { T, u, v, rho };
+    const size_t rho_off = (size_t)3 * nseg * nn * 40;
+    std::vector<double> V0((size_t)nseg * nn * 4), Vx((size_t)nseg * nn * 4), Vy((size_t)nseg * nn * 4);
+    std::vector<double> dcol((size_t)nz), sl((size_t)nz);
+    auto at = [&](std::vector<double>& V, int k, int i, int j) -> double* { return &V[(((size_t)k * nn) + (size_t)i * ny + j) * 4]; };
+    auto col_cubics = [&](const double* f, std::vector<double>& V, int i, int j){
+        geoac_natural_spline_slopes(nz, z, f, sl.data());
+        for(int k = 0; k < nseg; k++) geoac_spline_segment_cubic(z[k], z[k + 1], f[k], f[k + 1], sl[k], sl[k + 1], at(V, k, i, j), 1);
+    };
+    for(int f = 0; f < 4; f++){
+        for(int i = 0; i < nx; i++) for(int j = 0; j < ny; j++){
+            const double* col = F[f] + ((size_t)i * ny + j) * nz;
+            col_cubics(col, V0, i, j);                              // S_f: vertical natural spline of the values (:313-343)
+            if(f == 3) continue;                                   // rho is only ever evaluated through Eval_Spline_f
+            // S_fx: spline of the centred (one-sided at the edges) x-difference (:346-391)
+            int iu = std::min(i + 1, nx - 1), id = std::max(i - 1, 0);
+            const double* cu = F[f] + ((size_t)iu * ny + j) * nz; const double* cd = F[f] + ((size_t)id * ny + j) * nz;
+            for(int k = 0; k < nz; k++) dcol[k] = (cu[k] - cd[k]) / (x[iu] - x[id]);
+            col_cubics(dcol.data(), Vx, i, j);
+            // S_fy (:394-424)
+            int ju = std::min(j + 1, ny - 1), jd = std::max(j - 1, 0);
+            const double* du = F[f] + ((size_t)i * ny + ju) * nz; const double* dd = F[f] + ((size_t)i * ny + jd) * nz;
+            for(int k = 0; k < nz; k++) dcol[k] = (du[k] - dd[k]) / (y[ju] - y[jd]);
+            col_cubics(dcol.data(), Vy, i, j);
+        }
+        for(int k = 0; k < nseg; k++) for(int i = 0; i < nx; i++) for(int j = 0; j < ny; j++){
+            const int iu = std::min(i + 1, nx - 1), id = std::max(i - 1, 0), ju = std::min(j + 1, ny - 1), jd = std::max(j - 1, 0);
+            const double ix = 1.0 / (x[iu] - x[id]), iy = 1.0 / (y[ju] - y[jd]);
+            double* r = (f < 3) ? &tab[((((size_t)f * nseg + k) * nn) + (size_t)i * ny + j) * 40]
+                                : &tab[rho_off + (((size_t)k * nn) + (size_t)i * ny + j) * 16];
+            auto dx  = [&](std::vector<double>& V, int c){ return (at(V, k, iu, j)[c] - at(V, k, id, j)[c]) * ix; };
+            auto dy  = [&](std::vector<double>& V, int c){ return (at(V, k, i, ju)[c] - at(V, k, i, jd)[c]) * iy; };
+            auto dxy = [&](std::vector<double>& V, int c){ return (at(V, k, iu, ju)[c] - at(V, k, iu, jd)[c] - at(V, k, id, ju)[c] + at(V, k, id, jd)[c]) * (ix * iy); };
+            for(int c = 0; c < 4; c++){
+                r[0 + c] = at(V0, k, i, j)[c]; r[4 + c] = dx(V0, c); r[8 + c] = dy(V0, c); r[12 + c] = dxy(V0, c);
+                if(f < 3){
+                    r[16 + c] = at(Vx, k, i, j)[c]; r[20 + c] = dx(Vx, c); r[24 + c] = dxy(Vx, c);
+                    r[28 + c] = at(Vy, k, i, j)[c]; r[32 + c] = dy(Vy, c); r[36 + c] = dxy(Vy, c);
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+double geoac_grid_eval(int nx, int ny, int nz, const double* x, const double* y, const double* z, const double* tab,
+                       int field, double xq, double yq, double zq){
+    const int nseg = nz - 1, nn = nx * ny;
+    xq = std::min(std::max(xq, x[0]), x[nx - 1]); yq = std::min(std::max(yq, y[0]), y[ny - 1]); zq = std::min(std::max(zq, z[0]), z[nz - 1]);
+    int kx = 0, ky = 0, kz = 0;
+    while(kx < nx - 2 && xq >= x[kx + 1]) kx++;
+    while(ky < ny - 2 && yq >= y[ky + 1]) ky++;
+    while(kz < nseg - 1 && zq > z[kz + 1]) kz++;
+    const double t = zq - z[kz], dxs = x[kx + 1] - x[kx], dys = y[ky + 1] - y[ky];
+    const double xs = (xq - x[kx]) / dxs, ys = (yq - y[ky]) / dys;
+    auto herm = [](double s, double* h, double* g){ double s2 = s * s, s3 = s2 * s; h[1] = 3.0 * s2 - 2.0 * s3; h[0] = 1.0 - h[1]; g[0] = s - 2.0 * s2 + s3; g[1] = s3 - s2; };
+    double hxh[2], hxg[2], hyh[2], hyg[2];
+    herm(xs, hxh, hxg); herm(ys, hyh, hyg);
+    const size_t stride = field < 3 ? 40 : 16;
+    const double* base = field < 3 ? tab + (((size_t)field * nseg + kz) * nn) * 40 : tab + (size_t)3 * nseg * nn * 40 + ((size_t)kz * nn) * 16;
+    auto val = [&](const double* c){ return c[0] + t * (c[1] + t * (c[2] / 2.0 + t * c[3] / 6.0)); };
+    double v = 0.0;
+    for(int a = 0; a < 2; a++) for(int b = 0; b < 2; b++){
+        const double* r = base + ((size_t)(kx + a) * ny + (ky + b)) * stride;
+        v += hxh[a] * hyh[b] * val(r) + hxg[a] * hyh[b] * dxs * val(r + 4) + hxh[a] * hyg[b] * dxs * val(r + 8) + hxg[a] * hyg[b] * dxs * dys * val(r + 12);
+    }
+    return v;
 }
 
 void geoac_natural_spline_slopes(int n, const double* x, const double* f, double* slopes){

@@ -1,10 +1,11 @@
-// geoac_cli.cpp - host drivers `GeoAc2D`, `GeoAc3D`, `GeoAcGlobal` (built three times with -DGEOAC_CLI_SET=0/1/2):
+// geoac_cli.cpp - host drivers `GeoAc2D`, `GeoAc3D`, `GeoAcGlobal`, `GeoAc3D.RngDep` (built with -DGEOAC_CLI_SET=0/1/2/3):
 // the reference's `-prop` command line, .met input and `_results.dat` / `_raypaths.dat` / `_caustics-path#.dat` /
 // `atmo.dat` outputs, with the launch-angle fan integrated by libgeoac_hip.so on the GPU.
 //
 // Surface kept (grammar, defaults, ordering side effects, number formatting):
 //   GeoAcGlobal_RunProp  Code/GeoAcGlobal_main.cpp:116-332      GeoAc3D_RunProp  Code/GeoAc3D_main.cpp:106-313
 //   GeoAc2D_RunProp      Code/GeoAc2D_main.cpp:66-237           GeoAc_WriteProfile  Code/GeoAc/GeoAc.Interface{,.Global}.cpp:78-98
+//   GeoAc3D_RngDep_RunProp  Code/GeoAc3D.RngDep_main.cpp:119-334 (`-prop prefix loc_x loc_y [parameter=value ...]`)
 // Not provided here (out of the accelerated path): -interactive, -eig_search, -eig_direct.
 #include <strings.h>
 #include <cmath>
@@ -28,15 +29,17 @@ using namespace std;
 
 static const double Pi = 3.141592653589793238462643;
 static const double kGamR = 0.00040187, kR = 287.05, kGam = 1.4;
-static const char* kName = (GEOAC_CLI_SET == 0) ? "GeoAc2D" : (GEOAC_CLI_SET == 1) ? "GeoAc3D" : "GeoAcGlobal";
-static const int kEq = (GEOAC_CLI_SET == 0) ? GEOAC_EQ_2D : (GEOAC_CLI_SET == 1) ? GEOAC_EQ_3D : GEOAC_EQ_GLOBAL;
+static const char* kName = (GEOAC_CLI_SET == 0) ? "GeoAc2D" : (GEOAC_CLI_SET == 1) ? "GeoAc3D" : (GEOAC_CLI_SET == 2) ? "GeoAcGlobal" : "GeoAc3D.RngDep";
+static const int kEq = (GEOAC_CLI_SET == 0) ? GEOAC_EQ_2D : (GEOAC_CLI_SET == 1) ? GEOAC_EQ_3D : (GEOAC_CLI_SET == 2) ? GEOAC_EQ_GLOBAL : GEOAC_EQ_3D_RNGDEP;
+static const bool kRng = (GEOAC_CLI_SET == 3);                    // grid of profiles: -prop prefix loc_x loc_y, parameters from argv[5]
+static const bool kCart3 = (GEOAC_CLI_SET == 1 || GEOAC_CLI_SET == 3);   // x, y, z file layouts
 
 static bool string2bool(const string& v){          // GeoAc.Interface.cpp:125-128
     return !v.empty() && (strcasecmp(v.c_str(), "true") == 0 || atoi(v.c_str()) != 0);
 }
 
 static void usage(){
-    cout << '\n' << "Usage: " << kName << " -prop profile.met [parameter=value ...]" << '\n'
+    cout << '\n' << "Usage: " << kName << (kRng ? " -prop profile_prefix loc_x.dat loc_y.dat [parameter=value ...]" : " -prop profile.met [parameter=value ...]") << '\n'
          << "  GPU (MI355X) build of the " << kName << " launch-angle fan; parameters, defaults and output files follow" << '\n'
          << "  LANL-Seismoacoustics/GeoAc (see GeoAc_Manual.pdf).  Only the -prop option is provided by this build." << '\n' << '\n';
 }
@@ -81,6 +84,33 @@ static void write_profile(const Profile& p, const char* file_name, double azimut
     file_out.close();
 }
 
+// GeoAc_WriteProfile(file, x0, y0, azimuth): Interface.cpp:100-121 (range-dependent atmosphere sampled above the source)
+struct Grid {
+    int nx = 0, ny = 0, nz = 0;
+    vector<double> x, y, z, T, u, v, rho, tab;
+    double f(int field, double xq, double yq, double zq) const {
+        return geoac_grid_eval(nx, ny, nz, x.data(), y.data(), z.data(), tab.data(), field, xq, yq, zq);
+    }
+};
+static void write_profile_grid(const Grid& g, const char* file_name, double x0, double y0, double azimuth){
+    ofstream file_out; file_out.open(file_name);
+    if(!file_out.is_open()){ cout << "Error opening file, check file name." << '\n'; return; }
+    for(int m = 0; m < 1400; m++){
+        double z0 = m / 10.0;
+        double c = sqrt(kGamR * g.f(0, x0, y0, z0)), u = g.f(1, x0, y0, z0), v = g.f(2, x0, y0, z0), rho = g.f(3, x0, y0, z0);
+        file_out << z0 << '\t';
+        file_out << pow(c * 1000.0, 2) / (kR * kGam) << '\t';
+        file_out << u * 1000.0 << '\t';
+        file_out << v * 1000.0 << '\t';
+        file_out << rho << '\t';
+        file_out << rho * pow(c * 1000.0, 2) / kGam * 10.0 << '\t';
+        file_out << c << '\t';
+        file_out << c + cos(azimuth * Pi / 180.0) * u + sin(azimuth * Pi / 180.0) * v << '\t';
+        file_out << '\n';
+    }
+    file_out.close();
+}
+
 static int run_prop(char* inputs[], int count){
     double theta_min = 0.5, theta_max = 45.0, theta_step = 0.5;
     double phi_min = -90.0, phi_max = -90.0, phi_step = 1.0;
@@ -92,11 +122,15 @@ static int run_prop(char* inputs[], int count){
     const char* ProfileFormat = "zTuvdp";
     double z_grnd = 0.0, tweak_abs = 0.3;
     char input_check;
+    const int arg0 = kRng ? 5 : 3;
 
-    for(int i = 3; i < count; i++) if(strncmp(inputs[i], "profile_format=", 15) == 0) ProfileFormat = inputs[i] + 15;
+    for(int i = arg0; i < count; i++) if(strncmp(inputs[i], "profile_format=", 15) == 0) ProfileFormat = inputs[i] + 15;
 
-    // ---- load the profile BEFORE parsing the rest (z_grnd= therefore never reaches the wind taper: Q9) ----
+    // ---- stratified mains: load the profile BEFORE parsing the rest (z_grnd= therefore never reaches the wind taper: Q9);
+    //      the range-dependent main parses first and loads with the parsed z_grnd (GeoAc3D.RngDep_main.cpp:131-170) ----
     Profile prof;
+    Grid grid;
+    if(!kRng){
     prof.n = geoac_met_rows(inputs[2]);
     if(prof.n < 3){ cout << "Error opening file, check file name" << '\n'; return 1; }
     prof.x.resize(prof.n); prof.T.resize(prof.n); prof.u.resize(prof.n); prof.v.resize(prof.n); prof.rho.resize(prof.n);
@@ -109,12 +143,13 @@ static int run_prop(char* inputs[], int count){
     geoac_natural_spline_slopes(prof.n, prof.x.data(), prof.u.data(),   &prof.sl[prof.n]);
     geoac_natural_spline_slopes(prof.n, prof.x.data(), prof.v.data(),   &prof.sl[2 * (size_t)prof.n]);
     geoac_natural_spline_slopes(prof.n, prof.x.data(), prof.rho.data(), &prof.sl[3 * (size_t)prof.n]);
+    }
 
     geoac_params P;
     geoac_default_params(kEq, &P);
-    P.vert_limit = prof.x[prof.n - 1];                             // GeoAc_SetPropRegion
+    if(!kRng) P.vert_limit = prof.x[prof.n - 1];                   // GeoAc_SetPropRegion
 
-    for(int i = 3; i < count; i++){
+    for(int i = arg0; i < count; i++){
         const char* a = inputs[i];
         if(strncmp(a, "theta_min=", 10) == 0){ theta_min = atof(a + 10); }
         else if(strncmp(a, "theta_max=", 10) == 0){ theta_max = atof(a + 10); }
@@ -126,6 +161,11 @@ static int run_prop(char* inputs[], int count){
         else if(strncmp(a, "bounces=", 8) == 0){ bounces = atoi(a + 8); }
         else if(kEq == GEOAC_EQ_GLOBAL && strncmp(a, "lat_src=", 8) == 0){ src_a = atof(a + 8); }
         else if(kEq == GEOAC_EQ_GLOBAL && strncmp(a, "lon_src=", 8) == 0){ src_b = atof(a + 8); }
+        else if(kRng && strncmp(a, "x_src=", 6) == 0){ src_a = atof(a + 6); }
+        else if(kRng && strncmp(a, "y_src=", 6) == 0){ src_b = atof(a + 6); }
+        // the range-dependent main takes the region limits but GeoAc_SetPropRegion overwrites them right after loading (Q9)
+        else if(kRng && (strncmp(a, "x_min=", 6) == 0 || strncmp(a, "x_max=", 6) == 0 || strncmp(a, "y_min=", 6) == 0 || strncmp(a, "y_max=", 6) == 0)){ }
+        else if(kRng && strncmp(a, "alt_max=", 8) == 0){ }
         else if(strncmp(a, "z_src=", 6) == 0){ z_src = atof(a + 6); }
         else if(strncmp(a, "z_grnd=", 7) == 0){ z_grnd = atof(a + 7); }
         else if(kEq != GEOAC_EQ_2D && strncmp(a, "WriteAtmo=", 10) == 0){ WriteAtmo = string2bool(a + 10); }
@@ -136,7 +176,7 @@ static int run_prop(char* inputs[], int count){
         else if(strncmp(a, "WriteCaustics=", 14) == 0){ WriteCaustics = string2bool(a + 14); }
         else if(strncmp(a, "CalcAmp=", 8) == 0){ CalcAmp = string2bool(a + 8); }
         else if(strncmp(a, "alt_max=", 8) == 0){ P.vert_limit = atof(a + 8); }     // Global: a km altitude compared with a radius (Q9)
-        else if(strncmp(a, "rng_max=", 8) == 0){ P.range_limit = atof(a + 8); }
+        else if(!kRng && strncmp(a, "rng_max=", 8) == 0){ P.range_limit = atof(a + 8); }
         else {
             cout << "***WARNING*** Unrecognized parameter entry: " << a << '\n';
             cout << "Continue? (y/n):"; cin >> input_check;
@@ -145,24 +185,42 @@ static int run_prop(char* inputs[], int count){
     }
     if(kEq == GEOAC_EQ_2D){ WriteRays = true; WriteAtmo = true; }     // GeoAc2D always writes raypaths and atmo.dat
     if(WriteCaustics) CalcAmp = true;
+    if(kRng){
+        z_src = max(z_grnd, z_src);                                 // GeoAc3D.RngDep_main.cpp:165
+        if(geoac_grid_dims(inputs[2], inputs[3], inputs[4], &grid.nx, &grid.ny, &grid.nz)){ cout << "Error opening file, check file name" << '\n'; return 1; }
+        const size_t nn = (size_t)grid.nx * grid.ny * grid.nz;
+        grid.x.resize(grid.nx); grid.y.resize(grid.ny); grid.z.resize(grid.nz);
+        grid.T.resize(nn); grid.u.resize(nn); grid.v.resize(nn); grid.rho.resize(nn);
+        int lrc = geoac_grid_load(inputs[2], inputs[3], inputs[4], ProfileFormat, z_grnd, grid.nx, grid.ny, grid.nz, grid.x.data(), grid.y.data(), grid.z.data(),
+                                  grid.T.data(), grid.u.data(), grid.v.data(), grid.rho.data());
+        if(lrc == -2){ cout << "Unrecognized profile option: " << ProfileFormat << ".  Valid options are: zTuvdp and zuvwTdp" << '\n'; return 1; }
+        if(lrc){ cout << "Error opening file, check file name" << '\n'; return 1; }
+    }
 
     // output prefix = input path up to the first '.' (GeoAcGlobal_main.cpp:170-177)
     char file_title[64];
     { int m = 0; for(; m < 50 && inputs[2][m] != '\0' && inputs[2][m] != '.'; m++) file_title[m] = inputs[2][m]; file_title[m] = '\0'; }
     char output_buffer[96];
 
-    if(WriteAtmo) write_profile(prof, "atmo.dat", 90.0 - phi_min);
+    if(WriteAtmo && !kRng) write_profile(prof, "atmo.dat", 90.0 - phi_min);
+    if(WriteAtmo && kRng){
+        grid.tab.resize(geoac_grid_table_size(grid.nx, grid.ny, grid.nz));
+        geoac_grid_table(grid.nx, grid.ny, grid.nz, grid.x.data(), grid.y.data(), grid.z.data(), grid.T.data(), grid.u.data(), grid.v.data(), grid.rho.data(), grid.tab.data());
+        write_profile_grid(grid, "atmo.dat", src_a, src_b, 90.0 - phi_min);
+    }
 
     // ---- the fan on the GPU ----
     geoac_ctx* ctx = nullptr;
     int rc = geoac_create(&ctx, kEq, 0);
     if(rc){ cout << kName << ": " << geoac_strerror(rc) << '\n'; return 2; }
-    rc = geoac_upload_atmo_1d(ctx, prof.n, prof.x.data(), prof.T.data(), prof.u.data(), prof.v.data(), prof.rho.data(), prof.sl.data());
+    if(kRng) rc = geoac_upload_atmo_3d(ctx, grid.nx, grid.ny, grid.nz, grid.x.data(), grid.y.data(), grid.z.data(), grid.T.data(), grid.u.data(), grid.v.data(), grid.rho.data());
+    else     rc = geoac_upload_atmo_1d(ctx, prof.n, prof.x.data(), prof.T.data(), prof.u.data(), prof.v.data(), prof.rho.data(), prof.sl.data());
     if(rc){ cout << kName << ": " << geoac_last_error(ctx) << '\n'; return 2; }
     P.z_grnd = z_grnd; P.tweak_abs = tweak_abs; P.freq = freq; P.bounces = bounces; P.calc_amp = CalcAmp ? 1 : 0;
     P.mode = (WriteRays ? GEOAC_MODE_WRITE_RAYS : 0) | (WriteCaustics ? GEOAC_MODE_WRITE_CAUSTICS : 0);
     if(kEq == GEOAC_EQ_GLOBAL){ P.src[0] = z_src; P.src[1] = src_a; P.src[2] = src_b; }
     else if(kEq == GEOAC_EQ_3D){ P.src[0] = 0.0; P.src[1] = 0.0; P.src[2] = z_src; }
+    else if(kRng){ P.src[0] = src_a; P.src[1] = src_b; P.src[2] = z_src; }
     else { P.src[0] = z_src; P.src[1] = 0.0; P.src[2] = 0.0; }
     rc = geoac_set_params(ctx, &P);
     if(rc){ cout << kName << ": " << geoac_last_error(ctx) << '\n'; return 2; }
@@ -197,7 +255,7 @@ static int run_prop(char* inputs[], int count){
         results << "# theta [deg]" << '\t' << "phi [deg]" << '\t' << "n_b" << '\t' << "lat_0 [deg]" << '\t' << "lon_0 [deg]" << '\t' << "Travel Time [s]"
                 << '\t' << "Celerity [km/s]" << '\t' << "Turning Height [km]" << '\t' << "Inclination [deg]" << '\t' << "Back Azimuth [deg]"
                 << '\t' << "Geo. Atten. [dB]" << '\t' << "Atmo. Atten. [dB]" << '\n';
-    } else if(kEq == GEOAC_EQ_3D){
+    } else if(kCart3){
         results << "# theta [deg]" << '\t' << "phi [deg]" << '\t' << "n_b" << '\t' << "x_0 [km]" << '\t' << "y_0 [km]" << '\t' << "Travel Time [s]"
                 << '\t' << "Turning Height [km]" << '\t' << "Inclination [deg]" << '\t' << "Back Azimuth [deg]"
                 << '\t' << "Geo. Atten. [dB]" << '\t' << "Atmo. Atten. [dB]" << '\n';
@@ -209,7 +267,7 @@ static int run_prop(char* inputs[], int count){
         sprintf(output_buffer, "%s_raypaths.dat", file_title);
         raypath.open(output_buffer);
         if(kEq == GEOAC_EQ_GLOBAL)  raypath << "# z [km]" << '\t' << "Lat [deg]" << '\t' << "Long [deg]";
-        else if(kEq == GEOAC_EQ_3D) raypath << "# x [km]" << '\t' << "y [km]" << '\t' << "z [km]";
+        else if(kCart3)             raypath << "# x [km]" << '\t' << "y [km]" << '\t' << "z [km]";
         else                        raypath << "# r [km]" << '\t' << "z [km]";
         raypath << '\t' << "Geo. Atten. [dB]" << '\t' << "Atmo. Atten. [dB]" << '\t' << "Travel Time [s]" << '\n';
     }
@@ -220,7 +278,7 @@ static int run_prop(char* inputs[], int count){
             sprintf(output_buffer, "%s_caustics-path%i.dat", file_title, bnc);
             caustics[(size_t)bnc].open(output_buffer);
             if(kEq == GEOAC_EQ_GLOBAL)  caustics[(size_t)bnc] << "# z [km]" << '\t' << "Lat [deg]" << '\t' << "Long [deg]";
-            else if(kEq == GEOAC_EQ_3D) caustics[(size_t)bnc] << "# x [km]" << '\t' << "y [km]" << '\t' << "z [km]";
+            else if(kCart3)             caustics[(size_t)bnc] << "# x [km]" << '\t' << "y [km]" << '\t' << "z [km]";
             else                        caustics[(size_t)bnc] << "# r [km]" << '\t' << "z [km]";
             caustics[(size_t)bnc] << '\t' << "Travel Time [s]" << '\n';
         }
@@ -229,7 +287,7 @@ static int run_prop(char* inputs[], int count){
     size_t sp = 0;
     const size_t nsmp = smp.size() / GEOAC_SMP_STRIDE;
     for(long i = 0; i < nr; i++){
-        cout << "Plotting ray path w/ theta = " << th[(size_t)i] << ", phi = " << ph[(size_t)i] << '\n';
+        cout << "Plotting ray path w/ theta = " << th[(size_t)i] << ", phi = " << ph[(size_t)i] << (kRng ? "." : "") << '\n';
         // raypath / caustic rows of this ray (sorted by ray, leg, m)
         while(sp < nsmp && (long)smp[sp * GEOAC_SMP_STRIDE + GEOAC_SMP_RAY] == i){
             const double* S = &smp[sp * GEOAC_SMP_STRIDE];
@@ -241,7 +299,7 @@ static int run_prop(char* inputs[], int count){
                     raypath << '\t' << setprecision(8) << v[1];
                     raypath << '\t' << setprecision(8) << v[2];
                     raypath << '\t' << v[3] << '\t' << v[4] << '\t' << v[5] << '\n';
-                } else if(kEq == GEOAC_EQ_3D){
+                } else if(kCart3){
                     raypath << v[0] << '\t' << v[1] << '\t' << v[2] << '\t' << v[3] << '\t' << v[4] << '\t' << v[5] << '\n';
                 } else {
                     raypath << v[0] << '\t' << v[1] << '\t' << v[2] << '\t' << v[3] << '\t' << v[4] << '\n';
@@ -253,6 +311,8 @@ static int run_prop(char* inputs[], int count){
                     c << '\t' << setprecision(8) << v[1];
                     c << '\t' << setprecision(8) << v[2];
                     c << '\t' << v[3] << '\n';
+                } else if(kRng){                                     // the range-dependent main writes a literal 0.0 column before the time (:270-274); the sample row carries it
+                    c << v[0] << '\t' << v[1] << '\t' << v[2] << '\t' << v[3] << '\t' << v[4] << '\n';
                 } else if(kEq == GEOAC_EQ_3D){
                     c << v[0] << '\t' << v[1] << '\t' << v[2] << '\t' << v[3] << '\n';
                 } else {
@@ -275,7 +335,7 @@ static int run_prop(char* inputs[], int count){
                 results << '\t' << R[GEOAC_REC_TURN];
                 results << '\t' << R[GEOAC_REC_INCL];
                 results << '\t' << R[GEOAC_REC_BACKAZ];
-            } else if(kEq == GEOAC_EQ_3D){
+            } else if(kCart3){
                 results << '\t' << R[GEOAC_REC_STATE + 0];
                 results << '\t' << R[GEOAC_REC_STATE + 1];
                 results << '\t' << R[GEOAC_REC_TTIME];
@@ -305,7 +365,7 @@ static int run_prop(char* inputs[], int count){
 }
 
 int main(int argc, char* argv[]){
-    if(argc < 3){ usage(); return 0; }
+    if(argc < (kRng ? 5 : 3)){ usage(); return 0; }
     if(strncmp(argv[1], "-prop", 5) == 0) return run_prop(argv, argc);
     if(strncmp(argv[1], "-interactive", 12) == 0 || strncmp(argv[1], "-eig_search", 11) == 0 || strncmp(argv[1], "-eig_direct", 11) == 0){
         cout << kName << ": option " << argv[1] << " is not part of the GPU build (only -prop is accelerated)." << '\n';

@@ -36,6 +36,24 @@ int  geoac_grid_load(const char* prefix, const char* locx, const char* locy, con
                      int nx, int ny, int nz, double* x, double* y, double* z,
                      double* T, double* u, double* v, double* rho);
 
+/* table of the range-dependent Cartesian interpolant as the kernels read it (layout: geoac_amd/csrc/geoac_rngdep.h).  Per
+ * (field, kz, node) the vertical cubics (c0, c1, 2 c2, 6 c3) of F, DxF, DyF, DxyF, Vx, DxVx, DxyVx, Vy, DyVy, DxyVy for T, u, v
+ * (40 doubles) and F, DxF, DyF, DxyF for rho (16 doubles): V0 = S_f, Vx = S_fx, Vy = S_fy are the reference's three vertical
+ * natural splines per node (Set_Slopes_Multi, G2S_MultiDimSpline3D.cpp:306-425); D* are its evaluation-time finite differences
+ * (BiCubic_Deriv_*, :568-800), linear in the coefficients and centred at the node, taken once on the coefficients.
+ * Fields are [nx][ny][nz] as geoac_grid_load returns them. */
+size_t geoac_grid_table_size(int nx, int ny, int nz);
+int    geoac_grid_table(int nx, int ny, int nz, const double* x, const double* y, const double* z,
+                        const double* T, const double* u, const double* v, const double* rho, double* tab);
+/* scalar evaluation of field 0..3 (T, u, v, rho) at a point from that table, as the reference's Eval_Spline_f does (inputs
+ * clamped to the grid; y rows scaled by the x cell size, Q11).  Reporting only (atmo.dat): rays never come through here. */
+double geoac_grid_eval(int nx, int ny, int nz, const double* x, const double* y, const double* z, const double* tab,
+                       int field, double xq, double yq, double zq);
+
+/* cubic of one spline segment (values f0, f1 and slopes s0, s1 at x0 < x1) in powers of t = x - x0: c = (c0, c1, c2, c3), or
+ * (c0, c1, 2 c2, 6 c3) when deriv_form != 0 */
+void geoac_spline_segment_cubic(double x0, double x1, double f0, double f1, double s0, double s1, double* c, int deriv_form);
+
 /* natural cubic spline node slopes (Thomas algorithm, natural end conditions) */
 void geoac_natural_spline_slopes(int n, const double* x, const double* f, double* slopes);
 

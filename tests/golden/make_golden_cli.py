@@ -3,10 +3,12 @@ on small fans and stores their output FILES (data) under tests/golden/cli/<set>/
 import os
 import shutil
 import subprocess
+import sys
 import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 REF = os.path.join(ROOT, "oracle", "_ref")
 
 CASES = {
@@ -17,20 +19,32 @@ CASES = {
     "2d": ("GeoAc2D", ["theta_min=5", "theta_max=35", "theta_step=15", "azimuth=-80", "bounces=1", "WriteCaustics=True"]),
     "global_norays": ("GeoAcGlobal", ["theta_min=5", "theta_max=45", "theta_step=8", "azimuth=37", "WriteRays=False", "CalcAmp=False",
                                       "lat_src=41.131", "lon_src=-112.896", "z_src=1.0", "freq=0.5", "rng_max=900"]),
+    # range-dependent Cartesian main on the synthetic 5x5 grid (tests/rngdep_data.py): -prop p loc_x.dat loc_y.dat ...
+    "3drd": ("GeoAc3D.RngDep", ["theta_min=10", "theta_max=30", "theta_step=20", "phi_min=-90", "phi_max=-45", "phi_step=45",
+                                "bounces=1", "WriteCaustics=True", "WriteAtmo=True", "x_src=50", "y_src=-30", "z_src=0.5"]),
 }
 
 
 def main():
+    only = sys.argv[1:]
     for name, (binary, args) in CASES.items():
+        if only and name not in only:
+            continue
         out = os.path.join(HERE, "cli", name)
         shutil.rmtree(out, ignore_errors=True)
         os.makedirs(out)
         with tempfile.TemporaryDirectory() as td:
-            shutil.copy(os.path.join(HERE, "ToyAtmo.met"), os.path.join(td, "ToyAtmo.met"))
-            subprocess.run([os.path.join(REF, binary), "-prop", "ToyAtmo.met"] + args, cwd=td, check=True,
+            if binary.endswith("RngDep"):
+                import rngdep_data as RD
+                RD.write_grid(td)
+                inputs = ["p", "loc_x.dat", "loc_y.dat"]
+            else:
+                shutil.copy(os.path.join(HERE, "ToyAtmo.met"), os.path.join(td, "ToyAtmo.met"))
+                inputs = ["ToyAtmo.met"]
+            subprocess.run([os.path.join(REF, binary), "-prop"] + inputs + args, cwd=td, check=True,
                            stdout=subprocess.DEVNULL)
             for f in sorted(os.listdir(td)):
-                if f.endswith(".dat"):
+                if f.endswith(".dat") and not f.startswith("loc_"):
                     shutil.copy(os.path.join(td, f), os.path.join(out, f))
         with open(os.path.join(out, "ARGS"), "w") as fh:
             fh.write(binary + "\n" + "\n".join(args) + "\n")

@@ -43,13 +43,13 @@ def load_grid_columns():
     return g["z"], g["T"], g["u"], g["v"], g["rho"], g["p"]
 
 
-def write_grid(dirpath):
+def write_grid(dirpath, short_paths=True):
     """writes the files; returns (prefix, locx, locy).  Paths must stay short: the reference formats file names into a
     50-byte buffer (G2S_MultiDimSpline3D.cpp:112,154)."""
     os.makedirs(dirpath, exist_ok=True)
     z, T, u, v, rho, p = load_grid_columns()
     prefix = os.path.join(dirpath, "p")
-    assert len(prefix) < 40
+    assert len(prefix) < 40 or not short_paths     # only the reference needs short names
     for i in range(len(X_NODES)):
         for j in range(len(Y_NODES)):
             n = i * len(Y_NODES) + j
