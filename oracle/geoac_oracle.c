@@ -164,6 +164,7 @@ typedef struct {          /* EquationSets.3DRngDep.cpp:25-55 */
 } src_rd;
 
 struct grid3d;
+struct gridg;
 
 typedef struct {          /* EquationSets.2DStratified.cpp:24-30 */
     double c_eff, c_eff_0, c_eff_diff, c_eff_ddiff;
@@ -186,6 +187,7 @@ struct orc_ctx {
     src_global G; src_3d S3; src_2d S2; src_rd RD;
     /* range-dependent sets: grid atmosphere + lateral limits (GeoAc.Parameters.RngDep.cpp:24-28) */
     struct grid3d* G3;
+    struct gridg* GG;              /* Global.RngDep: x/y limits hold the lat/lon box (GeoAc.Parameters.Global.cpp:26-30) */
     double x_min_limit, x_max_limit, y_min_limit, y_max_limit;
     /* solution array, rows of EqCnt doubles (Interface.cpp:53-58), kept contiguous with stride 18 */
     double* sol; int64_t sol_rows;
@@ -194,11 +196,11 @@ struct orc_ctx {
 #define ROW(ctx,k) ((ctx)->sol + (size_t)(k) * SOLSTRIDE)
 
 orc_ctx* orc_create(int eqset){
-    if(eqset != GEOAC_EQ_2D && eqset != GEOAC_EQ_3D && eqset != GEOAC_EQ_GLOBAL && eqset != GEOAC_EQ_3D_RNGDEP) return NULL;
+    if(eqset != GEOAC_EQ_2D && eqset != GEOAC_EQ_3D && eqset != GEOAC_EQ_GLOBAL && eqset != GEOAC_EQ_3D_RNGDEP && eqset != GEOAC_EQ_GLOBAL_RNGDEP) return NULL;
     orc_ctx* c = (orc_ctx*)calloc(1, sizeof(orc_ctx));
     c->eqset = eqset;
     c->ds_min = 0.001; c->ds_max = 0.5;                       /* Parameters.cpp:19-20 */
-    if(eqset == GEOAC_EQ_GLOBAL){ c->ray_limit = 10000.0; c->r_earth = 6370.0; }   /* Parameters.Global.cpp:23 */
+    if(eqset == GEOAC_EQ_GLOBAL || eqset == GEOAC_EQ_GLOBAL_RNGDEP){ c->ray_limit = 10000.0; c->r_earth = 6370.0; }   /* Parameters.Global.cpp:23 */
     else { c->ray_limit = 5000.0; c->vert_limit = 200.0; c->range_limit = 2000.0; c->r_earth = 0.0; }  /* Parameters.cpp:23-25 */
     if(eqset == GEOAC_EQ_3D_RNGDEP){ c->vert_limit = 160.0; c->x_min_limit = -500.0; c->x_max_limit = 500.0; c->y_min_limit = -500.0; c->y_max_limit = 500.0; }  /* Parameters.RngDep.cpp:24-28 */
     c->tweak_abs = 0.3; c->z_grnd = 0.0;
@@ -211,7 +213,8 @@ static void free_atmo(orc_ctx* c){
     c->x = c->T = c->u = c->v = c->rho = c->sT = c->su = c->sv = c->srho = NULL; c->n = 0;
 }
 static void g3_free(struct grid3d* G);
-void orc_destroy(orc_ctx* c){ if(!c) return; free_atmo(c); g3_free(c->G3); free(c->sol); free(c); }
+static void gg_free(struct gridg* G);
+void orc_destroy(orc_ctx* c){ if(!c) return; free_atmo(c); g3_free(c->G3); gg_free(c->GG); free(c->sol); free(c); }
 
 static void alloc_atmo(orc_ctx* c, int n){
     free_atmo(c); c->n = n;
@@ -923,6 +926,7 @@ static void s2_reflect(orc_ctx* c, int k){
 }
 
 #include "geoac_oracle_rngdep.inc.c"
+#include "geoac_oracle_globalrd.inc.c"
 
 /* ------------------------------------------------------------------------------------------ */
 /* dispatch by equation set                                                                     */
@@ -931,16 +935,17 @@ static void update_sources(orc_ctx* c, const double* y){
     if(c->eqset == GEOAC_EQ_GLOBAL) g_update_sources(c, y);
     else if(c->eqset == GEOAC_EQ_3D) s3_update_sources(c, y);
     else if(c->eqset == GEOAC_EQ_3D_RNGDEP) rd_update_sources(c, y);
+    else if(c->eqset == GEOAC_EQ_GLOBAL_RNGDEP) grd_update_sources(c, y);
     else s2_update_sources(c, y);
 }
 static double eval_src_eq(const orc_ctx* c, const double* y, int q){
-    if(c->eqset == GEOAC_EQ_GLOBAL) return g_eval_src_eq(c, y, q);
+    if(c->eqset == GEOAC_EQ_GLOBAL || c->eqset == GEOAC_EQ_GLOBAL_RNGDEP) return g_eval_src_eq(c, y, q);   /* GlobalRngDep.cpp:390-458: same text */
     if(c->eqset == GEOAC_EQ_3D) return s3_eval_src_eq(c, y, q);
     if(c->eqset == GEOAC_EQ_3D_RNGDEP) return rd_eval_src_eq(c, y, q);
     return s2_eval_src_eq(c, y, q);
 }
 static double step_ds(const orc_ctx* c, const double* y){
-    if(c->eqset == GEOAC_EQ_GLOBAL) return set_ds(c, y[0] - (c->r_earth + c->z_grnd));
+    if(c->eqset == GEOAC_EQ_GLOBAL || c->eqset == GEOAC_EQ_GLOBAL_RNGDEP) return set_ds(c, y[0] - (c->r_earth + c->z_grnd));
     if(c->eqset == GEOAC_EQ_3D || c->eqset == GEOAC_EQ_3D_RNGDEP) return set_ds(c, y[2] - c->z_grnd);
     return set_ds(c, y[1] - c->z_grnd);
 }
@@ -948,10 +953,11 @@ static int break_check(const orc_ctx* c, int k){
     if(c->eqset == GEOAC_EQ_GLOBAL) return g_break_check(c, k);
     if(c->eqset == GEOAC_EQ_3D) return s3_break_check(c, k);
     if(c->eqset == GEOAC_EQ_3D_RNGDEP) return rd_break_check(c, k);
+    if(c->eqset == GEOAC_EQ_GLOBAL_RNGDEP) return grd_break_check(c, k);
     return s2_break_check(c, k);
 }
 static int ground_check(const orc_ctx* c, int k){
-    if(c->eqset == GEOAC_EQ_GLOBAL) return g_ground_check(c, k);
+    if(c->eqset == GEOAC_EQ_GLOBAL || c->eqset == GEOAC_EQ_GLOBAL_RNGDEP) return g_ground_check(c, k);
     if(c->eqset == GEOAC_EQ_3D) return s3_ground_check(c, k);
     if(c->eqset == GEOAC_EQ_3D_RNGDEP) return rd_ground_check(c, k);
     return s2_ground_check(c, k);
@@ -960,30 +966,35 @@ static double tt_seg(orc_ctx* c, int n){
     if(c->eqset == GEOAC_EQ_GLOBAL) return g_tt_seg(c, n);
     if(c->eqset == GEOAC_EQ_3D) return s3_tt_seg(c, n);
     if(c->eqset == GEOAC_EQ_3D_RNGDEP) return rd_tt_seg(c, n);
+    if(c->eqset == GEOAC_EQ_GLOBAL_RNGDEP) return grd_tt_seg(c, n);
     return s2_tt_seg(c, n);
 }
 static double att_seg(orc_ctx* c, int n, double f){
     if(c->eqset == GEOAC_EQ_GLOBAL) return g_att_seg(c, n, f);
     if(c->eqset == GEOAC_EQ_3D) return s3_att_seg(c, n, f);
     if(c->eqset == GEOAC_EQ_3D_RNGDEP) return rd_att_seg(c, n, f);
+    if(c->eqset == GEOAC_EQ_GLOBAL_RNGDEP) return grd_att_seg(c, n, f);
     return s2_att_seg(c, n, f);
 }
 static double jacobian(orc_ctx* c, int k){
     if(c->eqset == GEOAC_EQ_GLOBAL) return g_jacobian(c, k);
     if(c->eqset == GEOAC_EQ_3D) return s3_jacobian(c, k);
     if(c->eqset == GEOAC_EQ_3D_RNGDEP) return rd_jacobian(c, k);
+    if(c->eqset == GEOAC_EQ_GLOBAL_RNGDEP) return grd_jacobian(c, k);
     return s2_jacobian(c, k);
 }
 static double amplitude(orc_ctx* c, int k){
     if(c->eqset == GEOAC_EQ_GLOBAL) return g_amplitude(c, k);
     if(c->eqset == GEOAC_EQ_3D) return s3_amplitude(c, k);
     if(c->eqset == GEOAC_EQ_3D_RNGDEP) return rd_amplitude(c, k);
+    if(c->eqset == GEOAC_EQ_GLOBAL_RNGDEP) return grd_amplitude(c, k);
     return s2_amplitude(c, k);
 }
 static void reflect(orc_ctx* c, int k){
     if(c->eqset == GEOAC_EQ_GLOBAL) g_reflect(c, k);
     else if(c->eqset == GEOAC_EQ_3D) s3_reflect(c, k);
     else if(c->eqset == GEOAC_EQ_3D_RNGDEP) rd_reflect(c, k);
+    else if(c->eqset == GEOAC_EQ_GLOBAL_RNGDEP) grd_reflect(c, k);
     else s2_reflect(c, k);
 }
 
@@ -1057,7 +1068,10 @@ static void set_launch(orc_ctx* c, double theta_deg, double phi_deg){
 }
 
 static void set_ic(orc_ctx* c, const ref_fan_cfg* cfg){
-    if(c->eqset == GEOAC_EQ_GLOBAL){
+    if(c->eqset == GEOAC_EQ_GLOBAL_RNGDEP){
+        double z_src = DMAX(cfg->src[0], c->z_grnd);              /* GeoAcGlobal.RngDep_main.cpp:177 */
+        grd_set_ic(c, z_src, cfg->src[1]*Pi/180.0, cfg->src[2]*Pi/180.0);
+    } else if(c->eqset == GEOAC_EQ_GLOBAL){
         double z_src = DMAX(cfg->src[0], c->z_grnd);
         g_set_ic(c, z_src, cfg->src[1]*Pi/180.0, cfg->src[2]*Pi/180.0);
     } else if(c->eqset == GEOAC_EQ_3D){
@@ -1083,7 +1097,8 @@ int64_t orc_fan(orc_ctx* c, const ref_fan_cfg* cfg, int n, const double* theta_d
     const int bounces = cfg->bounces;
     const double freq = cfg->freq;
     const int hidx = is2d ? 1 : (is3d ? 2 : 0);         /* index of the height component */
-    const double hoff = (c->eqset == GEOAC_EQ_GLOBAL) ? c->r_earth : 0.0;
+    const int isgrd = (c->eqset == GEOAC_EQ_GLOBAL_RNGDEP);
+    const double hoff = (c->eqset == GEOAC_EQ_GLOBAL || isgrd) ? c->r_earth : 0.0;
 
     memset(rec, 0, sizeof(double) * (size_t)n * (bounces + 1) * GEOAC_REC_STRIDE);
     int64_t total_steps = 0, ns = 0;
@@ -1146,13 +1161,24 @@ int64_t orc_fan(orc_ctx* c, const ref_fan_cfg* cfg, int n, const double* theta_d
             R[GEOAC_REC_ATTEN] = attenuation;
 
             if(BreakCheck) break;
-            if(isrd) h_max = 0.0;                                           /* turning height per leg in the RngDep mains (Q8) */
+            if(isrd || isgrd) h_max = 0.0;                                           /* turning height per leg in the RngDep mains (Q8) */
             for(int m = 0; m < k; m++) h_max = DMAX(h_max, ROW(c, m)[hidx] - hoff);
 
             const double* yk = ROW(c, k);
             R[GEOAC_REC_VALID] = 1.0;
             R[GEOAC_REC_TURN]  = h_max;
-            if(c->eqset == GEOAC_EQ_GLOBAL){                                /* GeoAcGlobal_main.cpp:296-302 */
+            if(isgrd){                                                      /* GeoAcGlobal.RngDep_main.cpp:307-313: no leading minus (Q10) */
+                double lat_src = cfg->src[1], lon_src = cfg->src[2];
+                double z_src = DMAX(cfg->src[0], c->z_grnd);
+                double GC_Dist1 = pow(sin((yk[1] - lat_src*Pi/180.0)/2.0),2);
+                double GC_Dist2 = cos(lat_src*Pi/180.0) * cos(yk[1]) * pow(sin((yk[2] - lon_src*Pi/180.0)/2.0),2);
+                double inclination = asin(gg_c(c->GG, yk[0], yk[1], yk[2]) / gg_c(c->GG, c->r_earth + z_src, lat_src*Pi/180.0, lon_src*Pi/180.0) * yk[3]) * 180.0 / Pi;
+                double back_az = 90.0 - atan2(-yk[4], -yk[5]) * 180.0 / Pi;
+                if(back_az < -180.0) back_az += 360.0;
+                if(back_az >  180.0) back_az -= 360.0;
+                R[GEOAC_REC_INCL] = inclination; R[GEOAC_REC_BACKAZ] = back_az;
+                R[GEOAC_REC_RANGE] = 2.0 * c->r_earth * asin(sqrt(GC_Dist1+GC_Dist2));
+            } else if(c->eqset == GEOAC_EQ_GLOBAL){                         /* GeoAcGlobal_main.cpp:296-302 */
                 double lat_src = cfg->src[1], lon_src = cfg->src[2];
                 double z_src = DMAX(cfg->src[0], c->z_grnd);
                 double GC_Dist1 = pow(sin((yk[1] - lat_src*Pi/180.0)/2.0),2);
@@ -1241,6 +1267,16 @@ int orc_trace_leg0(orc_ctx* c, const ref_fan_cfg* cfg, double theta_deg, double 
 /* range-dependent API                                                                          */
 /* ------------------------------------------------------------------------------------------ */
 int orc_load_grid(orc_ctx* c, const char* prefix, const char* locx, const char* locy, const char* format, double z_grnd_at_load){
+    if(c->eqset == GEOAC_EQ_GLOBAL_RNGDEP){
+        gg_free(c->GG);
+        c->GG = gg_load(prefix, locx, locy, format, z_grnd_at_load, c->r_earth);
+        if(!c->GG) return -1;
+        /* GeoAc_SetPropRegion: G2S_GlobalMultiDimSpline3D.cpp:25-33 */
+        c->vert_limit = c->GG->r_max;
+        c->x_min_limit = c->GG->t_min; c->x_max_limit = c->GG->t_max;
+        c->y_min_limit = c->GG->p_min; c->y_max_limit = c->GG->p_max;
+        return c->GG->nr;
+    }
     if(c->eqset != GEOAC_EQ_3D_RNGDEP) return -10;
     g3_free(c->G3);
     c->G3 = g3_load(prefix, locx, locy, format, z_grnd_at_load);
@@ -1251,10 +1287,30 @@ int orc_load_grid(orc_ctx* c, const char* prefix, const char* locx, const char* 
     c->y_min_limit = c->G3->y_min; c->y_max_limit = c->G3->y_max;
     return c->G3->nz;
 }
-void orc_grid_dims(orc_ctx* c, int* nx, int* ny, int* nz){ *nx = c->G3->nx; *ny = c->G3->ny; *nz = c->G3->nz; }
+void orc_grid_dims(orc_ctx* c, int* nx, int* ny, int* nz){
+    if(c->GG){ *nx = c->GG->nt; *ny = c->GG->np; *nz = c->GG->nr; return; }
+    *nx = c->G3->nx; *ny = c->G3->ny; *nz = c->G3->nz;
+}
+void orc_grid_centre(orc_ctx* c, double* lat_deg, double* lon_deg){      /* GeoAcGlobal.RngDep_main.cpp:135-137 */
+    *lat_deg = (c->GG->tv[0] + c->GG->tv[c->GG->nt-1])/2.0 * 180.0/Pi;
+    *lon_deg = (c->GG->pv[0] + c->GG->pv[c->GG->np-1])/2.0 * 180.0/Pi;
+}
 
 /* out30[i]: AllOrder2 of T, u, v (10 each); api8[i]: c, rho, u, v, c_diff(z), u_diff(z), v_diff(z), c_diff(x) scalar API values */
 void orc_grid_probe(orc_ctx* c, int n, const double* x, const double* y, const double* z, double* out30, double* api8){
+    if(c->GG){                                                          /* (x, y, z) = (r, lat, lon); api8 = c, rho, u, v, dc/dr, du/dr, dv/dr, dc/dlat */
+        struct gridg* Q = c->GG;
+        for(int i = 0; i < n; i++){
+            gg_eval_all(Q, x[i], y[i], z[i], &Q->Temp, 1, out30 + 30*i);
+            gg_eval_all(Q, x[i], y[i], z[i], &Q->Windu, 1, out30 + 30*i + 10);
+            gg_eval_all(Q, x[i], y[i], z[i], &Q->Windv, 1, out30 + 30*i + 20);
+            double* a = api8 + 8*i;
+            a[0] = gg_c(Q, x[i], y[i], z[i]); a[1] = gg_rho(Q, x[i], y[i], z[i]); a[2] = gg_u(Q, x[i], y[i], z[i]); a[3] = gg_v(Q, x[i], y[i], z[i]);
+            a[4] = gg_c_diff(Q, x[i], y[i], z[i], 0); a[5] = gg_u_diff(Q, x[i], y[i], z[i], 0); a[6] = gg_v_diff(Q, x[i], y[i], z[i], 0);
+            a[7] = gg_c_diff(Q, x[i], y[i], z[i], 1);
+        }
+        return;
+    }
     struct grid3d* G = c->G3;
     for(int i = 0; i < n; i++){
         g3_eval_all(G, x[i], y[i], z[i], &G->Temp, 1, out30 + 30*i);

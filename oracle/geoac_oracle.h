@@ -43,6 +43,9 @@ int      orc_trace_leg0(orc_ctx*, const ref_fan_cfg* cfg, double theta_deg, doub
 /* range-dependent Cartesian set (GEOAC_EQ_3D_RNGDEP): grid of profiles <prefix><n>.met, n = ix*ny + iy */
 int      orc_load_grid(orc_ctx*, const char* prefix, const char* locx, const char* locy, const char* format, double z_grnd_at_load);
 void     orc_grid_dims(orc_ctx*, int* nx, int* ny, int* nz);
+/* range-dependent spherical set (GEOAC_EQ_GLOBAL_RNGDEP): same entry points; locx / locy = latitude / longitude node files
+ * [deg], probes take (r, lat, lon) [km, rad, rad].  orc_grid_centre: the mains' default source position [deg] */
+void     orc_grid_centre(orc_ctx*, double* lat_deg, double* lon_deg);
 void     orc_grid_probe(orc_ctx*, int n, const double* x, const double* y, const double* z, double* out30, double* api8);
 
 /* limits chosen by GeoAc_SetPropRegion for the loaded profile */

@@ -129,8 +129,46 @@ def main_rngdep():
     print("3drd ->", path, os.path.getsize(path) // 1024, "KiB;", os.path.getsize(RD.GRID_NPZ) // 1024, "KiB grid")
 
 
+def main_globalrd():
+    """Global.RngDep: synthetic 5x5 lat/lon grid (tests/rngdep_data.py), compiled reference libref_globalrd.so"""
+    import tempfile
+    import rngdep_data as RD
+    RD.save_grid_global_npz()
+    grid = RD.write_grid_global(os.path.join(tempfile.gettempdir(), "gg"))
+    eq = H.EQ_GLOBAL_RNGDEP
+    R = H.RefShim(eq, grid=grid)
+    out = {}
+    rng = np.random.default_rng(2025)
+    n = 400
+    r = 6370.0 + rng.uniform(-1, 141, n); lat = np.radians(rng.uniform(24, 38, n)); lon = np.radians(rng.uniform(-9, 9, n))
+    r[:6] = 6370.0 + np.array([0, 139.6, 10, 0.4, 70, 0.0]); lat[:6] = np.radians([25, 37, 31, 28, 34, 29.5]); lon[:6] = np.radians([-8, 8, 0, 4, -4, 0])
+    o30, a8 = R.grid_probe(r, lat, lon)
+    out.update(probe_r=r, probe_lat=lat, probe_lon=lon, probe_out30=o30, probe_api8=a8)
+    th = np.array([3.0, 9.0, 16.0, 24.0, 31.0, 40.0]); ph = np.array([-90.0, -35.0, 20.0, 75.0, 130.0, -160.0])
+    out.update(theta=th, phi=ph)
+    for amp in (1, 0):
+        for mode in (0, 3):
+            cfg = H.make_cfg(eq, bounces=1, calc_amp=bool(amp), mode=mode, src=(0.0, 31.0, 0.0))
+            steps, rec, smp, nsmp = R.fan(cfg, th, ph, smp_cap=40000)
+            tag = f"amp{amp}_mode{mode}"
+            out[f"rec_{tag}"] = rec; out[f"steps_{tag}"] = np.int64(steps); out[f"nsmp_{tag}"] = np.int64(nsmp)
+            if amp == 1 and mode == 3:
+                sel = np.arange(0, len(smp), 4)
+                out[f"smp_idx_{tag}"] = sel; out[f"smp_{tag}"] = smp[sel]
+    # off-centre elevated source, raised ground, other frequency, tighter lat/lon box (radians, as the break check compares them)
+    cfg = H.make_cfg(eq, bounces=2, calc_amp=True, mode=0, src=(1.5, 29.0, 1.0), z_grnd=0.3, freq=0.4, tweak_abs=0.6,
+                     xy_limits=tuple(np.radians([26.0, 36.5, -7.0, 6.0])))
+    steps, rec, _, _ = R.fan(cfg, th, ph)
+    out["rec_alt"] = rec; out["steps_alt"] = np.int64(steps)
+    path = os.path.join(OUT, "globalrd_small.npz")
+    np.savez_compressed(path, **out)
+    print("globalrd ->", path, os.path.getsize(path) // 1024, "KiB;", os.path.getsize(RD.GRID_GLOBAL_NPZ) // 1024, "KiB grid")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "rngdep":
+    if len(sys.argv) > 1 and sys.argv[1] == "globalrd":
+        main_globalrd()
+    elif len(sys.argv) > 1 and sys.argv[1] == "rngdep":
         main_rngdep()
     else:
         main()

@@ -11,8 +11,8 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 TOYATMO = os.path.join(GOLDEN_DIR, "ToyAtmo.met")
 
-EQ_2D, EQ_3D, EQ_GLOBAL, EQ_3D_RNGDEP = 0, 1, 2, 3
-EQ_NAMES = {EQ_2D: "2d", EQ_3D: "3d", EQ_GLOBAL: "global", EQ_3D_RNGDEP: "3drd"}
+EQ_2D, EQ_3D, EQ_GLOBAL, EQ_3D_RNGDEP, EQ_GLOBAL_RNGDEP = 0, 1, 2, 3, 4
+EQ_NAMES = {EQ_2D: "2d", EQ_3D: "3d", EQ_GLOBAL: "global", EQ_3D_RNGDEP: "3drd", EQ_GLOBAL_RNGDEP: "globalrd"}
 REC_STRIDE = 32
 SMP_STRIDE = 10
 REC = dict(VALID=0, STEPS=1, BROKE=2, TTIME=3, ATTEN=4, TURN=5, INCL=6, BACKAZ=7, AMP=8, RANGE=9, JACOB=10, STATE=12)
@@ -31,7 +31,7 @@ class FanCfg(ctypes.Structure):
 def make_cfg(eqset, bounces=2, calc_amp=True, mode=0, src=None, z_grnd=0.0, tweak_abs=0.3, freq=0.1,
              vert_limit=float("nan"), range_limit=float("nan"), xy_limits=None):
     if src is None:
-        src = (0.0, 30.0, 0.0) if eqset == EQ_GLOBAL else (0.0, 0.0, 0.0)
+        src = (0.0, 30.0, 0.0) if eqset in (EQ_GLOBAL, EQ_GLOBAL_RNGDEP) else (0.0, 0.0, 0.0)
     if xy_limits is None:
         xy_limits = (float("nan"),) * 4
     return FanCfg(z_grnd, tweak_abs, freq, vert_limit, range_limit, (ctypes.c_double * 3)(*src),

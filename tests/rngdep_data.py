@@ -62,3 +62,52 @@ def write_grid(dirpath, short_paths=True):
     with open(locy, "w") as fh:
         fh.write("".join(f"{y:.10g}\n" for y in Y_NODES))
     return prefix, locx, locy
+
+
+# ---- Global.RngDep: grid in latitude / longitude (degrees in the loc files), file index n = ilat*nlon + ilon
+#      (G2S_GlobalMultiDimSpline3D.cpp:159); cells of 3 x 4 degrees so that lat and lon scalings differ ----
+LAT_NODES = np.array([25.0, 28.0, 31.0, 34.0, 37.0])
+LON_NODES = np.array([-8.0, -4.0, 0.0, 4.0, 8.0])
+GRID_GLOBAL_NPZ = os.path.join(H.GOLDEN_DIR, "globalrd_grid.npz")
+
+
+def grid_columns_global():
+    raw = np.loadtxt(H.TOYATMO)[::THIN]
+    z = raw[:, 0]
+    nt, npn = len(LAT_NODES), len(LON_NODES)
+    T = np.zeros((nt, npn, len(z))); u = np.zeros_like(T); v = np.zeros_like(T); rho = np.zeros_like(T)
+    for i, la in enumerate(LAT_NODES):
+        for j, lo in enumerate(LON_NODES):
+            bump = np.exp(-((z - 45.0) / 25.0) ** 2)
+            a, b = (la - 31.0) / 6.0, lo / 8.0
+            T[i, j] = raw[:, 1] * (1.0 + 0.015 * np.sin(1.3 * a + 0.9 * b) * bump + 0.004 * np.cos(2.1 * a) * np.sin(2.4 * b))
+            u[i, j] = raw[:, 2] + 12.0 * a * bump + 3.0 * np.sin(1.7 * b)
+            v[i, j] = raw[:, 3] + 8.0 * b * bump - 2.5 * np.cos(1.6 * a) * np.exp(-z / 60.0)
+            rho[i, j] = raw[:, 4] * (1.0 + 0.01 * np.cos(1.2 * a - 1.4 * b))
+    return z, T, u, v, rho, raw[:, 5]
+
+
+def save_grid_global_npz():
+    z, T, u, v, rho, p = grid_columns_global()
+    np.savez_compressed(GRID_GLOBAL_NPZ, z=z, T=T, u=u, v=v, rho=rho, p=p, lat=LAT_NODES, lon=LON_NODES)
+
+
+def write_grid_global(dirpath, short_paths=True):
+    """writes g<n>.met, loc_lat.dat, loc_lon.dat; returns (prefix, loclat, loclon)"""
+    os.makedirs(dirpath, exist_ok=True)
+    g = np.load(GRID_GLOBAL_NPZ)
+    z, T, u, v, rho, p = g["z"], g["T"], g["u"], g["v"], g["rho"], g["p"]
+    prefix = os.path.join(dirpath, "g")
+    assert len(prefix) < 40 or not short_paths
+    for i in range(len(LAT_NODES)):
+        for j in range(len(LON_NODES)):
+            n = i * len(LON_NODES) + j
+            with open(f"{prefix}{n}.met", "w") as fh:
+                for k in range(len(z)):
+                    fh.write(f"{z[k]:.10g} {T[i, j, k]:.12g} {u[i, j, k]:.12g} {v[i, j, k]:.12g} {rho[i, j, k]:.12g} {p[k]:.10g}\n")
+    loclat, loclon = os.path.join(dirpath, "loc_lat.dat"), os.path.join(dirpath, "loc_lon.dat")
+    with open(loclat, "w") as fh:
+        fh.write("".join(f"{x:.10g}\n" for x in LAT_NODES))
+    with open(loclon, "w") as fh:
+        fh.write("".join(f"{y:.10g}\n" for y in LON_NODES))
+    return prefix, loclat, loclon
