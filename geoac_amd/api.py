@@ -49,6 +49,7 @@ def load_library():
     lib.geoac_last_error.argtypes = [ctypes.c_void_p]
     lib.geoac_version.restype = ctypes.c_char_p
     lib.geoac_grid_load.argtypes = None
+    lib.geoac_grid_load_eq.argtypes = None
     lib.geoac_fan_enumerate.restype = ctypes.c_long
     lib.geoac_fan_enumerate.argtypes = [ctypes.c_double] * 6 + [ctypes.c_long, _dp, _dp]
     _lib = lib
@@ -156,10 +157,10 @@ class FanContext:
         nx, ny, nz = nx.value, ny.value, nz.value
         x, y, z = np.zeros(nx), np.zeros(ny), np.zeros(nz)
         F = [np.zeros((nx, ny, nz)) for _ in range(4)]
-        rc = self.lib.geoac_grid_load(prefix.encode(), locx.encode(), locy.encode(), fmt.encode(), ctypes.c_double(z_grnd),
+        rc = self.lib.geoac_grid_load_eq(self.eqset, prefix.encode(), locx.encode(), locy.encode(), fmt.encode(), ctypes.c_double(z_grnd),
                                       nx, ny, nz, _p(x), _p(y), _p(z), *[_p(f) for f in F])
         if rc:
-            raise GeoAcError(f"geoac_grid_load -> {rc}")
+            raise GeoAcError(f"geoac_grid_load_eq -> {rc}")
         self.upload_atmo_3d(x, y, z, *F)
         return dict(x=x, y=y, z=z, T=F[0], u=F[1], v=F[2], rho=F[3])
 

@@ -238,14 +238,14 @@ int geoac_upload_atmo_1d(geoac_ctx* ctx, int n, const double* x, const double* T
 int geoac_upload_atmo_3d(geoac_ctx* ctx, int nx, int ny, int nz, const double* x, const double* y, const double* z,
                          const double* T, const double* u, const double* v, const double* rho){
     if(!ctx || nx < 2 || ny < 2 || nz < 3 || !x || !y || !z || !T || !u || !v || !rho) return fail(ctx, GEOAC_E_INVALID, "upload_atmo_3d: bad arguments");
-    if(ctx->eqset != GEOAC_EQ_3D_RNGDEP) return fail(ctx, GEOAC_E_UNSUPPORTED, "grid atmosphere needs the range-dependent Cartesian equation set");
+    if(ctx->eqset != GEOAC_EQ_3D_RNGDEP && ctx->eqset != GEOAC_EQ_GLOBAL_RNGDEP) return fail(ctx, GEOAC_E_UNSUPPORTED, "grid atmosphere needs one of the range-dependent equation sets");
     for(int i = 1; i < nx; i++) if(!(x[i] > x[i - 1])) return fail(ctx, GEOAC_E_INVALID, "upload_atmo_3d: x not strictly increasing");
     for(int i = 1; i < ny; i++) if(!(y[i] > y[i - 1])) return fail(ctx, GEOAC_E_INVALID, "upload_atmo_3d: y not strictly increasing");
     for(int i = 1; i < nz; i++) if(!(z[i] > z[i - 1])) return fail(ctx, GEOAC_E_INVALID, "upload_atmo_3d: z not strictly increasing");
     HIPCHK(hipSetDevice(ctx->device));
     // device table (geoac_rngdep.h) built on the host: vertical cubics of the node values and of the node-centred differences
     std::vector<double> tab(geoac_grid_table_size(nx, ny, nz));
-    geoac_grid_table(nx, ny, nz, x, y, z, T, u, v, rho, tab.data());
+    geoac_grid_table_eq(ctx->eqset, nx, ny, nz, x, y, z, T, u, v, rho, tab.data());
     HIPCHK(ctx->d_gx.ensure(sizeof(double) * nx)); HIPCHK(ctx->d_gy.ensure(sizeof(double) * ny)); HIPCHK(ctx->d_gz.ensure(sizeof(double) * nz));
     HIPCHK(ctx->d_gtab.ensure(sizeof(double) * tab.size()));
     HIPCHK(ctx->d_consts.ensure(sizeof(double) * 8));
@@ -297,16 +297,15 @@ int geoac_fan_set_angles(geoac_ctx* ctx, int n_rays, const double* theta_deg, co
 int geoac_fan_launch(geoac_ctx* ctx){
     if(!ctx) return GEOAC_E_INVALID;
     if(!ctx->have_atmo || !ctx->have_angles) return fail(ctx, GEOAC_E_INVALID, "fan_launch: atmosphere and angles must be uploaded first");
-    if(ctx->eqset == GEOAC_EQ_GLOBAL_RNGDEP)
-        return fail(ctx, GEOAC_E_UNSUPPORTED, "the spherical range-dependent equation set is not implemented on the GPU yet");
-    const bool is_grid = (ctx->eqset == GEOAC_EQ_3D_RNGDEP);
+    const bool is_grid = (ctx->eqset == GEOAC_EQ_3D_RNGDEP || ctx->eqset == GEOAC_EQ_GLOBAL_RNGDEP);
     if(is_grid != ctx->have_grid) return fail(ctx, GEOAC_E_INVALID, "fan_launch: atmosphere kind does not match the equation set");
     HIPCHK(hipSetDevice(ctx->device));
     const geoac_params& p = ctx->prm;
     GeoacDevParams P{};
     P.eqset = ctx->eqset; P.calc_amp = p.calc_amp ? 1 : 0; P.mode = p.mode; P.bounces = p.bounces;
     P.n_rays = ctx->n_rays; P.n_pad = ctx->n_pad;
-    const bool is_global = (ctx->eqset == GEOAC_EQ_GLOBAL);
+    const bool is_global = (ctx->eqset == GEOAC_EQ_GLOBAL);                                  // stratified spherical set (pair kernel, range test)
+    const bool is_sph = is_global || ctx->eqset == GEOAC_EQ_GLOBAL_RNGDEP;                   // geocentric radius as the height coordinate
     if(is_global){ P.E = p.calc_amp ? 18 : 6; P.pathw = 6; }
     else if(ctx->eqset == GEOAC_EQ_3D){ P.E = p.calc_amp ? 12 : 4; P.pathw = 4; }
     else if(is_grid){ P.E = p.calc_amp ? 18 : 6; P.pathw = 6; }
@@ -316,7 +315,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
     P.step_limit = (long long)(p.ray_limit * (int)(1.0 / (p.ds_min * 10)));   // GeoAc.Solver.cpp:14
     P.x_min = ctx->x[0]; P.x_max = ctx->x[ctx->n_nodes - 1];
     P.ds_min = p.ds_min; P.ds_max = p.ds_max;
-    P.r_earth = is_global ? p.r_earth : 0.0; P.z_grnd = p.z_grnd;
+    P.r_earth = is_sph ? p.r_earth : 0.0; P.z_grnd = p.z_grnd;
     P.ground = P.r_earth + p.z_grnd;
     P.vert_limit = p.vert_limit; P.range_limit = p.range_limit;
     if(is_global){

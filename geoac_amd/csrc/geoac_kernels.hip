@@ -768,6 +768,136 @@ template <bool AMP_> struct Eq3DRngDep {
     }
 };
 
+// Range-dependent spherical set (GeoAcGlobal.RngDep): EquationSets.GlobalRngDep.cpp + G2S_GlobalMultiDimSpline3D.cpp.
+// Grid axes in table order: x = latitude, y = longitude [rad], z = geocentric radius; xy_lim = lat/lon box of the break check.
+template <bool AMP_> struct EqGlobalRngDep {
+    static constexpr bool AMP = AMP_;
+    static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 0, LANES = 1;
+    static constexpr bool KM2 = false, HMAX_PER_LEG = true;         // linear intercept (Q1, GlobalRngDep.cpp:147-148); turning height per leg (Q8)
+
+    static DEVINL Medium as_medium(const Medium3& g){ Medium m; m.c = g.c; m.dc = g.dcz; m.u = g.u; m.du = g.duz; m.v = g.v; m.dv = g.dvz; m.rho = g.rho; return m; }
+    static DEVINL void fan_init(const GeoacDevParams& P){}
+    // GeoAc_SetInitialConditions: GlobalRngDep.cpp:77-137
+    static DEVINL void init(const GeoacDevParams& P, double th, double ph, double* y, RayCtx& C){
+        double z_src = P.src[0] < P.z_grnd ? P.z_grnd : P.src[0];     // GeoAcGlobal.RngDep_main.cpp:177
+        double r0 = z_src + P.r_earth;
+        double lat0 = P.src[1] * kPi / 180.0, lon0 = P.src[2] * kPi / 180.0;
+        Medium3 m = medium3_at<false, false, true>(P, lat0, lon0, r0);
+        double c0 = m.c;
+        double Mach[3] = { 0.0, m.v / c0, m.u / c0 };
+        double sth = sin(th), cth = cos(th), sph = sin(ph), cph = cos(ph);
+        double nu0[3]  = { sth, cth * sph, cth * cph };
+        double mlt[3]  = { cth, -sth * sph, -sth * cph };
+        double mlp[3]  = { 0.0, cth * cph, -cth * sph };
+        double MS = 1.0 + (nu0[0] * Mach[0] + nu0[1] * Mach[1] + nu0[2] * Mach[2]);
+        y[0] = r0; y[1] = lat0; y[2] = lon0;
+        for(int e = 0; e < 3; e++) y[3 + e] = nu0[e] / MS;
+        if(AMP){
+            double dlt = mlt[0] * Mach[0] + mlt[1] * Mach[1] + mlt[2] * Mach[2];
+            double dlp = mlp[0] * Mach[0] + mlp[1] * Mach[1] + mlp[2] * Mach[2];
+            for(int e = 0; e < 3; e++){
+                y[9 + e]  = mlt[e] / MS - nu0[e] / (MS * MS) * dlt;
+                y[15 + e] = mlp[e] / MS - nu0[e] / (MS * MS) * dlp;
+            }
+        }
+        C.c0 = c0; C.nu0 = 1.0 / MS;
+        fsincos(lat0, C.a[0], C.a[1]);
+        C.a[2] = 0.0; C.a[3] = 1.0; C.a[4] = 0.0; C.a[5] = 0.0;
+    }
+    static DEVINL double height(const GeoacDevParams& P, const double* y){ return y[0] - P.r_earth; }
+    static DEVINL double above_ground(const GeoacDevParams& P, const double* y){ return y[0] - P.ground; }
+    template <typename TabPtr>
+    static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
+        double s2, c2;
+        rot_small(C.a[0], C.a[1], yt[1] - y0[1], s2, c2);          // sin/cos(lat) carried along the ray, as in EqGlobal
+        globalrd_rhs<AMP>(P, seg, yt, s2, c2, dy);
+    }
+    // GeoAc_BreakCheck / GeoAc_GroundCheck: GlobalRngDep.cpp:523-545
+    static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, long long k, bool& brk, bool& gnd){
+        if((k & 63) == 0) fsincos(yn[1], C.t[0], C.t[1]);          // periodic exact re-sync
+        else rot_small(C.a[0], C.a[1], yn[1] - y[1], C.t[0], C.t[1]);
+        brk = (yn[0] > P.vert_limit) || (yn[1] < P.xy_lim[0]) || (yn[1] > P.xy_lim[1]) || (yn[2] < P.xy_lim[2]) || (yn[2] > P.xy_lim[3]);
+        gnd = yn[0] < P.ground;
+    }
+    static DEVINL void accept(RayCtx& C){ C.a[0] = C.t[0]; C.a[1] = C.t[1]; }
+    static DEVINL void restart(const GeoacDevParams& P, RayCtx& C, const double* y){ fsincos(y[1], C.a[0], C.a[1]); }
+    // arrival row: GeoAcGlobal.RngDep_main.cpp:304-329 (inclination without the leading minus: Q10)
+    static DEVINL void arrival(const GeoacDevParams& P, const RayCtx& C, int slot, const double* yn, double* R){
+        const double lat0 = P.src[1] * kPi / 180.0, lon0 = P.src[2] * kPi / 180.0;
+        Medium3 m = medium3_at<false, false, true>(P, yn[1], yn[2], yn[0]);
+        double incl = asin(m.c / C.c0 * yn[3]) * 180.0 / kPi;
+        double baz = 90.0 - atan2(-yn[4], -yn[5]) * 180.0 / kPi;
+        if(baz < -180.0) baz += 360.0;
+        if(baz > 180.0) baz -= 360.0;
+        double g1 = sin((yn[1] - lat0) / 2.0); g1 *= g1;
+        double g2 = sin((yn[2] - lon0) / 2.0); g2 = cos(lat0) * cos(yn[1]) * g2 * g2;
+        R[GEOAC_REC_INCL] = incl;
+        R[GEOAC_REC_BACKAZ] = baz;
+        R[GEOAC_REC_RANGE] = 2.0 * P.r_earth * asin(sqrt(g1 + g2));
+        if(AMP){
+            double amp, D;
+            amp_jac(P, C, slot, yn, amp, D);
+            R[GEOAC_REC_AMP] = amp;
+            R[GEOAC_REC_JACOB] = D;
+        }
+    }
+    // GeoAc_Jacobian / GeoAc_Amplitude: GlobalRngDep.cpp:617-652 (same expressions as the stratified set, medium from the grid)
+    static DEVINL void amp_jac(const GeoacDevParams& P, const RayCtx& C, int slot, const double* yr, double& amp, double& D){
+        double z_src = P.src[0] < P.z_grnd ? P.z_grnd : P.src[0];
+        const double lat0 = P.src[1] * kPi / 180.0, lon0 = P.src[2] * kPi / 180.0;
+        Medium m  = as_medium(medium3_at<true, false, true>(P, yr[1], yr[2], yr[0]));
+        Medium m0 = as_medium(medium3_at<true, false, true>(P, lat0, lon0, z_src + P.r_earth));
+        D = global_jacobian(m, yr);
+        double th_l = P.theta_deg[slot] * kPi / 180.0, ph_l = kPi / 2.0 - P.phi_deg[slot] * kPi / 180.0;
+        amp = global_amplitude(P, m, m0, yr, C.c0, C.nu0, th_l, ph_l, D);
+    }
+    // ApproximateIntercept + SetReflectionConditions: GlobalRngDep.cpp:141-210
+    static DEVINL void reflect(const GeoacDevParams& P, const RayCtx& C, const double* yn, double* y, const double* ym2){
+        double dr_k = yn[0] - y[0];
+        double dr_g = y[0] - P.ground;
+        double prev[E];
+        #pragma unroll
+        for(int e = 0; e < E; e++) prev[e] = y[e] + (y[e] - yn[e]) / dr_k * dr_g;
+        Medium3 mr = medium3_at<false, true, true>(P, prev[1], prev[2], prev[0]);
+        double c_ref = mr.c;
+        double dnu_r_ds = -1.0 / c_ref * (C.c0 / c_ref * mr.dcz + prev[4] * mr.dvz + prev[5] * mr.duz
+                                          + c_ref / prev[0] * (prev[4] * prev[4] + prev[5] * prev[5]));
+        #pragma unroll
+        for(int e = 0; e < E; e++) y[e] = prev[e];
+        y[0] = P.ground;
+        y[3] = -prev[3];
+        if(AMP){
+            y[6] = -prev[6]; y[12] = -prev[12];
+            double den = c_ref / C.c0 * prev[3];
+            y[9]  = -prev[9]  + 2.0 * dnu_r_ds * prev[6]  / den;
+            y[15] = -prev[15] + 2.0 * dnu_r_ds * prev[12] / den;
+        }
+    }
+    // one path segment: GlobalRngDep.cpp:549-612 (travel time), 657-693 (attenuation, sin(lat) in ds: Q3).  SuthBass reference
+    // state at radius z_grnd (clamps to the lowest node) and the LOCAL lat/lon (Atmo_State.Absorption.Global.cpp:31-32)
+    static DEVINL void segment(const GeoacDevParams& P, const double* st, size_t np, const double* a, const double* b, double& tt, double& at){
+        double ar = a[0], at_ = a[np], ap = a[2 * np], an0 = a[3 * np], an1 = a[4 * np], an2 = a[5 * np];
+        double dr = b[0] - ar, dt = b[np] - at_, dp = b[2 * np] - ap;
+        double r = ar + dr / 2.0, t = at_ + dt / 2.0, p = ap + dp / 2.0;
+        double sn, cs; fsincos(t, sn, cs);
+        double rdt = r * dt;
+        double e1 = r * cs * dp, e2 = r * sn * dp;
+        double ds_tt = sqrt(dr * dr + rdt * rdt + e1 * e1);
+        double ds_at = sqrt(dr * dr + rdt * rdt + e2 * e2);
+        double n0 = an0 + (b[3 * np] - an0) / 2.0, n1 = an1 + (b[4 * np] - an1) / 2.0, n2 = an2 + (b[5 * np] - an2) / 2.0;
+        double nu_mag = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+        Medium3 m = medium3_at<true, false, true>(P, t, p, r);
+        Medium3 g = medium3_at<true, false, true>(P, t, p, P.z_grnd);
+        double cp0 = m.c * n0 / nu_mag, cp1 = m.c * n1 / nu_mag + m.v, cp2 = m.c * n2 / nu_mag + m.u;
+        double cpm = sqrt(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
+        tt = ds_tt / cpm;
+        double cm = g.c * 1000.0;
+        double T_o = cm * cm / (kRgas * kGam);
+        double P_o = g.rho * (cm * cm) / kGam * 1000.0;
+        at = suthbass_alpha(P, r - P.r_earth, m.c, m.rho, P.freq, T_o, P_o) * ds_at;
+    }
+};
+
 
 template <bool AMP_> struct Eq3D {
     static constexpr bool AMP = AMP_;
@@ -1266,7 +1396,7 @@ __global__ void __launch_bounds__(256) k_accum(GeoacDevParams P){
             double amp_db = P.calc_amp ? 20.0 * log10(amp) : 0.0;
             double v[6] = {0, 0, 0, 0, 0, 0};
             int np3;                                                   // number of position columns
-            if(P.eqset == GEOAC_EQ_GLOBAL){ v[0] = row[0] - P.r_earth; v[1] = row[np] * 180.0 / kPi; v[2] = row[2 * np] * 180.0 / kPi; np3 = 3; }
+            if(P.eqset == GEOAC_EQ_GLOBAL || P.eqset == GEOAC_EQ_GLOBAL_RNGDEP){ v[0] = row[0] - P.r_earth; v[1] = row[np] * 180.0 / kPi; v[2] = row[2 * np] * 180.0 / kPi; np3 = 3; }
             else if(P.eqset == GEOAC_EQ_3D){ v[0] = row[0]; v[1] = row[np]; double z = row[2 * np]; v[2] = (z < 0.0 ? 0.0 : z); np3 = 3; }   // max(z, 0) in both files (GeoAc3D_main.cpp:257,267)
             else if(P.eqset == GEOAC_EQ_3D_RNGDEP){ v[0] = row[0]; v[1] = row[np]; double z = row[2 * np]; v[2] = (kind == 0) ? (z < 0.0 ? 0.0 : z) : z; np3 = 3;
                                                     if(kind == 1){ v[3] = 0.0; np3 = 4; } }                 // caustic rows: raw z and a 0.0 column (GeoAc3D.RngDep_main.cpp:279-284)
@@ -1316,6 +1446,8 @@ __global__ void __launch_bounds__(256) k_accum(GeoacDevParams P){
         case GEOAC_EQ_2D * 2 + 0:     { using EQ = Eq2D<false>;     CALL; } break; \
         case GEOAC_EQ_3D_RNGDEP * 2 + 1: { using EQ = Eq3DRngDep<true>;  CALL; } break; \
         case GEOAC_EQ_3D_RNGDEP * 2 + 0: { using EQ = Eq3DRngDep<false>; CALL; } break; \
+        case GEOAC_EQ_GLOBAL_RNGDEP * 2 + 1: { using EQ = EqGlobalRngDep<true>;  CALL; } break; \
+        case GEOAC_EQ_GLOBAL_RNGDEP * 2 + 0: { using EQ = EqGlobalRngDep<false>; CALL; } break; \
         default: return hipErrorNotSupported; }
 
 extern "C" hipError_t geoac_launch_init(const GeoacDevParams* P, hipStream_t s){

@@ -14,6 +14,11 @@
 // bytes each, instead of a 4x4 neighbourhood of scattered records - the path is bound by divergent table gathers.
 // The 16x16 matrix product + power sums of the reference are evaluated as the equivalent tensor Hermite form, accumulated
 // corner by corner.  Quirk Q11 kept: the scalar evaluators and the d2f/dz2 patch scale the y-derivative rows by the x cell size.
+//
+// The spherical set (GeoAcGlobal.RngDep, Code/Atmo/G2S_GlobalMultiDimSpline3D.cpp) uses the same scheme with x = latitude,
+// y = longitude [rad], z = geocentric radius and its own quirks (Q12; template flag GLB): the host table already carries the
+// reference's S_fx / S_fy slope systems and the truncated d/dr of those splines; here its scalar evaluators and d2f/dr2 patch
+// scale the y rows by the y cell size, and AllOrder2's mixed second derivatives stay in SCALED cell coordinates.
 #ifndef GEOAC_RNGDEP_H_
 #define GEOAC_RNGDEP_H_
 
@@ -106,7 +111,7 @@ DEVINL double dot4(const double* w, double F, double FX, double FY, double FXY, 
 //   patch f_y  : F = Dy V0,  FX = Dxy V0 dx,   FY = Dy Vy dy,        FXY = Dxy Vy dx dy     (its d/dy: f_yy)
 //   patch f_z  : F = V0',    FX = Vx' dx,      FY = Vy' dy,          FXY = Dxy V0' dx dy    (its d/dx, d/dy: f_xz, f_yz)
 //   patch f_zz : F = V0'',   FX = Dx V0'' dx,  FY = Dy V0'' dx (Q11, :1568-1571), FXY = Dxy V0'' dx dy
-template <bool ORDER2>
+template <bool ORDER2, bool GLB>
 DEVINL void grid_eval_all(const GeoacDevParams& P, int field, const GridLoc& L, double* out){
     const Herm hx = hermite(L.xs), hy = hermite(L.ys);
     const double dxs = L.dxs, dys = L.dys, dxy = dxs * dys;
@@ -125,7 +130,7 @@ DEVINL void grid_eval_all(const GeoacDevParams& P, int field, const GridLoc& L, 
             for(int i = 0; i < 10; i++) c[i] = load_cubic(r + 4 * i);
             CornerW w = corner_weights<ORDER2, ORDER2>(hx, hy, a, b);
             // fold the cell-size factors of the FX / FY / FXY rows into the weights
-            const double Wq = w.W[2] * dxs;                        // Q11 row of the f_zz patch
+            const double Wq = w.W[2] * (GLB ? dys : dxs);          // Cartesian: Q11 row of the f_zz patch (y row scaled by dx)
             w.W[1] *= dxs; w.W[2] *= dys; w.W[3] *= dxy;
             if(ORDER2){ w.D[1] *= dxs; w.D[2] *= dys; w.D[3] *= dxy; w.E[1] *= dxs; w.E[2] *= dys; w.E[3] *= dxy; }
             const double F = cub_val(c[GC_F], t, t6), DxF = cub_val(c[GC_DXF], t, t6), DyF = cub_val(c[GC_DYF], t, t6), DxyF = cub_val(c[GC_DXYF], t, t6);
@@ -147,7 +152,7 @@ DEVINL void grid_eval_all(const GeoacDevParams& P, int field, const GridLoc& L, 
             }
         }
     }
-    if(ORDER2){
+    if(ORDER2 && !GLB){                                            // spherical set: left in scaled coordinates (Q12c, :1328-1338, :1374-1384, :1420-1424)
         const double idxs = 1.0 / dxs, idys = 1.0 / dys;
         o[4] *= idxs; o[8] *= idxs; o[7] *= idys; o[5] *= idys; o[9] *= idys;
     }
@@ -155,7 +160,8 @@ DEVINL void grid_eval_all(const GeoacDevParams& P, int field, const GridLoc& L, 
     for(int i = 0; i < (ORDER2 ? 10 : 4); i++) out[i] = o[i];
 }
 
-// Eval_Spline_f (:806-863): scalar value, y rows scaled by dx_scalar (Q11)
+// Eval_Spline_f (:806-863): scalar value, y rows scaled by dx_scalar (Q11; the spherical twin :755-807 uses dp_scalar)
+template <bool GLB>
 DEVINL double grid_eval_f(const GeoacDevParams& P, int field, const GridLoc& L){
     const Herm hx = hermite(L.xs), hy = hermite(L.ys);
     const double t = L.t, t6 = t * (1.0 / 6.0);
@@ -171,13 +177,15 @@ DEVINL double grid_eval_f(const GeoacDevParams& P, int field, const GridLoc& L){
             #pragma unroll
             for(int i = 0; i < 4; i++) c[i] = load_cubic(r + 4 * i);
             CornerW w = corner_weights<false, false>(hx, hy, a, b);
-            w.W[1] *= L.dxs; w.W[2] *= L.dxs; w.W[3] *= L.dxs * L.dys;
+            w.W[1] *= L.dxs; w.W[2] *= (GLB ? L.dys : L.dxs); w.W[3] *= L.dxs * L.dys;
             v = dot4(w.W, cub_val(c[GC_F], t, t6), cub_val(c[GC_DXF], t, t6), cub_val(c[GC_DYF], t, t6), cub_val(c[GC_DXYF], t, t6), v);
         }
     }
     return v;
 }
 // Eval_Spline_df(.., index = 2, ..) (:920-939): df/dz patch, y rows scaled by dx_scalar (Q11); T, u, v only
+// (spherical twin: Eval_Spline_df(.., index = 0, ..), :823-842, y rows scaled by dp_scalar)
+template <bool GLB>
 DEVINL double grid_eval_dfdz(const GeoacDevParams& P, int field, const GridLoc& L){
     const Herm hx = hermite(L.xs), hy = hermite(L.ys);
     const double t = L.t, th = 0.5 * t;
@@ -190,28 +198,29 @@ DEVINL double grid_eval_dfdz(const GeoacDevParams& P, int field, const GridLoc& 
             const double* __restrict__ r = base + (size_t)corner_node(L, a, b) * GEOAC_GREC;
             const Cub cF = load_cubic(r + 4 * GC_F), cXY = load_cubic(r + 4 * GC_DXYF), cX = load_cubic(r + 4 * GC_VX), cY = load_cubic(r + 4 * GC_VY);
             CornerW w = corner_weights<false, false>(hx, hy, a, b);
-            w.W[1] *= L.dxs; w.W[2] *= L.dxs; w.W[3] *= L.dxs * L.dys;
+            w.W[1] *= L.dxs; w.W[2] *= (GLB ? L.dys : L.dxs); w.W[3] *= L.dxs * L.dys;
             v = dot4(w.W, cub_d1(cF, t, th), cub_d1(cX, t, th), cub_d1(cY, t, th), cub_d1(cXY, t, th), v);
         }
     }
     return v;
 }
 
-// scalar medium at a point (c(), u(), v(), rho() of G2S_MultiDimSpline3D.cpp:1633-1743, inputs clamped)
+// scalar medium at a point (c(), u(), v(), rho() of G2S_MultiDimSpline3D.cpp:1633-1743 / G2S_GlobalMultiDimSpline3D.cpp:1502-1611,
+// inputs clamped).  Arguments in table order: (x, y, z) Cartesian, (lat, lon, r) spherical; d*z = d/dz resp. d/dr.
 struct Medium3 { double c, u, v, rho, dcz, duz, dvz; };
-template <bool WANT_RHO, bool WANT_DZ>
+template <bool WANT_RHO, bool WANT_DZ, bool GLB = false>
 DEVINL Medium3 medium3_at(const GeoacDevParams& P, double x, double y, double z){
     double xe = clampd(x, P.gx[0], P.gx[P.gnx - 1]), ye = clampd(y, P.gy[0], P.gy[P.gny - 1]), ze = clampd(z, P.x_min, P.x_max);
     GridLoc L; grid_locate(P, xe, ye, ze, -1, L);
     Medium3 m;
-    m.c = sqrt(kGamR * grid_eval_f(P, 0, L));
-    m.u = grid_eval_f(P, 1, L);
-    m.v = grid_eval_f(P, 2, L);
-    m.rho = WANT_RHO ? grid_eval_f(P, 3, L) : 0.0;
+    m.c = sqrt(kGamR * grid_eval_f<GLB>(P, 0, L));
+    m.u = grid_eval_f<GLB>(P, 1, L);
+    m.v = grid_eval_f<GLB>(P, 2, L);
+    m.rho = WANT_RHO ? grid_eval_f<GLB>(P, 3, L) : 0.0;
     if(WANT_DZ){
-        m.dcz = kGamR / (2.0 * m.c) * grid_eval_dfdz(P, 0, L);
-        m.duz = grid_eval_dfdz(P, 1, L);
-        m.dvz = grid_eval_dfdz(P, 2, L);
+        m.dcz = kGamR / (2.0 * m.c) * grid_eval_dfdz<GLB>(P, 0, L);
+        m.duz = grid_eval_dfdz<GLB>(P, 1, L);
+        m.dvz = grid_eval_dfdz<GLB>(P, 2, L);
     } else { m.dcz = m.duz = m.dvz = 0.0; }
     return m;
 }
@@ -225,7 +234,7 @@ DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double
     kz = L.kz;
     double M[3][10];                                               // T, u, v and their derivatives; one (non-inlined) evaluator call per field
     #pragma unroll 1
-    for(int f = 0; f < 3; f++) grid_eval_all<AMP>(P, f, L, M[f]);
+    for(int f = 0; f < 3; f++) grid_eval_all<AMP, false>(P, f, L, M[f]);
     const double* T = M[0]; const double* U = M[1]; const double* V = M[2];
     const double n0 = y[3], n1 = y[4], n2 = y[5];
     const double qT = kGamR * T[0];
@@ -277,6 +286,115 @@ DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double
                 }
                 dy[9 + 6 * a + i] = icg * (e * Hn[i]
                                            - (dnu * dc[i] + numag * ddc + m[0] * U[1 + i] + m[1] * V[1 + i] + n0 * ddu + n1 * ddv));
+            }
+        }
+    }
+}
+
+// fused GeoAc_UpdateSources + GeoAc_EvalSrcEq of the range-dependent spherical set (EquationSets.GlobalRngDep.cpp:226-458):
+// the algebra of global_rhs (geoac_kernels.hip) with the full gradient and second-derivative matrices of c, u, v (w = 0).
+// y: r, lat, lon, nu_r, nu_t, nu_p | R_lt(3), mu_lt(3) | R_lp(3), mu_lp(3);  sth/cth = sin/cos(lat) from the caller.
+template <bool AMP>
+DEVINL void globalrd_rhs(const GeoacDevParams& P, int& kz, const double* y, double sth, double cth, double* dy){
+    const double r = y[0];
+    const double te = clampd(y[1], P.gx[0], P.gx[P.gnx - 1]), pe = clampd(y[2], P.gy[0], P.gy[P.gny - 1]), re = clampd(r, P.x_min, P.x_max);
+    GridLoc L; grid_locate(P, te, pe, re, kz, L);
+    kz = L.kz;
+    double M[3][10];                                               // table order: f, f_t, f_p, f_r, f_tt, f_pp, f_rr, f_tp, f_tr, f_pr
+    #pragma unroll 1
+    for(int f = 0; f < 3; f++) grid_eval_all<AMP, true>(P, f, L, M[f]);
+    const double* T = M[0]; const double* U = M[1]; const double* V = M[2];
+    // first derivatives in equation order (r, t, p) = table entries 3, 1, 2
+    const int fi[3] = { 3, 1, 2 };
+    const double n0 = y[3], n1 = y[4], n2 = y[5];
+    const double u = U[0], v = V[0];
+    const double qT = kGamR * T[0];
+    const double ic = frsq(qT);
+    const double c  = qT * ic;
+    const double hc = (0.5 * kGamR) * ic;
+    double dc[3], du[3], dv[3];
+    #pragma unroll
+    for(int i = 0; i < 3; i++){ dc[i] = hc * T[fi[i]]; du[i] = U[fi[i]]; dv[i] = V[fi[i]]; }
+    const double nn  = __builtin_fma(n0, n0, __builtin_fma(n1, n1, n2 * n2));
+    const double inm = frsq(nn);
+    const double numag = nn * inm;
+    const double cn  = c * inm;
+    const double cg0 = cn * n0;
+    const double cg1 = __builtin_fma(cn, n1, v);
+    const double cg2 = __builtin_fma(cn, n2, u);
+    const double icg = frsq(__builtin_fma(cg0, cg0, __builtin_fma(cg1, cg1, cg2 * cg2)));
+    const double ir  = frcp(r);
+    const double ico = frcp(cth);
+    const double tn  = sth * ico;
+    const double u0 = cg0 * icg, u1 = cg1 * icg, u2 = cg2 * icg;
+    const double G[3] = { 1.0, ir, ir * ico };                       // GeoCoeff (:258-260)
+    // GeoTerms (:262-268) with c_g substituted (see global_rhs)
+    const double nc12 = __builtin_fma(n1, cg1, n2 * cg2);
+    const double ncs  = __builtin_fma(n0, cth, n1 * sth);
+    const double n2cg2 = n2 * cg2;
+    double Tg[3], H[3];
+    Tg[0] = ir * nc12;
+    Tg[1] = __builtin_fma(n2cg2, tn, -(cn * n0) * n1);
+    Tg[2] = -n2 * __builtin_fma(cn, ncs, v * sth);
+    #pragma unroll
+    for(int i = 0; i < 3; i++) H[i] = __builtin_fma(numag, dc[i], __builtin_fma(n1, dv[i], n2 * du[i]));
+    dy[0] = u0;
+    dy[1] = G[1] * u1;
+    dy[2] = G[2] * u2;
+    #pragma unroll
+    for(int i = 0; i < 3; i++) dy[3 + i] = -(G[i] * icg) * (H[i] + Tg[i]);
+
+    if(AMP){
+        // second derivatives in equation order: [i][m] over (r, t, p) from table entries rr = 6, tt = 4, pp = 5, rt = 8, rp = 9, tp = 7
+        const int ij[3][3] = { {6, 8, 9}, {8, 4, 7}, {9, 7, 5} };
+        const double hc3 = (0.25 * kGamR * kGamR) * (ic * ic * ic);
+        const double ir2 = ir * ir, ico2 = ico * ico;
+        const double cnn1 = cn * n1, cnn2 = cn * n2;
+        #pragma unroll
+        for(int q = 0; q < 2; q++){
+            const double R[3] = { y[6 + 6 * q], y[7 + 6 * q], y[8 + 6 * q] };
+            const double m0 = y[9 + 6 * q], m1 = y[10 + 6 * q], m2 = y[11 + 6 * q];
+            double dca = 0.0, dua = 0.0, dva = 0.0;
+            #pragma unroll
+            for(int n = 0; n < 3; n++){ dca = __builtin_fma(R[n], dc[n], dca); dua = __builtin_fma(R[n], du[n], dua); dva = __builtin_fma(R[n], dv[n], dva); }
+            const double dnu = __builtin_fma(n0, m0, __builtin_fma(n1, m1, n2 * m2)) * inm;
+            const double al  = inm * __builtin_fma(-cn, dnu, dca);
+            const double a1  = __builtin_fma(n1, al, cn * m1);
+            const double a2  = __builtin_fma(n2, al, cn * m2);
+            const double dcg0 = __builtin_fma(n0, al, cn * m0);
+            const double dcg1 = a1 + dva;
+            const double dcg2 = a2 + dua;
+            const double e   = icg * __builtin_fma(u0, dcg0, __builtin_fma(u1, dcg1, u2 * dcg2));
+            const double w0 = __builtin_fma(icg, dcg0, -u0 * e);
+            const double w1 = __builtin_fma(icg, dcg1, -u1 * e);
+            const double w2 = __builtin_fma(icg, dcg2, -u2 * e);
+            double dG[3];
+            dG[0] = 0.0;
+            dG[1] = -R[0] * ir2;
+            dG[2] = G[2] * __builtin_fma(tn, R[1], -R[0] * ir);
+            const double s22 = __builtin_fma(m2, cg2, n2 * dcg2);
+            double dT[3];
+            dT[0] = __builtin_fma(dG[1], nc12, ir * __builtin_fma(m1, cg1, __builtin_fma(n1, dcg1, s22)));
+            dT[1] = __builtin_fma(-cnn1, m0, __builtin_fma(-n0, a1, __builtin_fma(tn, s22, (n2cg2 * R[1]) * ico2)));
+            const double dncs = __builtin_fma(m0, cth, __builtin_fma(m1, sth, R[1] * __builtin_fma(n1, cth, -n0 * sth)));
+            dT[2] = -__builtin_fma(__builtin_fma(m2, v, n2 * dva), sth,
+                                   __builtin_fma((n2 * v) * R[1], cth, __builtin_fma(a2, ncs, cnn2 * dncs)));
+            dy[6 + 6 * q] = w0;
+            dy[7 + 6 * q] = __builtin_fma(dG[1], u1, G[1] * w1);
+            dy[8 + 6 * q] = __builtin_fma(dG[2], u2, G[2] * w2);
+            #pragma unroll
+            for(int i = 0; i < 3; i++){
+                double ddc = 0.0, ddu = 0.0, ddv = 0.0;
+                #pragma unroll
+                for(int mm = 0; mm < 3; mm++){
+                    ddc = __builtin_fma(R[mm], __builtin_fma(hc, T[ij[i][mm]], -hc3 * (T[fi[i]] * T[fi[mm]])), ddc);
+                    ddu = __builtin_fma(R[mm], U[ij[i][mm]], ddu);
+                    ddv = __builtin_fma(R[mm], V[ij[i][mm]], ddv);
+                }
+                const double K = __builtin_fma(numag, ddc, __builtin_fma(n1, ddv, n2 * ddu));
+                // (:437-445)  -dG/|cg| (H + T) + G/|cg|^2 d|cg| H - G/|cg| (d|nu| dc + mu.(dv, du) + K + dT)
+                dy[9 + 6 * q + i] = icg * (-dG[i] * (H[i] + Tg[i])
+                                           + G[i] * (e * H[i] - (__builtin_fma(dnu, dc[i], __builtin_fma(m1, dv[i], __builtin_fma(m2, du[i], K))) + dT[i])));
             }
         }
     }

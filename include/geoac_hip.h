@@ -39,7 +39,7 @@ enum {
     GEOAC_EQ_3D            = 1,   /* GeoAc.EquationSets.3DStratified.cpp   E = 4 / 12  */
     GEOAC_EQ_GLOBAL        = 2,   /* GeoAc.EquationSets.Global.cpp         E = 6 / 18  */
     GEOAC_EQ_3D_RNGDEP     = 3,   /* GeoAc.EquationSets.3DRngDep.cpp       E = 6 / 18  */
-    GEOAC_EQ_GLOBAL_RNGDEP = 4    /* GeoAc.EquationSets.GlobalRngDep.cpp   (not yet implemented) */
+    GEOAC_EQ_GLOBAL_RNGDEP = 4    /* GeoAc.EquationSets.GlobalRngDep.cpp */
 };
 
 /* ---- status codes ---- */
@@ -98,7 +98,7 @@ typedef struct {
     int    calc_amp;      /* CalcAmp                                                */
     int    mode;          /* GEOAC_MODE_* bits                                      */
     int    sample_stride; /* 25 (GeoAcGlobal_main.cpp:269)                          */
-    double xy_limits[4];  /* RngDep sets: GeoAc_x_min/x_max/y_min/y_max_limit; NaN = grid extents (GeoAc_SetPropRegion) */
+    double xy_limits[4];  /* RngDep sets: GeoAc_x_min/x_max/y_min/y_max_limit (3D) or lat_min/lat_max/lon_min/lon_max [rad] (Global); NaN = grid extents (GeoAc_SetPropRegion) */
 } geoac_params;
 
 typedef struct geoac_ctx geoac_ctx;   /* opaque: owns device buffers, stream, events */
@@ -122,7 +122,9 @@ int  geoac_upload_atmo_1d(geoac_ctx* ctx, int n, const double* x, const double* 
 
 /* range-dependent Cartesian atmosphere (GEOAC_EQ_3D_RNGDEP): nx x ny profiles of nz nodes on common z nodes;
  * fields are [nx][ny][nz] row-major (T [K], u,v [km/s, tapered], rho).  Replaces Spline_Multi_G2S + Set_Slopes_Multi
- * (G2S_MultiDimSpline3D.cpp:306-425, 1603-1621): vertical natural splines of f, df/dx, df/dy per node are built here. */
+ * (G2S_MultiDimSpline3D.cpp:306-425, 1603-1621): vertical natural splines of f, df/dx, df/dy per node are built here.
+ * GEOAC_EQ_GLOBAL_RNGDEP (G2S_GlobalMultiDimSpline3D.cpp:313-431, 1473-1492): x = latitudes, y = longitudes [rad], z = geocentric
+ * radius [km]; xy_limits of geoac_params then hold GeoAc_lat_min/lat_max/lon_min/lon_max_limit [rad]. */
 int  geoac_upload_atmo_3d(geoac_ctx* ctx, int nx, int ny, int nz, const double* x, const double* y, const double* z,
                           const double* T, const double* u, const double* v, const double* rho);
 

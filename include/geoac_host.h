@@ -36,6 +36,12 @@ int  geoac_grid_load(const char* prefix, const char* locx, const char* locy, con
                      int nx, int ny, int nz, double* x, double* y, double* z,
                      double* T, double* u, double* v, double* rho);
 
+/* the same for either range-dependent set.  GEOAC_EQ_GLOBAL_RNGDEP: locx / locy hold latitudes / longitudes in degrees (returned in
+ * radians), z comes back as geocentric radius (+6370 km), taper width 0.2 km (G2S_GlobalMultiDimSpline3D.cpp:138-195) */
+int  geoac_grid_load_eq(int eqset, const char* prefix, const char* locx, const char* locy, const char* format, double z_grnd,
+                        int nx, int ny, int nz, double* x, double* y, double* z,
+                        double* T, double* u, double* v, double* rho);
+
 /* table of the range-dependent Cartesian interpolant as the kernels read it (layout: geoac_amd/csrc/geoac_rngdep.h).  Per
  * (field, kz, node) the vertical cubics (c0, c1, 2 c2, 6 c3) of F, DxF, DyF, DxyF, Vx, DxVx, DxyVx, Vy, DyVy, DxyVy for T, u, v
  * (40 doubles) and F, DxF, DyF, DxyF for rho (16 doubles): V0 = S_f, Vx = S_fx, Vy = S_fy are the reference's three vertical
@@ -49,6 +55,14 @@ int    geoac_grid_table(int nx, int ny, int nz, const double* x, const double* y
  * clamped to the grid; y rows scaled by the x cell size, Q11).  Reporting only (atmo.dat): rays never come through here. */
 double geoac_grid_eval(int nx, int ny, int nz, const double* x, const double* y, const double* z, const double* tab,
                        int field, double xq, double yq, double zq);
+
+/* either range-dependent set.  The spherical set (x = latitude, y = longitude [rad], z = radius) keeps the reference's quirks Q12:
+ * the S_fx / S_fy slope systems use its interior right-hand side, and the Vx / Vy cubics carry the truncated z-derivative;
+ * its scalar evaluator scales the y rows by the y cell size. */
+int    geoac_grid_table_eq(int eqset, int nx, int ny, int nz, const double* x, const double* y, const double* z,
+                           const double* T, const double* u, const double* v, const double* rho, double* tab);
+double geoac_grid_eval_eq(int eqset, int nx, int ny, int nz, const double* x, const double* y, const double* z, const double* tab,
+                          int field, double xq, double yq, double zq);
 
 /* cubic of one spline segment (values f0, f1 and slopes s0, s1 at x0 < x1) in powers of t = x - x0: c = (c0, c1, c2, c3), or
  * (c0, c1, 2 c2, 6 c3) when deriv_form != 0 */

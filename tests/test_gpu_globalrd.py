@@ -1,0 +1,68 @@
+"""GPU parity of the range-dependent spherical set (GeoAcGlobal.RngDep) against golden vectors from the compiled reference:
+synthetic 5x5 lat/lon grid of perturbed profiles, 3 x 4 degree cells (tests/rngdep_data.py)."""
+import numpy as np
+import pytest
+
+import harness as H
+import rngdep_data as RD
+from parity import compare_records, max_rel_errors
+
+pytestmark = pytest.mark.gpu
+EQ = H.EQ_GLOBAL_RNGDEP
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(f"{H.GOLDEN_DIR}/globalrd_small.npz")
+
+
+@pytest.fixture(scope="module")
+def grid(tmp_path_factory):
+    return RD.write_grid_global(str(tmp_path_factory.mktemp("gg")), short_paths=False)
+
+
+def _ctx(grid, **params):
+    import geoac_amd as G
+    ctx = G.FanContext(G.EQ_GLOBAL_RNGDEP, device=0)
+    ctx.load_grid(*grid, z_grnd=0.0)          # -prop loads before any z_grnd= is seen (GeoAcGlobal.RngDep_main.cpp:133)
+    ctx.set_params(**params)
+    return ctx
+
+
+@pytest.mark.parametrize("amp", [1, 0])
+def test_globalrd_fan_vs_golden(gold, grid, amp):
+    ctx = _ctx(grid, bounces=1, calc_amp=amp, mode=0, src=(0.0, 31.0, 0.0))
+    rec, steps = ctx.run(gold["theta"], gold["phi"])
+    want = gold[f"rec_amp{amp}_mode0"]
+    E = 18 if amp else 6
+    print("globalrd", amp, max_rel_errors(rec, want, E, 0))
+    assert steps == int(gold[f"steps_amp{amp}_mode0"])
+    compare_records(rec, want, E=E, hidx=0)
+
+
+def test_globalrd_alt_config_vs_golden(gold, grid):
+    ctx = _ctx(grid, bounces=2, calc_amp=1, mode=0, src=(1.5, 29.0, 1.0), z_grnd=0.3, freq=0.4, tweak_abs=0.6,
+               xy_limits=tuple(np.radians([26.0, 36.5, -7.0, 6.0])))
+    rec, steps = ctx.run(gold["theta"], gold["phi"])
+    print("globalrd alt", max_rel_errors(rec, gold["rec_alt"], 18, 0))
+    assert steps == int(gold["steps_alt"])
+    compare_records(rec, gold["rec_alt"], E=18, hidx=0)
+
+
+def test_globalrd_write_rays_caustics_vs_golden(gold, grid):
+    ctx = _ctx(grid, bounces=1, calc_amp=1, mode=3, src=(0.0, 31.0, 0.0))
+    rec, steps = ctx.run(gold["theta"], gold["phi"])
+    compare_records(rec, gold["rec_amp1_mode3"], E=18, hidx=0)
+    smp = ctx.fetch_samples()
+    assert len(smp) == int(gold["nsmp_amp1_mode3"])
+    gs = smp[gold["smp_idx_amp1_mode3"]]; ws = gold["smp_amp1_mode3"]
+    assert np.array_equal(gs[:, :4], ws[:, :4])
+    for col in range(4, 10):
+        d = np.abs(gs[:, col] - ws[:, col])
+        scale = np.maximum(np.abs(ws[:, col]), 1e-3 * max(np.abs(ws[:, col]).max(), 1e-30))
+        if col == 7:
+            ray_rows = ws[:, 3] == 0        # amplitude in dB on raypath rows: absolute 20 log10(1 + 1e-6); travel time on caustic rows
+            assert (d[ray_rows] <= 8.7e-6 + 1e-6 * np.abs(ws[ray_rows, col])).all()
+            assert (d[~ray_rows] / scale[~ray_rows] <= 1e-6).all()
+        else:
+            assert (d / scale).max() <= 1e-6, (col, (d / scale).max())
