@@ -1,4 +1,4 @@
-// geoac_cli.cpp - host drivers `GeoAc2D`, `GeoAc3D`, `GeoAcGlobal`, `GeoAc3D.RngDep` (built with -DGEOAC_CLI_SET=0/1/2/3):
+// geoac_cli.cpp - host drivers `GeoAc2D`, `GeoAc3D`, `GeoAcGlobal`, `GeoAc3D.RngDep`, `GeoAcGlobal.RngDep` (built with -DGEOAC_CLI_SET=0/1/2/3/4):
 // the reference's `-prop` command line, .met input and `_results.dat` / `_raypaths.dat` / `_caustics-path#.dat` /
 // `atmo.dat` outputs, with the launch-angle fan integrated by libgeoac_hip.so on the GPU.
 //
@@ -6,6 +6,7 @@
 //   GeoAcGlobal_RunProp  Code/GeoAcGlobal_main.cpp:116-332      GeoAc3D_RunProp  Code/GeoAc3D_main.cpp:106-313
 //   GeoAc2D_RunProp      Code/GeoAc2D_main.cpp:66-237           GeoAc_WriteProfile  Code/GeoAc/GeoAc.Interface{,.Global}.cpp:78-98
 //   GeoAc3D_RngDep_RunProp  Code/GeoAc3D.RngDep_main.cpp:119-334 (`-prop prefix loc_x loc_y [parameter=value ...]`)
+//   GeoAcGlobal_RngDep_RunProp  Code/GeoAcGlobal.RngDep_main.cpp:122-343 (`-prop prefix loc_lat loc_lon [parameter=value ...]`)
 // Not provided here (out of the accelerated path): -interactive, -eig_search, -eig_direct.
 #include <strings.h>
 #include <cmath>
@@ -29,17 +30,21 @@ using namespace std;
 
 static const double Pi = 3.141592653589793238462643;
 static const double kGamR = 0.00040187, kR = 287.05, kGam = 1.4;
-static const char* kName = (GEOAC_CLI_SET == 0) ? "GeoAc2D" : (GEOAC_CLI_SET == 1) ? "GeoAc3D" : (GEOAC_CLI_SET == 2) ? "GeoAcGlobal" : "GeoAc3D.RngDep";
-static const int kEq = (GEOAC_CLI_SET == 0) ? GEOAC_EQ_2D : (GEOAC_CLI_SET == 1) ? GEOAC_EQ_3D : (GEOAC_CLI_SET == 2) ? GEOAC_EQ_GLOBAL : GEOAC_EQ_3D_RNGDEP;
-static const bool kRng = (GEOAC_CLI_SET == 3);                    // grid of profiles: -prop prefix loc_x loc_y, parameters from argv[5]
+static const char* kName = (GEOAC_CLI_SET == 0) ? "GeoAc2D" : (GEOAC_CLI_SET == 1) ? "GeoAc3D" : (GEOAC_CLI_SET == 2) ? "GeoAcGlobal"
+                         : (GEOAC_CLI_SET == 3) ? "GeoAc3D.RngDep" : "GeoAcGlobal.RngDep";
+static const int kEq = (GEOAC_CLI_SET == 0) ? GEOAC_EQ_2D : (GEOAC_CLI_SET == 1) ? GEOAC_EQ_3D : (GEOAC_CLI_SET == 2) ? GEOAC_EQ_GLOBAL
+                     : (GEOAC_CLI_SET == 3) ? GEOAC_EQ_3D_RNGDEP : GEOAC_EQ_GLOBAL_RNGDEP;
+static const bool kRng = (GEOAC_CLI_SET >= 3);                    // grid of profiles: -prop prefix loc_x loc_y, parameters from argv[5]
+static const bool kRngC = (GEOAC_CLI_SET == 3), kRngS = (GEOAC_CLI_SET == 4);        // Cartesian / spherical grid main
 static const bool kCart3 = (GEOAC_CLI_SET == 1 || GEOAC_CLI_SET == 3);   // x, y, z file layouts
+static const bool kSph = (GEOAC_CLI_SET == 2 || GEOAC_CLI_SET == 4);     // z, lat, lon file layouts; source given as lat/lon
 
 static bool string2bool(const string& v){          // GeoAc.Interface.cpp:125-128
     return !v.empty() && (strcasecmp(v.c_str(), "true") == 0 || atoi(v.c_str()) != 0);
 }
 
 static void usage(){
-    cout << '\n' << "Usage: " << kName << (kRng ? " -prop profile_prefix loc_x.dat loc_y.dat [parameter=value ...]" : " -prop profile.met [parameter=value ...]") << '\n'
+    cout << '\n' << "Usage: " << kName << (kRngS ? " -prop profile_prefix loc_lat.dat loc_lon.dat [parameter=value ...]" : kRng ? " -prop profile_prefix loc_x.dat loc_y.dat [parameter=value ...]" : " -prop profile.met [parameter=value ...]") << '\n'
          << "  GPU (MI355X) build of the " << kName << " launch-angle fan; parameters, defaults and output files follow" << '\n'
          << "  LANL-Seismoacoustics/GeoAc (see GeoAc_Manual.pdf).  Only the -prop option is provided by this build." << '\n' << '\n';
 }
@@ -68,7 +73,7 @@ static void write_profile(const Profile& p, const char* file_name, double azimut
     ofstream file_out; file_out.open(file_name);
     if(!file_out.is_open()){ cout << "Error opening file, check file name." << '\n'; return; }
     for(int m = 0; m < 1400; m++){
-        double x0 = (kEq == GEOAC_EQ_GLOBAL ? 6370.0 : 0.0) + m / 10.0;
+        double x0 = (kSph ? 6370.0 : 0.0) + m / 10.0;
         double c = p.c(x0), u = p.uu(x0), v = p.vv(x0), rho = p.rr(x0);
         file_out << x0 << '\t';
         file_out << pow(c * 1000.0, 2) / (kR * kGam) << '\t';
@@ -78,7 +83,7 @@ static void write_profile(const Profile& p, const char* file_name, double azimut
         file_out << rho * pow(c * 1000.0, 2) / kGam * 10.0 << '\t';
         file_out << c << '\t';
         file_out << c + cos(azimuth * Pi / 180.0) * u + sin(azimuth * Pi / 180.0) * v;
-        if(kEq != GEOAC_EQ_GLOBAL) file_out << '\t';            // the Cartesian writer ends the row with a tab (Interface.cpp:93-94)
+        if(!kSph) file_out << '\t';            // the Cartesian writer ends the row with a tab (Interface.cpp:93-94)
         file_out << '\n';
     }
     file_out.close();
@@ -89,14 +94,15 @@ struct Grid {
     int nx = 0, ny = 0, nz = 0;
     vector<double> x, y, z, T, u, v, rho, tab;
     double f(int field, double xq, double yq, double zq) const {
-        return geoac_grid_eval(nx, ny, nz, x.data(), y.data(), z.data(), tab.data(), field, xq, yq, zq);
+        return geoac_grid_eval_eq(kEq, nx, ny, nz, x.data(), y.data(), z.data(), tab.data(), field, xq, yq, zq);
     }
 };
 static void write_profile_grid(const Grid& g, const char* file_name, double x0, double y0, double azimuth){
     ofstream file_out; file_out.open(file_name);
     if(!file_out.is_open()){ cout << "Error opening file, check file name." << '\n'; return; }
     for(int m = 0; m < 1400; m++){
-        double z0 = m / 10.0;
+        // Cartesian: (x_src, y_src, z) (Interface.cpp:100-121); spherical: (lat_src, lon_src [rad], r_earth + z), no trailing tab (Interface.Global.cpp:99-118)
+        double z0 = (kSph ? 6370.0 : 0.0) + m / 10.0;
         double c = sqrt(kGamR * g.f(0, x0, y0, z0)), u = g.f(1, x0, y0, z0), v = g.f(2, x0, y0, z0), rho = g.f(3, x0, y0, z0);
         file_out << z0 << '\t';
         file_out << pow(c * 1000.0, 2) / (kR * kGam) << '\t';
@@ -105,7 +111,8 @@ static void write_profile_grid(const Grid& g, const char* file_name, double x0, 
         file_out << rho << '\t';
         file_out << rho * pow(c * 1000.0, 2) / kGam * 10.0 << '\t';
         file_out << c << '\t';
-        file_out << c + cos(azimuth * Pi / 180.0) * u + sin(azimuth * Pi / 180.0) * v << '\t';
+        file_out << c + cos(azimuth * Pi / 180.0) * u + sin(azimuth * Pi / 180.0) * v;
+        if(!kSph) file_out << '\t';
         file_out << '\n';
     }
     file_out.close();
@@ -130,6 +137,24 @@ static int run_prop(char* inputs[], int count){
     //      the range-dependent main parses first and loads with the parsed z_grnd (GeoAc3D.RngDep_main.cpp:131-170) ----
     Profile prof;
     Grid grid;
+    auto load_grid = [&](double z_taper) -> int {
+        if(geoac_grid_dims(inputs[2], inputs[3], inputs[4], &grid.nx, &grid.ny, &grid.nz)){ cout << "Error opening file, check file name" << '\n'; return 1; }
+        const size_t nn = (size_t)grid.nx * grid.ny * grid.nz;
+        grid.x.resize(grid.nx); grid.y.resize(grid.ny); grid.z.resize(grid.nz);
+        grid.T.resize(nn); grid.u.resize(nn); grid.v.resize(nn); grid.rho.resize(nn);
+        int lrc = geoac_grid_load_eq(kEq, inputs[2], inputs[3], inputs[4], ProfileFormat, z_taper, grid.nx, grid.ny, grid.nz, grid.x.data(), grid.y.data(), grid.z.data(),
+                                     grid.T.data(), grid.u.data(), grid.v.data(), grid.rho.data());
+        if(lrc == -2){ cout << "Unrecognized profile option: " << ProfileFormat << ".  Valid options are: zTuvdp and zuvwTdp" << '\n'; return 1; }
+        if(lrc){ cout << "Error opening file, check file name" << '\n'; return 1; }
+        return 0;
+    };
+    if(kRngS){
+        // the spherical grid main loads first, with z_grnd = 0 (GeoAcGlobal.RngDep_main.cpp:130-133), and puts the default source at the
+        // centre of the grid (:135-137)
+        if(load_grid(0.0)) return 1;
+        src_a = (grid.x[0] + grid.x[(size_t)grid.nx - 1]) / 2.0 * 180.0 / Pi;
+        src_b = (grid.y[0] + grid.y[(size_t)grid.ny - 1]) / 2.0 * 180.0 / Pi;
+    }
     if(!kRng){
     prof.n = geoac_met_rows(inputs[2]);
     if(prof.n < 3){ cout << "Error opening file, check file name" << '\n'; return 1; }
@@ -159,13 +184,18 @@ static int run_prop(char* inputs[], int count){
         else if(kEq != GEOAC_EQ_2D && strncmp(a, "phi_step=", 9) == 0){ phi_step = atof(a + 9); }
         else if(strncmp(a, "azimuth=", 8) == 0){ phi_min = atof(a + 8); phi_max = atof(a + 8); phi_step = 1.0; }
         else if(strncmp(a, "bounces=", 8) == 0){ bounces = atoi(a + 8); }
-        else if(kEq == GEOAC_EQ_GLOBAL && strncmp(a, "lat_src=", 8) == 0){ src_a = atof(a + 8); }
-        else if(kEq == GEOAC_EQ_GLOBAL && strncmp(a, "lon_src=", 8) == 0){ src_b = atof(a + 8); }
-        else if(kRng && strncmp(a, "x_src=", 6) == 0){ src_a = atof(a + 6); }
-        else if(kRng && strncmp(a, "y_src=", 6) == 0){ src_b = atof(a + 6); }
+        else if(kSph && strncmp(a, "lat_src=", 8) == 0){ src_a = atof(a + 8); }
+        else if(kSph && strncmp(a, "lon_src=", 8) == 0){ src_b = atof(a + 8); }
+        else if(kRngC && strncmp(a, "x_src=", 6) == 0){ src_a = atof(a + 6); }
+        else if(kRngC && strncmp(a, "y_src=", 6) == 0){ src_b = atof(a + 6); }
         // the range-dependent main takes the region limits but GeoAc_SetPropRegion overwrites them right after loading (Q9)
-        else if(kRng && (strncmp(a, "x_min=", 6) == 0 || strncmp(a, "x_max=", 6) == 0 || strncmp(a, "y_min=", 6) == 0 || strncmp(a, "y_max=", 6) == 0)){ }
-        else if(kRng && strncmp(a, "alt_max=", 8) == 0){ }
+        else if(kRngC && (strncmp(a, "x_min=", 6) == 0 || strncmp(a, "x_max=", 6) == 0 || strncmp(a, "y_min=", 6) == 0 || strncmp(a, "y_max=", 6) == 0)){ }
+        else if(kRngC && strncmp(a, "alt_max=", 8) == 0){ }
+        // spherical grid main: the box limits are assigned as typed and compared with radians (GeoAcGlobal.RngDep_main.cpp:166-169)
+        else if(kRngS && strncmp(a, "lat_min=", 8) == 0){ P.xy_limits[0] = atof(a + 8); }
+        else if(kRngS && strncmp(a, "lat_max=", 8) == 0){ P.xy_limits[1] = atof(a + 8); }
+        else if(kRngS && strncmp(a, "lon_min=", 8) == 0){ P.xy_limits[2] = atof(a + 8); }
+        else if(kRngS && strncmp(a, "lon_max=", 8) == 0){ P.xy_limits[3] = atof(a + 8); }
         else if(strncmp(a, "z_src=", 6) == 0){ z_src = atof(a + 6); }
         else if(strncmp(a, "z_grnd=", 7) == 0){ z_grnd = atof(a + 7); }
         else if(kEq != GEOAC_EQ_2D && strncmp(a, "WriteAtmo=", 10) == 0){ WriteAtmo = string2bool(a + 10); }
@@ -185,16 +215,9 @@ static int run_prop(char* inputs[], int count){
     }
     if(kEq == GEOAC_EQ_2D){ WriteRays = true; WriteAtmo = true; }     // GeoAc2D always writes raypaths and atmo.dat
     if(WriteCaustics) CalcAmp = true;
-    if(kRng){
+    if(kRngC){
         z_src = max(z_grnd, z_src);                                 // GeoAc3D.RngDep_main.cpp:165
-        if(geoac_grid_dims(inputs[2], inputs[3], inputs[4], &grid.nx, &grid.ny, &grid.nz)){ cout << "Error opening file, check file name" << '\n'; return 1; }
-        const size_t nn = (size_t)grid.nx * grid.ny * grid.nz;
-        grid.x.resize(grid.nx); grid.y.resize(grid.ny); grid.z.resize(grid.nz);
-        grid.T.resize(nn); grid.u.resize(nn); grid.v.resize(nn); grid.rho.resize(nn);
-        int lrc = geoac_grid_load(inputs[2], inputs[3], inputs[4], ProfileFormat, z_grnd, grid.nx, grid.ny, grid.nz, grid.x.data(), grid.y.data(), grid.z.data(),
-                                  grid.T.data(), grid.u.data(), grid.v.data(), grid.rho.data());
-        if(lrc == -2){ cout << "Unrecognized profile option: " << ProfileFormat << ".  Valid options are: zTuvdp and zuvwTdp" << '\n'; return 1; }
-        if(lrc){ cout << "Error opening file, check file name" << '\n'; return 1; }
+        if(load_grid(z_grnd)) return 1;                              // this main parses first and loads with the parsed z_grnd (:131-170)
     }
 
     // output prefix = input path up to the first '.' (GeoAcGlobal_main.cpp:170-177)
@@ -205,8 +228,9 @@ static int run_prop(char* inputs[], int count){
     if(WriteAtmo && !kRng) write_profile(prof, "atmo.dat", 90.0 - phi_min);
     if(WriteAtmo && kRng){
         grid.tab.resize(geoac_grid_table_size(grid.nx, grid.ny, grid.nz));
-        geoac_grid_table(grid.nx, grid.ny, grid.nz, grid.x.data(), grid.y.data(), grid.z.data(), grid.T.data(), grid.u.data(), grid.v.data(), grid.rho.data(), grid.tab.data());
-        write_profile_grid(grid, "atmo.dat", src_a, src_b, 90.0 - phi_min);
+        geoac_grid_table_eq(kEq, grid.nx, grid.ny, grid.nz, grid.x.data(), grid.y.data(), grid.z.data(), grid.T.data(), grid.u.data(), grid.v.data(), grid.rho.data(), grid.tab.data());
+        if(kRngS) write_profile_grid(grid, "atmo.dat", src_a * Pi / 180.0, src_b * Pi / 180.0, 90.0 - phi_min);
+        else      write_profile_grid(grid, "atmo.dat", src_a, src_b, 90.0 - phi_min);
     }
 
     // ---- the fan on the GPU ----
@@ -218,9 +242,9 @@ static int run_prop(char* inputs[], int count){
     if(rc){ cout << kName << ": " << geoac_last_error(ctx) << '\n'; return 2; }
     P.z_grnd = z_grnd; P.tweak_abs = tweak_abs; P.freq = freq; P.bounces = bounces; P.calc_amp = CalcAmp ? 1 : 0;
     P.mode = (WriteRays ? GEOAC_MODE_WRITE_RAYS : 0) | (WriteCaustics ? GEOAC_MODE_WRITE_CAUSTICS : 0);
-    if(kEq == GEOAC_EQ_GLOBAL){ P.src[0] = z_src; P.src[1] = src_a; P.src[2] = src_b; }
+    if(kSph){ P.src[0] = z_src; P.src[1] = src_a; P.src[2] = src_b; }
     else if(kEq == GEOAC_EQ_3D){ P.src[0] = 0.0; P.src[1] = 0.0; P.src[2] = z_src; }
-    else if(kRng){ P.src[0] = src_a; P.src[1] = src_b; P.src[2] = z_src; }
+    else if(kRngC){ P.src[0] = src_a; P.src[1] = src_b; P.src[2] = z_src; }
     else { P.src[0] = z_src; P.src[1] = 0.0; P.src[2] = 0.0; }
     rc = geoac_set_params(ctx, &P);
     if(rc){ cout << kName << ": " << geoac_last_error(ctx) << '\n'; return 2; }
@@ -251,8 +275,8 @@ static int run_prop(char* inputs[], int count){
     ofstream results, raypath;
     sprintf(output_buffer, "%s_results.dat", file_title);
     results.open(output_buffer);
-    if(kEq == GEOAC_EQ_GLOBAL){
-        results << "# theta [deg]" << '\t' << "phi [deg]" << '\t' << "n_b" << '\t' << "lat_0 [deg]" << '\t' << "lon_0 [deg]" << '\t' << "Travel Time [s]"
+    if(kSph){
+        results << "# theta [deg]" << '\t' << "phi [deg]" << '\t' << (kRngS ? "Bounces" : "n_b") << '\t' << "lat_0 [deg]" << '\t' << "lon_0 [deg]" << '\t' << "Travel Time [s]"
                 << '\t' << "Celerity [km/s]" << '\t' << "Turning Height [km]" << '\t' << "Inclination [deg]" << '\t' << "Back Azimuth [deg]"
                 << '\t' << "Geo. Atten. [dB]" << '\t' << "Atmo. Atten. [dB]" << '\n';
     } else if(kCart3){
@@ -266,7 +290,7 @@ static int run_prop(char* inputs[], int count){
     if(WriteRays){
         sprintf(output_buffer, "%s_raypaths.dat", file_title);
         raypath.open(output_buffer);
-        if(kEq == GEOAC_EQ_GLOBAL)  raypath << "# z [km]" << '\t' << "Lat [deg]" << '\t' << "Long [deg]";
+        if(kSph)                    raypath << "# z [km]" << '\t' << "Lat [deg]" << '\t' << "Long [deg]";
         else if(kCart3)             raypath << "# x [km]" << '\t' << "y [km]" << '\t' << "z [km]";
         else                        raypath << "# r [km]" << '\t' << "z [km]";
         raypath << '\t' << "Geo. Atten. [dB]" << '\t' << "Atmo. Atten. [dB]" << '\t' << "Travel Time [s]" << '\n';
@@ -277,7 +301,7 @@ static int run_prop(char* inputs[], int count){
         for(int bnc = 0; bnc <= bounces; bnc++){
             sprintf(output_buffer, "%s_caustics-path%i.dat", file_title, bnc);
             caustics[(size_t)bnc].open(output_buffer);
-            if(kEq == GEOAC_EQ_GLOBAL)  caustics[(size_t)bnc] << "# z [km]" << '\t' << "Lat [deg]" << '\t' << "Long [deg]";
+            if(kSph)                    caustics[(size_t)bnc] << "# z [km]" << '\t' << "Lat [deg]" << '\t' << "Long [deg]";
             else if(kCart3)             caustics[(size_t)bnc] << "# x [km]" << '\t' << "y [km]" << '\t' << "z [km]";
             else                        caustics[(size_t)bnc] << "# r [km]" << '\t' << "z [km]";
             caustics[(size_t)bnc] << '\t' << "Travel Time [s]" << '\n';
@@ -287,14 +311,14 @@ static int run_prop(char* inputs[], int count){
     size_t sp = 0;
     const size_t nsmp = smp.size() / GEOAC_SMP_STRIDE;
     for(long i = 0; i < nr; i++){
-        cout << "Plotting ray path w/ theta = " << th[(size_t)i] << ", phi = " << ph[(size_t)i] << (kRng ? "." : "") << '\n';
+        cout << "Plotting ray path w/ theta = " << th[(size_t)i] << ", phi = " << ph[(size_t)i] << (kRngC ? "." : "") << '\n';
         // raypath / caustic rows of this ray (sorted by ray, leg, m)
         while(sp < nsmp && (long)smp[sp * GEOAC_SMP_STRIDE + GEOAC_SMP_RAY] == i){
             const double* S = &smp[sp * GEOAC_SMP_STRIDE];
             const int leg = (int)S[GEOAC_SMP_LEG], kind = (int)S[GEOAC_SMP_KIND];
             const double* v = S + GEOAC_SMP_V0;
             if(kind == 0 && WriteRays){
-                if(kEq == GEOAC_EQ_GLOBAL){
+                if(kSph){
                     raypath << v[0];
                     raypath << '\t' << setprecision(8) << v[1];
                     raypath << '\t' << setprecision(8) << v[2];
@@ -306,12 +330,12 @@ static int run_prop(char* inputs[], int count){
                 }
             } else if(kind == 1 && WriteCaustics && leg < legs){
                 ofstream& c = caustics[(size_t)leg];
-                if(kEq == GEOAC_EQ_GLOBAL){
+                if(kSph){
                     c << v[0];
                     c << '\t' << setprecision(8) << v[1];
                     c << '\t' << setprecision(8) << v[2];
                     c << '\t' << v[3] << '\n';
-                } else if(kRng){                                     // the range-dependent main writes a literal 0.0 column before the time (:270-274); the sample row carries it
+                } else if(kRngC){                                    // the range-dependent main writes a literal 0.0 column before the time (:270-274); the sample row carries it
                     c << v[0] << '\t' << v[1] << '\t' << v[2] << '\t' << v[3] << '\t' << v[4] << '\n';
                 } else if(kEq == GEOAC_EQ_3D){
                     c << v[0] << '\t' << v[1] << '\t' << v[2] << '\t' << v[3] << '\n';
@@ -327,7 +351,7 @@ static int run_prop(char* inputs[], int count){
             results << th[(size_t)i];
             results << '\t' << ph[(size_t)i];
             results << '\t' << b;
-            if(kEq == GEOAC_EQ_GLOBAL){
+            if(kSph){
                 results << '\t' << setprecision(8) << R[GEOAC_REC_STATE + 1] * 180.0 / Pi;
                 results << '\t' << setprecision(8) << R[GEOAC_REC_STATE + 2] * 180.0 / Pi;
                 results << '\t' << R[GEOAC_REC_TTIME];

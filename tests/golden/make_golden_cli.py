@@ -22,6 +22,9 @@ CASES = {
     # range-dependent Cartesian main on the synthetic 5x5 grid (tests/rngdep_data.py): -prop p loc_x.dat loc_y.dat ...
     "3drd": ("GeoAc3D.RngDep", ["theta_min=10", "theta_max=30", "theta_step=20", "phi_min=-90", "phi_max=-45", "phi_step=45",
                                 "bounces=1", "WriteCaustics=True", "WriteAtmo=True", "x_src=50", "y_src=-30", "z_src=0.5"]),
+    # range-dependent spherical main on the synthetic lat/lon grid: -prop g loc_lat.dat loc_lon.dat ... (default source = grid centre)
+    "globalrd": ("GeoAcGlobal.RngDep", ["theta_min=10", "theta_max=30", "theta_step=20", "phi_min=-90", "phi_max=-45", "phi_step=45",
+                                        "bounces=1", "WriteCaustics=True", "WriteAtmo=True", "z_src=0.5", "lon_src=1.25"]),
 }
 
 
@@ -34,7 +37,11 @@ def main():
         shutil.rmtree(out, ignore_errors=True)
         os.makedirs(out)
         with tempfile.TemporaryDirectory() as td:
-            if binary.endswith("RngDep"):
+            if binary == "GeoAcGlobal.RngDep":
+                import rngdep_data as RD
+                RD.write_grid_global(td)
+                inputs = ["g", "loc_lat.dat", "loc_lon.dat"]
+            elif binary.endswith("RngDep"):
                 import rngdep_data as RD
                 RD.write_grid(td)
                 inputs = ["p", "loc_x.dat", "loc_y.dat"]

@@ -1,4 +1,4 @@
-"""GPU test of the drop-in surface: the GeoAc2D / GeoAc3D / GeoAcGlobal / GeoAc3D.RngDep -prop drivers of this repo (GPU fan behind
+"""GPU test of the drop-in surface: the GeoAc2D / GeoAc3D / GeoAcGlobal / GeoAc3D.RngDep / GeoAcGlobal.RngDep -prop drivers of this repo (GPU fan behind
 the C ABI) must write the same files as the reference's own binaries: same file set, same line structure, every
 number equal to the printed precision (6-8 significant digits) up to one unit in the last printed place."""
 import os
@@ -40,7 +40,7 @@ def _compare_files(got, want):
     return nsame, ntok
 
 
-@pytest.mark.parametrize("case", ["global", "3d", "2d", "global_norays", "3drd"])
+@pytest.mark.parametrize("case", ["global", "3d", "2d", "global_norays", "3drd", "globalrd"])
 def test_cli_files_match_reference_binaries(case, tmp_path):
     gold = os.path.join(CLI_GOLD, case)
     args = open(os.path.join(gold, "ARGS")).read().split()
@@ -49,7 +49,11 @@ def test_cli_files_match_reference_binaries(case, tmp_path):
     if not os.path.exists(exe):
         import __graft_entry__
         __graft_entry__.build()
-    if binary.endswith("RngDep"):
+    if binary == "GeoAcGlobal.RngDep":
+        import rngdep_data as RD
+        RD.write_grid_global(str(tmp_path), short_paths=False)
+        inputs = ["g", "loc_lat.dat", "loc_lon.dat"]
+    elif binary.endswith("RngDep"):
         import rngdep_data as RD
         RD.write_grid(str(tmp_path), short_paths=False)      # the driver is run with relative names from cwd
         inputs = ["p", "loc_x.dat", "loc_y.dat"]
