@@ -42,6 +42,24 @@ def pmc_traffic_per_step():
         return None, None
 
 
+FP64_PEAK_TFLOPS = 78.6       # MI355X FP64 vector peak
+
+
+def pmc_fp64_flop_per_step():
+    """executed FP64 lane-flops per ray-step of the dominant kernel, from the SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 pass of the
+    newest committed PMC summary (the binding resource of this path is FP64 VALU, not HBM); None if absent."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            with open(f) as fh:
+                v = json.load(fh).get("k_rk4_fp64_flop_per_ray_step")
+            if v:
+                return float(v), os.path.basename(f)
+        except Exception:
+            pass
+    return None, None
+
+
 def cpu_baseline():
     """the reference's own serial loop on this box's host cores: three azimuth slices of the metric fan
     (270 rays, ~6e6 steps, 10-20 s), compiled reference if its prebuilt shim is present, else the plain-C port."""
@@ -174,6 +192,12 @@ def main():
                          "alg_bytes_per_step": B_ALG_PER_STEP,
                          "rk4_ms_per_pass": rk4_ms / args.steps, "postpass_ms_per_pass": post_ms / args.steps},
         }
+        fps, fp_src = pmc_fp64_flop_per_step()
+        if fps and rk4_ms > 0:
+            tf = fps * local_steps_per_pass * args.steps / (rk4_ms * 1e-3) / 1e12
+            # the honest "how busy is the binding unit" figure beside the contract's HBM roofline
+            out["roofline"]["fp64"] = {"flop_per_step": fps, "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": tf / FP64_PEAK_TFLOPS, "source": fp_src}
         if not args.no_cpu_baseline and n_gpus == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
