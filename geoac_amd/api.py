@@ -27,6 +27,17 @@ class Params(ctypes.Structure):
                 ("mode", ctypes.c_int), ("sample_stride", ctypes.c_int), ("xy_limits", ctypes.c_double * 4)]
 
 
+EIG_STRIDE = 16
+EIG = dict(RCVR=0, INDEX=1, BOUNCES=2, THETA=3, PHI=4, TTIME=5, CELERITY=6, AMP_DB=7, ATTEN_DB=8, INCL=9, BEARING=10, BACKAZ=11,
+           AZDEV=12, NSMP=13, SMP0=14)
+
+
+class EigParams(ctypes.Structure):
+    """geoac_eig_params (include/geoac_eig.h)"""
+    _fields_ = [("theta_min", ctypes.c_double), ("theta_max", ctypes.c_double), ("bnc_min", ctypes.c_int), ("bnc_max", ctypes.c_int),
+                ("iterations", ctypes.c_int), ("azimuth_err_lim", ctypes.c_double), ("verbose", ctypes.c_int)]
+
+
 def library_path():
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libgeoac_hip.so")
 
@@ -227,3 +238,45 @@ class FanContext:
         ms = (ctypes.c_double * 3)(); st = (ctypes.c_uint64 * 3)()
         self._chk(self.lib.geoac_last_timing(self._h, ms, st))
         return dict(ms_total=ms[0], ms_rk4=ms[1], ms_post=ms[2], epochs=int(st[0]), path_bytes_w=int(st[1]), path_bytes_r=int(st[2]))
+
+    # ---- eigenray searches (include/geoac_eig.h), spherical sets ----
+    def _eig_collect(self, res):
+        L = self.lib
+        L.geoac_eig_count.restype = ctypes.c_int64
+        L.geoac_eig_sample_count.restype = ctypes.c_int64
+        L.geoac_eig_log.restype = ctypes.c_char_p
+        L.geoac_eig_log.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        ne, ns = L.geoac_eig_count(res), L.geoac_eig_sample_count(res)
+        eig = np.zeros((max(ne, 1), EIG_STRIDE)); smp = np.zeros((max(ns, 1), 10))
+        if ne:
+            self._chk(L.geoac_eig_fetch(res, _p(eig)))
+        if ns:
+            self._chk(L.geoac_eig_fetch_samples(res, _p(smp)))
+        st = (ctypes.c_uint64 * 4)()
+        L.geoac_eig_stats(res, st)
+        return dict(eig=eig[:ne], smp=smp[:ns], stats=dict(launches=int(st[0]), rays=int(st[1]), steps=int(st[2]), rounds=int(st[3])))
+
+    def eig_search(self, receivers, theta_min=0.5, theta_max=45.0, bnc_min=0, bnc_max=0, iterations=25, azimuth_err_lim=2.0, verbose=False):
+        """GeoAc's -eig_search for every receiver [lat, lon] (degrees) around the context's source, decision rounds of all receivers
+        batched into fan launches.  Returns dict(eig [n][EIG_STRIDE], smp raypath rows, stats, logs)."""
+        rc_arr = _arr(receivers).reshape(-1, 2)
+        ep = EigParams(theta_min, theta_max, bnc_min, bnc_max, iterations, azimuth_err_lim, 1 if verbose else 0)
+        res = ctypes.c_void_p()
+        self._chk(self.lib.geoac_eig_search(self._h, ctypes.byref(ep), len(rc_arr), _p(rc_arr), ctypes.byref(res)))
+        out = self._eig_collect(res)
+        out["logs"] = [self.lib.geoac_eig_log(res, i).decode() for i in range(len(rc_arr))]
+        self.lib.geoac_eig_free.argtypes = [ctypes.c_void_p]
+        self.lib.geoac_eig_free(res)
+        return out
+
+    def eig_direct(self, receivers, theta_est, phi_est, bounces=0, iterations=25, verbose=False):
+        """-eig_direct: refinement from given inclination / azimuth-from-north estimates, one per receiver"""
+        rc_arr = _arr(receivers).reshape(-1, 2); th = _arr(theta_est); ph = _arr(phi_est)
+        ep = EigParams(0.5, 45.0, bounces, bounces, iterations, 2.0, 1 if verbose else 0)
+        res = ctypes.c_void_p()
+        self._chk(self.lib.geoac_eig_direct(self._h, ctypes.byref(ep), len(rc_arr), _p(rc_arr), _p(th), _p(ph), int(bounces), ctypes.byref(res)))
+        out = self._eig_collect(res)
+        out["logs"] = [self.lib.geoac_eig_log(res, i).decode() for i in range(len(rc_arr))]
+        self.lib.geoac_eig_free.argtypes = [ctypes.c_void_p]
+        self.lib.geoac_eig_free(res)
+        return out

@@ -40,6 +40,7 @@ struct DevBuf {
 
 struct geoac_ctx {
     int eqset = 0, device = 0;
+    int  spread_override = 0;        // GEOAC_SPREAD=n: force n-way lane thinning of the grid-set RK4 waves (1 = dense); 0 = automatic
     hipStream_t stream = nullptr; bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> evs;                  // per-epoch markers: [4e], [4e+1] around k_rk4 (ctx stream); [4e+2], [4e+3] around the post-pass (pp stream)
@@ -169,6 +170,8 @@ int geoac_create(geoac_ctx** out, int eqset, int device){
     if(ppb && atoi(ppb) > 0) ctx->pp_blocks = atoi(ppb);
     const char* npr = getenv("GEOAC_NO_PAIR");
     if(npr && atoi(npr) != 0) ctx->no_pair = true;
+    const char* nsp = getenv("GEOAC_SPREAD");
+    if(nsp && atoi(nsp) > 0) ctx->spread_override = atoi(nsp);
     const char* sc = getenv("GEOAC_SMP_CAP");
     if(sc && atoll(sc) > 0) ctx->smp_cap = atoll(sc);
     *out = ctx;
@@ -261,6 +264,17 @@ int geoac_upload_atmo_3d(geoac_ctx* ctx, int nx, int ny, int nz, const double* x
     const double ext[4] = { x[0], x[nx - 1], y[0], y[ny - 1] };
     for(int q = 0; q < 4; q++) if(!(ctx->prm.xy_limits[q] == ctx->prm.xy_limits[q])) ctx->prm.xy_limits[q] = ext[q];
     ctx->have_grid = true; ctx->have_atmo = true;
+    return GEOAC_OK;
+}
+
+int geoac_get_params(geoac_ctx* ctx, geoac_params* p){
+    if(!ctx || !p) return GEOAC_E_INVALID;
+    *p = ctx->prm;
+    return GEOAC_OK;
+}
+int geoac_get_eqset(geoac_ctx* ctx, int* eqset){
+    if(!ctx || !eqset) return GEOAC_E_INVALID;
+    *eqset = ctx->eqset;
     return GEOAC_OK;
 }
 
@@ -402,6 +416,15 @@ int geoac_fan_launch(geoac_ctx* ctx){
     if(wpb > 4) wpb = 4;                       // k_rk4 is compiled with __launch_bounds__(256): never launch a larger workgroup
     int block = 64 * wpb;
     if(!P.table_in_lds) block = 64;
+    // grid sets are bound by divergent table gathers (one cache line per active lane and load): while the fan has fewer waves than
+    // the chip has SIMDs, thin the waves out (1 wave per SIMD is what the kernel's register budget allows)
+    P.spread = 1;
+    if(is_grid){
+        // measured (tools/perf_rngdep.py, GEOAC_SPREAD sweep): 2-4 way thinning gains 5-20 %, 8+ loses again (path stores and the
+        // post-pass reads scatter), more waves than SIMDs loses a lot
+        while(P.spread < 4 && (long long)P.n_pad * (P.spread * 2) / 64 <= 1024) P.spread *= 2;
+        if(ctx->spread_override > 0){ P.spread = 1; while(P.spread * 2 <= ctx->spread_override && P.spread < 64) P.spread *= 2; }
+    }
 
     // ---- epoch pipeline: RK4 of epoch e on the context's stream, post-pass of epoch e on a second stream, chunk
     //      buffers alternate, so k_rk4(e+1) runs beside k_postpass(e)/k_accum(e).  The host only waits for the

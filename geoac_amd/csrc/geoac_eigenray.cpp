@@ -1,0 +1,461 @@
+// geoac_eigenray.cpp - batched eigenray searches for the spherical sets on top of the ray-fan C ABI (include/geoac_eig.h).
+//
+// Every receiver's search is the reference's straight-line logic (GeoAc.Eigenray.Global.cpp) running in its own host thread; wherever
+// the reference would propagate a ray the thread posts a request and sleeps.  When every live search is waiting, the calling thread
+// groups the requests by (bounces, CalcAmp, output mode), integrates each group as ONE fan launch on the GPU and wakes the searches
+// with their arrival records.  An inclination scan whose step does not depend on earlier arrivals (the first three passes of
+// GeoAc_EstimateEigenray) is requested as a whole and replayed in the reference's order afterwards.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <condition_variable>
+#include <iomanip>
+#include <map>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/geoac_eig.h"
+
+namespace {
+
+const double Pi = 3.141592653589793238462643;
+
+struct Request {
+    int bounces = 0, calc_amp = 0, mode = 0;
+    std::vector<double> th, ph;            // launch inclination, azimuth from north [deg]
+    std::vector<double> rec;               // [n][bounces+1][GEOAC_REC_STRIDE]
+    std::vector<double> smp;               // sample rows of these rays (GEOAC_SMP_RAY = index within the request)
+    bool done = false;
+    int  error = 0;
+};
+
+struct Eigenray { double v[GEOAC_EIG_STRIDE]; std::vector<double> smp; };
+
+struct Shared {
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::vector<Request*> pending;
+    int active = 0;                        // searches still running
+    int waiting = 0;                       // searches blocked in trace()
+    bool failed = false;
+};
+
+struct Geo {                               // spherical helpers of GeoAc.Eigenray.Global.cpp:25-43
+    double r_earth;
+    double bearing(double lat1, double long1, double lat2, double long2) const {
+        double term1 = sin((long2 - long1) * Pi / 180.0);
+        double term2 = cos(lat1 * Pi / 180.0) * tan(lat2 * Pi / 180.0) - sin(lat1 * Pi / 180.0) * cos((long2 - long1) * Pi / 180.0);
+        return atan2(term1, term2) * 180.0 / Pi;
+    }
+    double gc_distance(double lat1, double long1, double lat2, double long2) const {
+        double term1 = pow(sin((lat2 - lat1) * Pi / 180.0 / 2.0), 2);
+        double term2 = cos(lat1 * Pi / 180.0) * cos(lat2 * Pi / 180.0) * pow(sin((long2 - long1) * Pi / 180.0 / 2.0), 2);
+        return 2.0 * r_earth * asin(sqrt(term1 + term2));
+    }
+};
+
+const double d_theta_big = 0.25, d_theta_small = 0.002;     // GeoAc.Eigenray.Global.cpp:21-22
+double modify_d_theta(double dr, double dr_dtheta){           // :40-44
+    double width = 1.0 / 2.0 * pow(dr_dtheta, 2);
+    return d_theta_big - (d_theta_big - d_theta_small) * exp(-dr * dr / width);
+}
+
+struct Search {
+    Shared* sh = nullptr;
+    Geo geo{6370.0};
+    int eqset = GEOAC_EQ_GLOBAL;
+    int rcvr_index = 0;
+    double src[3] = {0, 0, 0};             // lat, lon [deg], z [km] (Source_Loc of the reference)
+    double rcv[2] = {0, 0};
+    double z_grnd = 0.0;
+    geoac_eig_params prm{};
+    bool verbose = false;
+    std::ostringstream log;                // the reference's cout for this receiver (sticky precision and all)
+    std::vector<Eigenray> found;
+    int eigenray_count = 0;
+
+    // ---- post a request and wait for the coordinator ----
+    bool trace(Request& rq){
+        std::unique_lock<std::mutex> lk(sh->mu);
+        rq.done = false;
+        sh->pending.push_back(&rq);
+        sh->waiting++;
+        sh->cv_work.notify_all();
+        sh->cv_done.wait(lk, [&]{ return rq.done || sh->failed; });
+        return rq.done && rq.error == 0 && !sh->failed;
+    }
+    // outcome of ray i of a request: BreakCheck of the reference's leg loop, last row solution[k][*]
+    static bool broke(const Request& rq, int i){
+        const int legs = rq.bounces + 1;
+        const double* R = &rq.rec[((size_t)i * legs + (legs - 1)) * GEOAC_REC_STRIDE];
+        return R[GEOAC_REC_VALID] == 0.0;
+    }
+    static const double* last_row(const Request& rq, int i){
+        const int legs = rq.bounces + 1;
+        // the row the reference reads after a break is the breaking leg's last row; only used for messages there
+        int l = legs - 1;
+        while(l > 0 && rq.rec[((size_t)i * legs + l) * GEOAC_REC_STRIDE + GEOAC_REC_STEPS] == 0.0) l--;
+        return &rq.rec[((size_t)i * legs + l) * GEOAC_REC_STRIDE];
+    }
+
+    // ---- GeoAc_EstimateEigenray: GeoAc.Eigenray.Global.cpp:46-136 ----
+    bool estimate(double theta_min, double theta_max, double& theta_estimate, double& phi_estimate, double& theta_next, int bounces){
+        const double azimuth_error_limit = prm.azimuth_err_lim;
+        double GC_r_rcvr = geo.gc_distance(src[0], src[1], rcv[0], rcv[1]);
+        double phi = geo.bearing(src[0], src[1], rcv[0], rcv[1]);
+        if(verbose){
+            log << '\t' << "Estimating eigenray angles for source-receiver separated by great circle distance " << GC_r_rcvr << " km, and azimuth " << phi;
+            log << " degrees from N.  Inclination limits: [" << theta_min << ", " << theta_max << "]." << '\n';
+        }
+        int iterations = 0;
+        theta_estimate = theta_max;
+        double r, r_prev, d_theta = d_theta_big, d_phi = 10.0;
+        bool theta_max_reached = false;
+        while(fabs(d_phi) > azimuth_error_limit && iterations < 5){
+            r = GC_r_rcvr; r_prev = GC_r_rcvr;
+            // the scan of this pass: with a fixed step all its rays are known now -> one request, replayed below
+            Request scan; scan.bounces = bounces; scan.calc_amp = 0; scan.mode = 0;
+            const bool batched = (iterations < 3);
+            if(batched){
+                for(double theta = theta_min; theta < theta_max; theta += d_theta){ scan.th.push_back(theta); scan.ph.push_back(phi); }
+                if(!scan.th.empty() && !trace(scan)) return false;
+            }
+            int j = 0;
+            bool crossed = false;
+            for(double theta = theta_min; theta < theta_max; theta += d_theta, j++){
+                if(theta + d_theta >= theta_max) theta_max_reached = true;
+                Request one; const Request* rq = &scan; int idx = j;
+                if(!batched){                                           // step depends on the previous arrival (:122): one ray at a time
+                    one.bounces = bounces; one.calc_amp = 0; one.mode = 0; one.th.push_back(theta); one.ph.push_back(phi);
+                    if(!trace(one)) return false;
+                    rq = &one; idx = 0;
+                }
+                const bool BreakCheck = broke(*rq, idx);
+                const double* Rk = last_row(*rq, idx);
+                const double lat_k = Rk[GEOAC_REC_STATE + 1] * 180.0 / Pi, lon_k = Rk[GEOAC_REC_STATE + 2] * 180.0 / Pi;
+                if(BreakCheck){ r = GC_r_rcvr; r_prev = GC_r_rcvr; }
+                else r = geo.gc_distance(src[0], src[1], lat_k, lon_k);
+                if(verbose){
+                    log << '\t' << '\t' << "Ray launched at inclination=" << (theta * Pi / 180.0) * 180.0 / Pi << " degrees arrives at range " << r;
+                    log << " km after " << bounces << " bounces.  Exact arrival at " << lat_k << " degrees N latitude, " << lon_k << " degrees E longitude" << '\n';
+                }
+                if((r - GC_r_rcvr) * (r_prev - GC_r_rcvr) < 0.0){
+                    if(iterations == 0) theta_next = theta;
+                    d_phi  = geo.bearing(src[0], src[1], rcv[0], rcv[1]);
+                    d_phi -= geo.bearing(src[0], src[1], lat_k, lon_k);
+                    while(d_phi > 180.0){ d_phi -= 360.0; }
+                    while(d_phi < -180.0){ d_phi += 360.0; }
+                    if(fabs(d_phi) < azimuth_error_limit){
+                        if(verbose) log << '\t' << '\t' << "Azimuth deviation less than " << azimuth_error_limit << " degrees.  Estimates acceptable." << '\n' << '\n';
+                        theta_estimate = theta - d_theta;
+                        phi_estimate = 90.0 - phi;
+                        return true;
+                    } else {
+                        if(verbose) log << '\t' << '\t' << "Azimuth deviation greater than " << azimuth_error_limit << " degrees.  Compensating and searching inclinations again." << '\n' << '\n';
+                        phi += d_phi * 0.9;
+                        theta_min = std::max(theta - 7.5, theta_min);
+                    }
+                    crossed = true;
+                    break;
+                }
+                if(iterations >= 3){ d_theta = modify_d_theta(r - GC_r_rcvr, (r - r_prev) / (2.0 * d_theta)); }
+                r_prev = r;
+            }
+            (void)crossed;
+            if(theta_max_reached){
+                theta_next = theta_max;
+                break;
+            }
+            iterations++;
+            if(iterations >= 1 && iterations < 3){ d_theta = d_theta_big / 2.0; }
+        }
+        if(verbose) log << '\t' << '\t' << "Reached maximum inclination angle or iteration limit." << '\n' << '\n';
+        return false;
+    }
+
+    // ---- GeoAc_3DEigenray_LM: GeoAc.Eigenray.Global.cpp:139-319 ----
+    void refine(double& lt, double& lp, int bnc_cnt, int iterate_limit){
+        double dr, dr_prev = 10000.0;
+        const double tolerance = 0.1;
+        const double lt_lim_step = 0.2, lp_lim_step = 0.2;
+        double step_scalar = 1.0;
+        long double lat, lon, d_lat, d_lon, d_lat_dlt, d_lon_dlt, d_lat_dlp, d_lon_dlp, det, dlt = 0, dlp = 0;
+        if(verbose) log << '\t' << '\t' << "Searching for exact eigenray using auxiliary parameters." << '\n';
+        for(int n = 0; n <= iterate_limit; n++){
+            if(n == iterate_limit){
+                if(verbose){ log << '\t' << '\t' << '\t' << "Search for exact eigenray maxed out iterations.  No eigneray idenfied." << '\n'; }
+                break;
+            }
+            Request rq; rq.bounces = bnc_cnt; rq.calc_amp = 1; rq.mode = 0;
+            rq.th.push_back(lt); rq.ph.push_back(90.0 - lp);
+            if(verbose) log << '\t' << '\t' << "Plotting ray path with theta = " << lt << ", phi = " << 90.0 - lp;
+            if(!trace(rq)) return;
+            if(broke(rq, 0)) break;
+            const double* S = &rq.rec[((size_t)bnc_cnt) * GEOAC_REC_STRIDE + GEOAC_REC_STATE];        // solution[k][*] of the last leg
+            lat = S[1]; lon = S[2];
+            dr = geo.gc_distance((double)(lat * 180.0 / Pi), (double)(lon * 180.0 / Pi), rcv[0], rcv[1]);
+            if(verbose) log << '\t' << '\t' << "Arrival at (" << std::setprecision(8) << (double)(lat * 180.0 / Pi) << ", " << (double)(lon * 180.0 / Pi) << "), distance to receiver = " << dr << " km." << '\n';
+
+            if(dr < tolerance){
+                // the reference re-propagates and accumulates travel time / attenuation with the raypath-writing loop (:198-238):
+                // same ray again with WriteRays on (segment form of Q7, samples every 25th step)
+                Request fin; fin.bounces = bnc_cnt; fin.calc_amp = 1; fin.mode = GEOAC_MODE_WRITE_RAYS;
+                fin.th.push_back(lt); fin.ph.push_back(90.0 - lp);
+                if(!trace(fin)) return;
+                const double* R = &fin.rec[((size_t)bnc_cnt) * GEOAC_REC_STRIDE];
+                const double* Sk = R + GEOAC_REC_STATE;
+                Eigenray e; memset(e.v, 0, sizeof e.v);
+                const double travel_time = R[GEOAC_REC_TTIME], attenuation = R[GEOAC_REC_ATTEN];
+                // arrival inclination: -asin(c_k / c_src nu_r) (:241); the fan record of the range-dependent main carries the opposite sign (Q10)
+                double arrival_incl = (eqset == GEOAC_EQ_GLOBAL_RNGDEP) ? -R[GEOAC_REC_INCL] : R[GEOAC_REC_INCL];
+                double bearing_back = geo.bearing(rcv[0], rcv[1], src[0], src[1]);
+                double back_az = 90.0 - atan2(-Sk[4], -Sk[5]) * 180.0 / Pi;
+                double back_az_dev = back_az - bearing_back;
+                if(back_az_dev > 180.0)  back_az_dev -= 360.0;
+                if(back_az_dev < -180.0) back_az_dev += 360.0;
+                e.v[GEOAC_EIG_RCVR] = rcvr_index; e.v[GEOAC_EIG_INDEX] = eigenray_count; e.v[GEOAC_EIG_BOUNCES] = bnc_cnt;
+                e.v[GEOAC_EIG_THETA] = lt; e.v[GEOAC_EIG_PHI] = 90.0 - lp;
+                e.v[GEOAC_EIG_TTIME] = travel_time;
+                e.v[GEOAC_EIG_CELERITY] = geo.gc_distance(src[0], src[1], rcv[0], rcv[1]) / travel_time;
+                e.v[GEOAC_EIG_AMP_DB] = 20.0 * log10(R[GEOAC_REC_AMP]);
+                e.v[GEOAC_EIG_ATTEN_DB] = -attenuation;
+                e.v[GEOAC_EIG_INCL] = arrival_incl; e.v[GEOAC_EIG_BEARING] = bearing_back; e.v[GEOAC_EIG_BACKAZ] = back_az; e.v[GEOAC_EIG_AZDEV] = back_az_dev;
+                e.smp = fin.smp;
+                e.v[GEOAC_EIG_NSMP] = (double)(e.smp.size() / GEOAC_SMP_STRIDE);
+                if(verbose){
+                    log << '\t' << '\t' << "Eigenray-" << eigenray_count << ".  " << bnc_cnt << " bounce(s)." << '\n';
+                    log << '\t' << '\t' << '\t' << "theta, phi = " << std::setprecision(8) << lt << ", " << 90.0 - lp << " degrees." << '\n';
+                    log << '\t' << '\t' << '\t' << "Travel Time = " << travel_time << " seconds." << '\n';
+                    log << '\t' << '\t' << '\t' << "Celerity = " << e.v[GEOAC_EIG_CELERITY] << " km/s." << '\n';
+                    log << '\t' << '\t' << '\t' << "Amplitude = " << e.v[GEOAC_EIG_AMP_DB] << " dB." << '\n';
+                    log << '\t' << '\t' << '\t' << "Atmospheric Attenuation = " << -attenuation << " dB." << '\n';
+                    log << '\t' << '\t' << '\t' << "Arrival inclination = " << arrival_incl << " degrees." << '\n';
+                    log << '\t' << '\t' << '\t' << "Bearing to source = " << bearing_back << " degrees." << '\n';
+                    log << '\t' << '\t' << '\t' << "Back azimuth of arrival = " << back_az << " degrees." << '\n';
+                    log << '\t' << '\t' << '\t' << "Azimuth Deviation = " << back_az_dev << " degrees." << '\n' << '\n';
+                } else {
+                    log << '\t' << "Eigenray identified:" << '\t' << "theta, phi = " << std::setprecision(8) << lt << ", " << 90.0 - lp << " degrees." << '\n';
+                }
+                found.push_back(e);
+                eigenray_count++;
+                break;
+            } else if(n > 0 && dr > dr_prev){
+                lt -= dlt * step_scalar;
+                lp -= dlp * step_scalar;
+                step_scalar /= 2.0;
+                if(sqrt(dlt * dlt + dlp * dlp) * step_scalar < 1.0e-12){
+                    if(verbose) log << '\t' << '\t' << '\t' << "Step size too small, psuedo-critical ray path likely." << '\n' << '\n';
+                    break;
+                }
+            } else {
+                step_scalar = std::min(1.0, step_scalar * 1.25);
+                d_lat = rcv[0] * Pi / 180.0 - lat;
+                d_lon = rcv[1] * Pi / 180.0 - lon;
+                const double rg = geo.r_earth + z_grnd;
+                d_lat_dlt = S[7]  - 1.0 / rg * S[4] / S[3] * S[6];
+                d_lat_dlp = S[13] - 1.0 / rg * S[4] / S[3] * S[12];
+                d_lon_dlt = S[8]  - 1.0 / (rg * cos(lat)) * S[5] / S[3] * S[6];
+                d_lon_dlp = S[14] - 1.0 / (rg * cos(lat)) * S[5] / S[3] * S[12];
+                det = d_lat_dlt * d_lon_dlp - d_lat_dlp * d_lon_dlt;
+                dlt = (d_lon_dlp * d_lat - d_lat_dlp * d_lon) / det * 180.0 / Pi;
+                dlp = (-d_lon_dlt * d_lat + d_lat_dlt * d_lon) / det * 180.0 / Pi;
+                if(dlt >  lt_lim_step) dlt =  lt_lim_step;
+                if(dlt < -lt_lim_step) dlt = -lt_lim_step;
+                if(dlp >  lp_lim_step) dlp =  lp_lim_step;
+                if(dlp < -lp_lim_step) dlp = -lp_lim_step;
+                lt += dlt * step_scalar;
+                lp += dlp * step_scalar;
+                dr_prev = dr;
+            }
+        }
+    }
+
+    // ---- the -eig_search driver loop: GeoAcGlobal_main.cpp:566-580 ----
+    void run_search(){
+        for(int n_bnc = prm.bnc_min; n_bnc <= prm.bnc_max; n_bnc++){
+            log << "Searching for " << n_bnc << " bounce eigenrays." << '\n';
+            double theta_start = prm.theta_min, theta_next = prm.theta_max, theta_est = 0, phi_est = 0;
+            while(theta_start < prm.theta_max){
+                bool ok = estimate(theta_start, prm.theta_max, theta_est, phi_est, theta_next, n_bnc);
+                if(sh->failed) return;
+                if(ok) refine(theta_est, phi_est, n_bnc, prm.iterations);
+                if(sh->failed) return;
+                theta_start = theta_next;
+            }
+        }
+        log << "Identified " << eigenray_count << " eigenray(s)." << '\n';
+    }
+    void run_direct(double theta_est, double phi_from_north, int bounces){
+        double lt = theta_est, lp = 90.0 - phi_from_north;
+        refine(lt, lp, bounces, prm.iterations);
+    }
+};
+
+}  // namespace
+
+struct geoac_eig_result {
+    std::vector<double> eig;               // count x GEOAC_EIG_STRIDE
+    std::vector<double> smp;
+    std::vector<std::string> logs;
+    uint64_t stats[4] = {0, 0, 0, 0};
+};
+
+// integrate all pending requests: one fan launch per (bounces, calc_amp, mode) group
+static int serve(geoac_ctx* ctx, const geoac_params& base, std::vector<Request*>& reqs, geoac_eig_result* res){
+    std::map<std::tuple<int, int, int>, std::vector<Request*>> groups;
+    for(Request* r : reqs) groups[std::make_tuple(r->bounces, r->calc_amp, r->mode)].push_back(r);
+    for(auto& g : groups){
+        geoac_params p = base;
+        p.bounces = std::get<0>(g.first); p.calc_amp = std::get<1>(g.first); p.mode = std::get<2>(g.first);
+        int rc = geoac_set_params(ctx, &p);
+        if(rc) return rc;
+        std::vector<double> th, ph;
+        for(Request* r : g.second){ th.insert(th.end(), r->th.begin(), r->th.end()); ph.insert(ph.end(), r->ph.begin(), r->ph.end()); }
+        const int n = (int)th.size();
+        const int legs = p.bounces + 1;
+        std::vector<double> rec((size_t)n * legs * GEOAC_REC_STRIDE);
+        uint64_t steps = 0;
+        rc = geoac_fan_run(ctx, n, th.data(), ph.data(), rec.data(), &steps);
+        if(rc) return rc;
+        res->stats[0] += 1; res->stats[1] += (uint64_t)n; res->stats[2] += steps;
+        std::vector<double> smp;
+        if(p.mode){
+            int64_t ns = 0;
+            rc = geoac_fan_sample_count(ctx, &ns); if(rc) return rc;
+            smp.resize((size_t)std::max<int64_t>(ns, 1) * GEOAC_SMP_STRIDE);
+            if(ns > 0){ rc = geoac_fan_fetch_samples(ctx, smp.data(), ns); if(rc) return rc; }
+            smp.resize((size_t)ns * GEOAC_SMP_STRIDE);
+        }
+        size_t off = 0, sp = 0;
+        const size_t nsmp = smp.size() / GEOAC_SMP_STRIDE;
+        for(Request* r : g.second){
+            const size_t m = r->th.size();
+            r->rec.assign(rec.begin() + off * legs * GEOAC_REC_STRIDE, rec.begin() + (off + m) * legs * GEOAC_REC_STRIDE);
+            r->smp.clear();
+            while(sp < nsmp && (size_t)smp[sp * GEOAC_SMP_STRIDE + GEOAC_SMP_RAY] < off + m){       // samples are sorted by ray
+                size_t b = r->smp.size();
+                r->smp.insert(r->smp.end(), smp.begin() + sp * GEOAC_SMP_STRIDE, smp.begin() + (sp + 1) * GEOAC_SMP_STRIDE);
+                r->smp[b + GEOAC_SMP_RAY] -= (double)off;
+                sp++;
+            }
+            off += m;
+        }
+    }
+    return 0;
+}
+
+static int run_all(geoac_ctx* ctx, const geoac_eig_params* ep, int n_rcvr, const double* rcvr, bool direct,
+                   const double* theta_est, const double* phi_est, int bounces, geoac_eig_result** out){
+    if(!ctx || !ep || n_rcvr < 1 || !rcvr || !out) return GEOAC_E_INVALID;
+    geoac_params base;
+    int rc = geoac_get_params(ctx, &base);
+    if(rc) return rc;
+    int eqset = 0;
+    rc = geoac_get_eqset(ctx, &eqset);
+    if(rc) return rc;
+    if(eqset != GEOAC_EQ_GLOBAL && eqset != GEOAC_EQ_GLOBAL_RNGDEP) return GEOAC_E_UNSUPPORTED;
+    geoac_eig_result* res = new geoac_eig_result();
+    Shared sh;
+    std::vector<Search> S((size_t)n_rcvr);
+    for(int i = 0; i < n_rcvr; i++){
+        Search& s = S[(size_t)i];
+        s.sh = &sh; s.geo.r_earth = base.r_earth; s.eqset = eqset; s.rcvr_index = i;
+        s.z_grnd = base.z_grnd;
+        s.src[0] = base.src[1]; s.src[1] = base.src[2]; s.src[2] = std::max(base.src[0], base.z_grnd);   // Source_Loc = (lat, lon, max(z, z_grnd))
+        s.rcv[0] = rcvr[2 * i]; s.rcv[1] = rcvr[2 * i + 1];
+        s.prm = *ep; s.verbose = ep->verbose != 0;
+    }
+    sh.active = n_rcvr;
+    std::vector<std::thread> threads;
+    for(int i = 0; i < n_rcvr; i++){
+        threads.emplace_back([&, i]{
+            Search& s = S[(size_t)i];
+            if(direct) s.run_direct(theta_est[i], phi_est[i], bounces); else s.run_search();
+            std::unique_lock<std::mutex> lk(sh.mu);
+            sh.active--;
+            sh.cv_work.notify_all();
+        });
+    }
+    int err = 0;
+    for(;;){
+        std::vector<Request*> batch;
+        {
+            std::unique_lock<std::mutex> lk(sh.mu);
+            sh.cv_work.wait(lk, [&]{ return sh.active == 0 || sh.waiting == sh.active; });
+            if(sh.active == 0) break;
+            batch.swap(sh.pending);
+        }
+        err = serve(ctx, base, batch, res);
+        res->stats[3] += 1;
+        {
+            std::unique_lock<std::mutex> lk(sh.mu);
+            if(err) sh.failed = true;
+            for(Request* r : batch){ r->done = true; r->error = err; }
+            sh.waiting -= (int)batch.size();
+            sh.cv_done.notify_all();
+        }
+    }
+    for(auto& t : threads) t.join();
+    geoac_set_params(ctx, &base);                                  // restore the caller's bounces / calc_amp / mode
+    if(err){ delete res; return err; }
+    for(int i = 0; i < n_rcvr; i++){
+        Search& s = S[(size_t)i];
+        for(Eigenray& e : s.found){
+            e.v[GEOAC_EIG_SMP0] = (double)(res->smp.size() / GEOAC_SMP_STRIDE);
+            const size_t idx = res->eig.size() / GEOAC_EIG_STRIDE;
+            res->eig.insert(res->eig.end(), e.v, e.v + GEOAC_EIG_STRIDE);
+            for(size_t q = 0; q + GEOAC_SMP_STRIDE <= e.smp.size(); q += GEOAC_SMP_STRIDE){
+                size_t b = res->smp.size();
+                res->smp.insert(res->smp.end(), e.smp.begin() + q, e.smp.begin() + q + GEOAC_SMP_STRIDE);
+                res->smp[b + GEOAC_SMP_RAY] = (double)idx;
+            }
+        }
+        res->logs.push_back(s.log.str());
+    }
+    *out = res;
+    return 0;
+}
+
+extern "C" {
+
+int geoac_eig_default_params(geoac_eig_params* p){
+    if(!p) return GEOAC_E_INVALID;
+    p->theta_min = 0.5; p->theta_max = 45.0; p->bnc_min = 0; p->bnc_max = 0; p->iterations = 25; p->azimuth_err_lim = 2.0; p->verbose = 0;
+    return 0;
+}
+int geoac_eig_search(geoac_ctx* ctx, const geoac_eig_params* p, int n_rcvr, const double* rcvr, geoac_eig_result** out){
+    return run_all(ctx, p, n_rcvr, rcvr, false, nullptr, nullptr, 0, out);
+}
+int geoac_eig_direct(geoac_ctx* ctx, const geoac_eig_params* p, int n_rcvr, const double* rcvr,
+                     const double* theta_est, const double* phi_est, int bounces, geoac_eig_result** out){
+    if(!theta_est || !phi_est || bounces < 0) return GEOAC_E_INVALID;
+    return run_all(ctx, p, n_rcvr, rcvr, true, theta_est, phi_est, bounces, out);
+}
+int64_t geoac_eig_count(const geoac_eig_result* r){ return r ? (int64_t)(r->eig.size() / GEOAC_EIG_STRIDE) : 0; }
+int geoac_eig_fetch(const geoac_eig_result* r, double* eig){
+    if(!r || !eig) return GEOAC_E_INVALID;
+    memcpy(eig, r->eig.data(), r->eig.size() * sizeof(double));
+    return 0;
+}
+int64_t geoac_eig_sample_count(const geoac_eig_result* r){ return r ? (int64_t)(r->smp.size() / GEOAC_SMP_STRIDE) : 0; }
+int geoac_eig_fetch_samples(const geoac_eig_result* r, double* smp){
+    if(!r || !smp) return GEOAC_E_INVALID;
+    memcpy(smp, r->smp.data(), r->smp.size() * sizeof(double));
+    return 0;
+}
+const char* geoac_eig_log(const geoac_eig_result* r, int rcvr){
+    if(!r || rcvr < 0 || rcvr >= (int)r->logs.size()) return "";
+    return r->logs[(size_t)rcvr].c_str();
+}
+int geoac_eig_stats(const geoac_eig_result* r, uint64_t stats[4]){
+    if(!r || !stats) return GEOAC_E_INVALID;
+    for(int i = 0; i < 4; i++) stats[i] = r->stats[i];
+    return 0;
+}
+void geoac_eig_free(geoac_eig_result* r){ delete r; }
+
+}  // extern "C"

@@ -1165,7 +1165,9 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
         for(int q = threadIdx.x; q < total; q += blockDim.x) lds_tab[q] = gtab[q];
         __syncthreads();
     }
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tid0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if(P.spread > 1 && (tid0 & (P.spread - 1))) return;         // sparse lanes (grid sets, small fans)
+    const int tid = (P.spread > 1) ? tid0 / P.spread : tid0;
     const int slot = (EQ::LANES == 2) ? (tid >> 1) : tid;       // ray slot
     const int q = (EQ::LANES == 2) ? (tid & 1) : 0;             // which derivative system this lane carries (pair kernel)
     if(slot >= P.n_pad) return;
@@ -1260,31 +1262,32 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
             R[GEOAC_REC_STEPS] = (double)k;
             P.legend[(size_t)nle * np + slot] = nr - 1; nle++;
             if(lim && !brk && !gnd) atomicOr(&P.counters[2], 1ull);
+            // the leg's last row solution[k][*] (both outcomes: arrival rows read it, and so do the eigenray scans' messages after a break)
+            double yf[18];
+            if(EQ::LANES == 2){
+                // assemble the reference's 18-component row from the lane pair (both lanes end up with the same row
+                // and store the same record)
+                #pragma unroll
+                for(int e = 0; e < 6; e++){
+                    yf[e] = yn[e];
+                    double mine = yn[6 + e], other = __shfl_xor(mine, 1);
+                    yf[6 + e]  = q ? other : mine;
+                    yf[12 + e] = q ? mine : other;
+                }
+            } else {
+                #pragma unroll
+                for(int e = 0; e < 18; e++) yf[e] = (e < E) ? yn[e < E ? e : 0] : 0.0;
+            }
+            #pragma unroll
+            for(int e = 0; e < ((EQ::LANES == 2) ? 18 : E); e++) R[GEOAC_REC_STATE + e] = yf[e];
             if(brk){
                 R[GEOAC_REC_BROKE] = 1.0;
                 done = true;
             } else {
                 R[GEOAC_REC_VALID] = 1.0;
                 R[GEOAC_REC_TURN] = hmax;
-                if(EQ::LANES == 2){
-                    // assemble the reference's 18-component row from the lane pair (both lanes end up with the same row
-                    // and store the same record)
-                    double yf[18];
-                    #pragma unroll
-                    for(int e = 0; e < 6; e++){
-                        yf[e] = yn[e];
-                        double mine = yn[6 + e], other = __shfl_xor(mine, 1);
-                        yf[6 + e]  = q ? other : mine;
-                        yf[12 + e] = q ? mine : other;
-                    }
-                    EqGlobal<true>::arrival(P, C, slot, yf, R);
-                    #pragma unroll
-                    for(int e = 0; e < 18; e++) R[GEOAC_REC_STATE + e] = yf[e];
-                } else {
-                    EQ::arrival(P, C, slot, yn, R);
-                    #pragma unroll
-                    for(int e = 0; e < E; e++) R[GEOAC_REC_STATE + e] = yn[e];
-                }
+                if(EQ::LANES == 2) EqGlobal<true>::arrival(P, C, slot, yf, R);
+                else EQ::arrival(P, C, slot, yn, R);
                 if(leg >= P.bounces){
                     done = true;
                 } else {
@@ -1459,8 +1462,8 @@ extern "C" hipError_t geoac_launch_init(const GeoacDevParams* P, hipStream_t s){
 template <class EQ>
 static hipError_t launch_rk4_t(const GeoacDevParams* P, int block, hipStream_t s){
     if(block < 64 || block > 256 || (block % 64) != 0) return hipErrorInvalidValue;   // k_rk4 carries __launch_bounds__(256)
-    const int lanes = P->n_pad * EQ::LANES;
-    dim3 b(block), g((lanes + block - 1) / block);
+    const long long lanes = (long long)P->n_pad * EQ::LANES * (P->spread > 1 ? P->spread : 1);
+    dim3 b(block), g((unsigned)((lanes + block - 1) / block));
     size_t lds = P->table_in_lds ? (size_t)P->nseg * GEOAC_SEGW * sizeof(double) : 0;
     const bool smp = (P->mode & (GEOAC_MODE_WRITE_RAYS | GEOAC_MODE_WRITE_CAUSTICS)) != 0;
     #define GEOAC_RK4_LAUNCH(LDSF, SMPF) do { \

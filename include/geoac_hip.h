@@ -129,6 +129,9 @@ int  geoac_upload_atmo_3d(geoac_ctx* ctx, int nx, int ny, int nz, const double* 
                           const double* T, const double* u, const double* v, const double* rho);
 
 int  geoac_set_params(geoac_ctx* ctx, const geoac_params* p);
+/* the parameters as they stand (defaults resolved: vert_limit, xy_limits after an atmosphere upload) and the equation set */
+int  geoac_get_params(geoac_ctx* ctx, geoac_params* p);
+int  geoac_get_eqset(geoac_ctx* ctx, int* eqset);
 
 /* launch angles in degrees, exactly the values of the reference's loop variables theta, phi */
 int  geoac_fan_set_angles(geoac_ctx* ctx, int n_rays, const double* theta_deg, const double* phi_deg);

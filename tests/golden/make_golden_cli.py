@@ -28,8 +28,46 @@ CASES = {
 }
 
 
+# eigenray modes of the spherical mains: (binary, option, args); the verbose stdout is kept as LOG.txt
+EIG_CASES = {
+    "eig_global": ("GeoAcGlobal", "-eig_search", ["lat_rcvr=30", "lon_rcvr=-2.5", "bnc_min=0", "bnc_max=1", "verbose=True"]),
+    "eig_global_direct": ("GeoAcGlobal", "-eig_direct", ["lat_rcvr=30.02", "lon_rcvr=-2.52", "theta_est=8.0", "bounces=0", "verbose=True"]),
+    "eig_globalrd": ("GeoAcGlobal.RngDep", "-eig_search", ["lat_rcvr=31.0", "lon_rcvr=-2.65", "theta_min=2", "theta_max=20", "bounces=0", "verbose=True"]),
+}
+
+
+def main_eig(only):
+    for name, (binary, opt, args) in EIG_CASES.items():
+        if only and name not in only:
+            continue
+        out = os.path.join(HERE, "cli", name)
+        shutil.rmtree(out, ignore_errors=True)
+        os.makedirs(out)
+        with tempfile.TemporaryDirectory() as td:
+            if binary == "GeoAcGlobal.RngDep":
+                import rngdep_data as RD
+                RD.write_grid_global(td)
+                inputs = ["g", "loc_lat.dat", "loc_lon.dat"]
+            else:
+                shutil.copy(os.path.join(HERE, "ToyAtmo.met"), os.path.join(td, "ToyAtmo.met"))
+                inputs = ["ToyAtmo.met"]
+            r = subprocess.run([os.path.join(REF, binary), opt] + inputs + args, cwd=td, check=True, stdout=subprocess.PIPE)
+            with open(os.path.join(out, "LOG.txt"), "wb") as fh:
+                fh.write(r.stdout)
+            for f in sorted(os.listdir(td)):
+                if f.endswith(".dat") and not f.startswith("loc_"):
+                    shutil.copy(os.path.join(td, f), os.path.join(out, f))
+        with open(os.path.join(out, "ARGS"), "w") as fh:
+            fh.write(binary + "\n" + opt + "\n" + "\n".join(args) + "\n")
+        print(name, sorted(os.listdir(out)), sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)) // 1024, "KiB")
+
+
 def main():
     only = sys.argv[1:]
+    if only and all(o.startswith("eig") for o in only):
+        return main_eig(only)
+    if not only:
+        main_eig(only)
     for name, (binary, args) in CASES.items():
         if only and name not in only:
             continue

@@ -1,0 +1,117 @@
+"""GPU test of the eigenray modes (-eig_search / -eig_direct of the spherical mains): the batched search of this repo
+(geoac_eig_search: one fan launch per decision round instead of one propagation per ray) must identify the reference's
+eigenrays through the reference's iteration sequence - same verbose log line for line, same result and raypath files,
+every number equal to its printed precision."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+import harness as H
+from test_gpu_cli import _compare_files, _tokens_close
+
+pytestmark = pytest.mark.gpu
+
+CLI_GOLD = os.path.join(H.GOLDEN_DIR, "cli")
+BIN = os.path.join(H.ROOT, "geoac_amd", "bin")
+
+
+def _compare_logs(got, want):
+    gl = [l for l in got.split("\n")]
+    wl = [l for l in want.split("\n")]
+    assert len(gl) == len(wl), f"log: {len(gl)} lines vs {len(wl)}"
+    for i, (g, w) in enumerate(zip(gl, wl)):
+        gt, wt = g.replace("\t", " ").split(" "), w.replace("\t", " ").split(" ")
+        assert len(gt) == len(wt), f"log line {i + 1}: {g!r} vs {w!r}"
+        for a, b in zip(gt, wt):
+            a2, b2 = a.rstrip(",.)").lstrip("(["), b.rstrip(",.)").lstrip("([")
+            if a2 == b2:
+                continue
+            try:
+                x, y = float(a2), float(b2)
+            except ValueError:
+                raise AssertionError(f"log line {i + 1}: {a!r} vs {b!r}")
+            # deviations are differences of nearly equal bearings: compare those on the scale of a degree
+            assert abs(x - y) <= 1.2e-5 * max(abs(x), abs(y)) + 2e-6, f"log line {i + 1}: {a!r} vs {b!r}\n{g}\n{w}"
+
+
+@pytest.mark.parametrize("case", ["eig_global", "eig_global_direct", "eig_globalrd"])
+def test_eigenray_modes_match_reference_binaries(case, tmp_path):
+    gold = os.path.join(CLI_GOLD, case)
+    args = open(os.path.join(gold, "ARGS")).read().split()
+    binary, opt, params = args[0], args[1], args[2:]
+    exe = os.path.join(BIN, binary)
+    if not os.path.exists(exe):
+        import __graft_entry__
+        __graft_entry__.build()
+    if binary == "GeoAcGlobal.RngDep":
+        import rngdep_data as RD
+        RD.write_grid_global(str(tmp_path), short_paths=False)
+        inputs = ["g", "loc_lat.dat", "loc_lon.dat"]
+    else:
+        shutil.copy(H.TOYATMO, tmp_path / "ToyAtmo.met")
+        inputs = ["ToyAtmo.met"]
+    r = subprocess.run([exe, opt] + inputs + params, cwd=tmp_path, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    print(r.stderr.decode().strip())
+    want_files = sorted(f for f in os.listdir(gold) if f.endswith(".dat"))
+    got_files = sorted(f for f in os.listdir(tmp_path) if f.endswith(".dat") and not f.startswith("loc_"))
+    assert got_files == want_files
+    _compare_logs(r.stdout.decode(), open(os.path.join(gold, "LOG.txt")).read())
+    for f in want_files:
+        if "Eigenray-" in f:
+            # amplitude [dB] near a zero crossing and the tiny attenuation of the first rows: compare on an absolute dB scale too
+            gl, wl = open(tmp_path / f).read().split("\n"), open(os.path.join(gold, f)).read().split("\n")
+            assert len(gl) == len(wl)
+            for i, (g, w) in enumerate(zip(gl, wl)):
+                gt, wt = g.split("\t"), w.split("\t")
+                assert len(gt) == len(wt)
+                for a, b in zip(gt, wt):
+                    if a == b:
+                        continue
+                    x, y = float(a), float(b)
+                    assert abs(x - y) <= 1.2e-5 * max(abs(x), abs(y)) + 1e-5, f"{f} line {i + 1}: {a!r} vs {b!r}"
+        else:
+            gl, wl = open(tmp_path / f).read(), open(os.path.join(gold, f)).read()
+            _compare_logs(gl, wl)
+
+
+def _ring(lat0, lon0, n, radius_deg=2.5):
+    """n receivers on a ring of `radius_deg` degrees of arc around (lat0, lon0) (config 5 of SURVEY §8d)"""
+    import numpy as np
+    az = np.arange(n) * (2.0 * np.pi / n)
+    lat = lat0 + radius_deg * np.cos(az)
+    lon = lon0 + radius_deg * np.sin(az) / np.cos(np.radians(lat0))
+    return np.stack([lat, lon], axis=1)
+
+
+def test_batched_receivers_equal_single_receiver_searches():
+    """batching is invisible: the eigenrays found for a receiver inside a 16-receiver batch are bit-identical to the ones of
+    a search run for that receiver alone, and the batch needs far fewer fan launches than the sum of the single searches"""
+    import numpy as np
+    import geoac_amd as G
+    ctx = G.FanContext(G.EQ_GLOBAL, device=0)
+    ctx.load_met(H.TOYATMO)
+    ctx.set_params(src=(0.0, 30.0, 0.0))
+    rcv = _ring(30.0, 0.0, 16)
+    all_ = ctx.eig_search(rcv, bnc_min=0, bnc_max=0)
+    assert len(all_["eig"]) >= 2                       # ToyAtmo: stratospheric arrivals on the downwind (western) side of the ring
+    launches_single = 0
+    with_rays = sorted(set(int(r) for r in all_["eig"][:, G.EIG["RCVR"]]))
+    picks = sorted(set(with_rays[:3] + [0, 5]))
+    for i in picks:
+        one = ctx.eig_search(rcv[i:i + 1], bnc_min=0, bnc_max=0)
+        launches_single += one["stats"]["launches"]
+        sel = all_["eig"][all_["eig"][:, G.EIG["RCVR"]] == i]
+        assert len(sel) == len(one["eig"])
+        a = sel[:, 1:G.EIG["SMP0"]]; b = one["eig"][:, 1:G.EIG["SMP0"]]
+        assert np.array_equal(a, b)
+        for k in range(len(sel)):
+            s0, n = int(sel[k, G.EIG["SMP0"]]), int(sel[k, G.EIG["NSMP"]])
+            t0 = int(one["eig"][k, G.EIG["SMP0"]])
+            assert np.array_equal(all_["smp"][s0:s0 + n, 1:], one["smp"][t0:t0 + n, 1:])
+    print("16 receivers:", all_["stats"], ";", len(picks), "single searches:", launches_single, "launches; receivers with eigenrays:", with_rays)
+    assert all_["stats"]["launches"] < 16 * launches_single / len(picks) / 2     # rounds mix scan and refinement groups
+    # every eigenray really reaches its receiver: arrival within the refinement's 0.1 km tolerance is implied by identification;
+    # celerity = distance / travel time must be acoustic
+    assert ((all_["eig"][:, G.EIG["CELERITY"]] > 0.2) & (all_["eig"][:, G.EIG["CELERITY"]] < 0.36)).all()
