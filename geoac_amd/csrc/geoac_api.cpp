@@ -272,6 +272,17 @@ int geoac_get_params(geoac_ctx* ctx, geoac_params* p){
     *p = ctx->prm;
     return GEOAC_OK;
 }
+// c, u, v, rho of the 1-D atmosphere at abscissa x (host evaluation; set-up / reporting only)
+int geoac_medium_1d(geoac_ctx* ctx, double x, double out[4]){
+    if(!ctx || !out) return GEOAC_E_INVALID;
+    if(!ctx->have_atmo || ctx->have_grid) return fail(ctx, GEOAC_E_INVALID, "medium_1d: no 1-D atmosphere uploaded");
+    const size_t n = (size_t)ctx->n_nodes;
+    out[0] = sqrt(kGamR * host_spline_f(ctx->x, ctx->T, ctx->sl.data(), x));
+    out[1] = host_spline_f(ctx->x, ctx->u, ctx->sl.data() + n, x);
+    out[2] = host_spline_f(ctx->x, ctx->v, ctx->sl.data() + 2 * n, x);
+    out[3] = host_spline_f(ctx->x, ctx->rho, ctx->sl.data() + 3 * n, x);
+    return GEOAC_OK;
+}
 int geoac_get_eqset(geoac_ctx* ctx, int* eqset){
     if(!ctx || !eqset) return GEOAC_E_INVALID;
     *eqset = ctx->eqset;

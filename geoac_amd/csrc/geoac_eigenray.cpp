@@ -1,4 +1,5 @@
-// geoac_eigenray.cpp - batched eigenray searches for the spherical sets on top of the ray-fan C ABI (include/geoac_eig.h).
+// geoac_eigenray.cpp - batched eigenray searches on top of the ray-fan C ABI (include/geoac_eig.h): spherical sets
+// (GeoAc.Eigenray.Global.cpp) and 3-D Cartesian sets (GeoAc.Eigenray.cpp).
 //
 // Every receiver's search is the reference's straight-line logic (GeoAc.Eigenray.Global.cpp) running in its own host thread; wherever
 // the reference would propagate a ray the thread posts a request and sleeps.  When every live search is waiting, the calling thread
@@ -12,6 +13,7 @@
 #include <condition_variable>
 #include <iomanip>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -64,12 +66,11 @@ double modify_d_theta(double dr, double dr_dtheta){           // :40-44
     return d_theta_big - (d_theta_big - d_theta_small) * exp(-dr * dr / width);
 }
 
-struct Search {
+struct SearchBase {
     Shared* sh = nullptr;
-    Geo geo{6370.0};
     int eqset = GEOAC_EQ_GLOBAL;
     int rcvr_index = 0;
-    double src[3] = {0, 0, 0};             // lat, lon [deg], z [km] (Source_Loc of the reference)
+    double src[3] = {0, 0, 0};             // Source_Loc of the reference: (lat, lon [deg], z) or (x, y, z) [km]
     double rcv[2] = {0, 0};
     double z_grnd = 0.0;
     geoac_eig_params prm{};
@@ -77,6 +78,9 @@ struct Search {
     std::ostringstream log;                // the reference's cout for this receiver (sticky precision and all)
     std::vector<Eigenray> found;
     int eigenray_count = 0;
+    virtual ~SearchBase(){}
+    virtual void run_search() = 0;
+    virtual void run_direct(double theta_est, double phi_from_north, int bounces) = 0;
 
     // ---- post a request and wait for the coordinator ----
     bool trace(Request& rq){
@@ -101,6 +105,11 @@ struct Search {
         while(l > 0 && rq.rec[((size_t)i * legs + l) * GEOAC_REC_STRIDE + GEOAC_REC_STEPS] == 0.0) l--;
         return &rq.rec[((size_t)i * legs + l) * GEOAC_REC_STRIDE];
     }
+};
+
+// ================= spherical sets: GeoAc.Eigenray.Global.cpp =================
+struct Search : SearchBase {
+    Geo geo{6370.0};
 
     // ---- GeoAc_EstimateEigenray: GeoAc.Eigenray.Global.cpp:46-136 ----
     bool estimate(double theta_min, double theta_max, double& theta_estimate, double& phi_estimate, double& theta_next, int bounces){
@@ -275,7 +284,7 @@ struct Search {
     }
 
     // ---- the -eig_search driver loop: GeoAcGlobal_main.cpp:566-580 ----
-    void run_search(){
+    void run_search() override {
         for(int n_bnc = prm.bnc_min; n_bnc <= prm.bnc_max; n_bnc++){
             log << "Searching for " << n_bnc << " bounce eigenrays." << '\n';
             double theta_start = prm.theta_min, theta_next = prm.theta_max, theta_est = 0, phi_est = 0;
@@ -289,9 +298,224 @@ struct Search {
         }
         log << "Identified " << eigenray_count << " eigenray(s)." << '\n';
     }
-    void run_direct(double theta_est, double phi_from_north, int bounces){
+    void run_direct(double theta_est, double phi_from_north, int bounces) override {
         double lt = theta_est, lp = 90.0 - phi_from_north;
         refine(lt, lp, bounces, prm.iterations);
+    }
+};
+
+// ================= 3-D Cartesian sets: GeoAc.Eigenray.cpp =================
+double modify_d_theta_cart(double dr, double dr_dtheta){       // GeoAc.Eigenray.cpp:24-28
+    double width = 2.0 * pow(dr_dtheta, 2);
+    return d_theta_big - (d_theta_big - d_theta_small) * exp(-dr * dr / width);
+}
+
+struct SearchCart : SearchBase {
+    bool strat = true;                     // GeoAc_AtmoStrat: GeoAc3D (12-component rows) vs GeoAc3D.RngDep (18)
+    double M_Comps[3] = {0, 0, 0};         // wind Mach numbers at the source (stratified set only, :130-134)
+
+    // ---- GeoAc_EstimateEigenray: GeoAc.Eigenray.cpp:30-121 ----
+    bool estimate(double theta_min, double theta_max, double& theta_estimate, double& phi_estimate, double& theta_next, int bounces){
+        const double azimuth_error_limit = prm.azimuth_err_lim;
+        double r_rcvr = sqrt(pow(rcv[0] - src[0], 2) + pow(rcv[1] - src[1], 2));
+        double phi = 180.0 / 3.14159 * atan2(rcv[1] - src[1], rcv[0] - src[0]);
+        if(verbose){
+            log << '\t' << "Estimating eigenray angles for source-receiver separated by " << r_rcvr << " km, and azimuth " << 90.0 - phi;
+            log << " degrees from N.  Inclination limits: [" << theta_min << ", " << theta_max << "]." << '\n';
+        }
+        int iterations = 0;
+        theta_estimate = theta_max;
+        double r, r_prev, d_theta = d_theta_big, d_phi = 10.0;
+        bool theta_max_reached = false;
+        while(fabs(d_phi) > azimuth_error_limit && iterations < 5){
+            r = r_rcvr; r_prev = r_rcvr;
+            Request scan; scan.bounces = bounces; scan.calc_amp = 0; scan.mode = 0;
+            const bool batched = (iterations < 3);
+            if(batched){
+                for(double theta = theta_min; theta <= theta_max; theta += d_theta){ scan.th.push_back(theta); scan.ph.push_back(90.0 - phi); }
+                if(!scan.th.empty() && !trace(scan)) return false;
+            }
+            int j = 0;
+            for(double theta = theta_min; theta <= theta_max; theta += d_theta, j++){
+                if(theta + d_theta >= theta_max) theta_max_reached = true;
+                Request one; const Request* rq = &scan; int idx = j;
+                if(!batched){
+                    one.bounces = bounces; one.calc_amp = 0; one.mode = 0; one.th.push_back(theta); one.ph.push_back(90.0 - phi);
+                    if(!trace(one)) return false;
+                    rq = &one; idx = 0;
+                }
+                const bool BreakCheck = broke(*rq, idx);
+                const double* Rk = last_row(*rq, idx);
+                const double xk = Rk[GEOAC_REC_STATE + 0], yk = Rk[GEOAC_REC_STATE + 1];
+                if(verbose){
+                    log << '\t' << '\t' << "Ray launched at " << theta << " degrees arrives at range " << sqrt(pow(xk - src[0], 2) + pow(yk - src[1], 2));
+                    log << " km after " << bounces << " reflections." << '\t' << "Exact arrival at " << xk << " km East, " << yk << " km North" << '\n';
+                }
+                if(BreakCheck){ r = r_rcvr; r_prev = r_rcvr; }
+                else { r = sqrt(pow(xk - src[0], 2) + pow(yk - src[1], 2)); }
+                if((r - r_rcvr) * (r_prev - r_rcvr) < 0.0){
+                    if(iterations == 0) theta_next = theta;
+                    d_phi = (atan2(rcv[1] - src[1], rcv[0] - src[0]) - atan2(yk - src[1], xk - src[0])) * 180.0 / Pi;
+                    while(d_phi > 180.0)  d_phi -= 360.0;
+                    while(d_phi < -180.0) d_phi += 360.0;
+                    if(fabs(d_phi) < azimuth_error_limit){
+                        if(verbose) log << '\t' << '\t' << "Azimuth deviation = " << d_phi << ".  Less than " << azimuth_error_limit << " degrees.  Estimates acceptable." << '\n' << '\n';
+                        theta_estimate = theta - d_theta;
+                        phi_estimate = phi;
+                        return true;
+                    } else {
+                        if(verbose) log << '\t' << '\t' << "Azimuth deviation = " << d_phi << ".  Greater than " << azimuth_error_limit << " degrees.  Compensating and searching inclinations again." << '\n' << '\n';
+                        phi += d_phi * 0.9;
+                        theta_min = std::max(theta - 7.5, theta_min);
+                    }
+                    break;
+                }
+                if(iterations >= 3){ d_theta = modify_d_theta_cart(r - r_rcvr, (r - r_prev) / (2.0 * d_theta)); }
+                r_prev = r;
+            }
+            if(theta_max_reached){
+                theta_next = theta_max;
+                break;
+            }
+            iterations++;
+            if(iterations >= 1 && iterations < 3){ d_theta = d_theta_big / 2.0; }
+        }
+        if(verbose) log << '\t' << '\t' << "Reached maximum inclination angle or iteration limit." << '\n';
+        return false;
+    }
+
+    // ---- GeoAc_3DEigenray_LM: GeoAc.Eigenray.cpp:123-335 ----
+    void refine(double& theta, double& phi, int bnc_cnt, int iterate_limit){
+        double dr, dr_prev = 10000.0;
+        const double tolerance = 0.1;
+        const double theta_lim_step = 0.2, phi_lim_step = 0.2;
+        double step_scalar = 1.0;
+        double nu0[3], M, nu0_xy[2] = {0, 0};
+        long double x, y, dx, dy, dx_dt, dy_dt, dx_dp, dy_dp;
+        long double det, dt = 0, dp = 0;
+        if(verbose) log << '\t' << '\t' << "Searching for exact eigenray using auxiliary parameters." << '\n';
+        for(int n = 0; n <= iterate_limit; n++){
+            if(n == iterate_limit){
+                if(verbose){ log << '\t' << '\t' << '\t' << "Search for exact eigenray maxed out iterations.  No eigneray idenfied." << '\n' << '\n'; }
+                break;
+            }
+            const double GeoAc_theta = theta * Pi / 180.0, GeoAc_phi = phi * Pi / 180.0;
+            if(strat){
+                nu0[0] = cos(GeoAc_theta) * cos(GeoAc_phi);
+                nu0[1] = cos(GeoAc_theta) * sin(GeoAc_phi);
+                nu0[2] = sin(GeoAc_theta);
+                M = 1.0 + (nu0[0] * M_Comps[0] + nu0[1] * M_Comps[1] + nu0[2] * M_Comps[2]);
+                nu0_xy[0] = nu0[0] / M;
+                nu0_xy[1] = nu0[1] / M;
+            }
+            Request rq; rq.bounces = bnc_cnt; rq.calc_amp = 1; rq.mode = 0;
+            rq.th.push_back(theta); rq.ph.push_back(90.0 - phi);
+            if(verbose) log << '\t' << '\t' << "Plotting ray path with theta = " << theta << ", phi = " << 90.0 - phi;
+            if(!trace(rq)) return;
+            if(broke(rq, 0)){
+                if(verbose) log << '\t' << "Ray path left propagation region." << '\n';
+                break;
+            }
+            const double* S = &rq.rec[((size_t)bnc_cnt) * GEOAC_REC_STRIDE + GEOAC_REC_STATE];
+            x = S[0]; dx = rcv[0] - x;
+            y = S[1]; dy = rcv[1] - y;
+            dr = (double)sqrtl(dx * dx + dy * dy);
+            if(verbose) log << '\t' << '\t' << "Arrival after " << bnc_cnt << " reflections at (" << (double)x << ", " << (double)y << "), distance to receiver = " << dr << " km." << '\n';
+
+            if(dr < tolerance){
+                Request fin; fin.bounces = bnc_cnt; fin.calc_amp = 1; fin.mode = GEOAC_MODE_WRITE_RAYS;
+                fin.th.push_back(theta); fin.ph.push_back(90.0 - phi);
+                if(!trace(fin)) return;
+                const double* R = &fin.rec[((size_t)bnc_cnt) * GEOAC_REC_STRIDE];
+                const double* Sk = R + GEOAC_REC_STATE;
+                Eigenray e; memset(e.v, 0, sizeof e.v);
+                const double travel_time = R[GEOAC_REC_TTIME], attenuation = R[GEOAC_REC_ATTEN];
+                double back_az = strat ? (90.0 - GeoAc_phi * 180.0 / Pi) + 180.0 : 90.0 - atan2(-Sk[4], -Sk[3]) * 180.0 / Pi;
+                double arrival_incl = R[GEOAC_REC_INCL];          // -asin(c(x_k, y_k, z_grnd) / c(src) nu_z) in both mains' records
+                double az_to_src = 90.0 - atan2(src[1] - rcv[1], src[0] - rcv[0]) * 180.0 / Pi;
+                double back_az_dev = back_az - az_to_src;
+                while(back_az > 180.0)      back_az -= 360.0;
+                while(back_az < -180.0)     back_az += 360.0;
+                while(back_az_dev > 180.0)  back_az_dev -= 360.0;
+                while(back_az_dev < -180.0) back_az_dev += 360.0;
+                e.v[GEOAC_EIG_RCVR] = rcvr_index; e.v[GEOAC_EIG_INDEX] = eigenray_count; e.v[GEOAC_EIG_BOUNCES] = bnc_cnt;
+                e.v[GEOAC_EIG_THETA] = theta; e.v[GEOAC_EIG_PHI] = 90.0 - phi;
+                e.v[GEOAC_EIG_TTIME] = travel_time;
+                e.v[GEOAC_EIG_CELERITY] = sqrt(pow(Sk[0] - src[0], 2) + pow(Sk[1] - src[1], 2)) / travel_time;
+                e.v[GEOAC_EIG_AMP_DB] = 20.0 * log10(R[GEOAC_REC_AMP]);
+                e.v[GEOAC_EIG_ATTEN_DB] = -attenuation;
+                e.v[GEOAC_EIG_INCL] = arrival_incl; e.v[GEOAC_EIG_BEARING] = az_to_src; e.v[GEOAC_EIG_BACKAZ] = back_az; e.v[GEOAC_EIG_AZDEV] = back_az_dev;
+                e.smp = fin.smp;
+                e.v[GEOAC_EIG_NSMP] = (double)(e.smp.size() / GEOAC_SMP_STRIDE);
+                if(!verbose) log << '\t' << "Eigenray identified:" << '\t' << "theta, phi = " << std::setprecision(8) << theta << ", " << 90.0 - phi << " degrees." << '\n';
+                if(verbose){
+                    log << '\t' << '\t' << "Eigenray Identified:" << '\n';
+                    log << '\t' << '\t' << '\t' << "theta, phi = " << std::setprecision(8) << theta << ", " << 90.0 - phi << " degrees." << '\n';
+                    log << '\t' << '\t' << '\t' << "Travel Time = " << travel_time << " seconds." << '\n';
+                    log << '\t' << '\t' << '\t' << "Celerity = " << e.v[GEOAC_EIG_CELERITY] << " km/s." << '\n';
+                    log << '\t' << '\t' << '\t' << "Amplitude (geometric) = " << e.v[GEOAC_EIG_AMP_DB] << " dB." << '\n';
+                    log << '\t' << '\t' << '\t' << "Atmospheric Attenuation = " << -attenuation << " dB." << '\n';
+                    log << '\t' << '\t' << '\t' << "Arrival inclination = " << arrival_incl << " degrees." << '\n';
+                    log << '\t' << '\t' << '\t' << "Azimuth to source = " << az_to_src << '\n';
+                    log << '\t' << '\t' << '\t' << "Back Azimuth of arrival = " << back_az << '\n';
+                    log << '\t' << '\t' << '\t' << "Azimuth Deviation = " << back_az_dev << " degrees." << '\n' << '\n';
+                }
+                found.push_back(e);
+                eigenray_count++;
+                break;
+            } else if(n > 0 && dr > dr_prev){
+                theta -= dt * step_scalar;
+                phi -= dp * step_scalar;
+                step_scalar /= 2.0;
+                if(sqrt(dt * dt + dp * dp) * step_scalar < 1.0e-12){
+                    if(verbose) log << '\t' << '\t' << '\t' << "Step size too small, psuedo-critical ray path likely." << '\n' << '\n';
+                    break;
+                }
+            } else {
+                step_scalar = std::min(1.0, step_scalar * 1.25);
+                if(strat){
+                    dx_dt = S[4] - nu0_xy[0] / S[3] * S[6];
+                    dy_dt = S[5] - nu0_xy[1] / S[3] * S[6];
+                    dx_dp = S[8] - nu0_xy[0] / S[3] * S[10];
+                    dy_dp = S[9] - nu0_xy[1] / S[3] * S[10];
+                } else {
+                    dx_dt = S[6] - S[3] / S[5] * S[8];
+                    dy_dt = S[7] - S[4] / S[5] * S[8];
+                    dx_dp = S[12] - S[3] / S[5] * S[14];
+                    dy_dp = S[13] - S[4] / S[5] * S[14];
+                }
+                det = dx_dt * dy_dp - dx_dp * dy_dt;
+                dt = 1.0 / det * (dy_dp * dx - dx_dp * dy) * 180.0 / Pi;
+                dp = 1.0 / det * (dx_dt * dy - dy_dt * dx) * 180.0 / Pi;
+                if(dt > theta_lim_step)  dt =  theta_lim_step;
+                if(dp > phi_lim_step)    dp =  phi_lim_step;
+                if(dt < -theta_lim_step) dt = -theta_lim_step;
+                if(dp < -phi_lim_step)   dp = -phi_lim_step;
+                theta += dt * step_scalar;
+                phi += dp * step_scalar;
+                dr_prev = dr;
+            }
+        }
+    }
+
+    // ---- the -eig_search driver loop: GeoAc3D_main.cpp:531-543 ----
+    void run_search() override {
+        for(int n_bnc = prm.bnc_min; n_bnc <= prm.bnc_max; n_bnc++){
+            log << "Searching for " << n_bnc << " bounce eigenray(s) between " << prm.theta_min << " and " << prm.theta_max << "." << '\n';
+            double theta_start = prm.theta_min, theta_next = prm.theta_max, theta_est = 0, phi_est = 0;
+            while(theta_start < prm.theta_max){
+                bool ok = estimate(theta_start, prm.theta_max, theta_est, phi_est, theta_next, n_bnc);
+                if(sh->failed) return;
+                if(ok) refine(theta_est, phi_est, n_bnc, prm.iterations);
+                if(sh->failed) return;
+                theta_start = theta_next;
+            }
+        }
+        log << '\t' << "Identified " << eigenray_count << " eigenray(s)." << '\n';
+    }
+    void run_direct(double theta_est, double phi_from_north, int bounces) override {
+        double theta = theta_est, phi = 90.0 - phi_from_north;
+        refine(theta, phi, bounces, prm.iterations);
     }
 };
 
@@ -357,23 +581,39 @@ static int run_all(geoac_ctx* ctx, const geoac_eig_params* ep, int n_rcvr, const
     int eqset = 0;
     rc = geoac_get_eqset(ctx, &eqset);
     if(rc) return rc;
-    if(eqset != GEOAC_EQ_GLOBAL && eqset != GEOAC_EQ_GLOBAL_RNGDEP) return GEOAC_E_UNSUPPORTED;
+    const bool sph = (eqset == GEOAC_EQ_GLOBAL || eqset == GEOAC_EQ_GLOBAL_RNGDEP);
+    const bool cart = (eqset == GEOAC_EQ_3D || eqset == GEOAC_EQ_3D_RNGDEP);
+    if(!sph && !cart) return GEOAC_E_UNSUPPORTED;
+    double mach[3] = {0, 0, 0};
+    if(eqset == GEOAC_EQ_3D){                                       // u/c, v/c, w/c at the source (GeoAc.Eigenray.cpp:130-134)
+        double m4[4];
+        rc = geoac_medium_1d(ctx, std::max(base.src[2], base.z_grnd), m4);
+        if(rc) return rc;
+        mach[0] = m4[1] / m4[0]; mach[1] = m4[2] / m4[0]; mach[2] = 0.0 / m4[0];
+    }
     geoac_eig_result* res = new geoac_eig_result();
     Shared sh;
-    std::vector<Search> S((size_t)n_rcvr);
+    std::vector<std::unique_ptr<SearchBase>> S;
     for(int i = 0; i < n_rcvr; i++){
-        Search& s = S[(size_t)i];
-        s.sh = &sh; s.geo.r_earth = base.r_earth; s.eqset = eqset; s.rcvr_index = i;
-        s.z_grnd = base.z_grnd;
-        s.src[0] = base.src[1]; s.src[1] = base.src[2]; s.src[2] = std::max(base.src[0], base.z_grnd);   // Source_Loc = (lat, lon, max(z, z_grnd))
-        s.rcv[0] = rcvr[2 * i]; s.rcv[1] = rcvr[2 * i + 1];
-        s.prm = *ep; s.verbose = ep->verbose != 0;
+        std::unique_ptr<SearchBase> sp;
+        if(sph){
+            Search* q = new Search(); q->geo.r_earth = base.r_earth; sp.reset(q);
+            q->src[0] = base.src[1]; q->src[1] = base.src[2]; q->src[2] = std::max(base.src[0], base.z_grnd);   // Source_Loc = (lat, lon, max(z, z_grnd))
+        } else {
+            SearchCart* q = new SearchCart(); q->strat = (eqset == GEOAC_EQ_3D); sp.reset(q);
+            for(int c = 0; c < 3; c++) q->M_Comps[c] = mach[c];
+            q->src[0] = base.src[0]; q->src[1] = base.src[1]; q->src[2] = std::max(base.src[2], base.z_grnd);   // Source_Loc = (x, y, max(z, z_grnd))
+        }
+        sp->sh = &sh; sp->eqset = eqset; sp->rcvr_index = i; sp->z_grnd = base.z_grnd;
+        sp->rcv[0] = rcvr[2 * i]; sp->rcv[1] = rcvr[2 * i + 1];
+        sp->prm = *ep; sp->verbose = ep->verbose != 0;
+        S.push_back(std::move(sp));
     }
     sh.active = n_rcvr;
     std::vector<std::thread> threads;
     for(int i = 0; i < n_rcvr; i++){
         threads.emplace_back([&, i]{
-            Search& s = S[(size_t)i];
+            SearchBase& s = *S[(size_t)i];
             if(direct) s.run_direct(theta_est[i], phi_est[i], bounces); else s.run_search();
             std::unique_lock<std::mutex> lk(sh.mu);
             sh.active--;
@@ -403,7 +643,7 @@ static int run_all(geoac_ctx* ctx, const geoac_eig_params* ep, int n_rcvr, const
     geoac_set_params(ctx, &base);                                  // restore the caller's bounces / calc_amp / mode
     if(err){ delete res; return err; }
     for(int i = 0; i < n_rcvr; i++){
-        Search& s = S[(size_t)i];
+        SearchBase& s = *S[(size_t)i];
         for(Eigenray& e : s.found){
             e.v[GEOAC_EIG_SMP0] = (double)(res->smp.size() / GEOAC_SMP_STRIDE);
             const size_t idx = res->eig.size() / GEOAC_EIG_STRIDE;

@@ -9,7 +9,7 @@
 //   GeoAcGlobal_RngDep_RunProp  Code/GeoAcGlobal.RngDep_main.cpp:122-343 (`-prop prefix loc_lat loc_lon [parameter=value ...]`)
 //   GeoAcGlobal_RunEigSearch / RunEigDirect (+ the .RngDep twins)  Code/GeoAcGlobal_main.cpp:496-660, Code/GeoAcGlobal.RngDep_main.cpp:518-693
 //     (spherical mains only; the searches themselves are geoac_eig_search / geoac_eig_direct, include/geoac_eig.h)
-// Not provided here (out of the accelerated path): -interactive; -eig_* of the Cartesian mains.
+// Not provided here (out of the accelerated path): -interactive.
 #include <strings.h>
 #include <cmath>
 #include <cstdio>
@@ -391,11 +391,13 @@ static int run_prop(char* inputs[], int count){
     return 0;
 }
 
-// ---- -eig_search / -eig_direct of the spherical mains (GeoAcGlobal_main.cpp:496-660, GeoAcGlobal.RngDep_main.cpp:518-693) ----
+// ---- -eig_search / -eig_direct (GeoAcGlobal_main.cpp:496-660, GeoAcGlobal.RngDep_main.cpp:518-693, GeoAc3D_main.cpp:458-610,
+//      GeoAc3D.RngDep_main.cpp:497-670); the searches themselves are geoac_eig_search / geoac_eig_direct ----
 static int run_eig(char* inputs[], int count, bool direct){
     double Source_Loc[3] = {30.0, 0.0, 0.0};
     double Receiver_Loc[2] = {30.0, -2.5};
-    double theta_est = 10.0, phi_est = 45.0;
+    if(kCart3){ Source_Loc[0] = 0.0; Source_Loc[1] = 0.0; Receiver_Loc[0] = -250.0; Receiver_Loc[1] = 0.0; }
+    double theta_est = kCart3 ? 0.5 : 10.0, phi_est = 45.0;
     int bounces = 0;
     bool verbose_output = false;
     const char* ProfileFormat = "zTuvdp";
@@ -407,19 +409,21 @@ static int run_eig(char* inputs[], int count, bool direct){
 
     for(int i = arg0; i < count; i++){
         if(strncmp(inputs[i], "profile_format=", 15) == 0) ProfileFormat = inputs[i] + 15;
-        else if(kRngS && strncmp(inputs[i], "z_grnd=", 7) == 0) z_grnd = atof(inputs[i] + 7);       // the grid main reads z_grnd= before loading (:530-533)
+        else if(kRng && strncmp(inputs[i], "z_grnd=", 7) == 0) z_grnd = atof(inputs[i] + 7);        // the grid mains know z_grnd when they load
     }
     Profile prof; Grid grid;
-    if(kRngS){
+    if(kRng){
         if(geoac_grid_dims(inputs[2], inputs[3], inputs[4], &grid.nx, &grid.ny, &grid.nz)){ cout << "Error opening file, check file name" << '\n'; return 1; }
         const size_t nn = (size_t)grid.nx * grid.ny * grid.nz;
         grid.x.resize(grid.nx); grid.y.resize(grid.ny); grid.z.resize(grid.nz);
         grid.T.resize(nn); grid.u.resize(nn); grid.v.resize(nn); grid.rho.resize(nn);
         if(geoac_grid_load_eq(kEq, inputs[2], inputs[3], inputs[4], ProfileFormat, z_grnd, grid.nx, grid.ny, grid.nz, grid.x.data(), grid.y.data(), grid.z.data(),
                               grid.T.data(), grid.u.data(), grid.v.data(), grid.rho.data())){ cout << "Error opening file, check file name" << '\n'; return 1; }
-        const double t0 = grid.x[0], t1 = grid.x[(size_t)grid.nx - 1], p0 = grid.y[0], p1 = grid.y[(size_t)grid.ny - 1];
-        Source_Loc[0] = (t0 + t1) / 2.0 * 180.0 / Pi; Source_Loc[1] = (p0 + p1) / 2.0 * 180.0 / Pi; Source_Loc[2] = 0.0;     // :537-539
-        Receiver_Loc[0] = (t0 + t1) * 0.75 * 180.0 / Pi; Receiver_Loc[1] = (p0 + p1) * 0.75 * 180.0 / Pi;               // :541-542
+        if(kRngS){
+            const double t0 = grid.x[0], t1 = grid.x[(size_t)grid.nx - 1], p0 = grid.y[0], p1 = grid.y[(size_t)grid.ny - 1];
+            Source_Loc[0] = (t0 + t1) / 2.0 * 180.0 / Pi; Source_Loc[1] = (p0 + p1) / 2.0 * 180.0 / Pi; Source_Loc[2] = 0.0;     // :537-539
+            Receiver_Loc[0] = (t0 + t1) * 0.75 * 180.0 / Pi; Receiver_Loc[1] = (p0 + p1) * 0.75 * 180.0 / Pi;               // :541-542
+        }
     } else {
         prof.n = geoac_met_rows(inputs[2]);
         if(prof.n < 3){ cout << "Error opening file, check file name" << '\n'; return 1; }
@@ -441,12 +445,16 @@ static int run_eig(char* inputs[], int count, bool direct){
         else if(!direct && strncmp(a, "bnc_max=", 8) == 0){ E.bnc_max = atoi(a + 8); }
         else if(strncmp(a, "bounces=", 8) == 0){ E.bnc_min = atoi(a + 8); E.bnc_max = atoi(a + 8); bounces = atoi(a + 8); }
         else if(direct && strncmp(a, "theta_est=", 10) == 0){ theta_est = atof(a + 10); }
-        else if(direct && strncmp(a, "phi_est=", 8) == 0){ }                                           // read after the bearing is known (:640-643)
-        else if(strncmp(a, "lat_src=", 8) == 0){ Source_Loc[0] = atof(a + 8); }
-        else if(strncmp(a, "lon_src=", 8) == 0){ Source_Loc[1] = atof(a + 8); }
+        else if(direct && strncmp(a, "phi_est=", 8) == 0){ }                                           // read after the bearing is known
+        else if(kSph && strncmp(a, "lat_src=", 8) == 0){ Source_Loc[0] = atof(a + 8); }
+        else if(kSph && strncmp(a, "lon_src=", 8) == 0){ Source_Loc[1] = atof(a + 8); }
+        else if(kRngC && strncmp(a, "x_src=", 6) == 0){ Source_Loc[0] = atof(a + 6); }
+        else if(kRngC && strncmp(a, "y_src=", 6) == 0){ Source_Loc[1] = atof(a + 6); }
         else if(strncmp(a, "z_src=", 6) == 0){ Source_Loc[2] = atof(a + 6); }
-        else if(strncmp(a, "lat_rcvr=", 9) == 0){ Receiver_Loc[0] = atof(a + 9); }
-        else if(strncmp(a, "lon_rcvr=", 9) == 0){ Receiver_Loc[1] = atof(a + 9); }
+        else if(kSph && strncmp(a, "lat_rcvr=", 9) == 0){ Receiver_Loc[0] = atof(a + 9); }
+        else if(kSph && strncmp(a, "lon_rcvr=", 9) == 0){ Receiver_Loc[1] = atof(a + 9); }
+        else if(kCart3 && strncmp(a, "x_rcvr=", 7) == 0){ Receiver_Loc[0] = atof(a + 7); }
+        else if(kCart3 && strncmp(a, "y_rcvr=", 7) == 0){ Receiver_Loc[1] = atof(a + 7); }
         else if(strncmp(a, "Verbose=", 8) == 0 || strncmp(a, "verbose=", 8) == 0){ verbose_output = string2bool(a + 8); }
         else if(!direct && strncmp(a, "azimuth_err_lim=", 16) == 0){ E.azimuth_err_lim = atof(a + 16); }
         else if(strncmp(a, "iterations=", 11) == 0){ E.iterations = (int)atof(a + 11); }
@@ -454,8 +462,10 @@ static int run_eig(char* inputs[], int count, bool direct){
         else if(strncmp(a, "abs_coeff=", 10) == 0){ tweak_abs = max(0.0, atof(a + 10)); }
         else if(strncmp(a, "z_grnd=", 7) == 0){ z_grnd = atof(a + 7); }
         else if(strncmp(a, "profile_format=", 15) == 0){ }
+        else if(kRngC && strncmp(a, "alt_max=", 8) == 0){ }                                           // overwritten by GeoAc_SetPropRegion after the load (Q9)
+        else if(kRngC && (strncmp(a, "x_min=", 6) == 0 || strncmp(a, "x_max=", 6) == 0 || strncmp(a, "y_min=", 6) == 0 || strncmp(a, "y_max=", 6) == 0)){ }
         else if(strncmp(a, "alt_max=", 8) == 0){ P.vert_limit = atof(a + 8); }
-        else if(!kRngS && strncmp(a, "rng_max=", 8) == 0){ P.range_limit = atof(a + 8); }
+        else if(!kRng && strncmp(a, "rng_max=", 8) == 0){ P.range_limit = atof(a + 8); }
         else if(kRngS && strncmp(a, "lat_min=", 8) == 0){ P.xy_limits[0] = atof(a + 8); }
         else if(kRngS && strncmp(a, "lat_max=", 8) == 0){ P.xy_limits[1] = atof(a + 8); }
         else if(kRngS && strncmp(a, "lon_min=", 8) == 0){ P.xy_limits[2] = atof(a + 8); }
@@ -472,11 +482,12 @@ static int run_eig(char* inputs[], int count, bool direct){
     geoac_ctx* ctx = nullptr;
     int rc = geoac_create(&ctx, kEq, 0);
     if(rc){ cout << kName << ": " << geoac_strerror(rc) << '\n'; return 2; }
-    if(kRngS) rc = geoac_upload_atmo_3d(ctx, grid.nx, grid.ny, grid.nz, grid.x.data(), grid.y.data(), grid.z.data(), grid.T.data(), grid.u.data(), grid.v.data(), grid.rho.data());
-    else      rc = geoac_upload_atmo_1d(ctx, prof.n, prof.x.data(), prof.T.data(), prof.u.data(), prof.v.data(), prof.rho.data(), prof.sl.data());
+    if(kRng) rc = geoac_upload_atmo_3d(ctx, grid.nx, grid.ny, grid.nz, grid.x.data(), grid.y.data(), grid.z.data(), grid.T.data(), grid.u.data(), grid.v.data(), grid.rho.data());
+    else     rc = geoac_upload_atmo_1d(ctx, prof.n, prof.x.data(), prof.T.data(), prof.u.data(), prof.v.data(), prof.rho.data(), prof.sl.data());
     if(rc){ cout << kName << ": " << geoac_last_error(ctx) << '\n'; return 2; }
     P.z_grnd = z_grnd; P.tweak_abs = tweak_abs; P.freq = freq;
-    P.src[0] = Source_Loc[2]; P.src[1] = Source_Loc[0]; P.src[2] = Source_Loc[1];
+    if(kSph){ P.src[0] = Source_Loc[2]; P.src[1] = Source_Loc[0]; P.src[2] = Source_Loc[1]; }
+    else    { P.src[0] = Source_Loc[0]; P.src[1] = Source_Loc[1]; P.src[2] = Source_Loc[2]; }
     rc = geoac_set_params(ctx, &P);
     if(rc){ cout << kName << ": " << geoac_last_error(ctx) << '\n'; return 2; }
 
@@ -487,11 +498,14 @@ static int run_eig(char* inputs[], int count, bool direct){
     geoac_eig_result* res = nullptr;
     ofstream results;
     if(direct){
-        // bearing to the receiver unless phi_est= was given (:636-643)
-        double term1 = sin((Receiver_Loc[1] - Source_Loc[1]) * Pi / 180.0);
-        double term2 = cos(Source_Loc[0] * Pi / 180.0) * tan(Receiver_Loc[0] * Pi / 180.0) - sin(Source_Loc[0] * Pi / 180.0) * cos((Receiver_Loc[1] - Source_Loc[1]) * Pi / 180.0);
-        phi_est = 90.0 - atan2(term1, term2) * 180.0 / Pi;
-        for(int i = 3; i < count; i++) if(strncmp(inputs[i], "phi_est=", 8) == 0) phi_est = 90.0 - atof(inputs[i] + 8);
+        if(kSph){       // bearing to the receiver unless phi_est= was given (GeoAcGlobal_main.cpp:636-643)
+            double term1 = sin((Receiver_Loc[1] - Source_Loc[1]) * Pi / 180.0);
+            double term2 = cos(Source_Loc[0] * Pi / 180.0) * tan(Receiver_Loc[0] * Pi / 180.0) - sin(Source_Loc[0] * Pi / 180.0) * cos((Receiver_Loc[1] - Source_Loc[1]) * Pi / 180.0);
+            phi_est = 90.0 - atan2(term1, term2) * 180.0 / Pi;
+        } else {        // GeoAc3D_main.cpp:588: azimuth of the receiver position itself
+            phi_est = 180.0 / 3.14159 * atan2(Receiver_Loc[1], Receiver_Loc[0]);
+        }
+        for(int i = arg0; i < count; i++) if(strncmp(inputs[i], "phi_est=", 8) == 0) phi_est = 90.0 - atof(inputs[i] + 8);
         double phi_from_north = 90.0 - phi_est;
         rc = geoac_eig_direct(ctx, &E, 1, Receiver_Loc, &theta_est, &phi_from_north, bounces, &res);
     } else {
@@ -499,8 +513,8 @@ static int run_eig(char* inputs[], int count, bool direct){
         results.open(output_buffer);
         results << kName << " - Eigenray Run Summary:" << '\n';
         results << '\t' << "Profile used: " << inputs[2] << '\n';
-        results << '\t' << "Source Location (lat, lon, elev) : (" << Source_Loc[0] << ", " << Source_Loc[1] << ", " << Source_Loc[2] << ")." << '\n';
-        results << '\t' << "Receiver Location (lat, lon, elev) : (" << Receiver_Loc[0] << ", " << Receiver_Loc[1] << ", " << z_grnd << ")." << '\n';
+        results << '\t' << (kSph ? "Source Location (lat, lon, elev) : (" : "Source Location (kilometers) : (") << Source_Loc[0] << ", " << Source_Loc[1] << ", " << Source_Loc[2] << ")." << '\n';
+        results << '\t' << (kSph ? "Receiver Location (lat, lon, elev) : (" : "Receiver Location (kilometers) : (") << Receiver_Loc[0] << ", " << Receiver_Loc[1] << ", " << z_grnd << ")." << '\n';
         results << '\t' << "Inclination range (degrees): " << E.theta_min << " - " << E.theta_max << "." << '\n';
         results << '\t' << "Ground reflection (bounce) limits: " << E.bnc_min << " - " << E.bnc_max << "." << '\n' << '\n';
         rc = geoac_eig_search(ctx, &E, 1, Receiver_Loc, &res);
@@ -514,25 +528,31 @@ static int run_eig(char* inputs[], int count, bool direct){
     if(ns) geoac_eig_fetch_samples(res, smp.data());
     for(int64_t e = 0; e < ne; e++){
         const double* V = &eig[(size_t)e * GEOAC_EIG_STRIDE];
-        // <title>_Eigenray-N.dat (:187-238): the first leg prints lat/lon with 8 digits through Pi, later legs with the stream's current
-        // precision through 3.14159 and the attenuation without its minus sign
         sprintf(output_buffer, "%s_Eigenray-%i.dat", file_title, (int)V[GEOAC_EIG_INDEX]);
         ofstream raypath; raypath.open(output_buffer);
-        raypath << "# z [km]" << '\t' << "lat [deg]" << '\t' << "lon [deg]" << '\t' << "Geo. Atten. [dB]" << '\t' << "Atmo. Atten. [dB]" << '\t' << "Travel Time [s]" << '\n';
+        if(kSph) raypath << "# z [km]" << '\t' << "lat [deg]" << '\t' << "lon [deg]";
+        else     raypath << "# x [km]" << '\t' << "y [km]" << '\t' << "z [km]";
+        raypath << '\t' << "Geo. Atten. [dB]" << '\t' << "Atmo. Atten. [dB]" << '\t' << "Travel Time [s]" << '\n';
         const size_t s0 = (size_t)V[GEOAC_EIG_SMP0], sn = (size_t)V[GEOAC_EIG_NSMP];
         for(size_t q = s0; q < s0 + sn; q++){
             const double* S = &smp[q * GEOAC_SMP_STRIDE];
             const double* v = S + GEOAC_SMP_V0;
-            if((int)S[GEOAC_SMP_LEG] == 0){
+            const bool first_leg = ((int)S[GEOAC_SMP_LEG] == 0);
+            if(kSph && first_leg){
+                // Eigenray.Global.cpp:207-214: lat/lon with 8 digits through Pi ...
                 raypath << v[0];
                 raypath << '\t' << setprecision(8) << v[1];
                 raypath << '\t' << setprecision(8) << v[2];
                 raypath << '\t' << v[3] << '\t' << v[4] << '\t' << v[5] << '\n';
-            } else {
+            } else if(kSph){
+                // ... :226-233: later legs through 3.14159 and the attenuation without its minus sign
                 raypath << v[0];
                 raypath << '\t' << (v[1] * Pi / 180.0) * 180.0 / 3.14159;
                 raypath << '\t' << (v[2] * Pi / 180.0) * 180.0 / 3.14159;
                 raypath << '\t' << v[3] << '\t' << -v[4] << '\t' << v[5] << '\n';
+            } else {
+                // Eigenray.cpp:222-246: x, y, z; later legs print the attenuation without its minus sign
+                raypath << v[0] << '\t' << v[1] << '\t' << v[2] << '\t' << v[3] << '\t' << (first_leg ? v[4] : -v[4]) << '\t' << v[5] << '\n';
             }
         }
         raypath.close();
@@ -544,8 +564,13 @@ static int run_eig(char* inputs[], int count, bool direct){
             results << '\t' << "Amplitude (geometric) = " << V[GEOAC_EIG_AMP_DB] << " dB." << '\n';
             results << '\t' << "Atmospheric attenuation = " << V[GEOAC_EIG_ATTEN_DB] << " dB." << '\n';
             results << '\t' << "Arrival inclination = " << V[GEOAC_EIG_INCL] << " degrees." << '\n';
-            results << '\t' << "Bearing to source = " << V[GEOAC_EIG_BEARING] << " degrees." << '\n';
-            results << '\t' << "Back azimuth of arrival = " << V[GEOAC_EIG_BACKAZ] << " degrees." << '\n';
+            if(kSph){
+                results << '\t' << "Bearing to source = " << V[GEOAC_EIG_BEARING] << " degrees." << '\n';
+                results << '\t' << "Back azimuth of arrival = " << V[GEOAC_EIG_BACKAZ] << " degrees." << '\n';
+            } else {
+                results << '\t' << "Azimuth to source = " << V[GEOAC_EIG_BEARING] << '\n';
+                results << '\t' << "Back azimuth of arrival = " << V[GEOAC_EIG_BACKAZ] << '\n';
+            }
             results << '\t' << "Azimuth deviation = " << V[GEOAC_EIG_AZDEV] << " degrees." << '\n' << '\n';
         }
     }
@@ -560,8 +585,8 @@ static int run_eig(char* inputs[], int count, bool direct){
 int main(int argc, char* argv[]){
     if(argc < (kRng ? 5 : 3)){ usage(); return 0; }
     if(strncmp(argv[1], "-prop", 5) == 0) return run_prop(argv, argc);
-    if(kSph && strncmp(argv[1], "-eig_search", 11) == 0) return run_eig(argv, argc, false);
-    if(kSph && strncmp(argv[1], "-eig_direct", 11) == 0) return run_eig(argv, argc, true);
+    if(kEq != GEOAC_EQ_2D && strncmp(argv[1], "-eig_search", 11) == 0) return run_eig(argv, argc, false);
+    if(kEq != GEOAC_EQ_2D && strncmp(argv[1], "-eig_direct", 11) == 0) return run_eig(argv, argc, true);
     if(strncmp(argv[1], "-interactive", 12) == 0 || strncmp(argv[1], "-eig_search", 11) == 0 || strncmp(argv[1], "-eig_direct", 11) == 0){
         cout << kName << ": option " << argv[1] << " is not part of this GPU build." << '\n';
         return 3;

@@ -1,14 +1,16 @@
-/* geoac_eig.h - eigenray searches on top of the ray-fan C ABI (geoac_hip.h), spherical sets.
+/* geoac_eig.h - eigenray searches on top of the ray-fan C ABI (geoac_hip.h): spherical sets and 3-D Cartesian sets.
  *
  * Replaces the callers of the hot path in GeoAc's -eig_search / -eig_direct modes:
  *   GeoAc_EstimateEigenray   Code/GeoAc/GeoAc.Eigenray.Global.cpp:46-136   inclination scans at the great-circle bearing
  *   GeoAc_3DEigenray_LM      Code/GeoAc/GeoAc.Eigenray.Global.cpp:139-319  Newton refinement with the auxiliary (Jacobian) equations
  *   the driver loops         Code/GeoAcGlobal_main.cpp:566-580, Code/GeoAcGlobal.RngDep_main.cpp:604-616
+ *   and the Cartesian twins  Code/GeoAc/GeoAc.Eigenray.cpp:30-121, 123-335; Code/GeoAc3D_main.cpp:531-543, Code/GeoAc3D.RngDep_main.cpp
  * The reference traces one ray at a time; here every decision point of every receiver's search asks for the rays it needs and the
  * requests of all receivers are integrated together as ONE fan launch per round (an inclination scan is a single launch of up to
  * (theta_max - theta_min) / d_theta rays instead of that many sequential propagations).  The decisions are then replayed on the host in
  * the reference's order, so the eigenray list and the iteration log are the reference's.
- * Context requirements: equation set GEOAC_EQ_GLOBAL or GEOAC_EQ_GLOBAL_RNGDEP, atmosphere uploaded, parameters set (source position,
+ * Context requirements: equation set GEOAC_EQ_GLOBAL / _GLOBAL_RNGDEP (receivers = latitude, longitude [deg]) or GEOAC_EQ_3D / _3D_RNGDEP
+ * (receivers = x, y [km]; GEOAC_EIG_BEARING then holds the azimuth from the receiver to the source), atmosphere uploaded, parameters set (source position,
  * z_grnd, freq, tweak_abs, limits are taken from geoac_set_params; bounces / calc_amp / mode are managed by the search and restored).
  */
 #ifndef GEOAC_EIG_H_

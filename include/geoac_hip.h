@@ -132,6 +132,8 @@ int  geoac_set_params(geoac_ctx* ctx, const geoac_params* p);
 /* the parameters as they stand (defaults resolved: vert_limit, xy_limits after an atmosphere upload) and the equation set */
 int  geoac_get_params(geoac_ctx* ctx, geoac_params* p);
 int  geoac_get_eqset(geoac_ctx* ctx, int* eqset);
+/* c [km/s], u, v [km/s], rho of the uploaded 1-D atmosphere at abscissa x, evaluated on the host (set-up / reporting only) */
+int  geoac_medium_1d(geoac_ctx* ctx, double x, double out[4]);
 
 /* launch angles in degrees, exactly the values of the reference's loop variables theta, phi */
 int  geoac_fan_set_angles(geoac_ctx* ctx, int n_rays, const double* theta_deg, const double* phi_deg);

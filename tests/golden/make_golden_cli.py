@@ -32,6 +32,9 @@ CASES = {
 EIG_CASES = {
     "eig_global": ("GeoAcGlobal", "-eig_search", ["lat_rcvr=30", "lon_rcvr=-2.5", "bnc_min=0", "bnc_max=1", "verbose=True"]),
     "eig_global_direct": ("GeoAcGlobal", "-eig_direct", ["lat_rcvr=30.02", "lon_rcvr=-2.52", "theta_est=8.0", "bounces=0", "verbose=True"]),
+    "eig_3d": ("GeoAc3D", "-eig_search", ["x_rcvr=-250", "y_rcvr=0", "bnc_min=0", "bnc_max=1", "verbose=True"]),
+    "eig_3d_direct": ("GeoAc3D", "-eig_direct", ["x_rcvr=-252", "y_rcvr=3", "theta_est=8.0", "bounces=0", "verbose=True"]),
+    "eig_3drd": ("GeoAc3D.RngDep", "-eig_search", ["x_rcvr=-250", "y_rcvr=20", "theta_min=2", "theta_max=20", "bounces=0", "verbose=True"]),
     "eig_globalrd": ("GeoAcGlobal.RngDep", "-eig_search", ["lat_rcvr=31.0", "lon_rcvr=-2.65", "theta_min=2", "theta_max=20", "bounces=0", "verbose=True"]),
 }
 
@@ -48,6 +51,10 @@ def main_eig(only):
                 import rngdep_data as RD
                 RD.write_grid_global(td)
                 inputs = ["g", "loc_lat.dat", "loc_lon.dat"]
+            elif binary == "GeoAc3D.RngDep":
+                import rngdep_data as RD
+                RD.write_grid(td)
+                inputs = ["p", "loc_x.dat", "loc_y.dat"]
             else:
                 shutil.copy(os.path.join(HERE, "ToyAtmo.met"), os.path.join(td, "ToyAtmo.met"))
                 inputs = ["ToyAtmo.met"]

@@ -36,7 +36,7 @@ def _compare_logs(got, want):
             assert abs(x - y) <= 1.2e-5 * max(abs(x), abs(y)) + 2e-6, f"log line {i + 1}: {a!r} vs {b!r}\n{g}\n{w}"
 
 
-@pytest.mark.parametrize("case", ["eig_global", "eig_global_direct", "eig_globalrd"])
+@pytest.mark.parametrize("case", ["eig_global", "eig_global_direct", "eig_globalrd", "eig_3d", "eig_3d_direct", "eig_3drd"])
 def test_eigenray_modes_match_reference_binaries(case, tmp_path):
     gold = os.path.join(CLI_GOLD, case)
     args = open(os.path.join(gold, "ARGS")).read().split()
@@ -49,6 +49,10 @@ def test_eigenray_modes_match_reference_binaries(case, tmp_path):
         import rngdep_data as RD
         RD.write_grid_global(str(tmp_path), short_paths=False)
         inputs = ["g", "loc_lat.dat", "loc_lon.dat"]
+    elif binary == "GeoAc3D.RngDep":
+        import rngdep_data as RD
+        RD.write_grid(str(tmp_path), short_paths=False)
+        inputs = ["p", "loc_x.dat", "loc_y.dat"]
     else:
         shutil.copy(H.TOYATMO, tmp_path / "ToyAtmo.met")
         inputs = ["ToyAtmo.met"]
