@@ -1,0 +1,75 @@
+"""One GPU, every configuration of BASELINE.json (`configs`), one JSON line each: ray-steps/s of the GPU path.  The headline metric
+is bench.py's; this table documents the other configurations (parity for each is in tests/).  usage: bench_configs.py [cfg ...]"""
+import json, os, sys, time, tempfile
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import geoac_amd as G
+import harness as H
+
+
+def run_fan(ctx, th, ph, reps=2):
+    ctx.set_angles(th, ph)
+    ctx.launch()                                   # warm-up (allocations, first-touch)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.launch()
+    dt = (time.perf_counter() - t0) / reps
+    return ctx.total_steps(), dt
+
+
+def cfg1():
+    ctx = G.FanContext(G.EQ_2D, device=0); ctx.load_met(H.TOYATMO)
+    ctx.set_params(bounces=2, calc_amp=1, mode=1)
+    th, ph = G.fan_enumerate(theta_min=1.0, theta_max=10.0, theta_step=1.0, phi_min=-90.0, phi_max=-90.0)
+    steps, dt = run_fan(ctx, th, ph)
+    return dict(config="cfg1 GeoAc2D -prop ToyAtmo.met theta 1..10 (10 rays, WriteRays)", rays=len(th), ray_steps=steps, seconds=dt)
+
+
+def cfg2():
+    ctx = G.FanContext(G.EQ_3D, device=0); ctx.load_met(H.TOYATMO)
+    ctx.set_params(bounces=2, calc_amp=1, mode=0)
+    th, ph = G.fan_enumerate(phi_min=-180.0, phi_max=179.0, phi_step=1.0)
+    steps, dt = run_fan(ctx, th, ph)
+    return dict(config="cfg2 GeoAc3D 360 az x 90 incl, bounces=2, CalcAmp=True", rays=len(th), ray_steps=steps, seconds=dt)
+
+
+def cfg3():
+    ctx = G.FanContext(G.EQ_GLOBAL, device=0); ctx.load_met(H.TOYATMO)
+    ctx.set_params(bounces=3, calc_amp=1, mode=0, src=(0.0, 30.0, 0.0))
+    th, ph = G.fan_enumerate(theta_min=0.25, theta_max=45.0, theta_step=0.25, phi_min=-180.0, phi_max=179.5, phi_step=0.5)
+    steps, dt = run_fan(ctx, th, ph, reps=1)
+    return dict(config="cfg3 GeoAcGlobal 720 az x 180 incl, bounces=3, CalcAmp=True", rays=len(th), ray_steps=steps, seconds=dt)
+
+
+def cfg4():
+    import rngdep_data as RD
+    grid = RD.write_grid(os.path.join(tempfile.gettempdir(), "gdb"), short_paths=False)
+    ctx = G.FanContext(G.EQ_3D_RNGDEP, device=0); ctx.load_grid(*grid)
+    ctx.set_params(bounces=1, calc_amp=1, mode=0, src=(0.0, 0.0, 0.0))
+    # one GPU's share of the 1000 az x 1000 incl fan sharded over 8 GPUs: 125 azimuths
+    th, ph = G.fan_enumerate(theta_min=0.05, theta_max=50.0, theta_step=0.05, phi_min=-180.0, phi_max=-180.0 + 124 * 0.36, phi_step=0.36)
+    steps, dt = run_fan(ctx, th, ph, reps=1)
+    return dict(config="cfg4 GeoAc3D.RngDep 5x5 grid, 1/8 of 1000 az x 1000 incl (125 az), bounces=1, CalcAmp=True", rays=len(th), ray_steps=steps, seconds=dt)
+
+
+def cfg5():
+    import rngdep_data as RD
+    grid = RD.write_grid_global(os.path.join(tempfile.gettempdir(), "ggb"), short_paths=False)
+    ctx = G.FanContext(G.EQ_GLOBAL_RNGDEP, device=0); ctx.load_grid(*grid)
+    ctx.set_params(src=(0.0, 31.0, 0.0))
+    n = 8                                           # one GPU's share of the 64-receiver ring sharded over 8 GPUs
+    az = np.arange(n) * (2.0 * np.pi / 64)
+    rcv = np.stack([31.0 + 2.5 * np.cos(az), 2.5 * np.sin(az) / np.cos(np.radians(31.0))], axis=1)
+    t0 = time.perf_counter(); out = ctx.eig_search(rcv, bnc_min=0, bnc_max=2); dt = time.perf_counter() - t0
+    st = out["stats"]
+    return dict(config="cfg5 GeoAcGlobal.RngDep -eig_search, 8 of 64 receivers on a 2.5 deg ring, bounces 0..2", rays=st["rays"], ray_steps=st["steps"],
+                seconds=dt, eigenrays=int(len(out["eig"])), fan_launches=st["launches"])
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"]
+    for w in which:
+        r = globals()[w]()
+        r["ray_steps_per_s"] = r["ray_steps"] / r["seconds"]
+        print(json.dumps(r), flush=True)
