@@ -40,6 +40,7 @@ struct DevBuf {
 
 struct geoac_ctx {
     int eqset = 0, device = 0;
+    bool no_quad = false;            // GEOAC_NO_QUAD=1: never use the four-lanes-per-ray grid kernels
     int  spread_override = 0;        // GEOAC_SPREAD=n: force n-way lane thinning of the grid-set RK4 waves (1 = dense); 0 = automatic
     hipStream_t stream = nullptr; bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -170,6 +171,8 @@ int geoac_create(geoac_ctx** out, int eqset, int device){
     if(ppb && atoi(ppb) > 0) ctx->pp_blocks = atoi(ppb);
     const char* npr = getenv("GEOAC_NO_PAIR");
     if(npr && atoi(npr) != 0) ctx->no_pair = true;
+    const char* nq = getenv("GEOAC_NO_QUAD");
+    if(nq && atoi(nq) != 0) ctx->no_quad = true;
     const char* nsp = getenv("GEOAC_SPREAD");
     if(nsp && atoi(nsp) > 0) ctx->spread_override = atoi(nsp);
     const char* sc = getenv("GEOAC_SMP_CAP");
@@ -420,6 +423,11 @@ int geoac_fan_launch(geoac_ctx* ctx){
     }
     P.pp_blocks = ctx->pp_blocks;
     P.lanes_per_ray = (is_global && p.calc_amp && !sampling && !ctx->no_pair) ? 2 : 1;
+    // grid sets, small fans: four lanes per ray (one cell corner each) while that still leaves one wave per SIMD
+    if(is_grid && !ctx->no_quad){
+        if((long long)P.n_pad * 4 / 64 <= 1024) P.lanes_per_ray = 4;
+        else if((long long)P.n_pad * 2 / 64 <= 1024) P.lanes_per_ray = 2;
+    }
     // RK4 workgroup shape: with the table in LDS one workgroup owns a CU, so spread the waves over the 256 CUs
     int waves = P.n_pad * P.lanes_per_ray / 64;
     int wpb = (waves + 255) / 256;
@@ -430,7 +438,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
     // grid sets are bound by divergent table gathers (one cache line per active lane and load): while the fan has fewer waves than
     // the chip has SIMDs, thin the waves out (1 wave per SIMD is what the kernel's register budget allows)
     P.spread = 1;
-    if(is_grid){
+    if(is_grid && P.lanes_per_ray == 1){
         // measured (tools/perf_rngdep.py, GEOAC_SPREAD sweep): 2-4 way thinning gains 5-20 %, 8+ loses again (path stores and the
         // post-pass reads scatter), more waves than SIMDs loses a lot
         while(P.spread < 4 && (long long)P.n_pad * (P.spread * 2) / 64 <= 1024) P.spread *= 2;

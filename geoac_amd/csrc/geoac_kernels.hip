@@ -472,6 +472,7 @@ DEVINL void cart2_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCt
 template <bool AMP_> struct EqGlobal {
     static constexpr bool AMP = AMP_;
     static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 0, LANES = 1;
+    static constexpr bool SPLIT = false;                            // true: the lanes of a ray carry DIFFERENT parts of its state (EqGlobalPair)
     static constexpr bool KM2 = false, HMAX_PER_LEG = false;        // linear intercept only (Q1); turning height accumulates over legs
 
     // GeoAc_SetInitialConditions: EquationSets.Global.cpp:76-136
@@ -613,6 +614,7 @@ template <bool AMP_> struct EqGlobal {
 // a wave on every SIMD for the 32 400-ray metric fan.  Lanes exchange values only at leg ends (arrival record).
 struct EqGlobalPair : EqGlobal<true> {
     static constexpr int E = 12, LANES = 2;
+    static constexpr bool SPLIT = true;
     template <typename TabPtr>
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
         double s2, c2;
@@ -642,9 +644,10 @@ struct EqGlobalPair : EqGlobal<true> {
 #include "geoac_rngdep.h"
 
 // Range-dependent Cartesian set (GeoAc3D.RngDep): EquationSets.3DRngDep.cpp + G2S_MultiDimSpline3D.cpp
-template <bool AMP_> struct Eq3DRngDep {
+template <bool AMP_, int NL_ = 1> struct Eq3DRngDep {
     static constexpr bool AMP = AMP_;
-    static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 2, LANES = 1;
+    static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 2, LANES = NL_;            // NL_ = 1, 2 or 4 lanes per ray, each evaluating 4/NL_ of the cell corners (identical state otherwise)
+    static constexpr bool SPLIT = false;
     static constexpr bool KM2 = true, HMAX_PER_LEG = true;          // quadratic intercept; turning height per leg (Q8)
 
     // SuthBass reference state at (0, 0, z_grnd) (Atmo_State.Absorption.cpp:31-33), once per fan
@@ -682,7 +685,7 @@ template <bool AMP_> struct Eq3DRngDep {
     static DEVINL double above_ground(const GeoacDevParams& P, const double* y){ return y[2] - P.ground; }
     template <typename TabPtr>
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
-        rngdep_rhs<AMP>(P, seg, yt, dy);
+        rngdep_rhs<AMP, NL_>(P, seg, yt, dy, (int)(threadIdx.x & (NL_ - 1)));
     }
     // 3DRngDep.cpp:451-472
     static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, long long k, bool& brk, bool& gnd){
@@ -770,9 +773,10 @@ template <bool AMP_> struct Eq3DRngDep {
 
 // Range-dependent spherical set (GeoAcGlobal.RngDep): EquationSets.GlobalRngDep.cpp + G2S_GlobalMultiDimSpline3D.cpp.
 // Grid axes in table order: x = latitude, y = longitude [rad], z = geocentric radius; xy_lim = lat/lon box of the break check.
-template <bool AMP_> struct EqGlobalRngDep {
+template <bool AMP_, int NL_ = 1> struct EqGlobalRngDep {
     static constexpr bool AMP = AMP_;
-    static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 0, LANES = 1;
+    static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 0, LANES = NL_;
+    static constexpr bool SPLIT = false;
     static constexpr bool KM2 = false, HMAX_PER_LEG = true;         // linear intercept (Q1, GlobalRngDep.cpp:147-148); turning height per leg (Q8)
 
     static DEVINL Medium as_medium(const Medium3& g){ Medium m; m.c = g.c; m.dc = g.dcz; m.u = g.u; m.du = g.duz; m.v = g.v; m.dv = g.dvz; m.rho = g.rho; return m; }
@@ -810,7 +814,7 @@ template <bool AMP_> struct EqGlobalRngDep {
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
         double s2, c2;
         rot_small(C.a[0], C.a[1], yt[1] - y0[1], s2, c2);          // sin/cos(lat) carried along the ray, as in EqGlobal
-        globalrd_rhs<AMP>(P, seg, yt, s2, c2, dy);
+        globalrd_rhs<AMP, NL_>(P, seg, yt, s2, c2, dy, (int)(threadIdx.x & (NL_ - 1)));
     }
     // GeoAc_BreakCheck / GeoAc_GroundCheck: GlobalRngDep.cpp:523-545
     static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, long long k, bool& brk, bool& gnd){
@@ -902,6 +906,7 @@ template <bool AMP_> struct EqGlobalRngDep {
 template <bool AMP_> struct Eq3D {
     static constexpr bool AMP = AMP_;
     static constexpr int E = AMP_ ? 12 : 4, PW = 4, HIDX = 2, LANES = 1;
+    static constexpr bool SPLIT = false;
     static constexpr bool KM2 = true, HMAX_PER_LEG = false;                               // quadratic intercept needs row k-2
 
     // GeoAc_SetInitialConditions: EquationSets.3DStratified.cpp:69-131
@@ -1024,6 +1029,7 @@ template <bool AMP_> struct Eq3D {
 template <bool AMP_> struct Eq2D {
     static constexpr bool AMP = AMP_;
     static constexpr int E = AMP_ ? 6 : 3, PW = 2, HIDX = 1, LANES = 1;
+    static constexpr bool SPLIT = false;
     static constexpr bool KM2 = true, HMAX_PER_LEG = false;
 
     // GeoAc_SetInitialConditions: EquationSets.2DStratified.cpp:38-68
@@ -1138,7 +1144,8 @@ __global__ void __launch_bounds__(256) k_init(GeoacDevParams P){
 template <class EQ>
 DEVINL void write_row(const GeoacDevParams& P, int row, int slot, int q, const double* y){
     double* p = P.path + ((size_t)row * EQ::PW) * P.n_pad + slot;
-    if(EQ::LANES == 2){                    // pair kernel: lane parity 0 stores r, lat, lon; parity 1 stores nu_r, nu_t, nu_p
+    if(!EQ::SPLIT && EQ::LANES > 1 && q != 0) return;   // multi-lane grid kernels: the lanes hold the same row, lane 0 stores it
+    if(EQ::SPLIT){                    // pair kernel: lane parity 0 stores r, lat, lon; parity 1 stores nu_r, nu_t, nu_p
         p += (size_t)(3 * q) * P.n_pad;
         #pragma unroll
         for(int c = 0; c < 3; c++) p[(size_t)c * P.n_pad] = q ? y[c + 3] : y[c];
@@ -1168,8 +1175,8 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
     const int tid0 = blockIdx.x * blockDim.x + threadIdx.x;
     if(P.spread > 1 && (tid0 & (P.spread - 1))) return;         // sparse lanes (grid sets, small fans)
     const int tid = (P.spread > 1) ? tid0 / P.spread : tid0;
-    const int slot = (EQ::LANES == 2) ? (tid >> 1) : tid;       // ray slot
-    const int q = (EQ::LANES == 2) ? (tid & 1) : 0;             // which derivative system this lane carries (pair kernel)
+    const int slot = tid / EQ::LANES;                           // ray slot
+    const int q = tid % EQ::LANES;                              // pair kernel: which derivative system this lane carries; quad kernels: which cell corner
     if(slot >= P.n_pad) return;
     const size_t np = (size_t)P.n_pad;
     double* st = P.state + slot;
@@ -1182,7 +1189,7 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
     static_assert(!EQ::KM2 || ST_YM2 + E <= ST_DPREV, "state block: ym2[] overruns ST_DPREV");
     double y[E], ym2[EQ::KM2 ? E : 1];
     #pragma unroll
-    for(int e = 0; e < E; e++) y[e] = st[(ST_Y0 + ((EQ::LANES == 2 && e >= 6) ? e + 6 * q : e)) * np];
+    for(int e = 0; e < E; e++) y[e] = st[(ST_Y0 + ((EQ::SPLIT && e >= 6) ? e + 6 * q : e)) * np];
     if(EQ::KM2){
         #pragma unroll
         for(int e = 0; e < E; e++) ym2[e] = st[(ST_YM2 + e) * np];
@@ -1264,7 +1271,7 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
             if(lim && !brk && !gnd) atomicOr(&P.counters[2], 1ull);
             // the leg's last row solution[k][*] (both outcomes: arrival rows read it, and so do the eigenray scans' messages after a break)
             double yf[18];
-            if(EQ::LANES == 2){
+            if(EQ::SPLIT){
                 // assemble the reference's 18-component row from the lane pair (both lanes end up with the same row
                 // and store the same record)
                 #pragma unroll
@@ -1279,14 +1286,14 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
                 for(int e = 0; e < 18; e++) yf[e] = (e < E) ? yn[e < E ? e : 0] : 0.0;
             }
             #pragma unroll
-            for(int e = 0; e < ((EQ::LANES == 2) ? 18 : E); e++) R[GEOAC_REC_STATE + e] = yf[e];
+            for(int e = 0; e < (EQ::SPLIT ? 18 : E); e++) R[GEOAC_REC_STATE + e] = yf[e];
             if(brk){
                 R[GEOAC_REC_BROKE] = 1.0;
                 done = true;
             } else {
                 R[GEOAC_REC_VALID] = 1.0;
                 R[GEOAC_REC_TURN] = hmax;
-                if(EQ::LANES == 2) EqGlobal<true>::arrival(P, C, slot, yf, R);
+                if(EQ::SPLIT) EqGlobal<true>::arrival(P, C, slot, yf, R);
                 else EQ::arrival(P, C, slot, yn, R);
                 if(leg >= P.bounces){
                     done = true;
@@ -1310,7 +1317,7 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
 
     // ---- save state (pair kernel: both lanes store the identical base ray; each stores its own derivative system) ----
     #pragma unroll
-    for(int e = 0; e < E; e++) st[(ST_Y0 + ((EQ::LANES == 2 && e >= 6) ? e + 6 * q : e)) * np] = y[e];
+    for(int e = 0; e < E; e++) st[(ST_Y0 + ((EQ::SPLIT && e >= 6) ? e + 6 * q : e)) * np] = y[e];
     if(EQ::KM2){
         #pragma unroll
         for(int e = 0; e < E; e++) st[(ST_YM2 + e) * np] = ym2[e];
@@ -1453,6 +1460,24 @@ __global__ void __launch_bounds__(256) k_accum(GeoacDevParams P){
         case GEOAC_EQ_GLOBAL_RNGDEP * 2 + 0: { using EQ = EqGlobalRngDep<false>; CALL; } break; \
         default: return hipErrorNotSupported; }
 
+// RK4 only: the grid sets have four-lanes-per-ray variants (small fans)
+#define GEOAC_DISPATCH_EQ_RK4(P, CALL) \
+    if((P)->lanes_per_ray == 4){ \
+        switch((P)->eqset * 2 + ((P)->calc_amp ? 1 : 0)){ \
+            case GEOAC_EQ_3D_RNGDEP * 2 + 1: { using EQ = Eq3DRngDep<true, 4>;  CALL; } break; \
+            case GEOAC_EQ_3D_RNGDEP * 2 + 0: { using EQ = Eq3DRngDep<false, 4>; CALL; } break; \
+            case GEOAC_EQ_GLOBAL_RNGDEP * 2 + 1: { using EQ = EqGlobalRngDep<true, 4>;  CALL; } break; \
+            case GEOAC_EQ_GLOBAL_RNGDEP * 2 + 0: { using EQ = EqGlobalRngDep<false, 4>; CALL; } break; \
+            default: return hipErrorNotSupported; } \
+    } else if((P)->lanes_per_ray == 2 && (P)->gtab){ \
+        switch((P)->eqset * 2 + ((P)->calc_amp ? 1 : 0)){ \
+            case GEOAC_EQ_3D_RNGDEP * 2 + 1: { using EQ = Eq3DRngDep<true, 2>;  CALL; } break; \
+            case GEOAC_EQ_3D_RNGDEP * 2 + 0: { using EQ = Eq3DRngDep<false, 2>; CALL; } break; \
+            case GEOAC_EQ_GLOBAL_RNGDEP * 2 + 1: { using EQ = EqGlobalRngDep<true, 2>;  CALL; } break; \
+            case GEOAC_EQ_GLOBAL_RNGDEP * 2 + 0: { using EQ = EqGlobalRngDep<false, 2>; CALL; } break; \
+            default: return hipErrorNotSupported; } \
+    } else GEOAC_DISPATCH_EQ(P, CALL)
+
 extern "C" hipError_t geoac_launch_init(const GeoacDevParams* P, hipStream_t s){
     dim3 b(256), g((P->n_pad + 255) / 256);
     GEOAC_DISPATCH_EQ(P, hipLaunchKernelGGL(k_init<EQ>, g, b, 0, s, *P));
@@ -1479,8 +1504,8 @@ static hipError_t launch_rk4_t(const GeoacDevParams* P, int block, hipStream_t s
 }
 
 extern "C" hipError_t geoac_launch_rk4(const GeoacDevParams* P, int block, hipStream_t s){
-    if(P->lanes_per_ray == 2) return launch_rk4_t<EqGlobalPair>(P, block, s);
-    GEOAC_DISPATCH_EQ(P, return launch_rk4_t<EQ>(P, block, s));
+    if(P->lanes_per_ray == 2 && !P->gtab) return launch_rk4_t<EqGlobalPair>(P, block, s);
+    GEOAC_DISPATCH_EQ_RK4(P, return launch_rk4_t<EQ>(P, block, s));
     return hipErrorNotSupported;
 }
 

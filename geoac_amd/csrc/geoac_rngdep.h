@@ -111,8 +111,26 @@ DEVINL double dot4(const double* w, double F, double FX, double FY, double FXY, 
 //   patch f_y  : F = Dy V0,  FX = Dxy V0 dx,   FY = Dy Vy dy,        FXY = Dxy Vy dx dy     (its d/dy: f_yy)
 //   patch f_z  : F = V0',    FX = Vx' dx,      FY = Vy' dy,          FXY = Dxy V0' dx dy    (its d/dx, d/dy: f_xz, f_yz)
 //   patch f_zz : F = V0'',   FX = Dx V0'' dx,  FY = Dy V0'' dx (Q11, :1568-1571), FXY = Dxy V0'' dx dy
-template <bool ORDER2, bool GLB>
-DEVINL void grid_eval_all(const GeoacDevParams& P, int field, const GridLoc& L, double* out){
+// butterfly sum over the four lanes of a quad (DPP quad_perm [1,0,3,2] then [2,3,0,1]); every lane ends with the bit-identical total
+DEVINL double quad_sum(double v){
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    double w = __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true));
+    v += w;
+    lo = __double2loint(v); hi = __double2hiint(v);
+    w = __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true));
+    return v + w;
+}
+
+DEVINL double pair_sum(double v){
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    double w = __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true));
+    return v + w;
+}
+
+// NL = 2 or 4 lanes per ray (small fans).  Lane cq of the group evaluates 4/NL of the cell corners and the partial sums are added
+// across the group: 3 (NL = 4) or 6 (NL = 2) dependent gather batches per RHS instead of 12 (the kernel is bound by their latency).
+template <bool ORDER2, bool GLB, int NL = 1>
+DEVINL void grid_eval_all(const GeoacDevParams& P, int field, const GridLoc& L, double* out, int cq = 0){
     const Herm hx = hermite(L.xs), hy = hermite(L.ys);
     const double dxs = L.dxs, dys = L.dys, dxy = dxs * dys;
     const double t = L.t, th = 0.5 * t, t6 = t * (1.0 / 6.0);
@@ -120,8 +138,8 @@ DEVINL void grid_eval_all(const GeoacDevParams& P, int field, const GridLoc& L, 
     double o[10];
     #pragma unroll
     for(int i = 0; i < 10; i++) o[i] = 0.0;
-    #pragma unroll 1
-    for(int cn = 0; cn < 4; cn++){
+    #pragma unroll (ORDER2 ? 1 : 2)                               // geometry-only kernels have registers to keep two corners' loads in flight
+    for(int cn = cq * (4 / NL); cn < (cq + 1) * (4 / NL); cn++){
         {
             const int a = cn >> 1, b = cn & 1;
             const double* __restrict__ r = base + (size_t)corner_node(L, a, b) * GEOAC_GREC;
@@ -151,6 +169,10 @@ DEVINL void grid_eval_all(const GeoacDevParams& P, int field, const GridLoc& L, 
                 o[6] = __builtin_fma(w.W[0], Fzz, __builtin_fma(w.W[1], DxFzz, __builtin_fma(Wq, DyFzz, __builtin_fma(w.W[3], DxyFzz, o[6]))));
             }
         }
+    }
+    if(NL > 1){
+        #pragma unroll
+        for(int i = 0; i < (ORDER2 ? 10 : 4); i++) o[i] = (NL == 4) ? quad_sum(o[i]) : pair_sum(o[i]);
     }
     if(ORDER2 && !GLB){                                            // spherical set: left in scaled coordinates (Q12c, :1328-1338, :1374-1384, :1420-1424)
         const double idxs = 1.0 / dxs, idys = 1.0 / dys;
@@ -227,14 +249,14 @@ DEVINL Medium3 medium3_at(const GeoacDevParams& P, double x, double y, double z)
 
 // fused GeoAc_UpdateSources + GeoAc_EvalSrcEq of the range-dependent Cartesian set (EquationSets.3DRngDep.cpp:218-393)
 // y: x, y, z, nu_x, nu_y, nu_z | X_th(3), mu_th(3) | X_ph(3), mu_ph(3)
-template <bool AMP>
-DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double* dy){
+template <bool AMP, int NL = 1>
+DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double* dy, int cq = 0){
     const double xe = clampd(y[0], P.gx[0], P.gx[P.gnx - 1]), ye = clampd(y[1], P.gy[0], P.gy[P.gny - 1]), ze = clampd(y[2], P.x_min, P.x_max);
     GridLoc L; grid_locate(P, xe, ye, ze, kz, L);
     kz = L.kz;
     double M[3][10];                                               // T, u, v and their derivatives; one (non-inlined) evaluator call per field
     #pragma unroll 1
-    for(int f = 0; f < 3; f++) grid_eval_all<AMP, false>(P, f, L, M[f]);
+    for(int f = 0; f < 3; f++) grid_eval_all<AMP, false, NL>(P, f, L, M[f], cq);
     const double* T = M[0]; const double* U = M[1]; const double* V = M[2];
     const double n0 = y[3], n1 = y[4], n2 = y[5];
     const double qT = kGamR * T[0];
@@ -294,15 +316,15 @@ DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double
 // fused GeoAc_UpdateSources + GeoAc_EvalSrcEq of the range-dependent spherical set (EquationSets.GlobalRngDep.cpp:226-458):
 // the algebra of global_rhs (geoac_kernels.hip) with the full gradient and second-derivative matrices of c, u, v (w = 0).
 // y: r, lat, lon, nu_r, nu_t, nu_p | R_lt(3), mu_lt(3) | R_lp(3), mu_lp(3);  sth/cth = sin/cos(lat) from the caller.
-template <bool AMP>
-DEVINL void globalrd_rhs(const GeoacDevParams& P, int& kz, const double* y, double sth, double cth, double* dy){
+template <bool AMP, int NL = 1>
+DEVINL void globalrd_rhs(const GeoacDevParams& P, int& kz, const double* y, double sth, double cth, double* dy, int cq = 0){
     const double r = y[0];
     const double te = clampd(y[1], P.gx[0], P.gx[P.gnx - 1]), pe = clampd(y[2], P.gy[0], P.gy[P.gny - 1]), re = clampd(r, P.x_min, P.x_max);
     GridLoc L; grid_locate(P, te, pe, re, kz, L);
     kz = L.kz;
     double M[3][10];                                               // table order: f, f_t, f_p, f_r, f_tt, f_pp, f_rr, f_tp, f_tr, f_pr
     #pragma unroll 1
-    for(int f = 0; f < 3; f++) grid_eval_all<AMP, true>(P, f, L, M[f]);
+    for(int f = 0; f < 3; f++) grid_eval_all<AMP, true, NL>(P, f, L, M[f], cq);
     const double* T = M[0]; const double* U = M[1]; const double* V = M[2];
     // first derivatives in equation order (r, t, p) = table entries 3, 1, 2
     const int fi[3] = { 3, 1, 2 };
