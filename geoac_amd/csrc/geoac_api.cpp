@@ -422,7 +422,8 @@ int geoac_fan_launch(geoac_ctx* ctx){
         P.seg_safe = (hmin >= 1.001 * ds_bound) ? 1 : 0;
     }
     P.pp_blocks = ctx->pp_blocks;
-    P.lanes_per_ray = (is_global && p.calc_amp && !sampling && !ctx->no_pair) ? 2 : 1;
+    // two lanes per ray shorten the serial chain (x1.25) at twice the lanes: only worth it while the fan leaves SIMDs idle
+    P.lanes_per_ray = (is_global && p.calc_amp && !sampling && !ctx->no_pair && (long long)P.n_pad * 2 / 64 <= 1024) ? 2 : 1;
     // grid sets, small fans: four lanes per ray (one cell corner each) while that still leaves one wave per SIMD
     if(is_grid && !ctx->no_quad){
         if((long long)P.n_pad * 4 / 64 <= 1024) P.lanes_per_ray = 4;
