@@ -41,3 +41,35 @@ def gather_records(rec_local, n_az, n_theta, group=None):
         idx = (az[:, None] * n_theta + torch.arange(n_theta, device=rec_local.device)[None, :]).reshape(-1)
         full[idx] = out[r, : sizes[r]]
     return full
+
+
+def shard_receivers(n_rcvr, rank, world):
+    """eigenray searches shard by receiver: rank r takes receivers r, r+world, ...; returns their indices"""
+    return np.arange(rank, n_rcvr, world)
+
+
+def gather_eigenrays(eig_local, rcvr_index_local, group=None):
+    """all-gather per-rank eigenray tables [n_local][EIG_STRIDE] (torch tensors; counts differ per rank) and return one table
+    ordered by (global receiver index, eigenray number).  Column 0 of the local tables holds the LOCAL receiver index of
+    geoac_eig_search; `rcvr_index_local` (the array shard_receivers returned) maps it back to the global one."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    dev = eig_local.device
+    eig = eig_local.clone()
+    if eig.shape[0]:
+        eig[:, 0] = torch.as_tensor(np.asarray(rcvr_index_local), dtype=eig.dtype, device=dev)[eig[:, 0].long()]
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([eig.shape[0]], dtype=torch.int64, device=dev), group=group)
+    counts = [int(c.item()) for c in counts]
+    nmax = max(max(counts), 1)
+    pad = torch.zeros((nmax, eig.shape[1]), dtype=eig.dtype, device=dev)
+    pad[: eig.shape[0]] = eig
+    out = torch.empty((world * nmax, eig.shape[1]), dtype=eig.dtype, device=dev)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    out = out.view(world, nmax, eig.shape[1])
+    full = torch.cat([out[r, : counts[r]] for r in range(world)], dim=0)
+    if full.shape[0]:
+        key = full[:, 0] * 1e6 + full[:, 1]
+        full = full[torch.argsort(key)]
+    return full

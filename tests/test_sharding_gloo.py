@@ -10,7 +10,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import geoac_amd as G
-from geoac_amd.sharding import gather_records, shard_by_azimuth, shard_sizes
+from geoac_amd.sharding import gather_eigenrays, gather_records, shard_by_azimuth, shard_receivers, shard_sizes
 
 
 def _fake_records(theta, phi, legs=3, stride=32):
@@ -75,3 +75,40 @@ def test_shard_by_azimuth_covers_fan_once():
         _, _, idx = shard_by_azimuth(th, ph, 90, r, 8)
         seen[idx] += 1
     assert (seen == 1).all()
+
+
+def _fake_eigenrays(rcvr_global):
+    """deterministic stand-in: receiver g has (g % 3) eigenrays"""
+    rows = []
+    for local, g in enumerate(rcvr_global):
+        for k in range(int(g) % 3):
+            row = np.zeros(16); row[0] = local; row[1] = k; row[3] = 5.0 + g + 0.25 * k; row[5] = 800.0 + g
+            rows.append(row)
+    return np.array(rows).reshape(-1, 16)
+
+
+def _eig_worker(rank, world, port, n_rcvr, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard_receivers(n_rcvr, rank, world)
+    full = gather_eigenrays(torch.from_numpy(_fake_eigenrays(mine)), mine)
+    want = _fake_eigenrays(np.arange(n_rcvr))
+    want[:, 0] = [g for g in range(n_rcvr) for _ in range(g % 3)]
+    q.put((rank, np.array_equal(full.numpy(), want)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_rcvr", [(2, 7), (3, 8)])
+def test_receiver_sharding_gathers_every_eigenray_once(world, n_rcvr):
+    """config 5 shards by receiver: the gathered eigenray table must not depend on the rank count"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eig_worker, args=(r, world, port, n_rcvr, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res), res
