@@ -33,16 +33,19 @@ static constexpr double kGamR = 0.00040187;                    // G2S_GlobalSpli
 // two Newton steps bring both to <= 1 ulp (measured 0 / 2.6e-16) at 24 / 35 ns per wave-instruction group instead of
 // the 33 / 49+33 ns of the IEEE division / sqrt+division expansions (tools/ubench_fp64.hip, one wave per SIMD).
 DEVINL double frcp(double x){
+    // v_rcp_f64 is a 24-bit seed on gfx950: one third-order step (r (1 + e + e^2), e = 1 - x r) leaves e^3 ~ 2^-72
     double r = __builtin_amdgcn_rcp(x);
-    double e = __builtin_fma(-x, r, 1.0); r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-x, r, 1.0); return __builtin_fma(r, e, r);
+    double e = __builtin_fma(-x, r, 1.0);
+    double t = __builtin_fma(e, e, e);
+    return __builtin_fma(r, t, r);
 }
 DEVINL double frsq(double x){
+    // y (1 - e)^(-1/2) = y (1 + e/2 + 3 e^2 / 8 + ...), e = 1 - x y^2: one third-order step from the 24-bit seed
     double y = __builtin_amdgcn_rsq(x);
-    double g = x * y, h = 0.5 * y;
-    double e = __builtin_fma(-h, g, 0.5); y = __builtin_fma(y, e, y);
-    g = x * y; h = 0.5 * y;
-    e = __builtin_fma(-h, g, 0.5); return __builtin_fma(y, e, y);
+    double g = x * y;
+    double e = __builtin_fma(-g, y, 1.0);
+    double p = __builtin_fma(e, 0.375, 0.5);
+    return __builtin_fma(y * e, p, y);
 }
 // rotate (sin a, cos a) by a small angle d (|d| << 1): series to d^6, error < 1e-17 for |d| < 0.03
 DEVINL void rot_small(double sa, double ca, double d, double& s, double& c){
