@@ -79,6 +79,7 @@ struct GeoacDevParams {
     const double* gtab;             // [4 fields][nseg][gnx*gny][12]: cubics of f, df/dx, df/dy per node and vertical segment
     double        xy_lim[4];        // x_min, x_max, y_min, y_max break limits (GeoAc.Parameters.RngDep.cpp:24-28)
     double*       dev_consts;       // [0] T_o, [1] P_o of SuthBass evaluated on the device (RngDep: medium at (0, 0, z_grnd))
+    const int*    perm;             // slot -> ray index of the caller's order (records and samples are written in the caller's order); NULL = identity
     const double* theta_deg;        // [n_rays]
     const double* phi_deg;
     double*       state;            // [ST_NSTATE][n_pad]

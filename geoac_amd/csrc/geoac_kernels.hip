@@ -1268,7 +1268,7 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
 
         if(brk || gnd || lim){
             // ---- leg end: record (GeoAcGlobal_main.cpp:293-317 and twins) ----
-            double* R = P.rec + ((size_t)slot * (P.bounces + 1) + leg) * GEOAC_REC_STRIDE;
+            double* R = P.rec + ((size_t)(P.perm ? P.perm[slot] : slot) * (P.bounces + 1) + leg) * GEOAC_REC_STRIDE;
             R[GEOAC_REC_STEPS] = (double)k;
             P.legend[(size_t)nle * np + slot] = nr - 1; nle++;
             if(lim && !brk && !gnd) atomicOr(&P.counters[2], 1ull);
@@ -1404,7 +1404,7 @@ __global__ void __launch_bounds__(256) k_accum(GeoacDevParams P){
         if(o < (unsigned long long)P.smp_cap){
             double* S = P.smp_out + o * GEOAC_SMP_STRIDE;
             const double* row = P.path + ((size_t)crow * P.pathw) * np + slot;
-            S[GEOAC_SMP_RAY] = (double)slot; S[GEOAC_SMP_LEG] = (double)leg; S[GEOAC_SMP_M] = (double)m; S[GEOAC_SMP_KIND] = (double)kind;
+            S[GEOAC_SMP_RAY] = (double)(P.perm ? P.perm[slot] : slot); S[GEOAC_SMP_LEG] = (double)leg; S[GEOAC_SMP_M] = (double)m; S[GEOAC_SMP_KIND] = (double)kind;
             double amp = P.ev_amp[(size_t)ev * np + slot];
             double amp_db = P.calc_amp ? 20.0 * log10(amp) : 0.0;
             double v[6] = {0, 0, 0, 0, 0, 0};
@@ -1435,7 +1435,7 @@ __global__ void __launch_bounds__(256) k_accum(GeoacDevParams P){
         emit_events(i + 1);     // raypath / caustic rows at chunk row i+1: the sums now include segment (m-1, m) (GeoAcGlobal_main.cpp:266-284)
         if(last){
             if(!rays_form){ tt += ltt; at += lat; ltt = 0.0; lat = 0.0; }
-            double* R = P.rec + ((size_t)slot * (P.bounces + 1) + leg) * GEOAC_REC_STRIDE;
+            double* R = P.rec + ((size_t)(P.perm ? P.perm[slot] : slot) * (P.bounces + 1) + leg) * GEOAC_REC_STRIDE;
             R[GEOAC_REC_TTIME] = tt;
             R[GEOAC_REC_ATTEN] = at;
             leg++; cur_end = i + 1; e++;
