@@ -47,11 +47,12 @@ DEVINL double frsq(double x){
     double p = __builtin_fma(e, 0.375, 0.5);
     return __builtin_fma(y * e, p, y);
 }
-// rotate (sin a, cos a) by a small angle d (|d| << 1): series to d^6, error < 1e-17 for |d| < 0.03
+// rotate (sin a, cos a) by a small angle d.  |d| <= ds_max / r_earth < 1e-4 for every caller (one RK4 stage or step of at most
+// 0.5 km at r >= 6370 km), so sin d = d (1 - d^2/6), cos d = 1 - d^2/2 (1 - d^2/12) are exact to < 1e-17 relative
 DEVINL void rot_small(double sa, double ca, double d, double& s, double& c){
     double d2 = d * d;
-    double sd = d * __builtin_fma(d2 * (-1.0 / 6.0), __builtin_fma(d2, -1.0 / 20.0, 1.0), 1.0);
-    double cd = __builtin_fma(d2 * (-0.5), __builtin_fma(d2 * (-1.0 / 12.0), __builtin_fma(d2, -1.0 / 30.0, 1.0), 1.0), 1.0);
+    double sd = d * __builtin_fma(d2, -1.0 / 6.0, 1.0);
+    double cd = __builtin_fma(d2 * (-0.5), __builtin_fma(d2, -1.0 / 12.0, 1.0), 1.0);
     s = __builtin_fma(sa, cd, ca * sd);
     c = __builtin_fma(ca, cd, -sa * sd);
 }
