@@ -44,7 +44,8 @@ struct geoac_ctx {
                                      // Ray length is mostly a function of inclination (ground-hugging rays take 1 m steps), so whole waves finish early
                                      // instead of every wave waiting for its one long ray: the post-pass then lands on idle SIMDs (metric fan +13 %)
     DevBuf perm; bool have_perm = false;
-    bool no_quad = false;            // GEOAC_NO_QUAD=1: never use the four-lanes-per-ray grid kernels
+    bool no_quad = false;            // GEOAC_NO_QUAD=1: never use the multi-lane grid kernels
+    int  grid_lanes = 0;             // GEOAC_GRID_LANES=1|2|4: force the lanes-per-ray variant of the grid kernels (tests); 0 = by fan size
     int  spread_override = 0;        // GEOAC_SPREAD=n: force n-way lane thinning of the grid-set RK4 waves (1 = dense); 0 = automatic
     hipStream_t stream = nullptr; bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -179,6 +180,8 @@ int geoac_create(geoac_ctx** out, int eqset, int device){
     if(srt) ctx->sort_rays = (atoi(srt) != 0);
     const char* nq = getenv("GEOAC_NO_QUAD");
     if(nq && atoi(nq) != 0) ctx->no_quad = true;
+    const char* gl = getenv("GEOAC_GRID_LANES");
+    if(gl && (atoi(gl) == 1 || atoi(gl) == 2 || atoi(gl) == 4)) ctx->grid_lanes = atoi(gl);
     const char* nsp = getenv("GEOAC_SPREAD");
     if(nsp && atoi(nsp) > 0) ctx->spread_override = atoi(nsp);
     const char* sc = getenv("GEOAC_SMP_CAP");
@@ -449,6 +452,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
         if((long long)P.n_pad * 4 / 64 <= 1024) P.lanes_per_ray = 4;
         else if((long long)P.n_pad * 2 / 64 <= 1024) P.lanes_per_ray = 2;
     }
+    if(is_grid && ctx->grid_lanes) P.lanes_per_ray = ctx->grid_lanes;
     // RK4 workgroup shape: with the table in LDS one workgroup owns a CU, so spread the waves over the 256 CUs
     int waves = P.n_pad * P.lanes_per_ray / 64;
     int wpb = (waves + 255) / 256;

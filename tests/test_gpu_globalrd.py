@@ -66,3 +66,13 @@ def test_globalrd_write_rays_caustics_vs_golden(gold, grid):
             assert (d[~ray_rows] / scale[~ray_rows] <= 1e-6).all()
         else:
             assert (d / scale).max() <= 1e-6, (col, (d / scale).max())
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 4])
+def test_every_lanes_per_ray_variant_vs_golden(gold, grid, lanes, monkeypatch):
+    monkeypatch.setenv("GEOAC_GRID_LANES", str(lanes))
+    ctx = _ctx(grid, bounces=1, calc_amp=1, mode=3, src=(0.0, 31.0, 0.0))
+    rec, steps = ctx.run(gold["theta"], gold["phi"])
+    assert steps == int(gold["steps_amp1_mode3"])
+    compare_records(rec, gold["rec_amp1_mode3"], E=18, hidx=0)
+    assert len(ctx.fetch_samples()) == int(gold["nsmp_amp1_mode3"])

@@ -67,3 +67,17 @@ def test_rngdep_write_rays_caustics_vs_golden(gold, grid):
             assert (d[~ray_rows] / scale[~ray_rows] <= 1e-6).all()
         else:
             assert (d / scale).max() <= 1e-6, (col, (d / scale).max())
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 4])
+def test_every_lanes_per_ray_variant_vs_golden(gold, grid, lanes, monkeypatch):
+    """the grid kernels exist with 1, 2 and 4 lanes per ray (picked by fan size); force each on the golden fan"""
+    monkeypatch.setenv("GEOAC_GRID_LANES", str(lanes))
+    ctx = _ctx(grid, bounces=1, calc_amp=1, mode=0, src=(0.0, 0.0, 0.0))
+    rec, steps = ctx.run(gold["theta"], gold["phi"])
+    assert steps == int(gold["steps_amp1_mode0"])
+    compare_records(rec, gold["rec_amp1_mode0"], E=18, hidx=2)
+    ctx = _ctx(grid, bounces=1, calc_amp=0, mode=0, src=(0.0, 0.0, 0.0))
+    rec, steps = ctx.run(gold["theta"], gold["phi"])
+    assert steps == int(gold["steps_amp0_mode0"])
+    compare_records(rec, gold["rec_amp0_mode0"], E=6, hidx=2)
