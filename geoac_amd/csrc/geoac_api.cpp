@@ -390,10 +390,13 @@ int geoac_fan_launch(geoac_ctx* ctx){
         }
         P.src_trig[0] = sin(p.src[1] * kPi / 180.0); P.src_trig[1] = cos(p.src[1] * kPi / 180.0);
     }
-    // ---- epoch size: keep the path chunk around <= 3 GiB ----
+    // ---- epoch size: 8192 rows unless a path chunk would pass 16 GiB (two chunks + two contrib buffers = 43 GiB of the 288).
+    //      Measured on the metric fan (GEOAC_S_ROWS sweep): 1024 rows 243 ms, 2048 236, 4096 228, 8192 224.5, 16384 231, 32768 243 per
+    //      pass - every epoch boundary costs a launch + host round trip + table reload + a post-pass burst against full RK4
+    //      occupancy, while very long epochs leave the last post-pass uncovered ----
     size_t row_bytes = (size_t)P.pathw * P.n_pad * sizeof(double);
-    long long s_rows = (long long)((3ull << 30) / row_bytes);
-    if(s_rows > 2048) s_rows = 2048;
+    long long s_rows = (long long)((16ull << 30) / row_bytes);
+    if(s_rows > 8192) s_rows = 8192;
     if(s_rows < 64) s_rows = 64;
     if(ctx->s_rows_override >= 8) s_rows = ctx->s_rows_override;
     P.s_rows = (int)s_rows;
