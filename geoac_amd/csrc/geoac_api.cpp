@@ -16,7 +16,8 @@
 
 extern "C" void geoac_natural_spline_slopes(int n, const double* x, const double* f, double* slopes);
 extern "C" hipError_t geoac_launch_init(const GeoacDevParams* P, hipStream_t s);
-extern "C" hipError_t geoac_launch_rk4(const GeoacDevParams* P, int block, hipStream_t s);
+extern "C" hipError_t geoac_launch_rk4(const GeoacDevParams* P, int block, hipStream_t s, unsigned* n_wg);
+extern "C" hipError_t geoac_launch_gate(const GeoacDevParams* P, unsigned long long expected, hipStream_t s);
 extern "C" hipError_t geoac_launch_postpass(const GeoacDevParams* P, int rows, hipStream_t s);
 
 namespace {
@@ -62,9 +63,11 @@ struct geoac_ctx {
     bool have_grid = false;
     // device
     DevBuf seg, rhot, theta, phi, state, rec, counters;
-    DevBuf path[2], contrib[2], nrows[2], legend[2], nlegend[2];   // double-buffered epoch chunks (RK4 of epoch e+1 overlaps the post-pass of e)
+    DevBuf path[3], contrib[3], nrows[3], legend[3], nlegend[3];   // epoch chunks, two or three in rotation (RK4 of epoch e+1 overlaps the post-pass of e)
     hipStream_t pp_stream = nullptr;                                // post-pass stream
-    DevBuf ev_row[2], ev_m[2], ev_amp[2], nev[2], smp_out;          // WriteRays / WriteCaustics events and the sample list
+    hipStream_t rk4b_stream = nullptr;                              // second RK4 stream (hybrid fans: the one-lane launch)
+    std::vector<hipEvent_t> evj;                                    // per epoch: the second RK4 launch has finished
+    DevBuf ev_row[3], ev_m[3], ev_amp[3], nev[3], smp_out;          // WriteRays / WriteCaustics events and the sample list
     long long smp_cap = 4ll << 20;                                  // sample records the device list can hold (GEOAC_SMP_CAP)
     unsigned long long n_samples = 0;
     unsigned long long* h_counters = nullptr;     // pinned
@@ -77,6 +80,9 @@ struct geoac_ctx {
     int pp_blocks = 0;                            // GEOAC_PP_BLOCKS: post-pass grid (256-thread blocks); 0 = one block per 256 segments.
                                                   // Measured: a short full-occupancy burst disturbs k_rk4 LESS than a long thin sweep
                                                   // (avg k_rk4 launch 10.9 ms vs 11.7-12.8 ms at 8192-256 blocks).
+    double pair_frac = 0.10;                      // hybrid fans: share of the inclination-sorted rays that get two lanes (GEOAC_PAIR_FRAC; >= 1: all)
+    double hybrid_rows = 0.75;                    // hybrid fans: rows per epoch of the one-lane launch relative to the two-lane launch (GEOAC_HYBRID_ROWS)
+    bool no_gate = false;                         // GEOAC_NO_GATE=1: post-pass not held back behind the next RK4 launch (A/B measurements)
     bool no_pair = false;                         // GEOAC_NO_PAIR=1: force one lane per ray (A/B measurements)
     std::string err;
 };
@@ -160,9 +166,14 @@ int geoac_create(geoac_ctx** out, int eqset, int device){
     if(hipSetDevice(device) != hipSuccess) return GEOAC_E_NODEVICE;
     geoac_ctx* ctx = new geoac_ctx();
     ctx->eqset = eqset; ctx->device = device;
-    if(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess){ delete ctx; return GEOAC_E_HIP; }
+    // RK4 launches must win the CUs at every epoch boundary: the post-pass of the previous epoch becomes runnable at the same
+    // moment and its short workgroups would otherwise occupy the CUs the RK4 workgroups (153 KB of LDS each) need
+    int prio_lo = 0, prio_hi = 0;
+    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);          // lo = least urgent (numerically largest)
+    if(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_hi) != hipSuccess){ delete ctx; return GEOAC_E_HIP; }
     ctx->own_stream = true;
-    if(hipStreamCreateWithFlags(&ctx->pp_stream, hipStreamNonBlocking) != hipSuccess){ delete ctx; return GEOAC_E_HIP; }
+    if(hipStreamCreateWithPriority(&ctx->pp_stream, hipStreamNonBlocking, prio_lo) != hipSuccess){ delete ctx; return GEOAC_E_HIP; }
+    if(hipStreamCreateWithPriority(&ctx->rk4b_stream, hipStreamNonBlocking, prio_hi) != hipSuccess){ delete ctx; return GEOAC_E_HIP; }
     hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
     if(hipHostMalloc((void**)&ctx->h_counters, 16 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess){
         delete ctx; return GEOAC_E_HIP;
@@ -176,6 +187,12 @@ int geoac_create(geoac_ctx** out, int eqset, int device){
     if(ppb && atoi(ppb) > 0) ctx->pp_blocks = atoi(ppb);
     const char* npr = getenv("GEOAC_NO_PAIR");
     if(npr && atoi(npr) != 0) ctx->no_pair = true;
+    const char* pf = getenv("GEOAC_PAIR_FRAC");
+    if(pf && atof(pf) >= 0.0) ctx->pair_frac = atof(pf);
+    const char* hr = getenv("GEOAC_HYBRID_ROWS");
+    if(hr && atof(hr) > 0.0 && atof(hr) <= 1.0) ctx->hybrid_rows = atof(hr);
+    const char* ng = getenv("GEOAC_NO_GATE");
+    if(ng && atoi(ng) != 0) ctx->no_gate = true;
     const char* srt = getenv("GEOAC_SORT");
     if(srt) ctx->sort_rays = (atoi(srt) != 0);
     const char* nq = getenv("GEOAC_NO_QUAD");
@@ -194,9 +211,10 @@ int geoac_destroy(geoac_ctx* ctx){
     if(!ctx) return GEOAC_E_INVALID;
     hipSetDevice(ctx->device);
     if(ctx->stream) hipStreamSynchronize(ctx->stream);
-    DevBuf* bufs[] = { &ctx->seg, &ctx->rhot, &ctx->theta, &ctx->phi, &ctx->state, &ctx->rec, &ctx->counters,
-                       &ctx->path[0], &ctx->path[1], &ctx->contrib[0], &ctx->contrib[1], &ctx->nrows[0], &ctx->nrows[1],
-                       &ctx->legend[0], &ctx->legend[1], &ctx->nlegend[0], &ctx->nlegend[1],
+    DevBuf* bufs[] = { &ctx->seg, &ctx->rhot, &ctx->theta, &ctx->phi, &ctx->state, &ctx->rec, &ctx->counters, &ctx->perm,
+                       &ctx->path[0], &ctx->path[1], &ctx->path[2], &ctx->contrib[0], &ctx->contrib[1], &ctx->contrib[2],
+                       &ctx->nrows[0], &ctx->nrows[1], &ctx->nrows[2], &ctx->legend[0], &ctx->legend[1], &ctx->legend[2],
+                       &ctx->nlegend[0], &ctx->nlegend[1], &ctx->nlegend[2],
                        &ctx->ev_row[0], &ctx->ev_row[1], &ctx->ev_m[0], &ctx->ev_m[1], &ctx->ev_amp[0], &ctx->ev_amp[1],
                        &ctx->nev[0], &ctx->nev[1], &ctx->smp_out,
                        &ctx->d_gx, &ctx->d_gy, &ctx->d_gz, &ctx->d_gtab, &ctx->d_consts };
@@ -205,6 +223,8 @@ int geoac_destroy(geoac_ctx* ctx){
     if(ctx->ev0) hipEventDestroy(ctx->ev0);
     if(ctx->ev1) hipEventDestroy(ctx->ev1);
     for(hipEvent_t e : ctx->evs) hipEventDestroy(e);
+    for(hipEvent_t e : ctx->evj) hipEventDestroy(e);
+    if(ctx->rk4b_stream) hipStreamDestroy(ctx->rk4b_stream);
     if(ctx->pp_stream) hipStreamDestroy(ctx->pp_stream);
     if(ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -385,6 +405,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
         double rg = host_spline_f(ctx->x, ctx->rho, ctx->sl.data() + 3 * (size_t)ctx->n_nodes, p.z_grnd);
         double cg = sqrt(kGamR * Tg) * 1000.0;
         P.T_o = cg * cg / (kRgas * kGam);
+        P.cbrt_To = cbrt(P.T_o);
         P.P_o = rg * (cg * cg) / kGam * 1000.0;
         P.c000 = sqrt(kGamR * host_spline_f(ctx->x, ctx->T, ctx->sl.data(), 0.0));       // c(0,0,0), 3DStratified.cpp:367
         }
@@ -425,13 +446,6 @@ int geoac_fan_launch(geoac_ctx* ctx){
         }
         P.smp_out = (double*)ctx->smp_out.p;
     }
-    for(int b = 0; b < 2; b++){
-        HIPCHK(ctx->path[b].ensure(row_bytes * (size_t)P.s_rows));
-        HIPCHK(ctx->contrib[b].ensure(sizeof(double) * 2 * (size_t)P.n_pad * P.s_rows));
-        HIPCHK(ctx->nrows[b].ensure(sizeof(int) * (size_t)P.n_pad));
-        HIPCHK(ctx->nlegend[b].ensure(sizeof(int) * (size_t)P.n_pad));
-        HIPCHK(ctx->legend[b].ensure(sizeof(int) * (size_t)P.n_pad * GEOAC_MAXLEGS));
-    }
     HIPCHK(ctx->rec.ensure(sizeof(double) * (size_t)ctx->n_rays * ctx->legs * GEOAC_REC_STRIDE));
     HIPCHK(ctx->counters.ensure(8 * sizeof(unsigned long long)));
     P.seg = (const double*)ctx->seg.p; P.rho = (const double*)ctx->rhot.p;
@@ -448,6 +462,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
         P.seg_safe = (hmin >= 1.001 * ds_bound) ? 1 : 0;
     }
     P.pp_blocks = ctx->pp_blocks;
+    P.slot_lo = 0; P.slot_hi = P.n_pad;
     // two lanes per ray shorten the serial chain (x1.25) at twice the lanes: only worth it while the fan leaves SIMDs idle
     P.lanes_per_ray = (is_global && p.calc_amp && !sampling && !ctx->no_pair && (long long)P.n_pad * 2 / 64 <= 1024) ? 2 : 1;
     // grid sets, small fans: four lanes per ray (one cell corner each) while that still leaves one wave per SIMD
@@ -473,6 +488,30 @@ int geoac_fan_launch(geoac_ctx* ctx){
         if(ctx->spread_override > 0){ P.spread = 1; while(P.spread * 2 <= ctx->spread_override && P.spread < 64) P.spread *= 2; }
     }
 
+    // ---- hybrid fan (Global set, CalcAmp, inclination-sorted): the two-lane kernel shortens the serial chain of a ray by x1.25 but
+    //      doubles its lanes, and with one wave on every SIMD the post-pass (168 VGPRs beside 384) cannot run next to the RK4 waves at
+    //      all: the epochs then serialise RK4 and post-pass.  Only the longest rays set the finish time, and those are the shallow
+    //      ones (metric fan: 54 k steps at 0.5 deg, <= 37 k above 5 deg): so the lowest-inclination share of the sorted fan gets two
+    //      lanes, the rest one lane (a concurrent launch on a second stream with proportionally fewer rows per epoch so that both
+    //      finish an epoch together), and the CUs that stay free run the post-pass throughout. ----
+    int n_pair = 0;                                   // slots [0, n_pair): two lanes per ray; [n_pair, n_pad): one lane
+    const bool hybrid = (P.lanes_per_ray == 2 && !is_grid && ctx->have_perm && ctx->pair_frac < 1.0 && !ctx->no_overlap &&
+                         (long long)P.n_pad * 2 / 64 > 512);   // a fan that leaves half the SIMDs idle anyway keeps two lanes for every ray
+    if(hybrid){
+        n_pair = (int)(((long long)(ctx->pair_frac * ctx->n_rays) + 127) / 128 * 128);
+        if(n_pair >= P.n_pad) n_pair = P.n_pad;
+    }
+    const bool split = hybrid && n_pair < P.n_pad;
+    if(hybrid && n_pair == 0) P.lanes_per_ray = 1;
+    const int n_chunks = split ? 3 : 2;               // the post-pass of a hybrid fan may lag the RK4 by more than one epoch
+    for(int b = 0; b < n_chunks; b++){
+        HIPCHK(ctx->path[b].ensure(row_bytes * (size_t)P.s_rows));
+        HIPCHK(ctx->contrib[b].ensure(sizeof(double) * 2 * (size_t)P.n_pad * P.s_rows));
+        HIPCHK(ctx->nrows[b].ensure(sizeof(int) * (size_t)P.n_pad));
+        HIPCHK(ctx->nlegend[b].ensure(sizeof(int) * (size_t)P.n_pad));
+        HIPCHK(ctx->legend[b].ensure(sizeof(int) * (size_t)P.n_pad * GEOAC_MAXLEGS));
+    }
+
     // ---- epoch pipeline: RK4 of epoch e on the context's stream, post-pass of epoch e on a second stream, chunk
     //      buffers alternate, so k_rk4(e+1) runs beside k_postpass(e)/k_accum(e).  The host only waits for the
     //      live-ray count of each RK4 launch (it must know when to stop). ----
@@ -483,34 +522,69 @@ int geoac_fan_launch(geoac_ctx* ctx){
     ctx->n_epochs = 0; ctx->path_bytes_w = 0; ctx->path_bytes_r = 0;
     const long long max_epochs = (P.step_limit * (long long)ctx->legs) / (P.s_rows > 4 ? (P.s_rows - 3) : 1) + ctx->legs + 2;
     unsigned long long live = 1;
+    // post-pass of one epoch on the second stream; gate_expected > 0: only after that many RK4 workgroups of this fan are resident
+    auto enqueue_post = [&](const GeoacDevParams& Pq, size_t e, unsigned long long gate_expected) -> int {
+        HIPCHK(hipStreamWaitEvent(sp, ctx->evs[4 * e + 1], 0));
+        if(gate_expected > 0 && sp != s && !ctx->no_gate) HIPCHK(geoac_launch_gate(&Pq, gate_expected, sp));
+        HIPCHK(hipEventRecord(ctx->evs[4 * e + 2], sp));
+        HIPCHK(geoac_launch_postpass(&Pq, Pq.s_rows, sp));
+        HIPCHK(hipEventRecord(ctx->evs[4 * e + 3], sp));
+        return GEOAC_OK;
+    };
+    // RK4 workgroups that can be resident at once (k_rk4 runs one wave per SIMD; with the table in LDS one workgroup per CU)
+    const unsigned wg_room = P.table_in_lds ? 192u : (unsigned)(768 / (block / 64));
+    unsigned long long wg_seen = 0;                   // RK4 workgroups launched in the earlier epochs of this fan
+    GeoacDevParams Pprev = P; bool have_prev = false;
     while(live > 0){
         const size_t e = (size_t)ctx->n_epochs, eb = 4 * e;
-        const int b = (int)(e & 1);
+        const int b = (int)(e % (size_t)n_chunks);
         while(ctx->evs.size() < eb + 4){ hipEvent_t ev; HIPCHK(hipEventCreate(&ev)); ctx->evs.push_back(ev); }
+        while(ctx->evj.size() < e + 1){ hipEvent_t ev; HIPCHK(hipEventCreate(&ev)); ctx->evj.push_back(ev); }
         GeoacDevParams Pe = P;
         Pe.path = (double*)ctx->path[b].p; Pe.contrib = (double*)ctx->contrib[b].p;
         Pe.nrows = (int*)ctx->nrows[b].p; Pe.legend = (int*)ctx->legend[b].p; Pe.nlegend = (int*)ctx->nlegend[b].p;
         if(sampling){ Pe.ev_row = (int*)ctx->ev_row[b].p; Pe.ev_m = (int*)ctx->ev_m[b].p; Pe.ev_amp = (double*)ctx->ev_amp[b].p; Pe.nev = (int*)ctx->nev[b].p; }
-        if(e >= 2) HIPCHK(hipStreamWaitEvent(s, ctx->evs[4 * (e - 2) + 3], 0));      // chunk b free again?
+        if(e >= (size_t)n_chunks) HIPCHK(hipStreamWaitEvent(s, ctx->evs[4 * (e - n_chunks) + 3], 0));      // chunk b free again?
         HIPCHK(hipMemsetAsync((char*)ctx->counters.p + sizeof(unsigned long long), 0, sizeof(unsigned long long), s));
         HIPCHK(hipEventRecord(ctx->evs[eb], s));
-        HIPCHK(geoac_launch_rk4(&Pe, block, s));
+        unsigned n_wg = 0, n_wg1 = 0;
+        if(split){
+            GeoacDevParams P1 = Pe;                   // one lane per ray, fewer rows: on the second RK4 stream
+            P1.lanes_per_ray = 1; P1.slot_lo = n_pair; P1.slot_hi = P.n_pad;
+            P1.s_rows = std::max(8, (int)(ctx->hybrid_rows * P.s_rows));
+            HIPCHK(hipStreamWaitEvent(ctx->rk4b_stream, ctx->evs[eb], 0));
+            HIPCHK(geoac_launch_rk4(&P1, 256, ctx->rk4b_stream, &n_wg1));
+            HIPCHK(hipEventRecord(ctx->evj[e], ctx->rk4b_stream));
+            Pe.slot_lo = 0; Pe.slot_hi = n_pair;
+            HIPCHK(geoac_launch_rk4(&Pe, 256, s, &n_wg));
+            HIPCHK(hipStreamWaitEvent(s, ctx->evj[e], 0));
+            Pe.slot_hi = P.n_pad;
+        } else {
+            HIPCHK(geoac_launch_rk4(&Pe, block, s, &n_wg));
+        }
         HIPCHK(hipEventRecord(ctx->evs[eb + 1], s));
         HIPCHK(hipMemcpyAsync(ctx->h_counters, ctx->counters.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamWaitEvent(sp, ctx->evs[eb + 1], 0));
-        HIPCHK(hipEventRecord(ctx->evs[eb + 2], sp));
-        HIPCHK(geoac_launch_postpass(&Pe, Pe.s_rows, sp));
-        HIPCHK(hipEventRecord(ctx->evs[eb + 3], sp));
+        // the post-pass of the previous epoch goes behind this epoch's RK4 workgroups (see k_gate)
+        if(have_prev){ int rc = enqueue_post(Pprev, e - 1, wg_seen + std::min(n_wg + n_wg1, wg_room)); if(rc != GEOAC_OK) return rc; }
+        wg_seen += n_wg + n_wg1;
+        Pprev = Pe; have_prev = true;
         HIPCHK(hipStreamSynchronize(s));
         live = ctx->h_counters[1];
         ctx->n_epochs++;
         if((long long)ctx->n_epochs > max_epochs) return fail(ctx, GEOAC_E_CAPACITY, "fan_launch: epoch bound exceeded");
     }
+    { int rc = enqueue_post(Pprev, (size_t)ctx->n_epochs - 1, 0); if(rc != GEOAC_OK) return rc; }
     HIPCHK(hipStreamWaitEvent(s, ctx->evs[4 * (ctx->n_epochs - 1) + 3], 0));
     HIPCHK(hipEventRecord(ctx->ev1, s));
     HIPCHK(hipMemcpyAsync(ctx->h_counters + 4, ctx->counters.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     ctx->n_samples = ctx->h_counters[4 + 3];
+#ifdef GEOAC_DBG_CLOCK
+    HIPCHK(hipMemcpy(ctx->h_counters + 8, (char*)ctx->counters.p + 4 * sizeof(unsigned long long), 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[dbg clock] multi-lane launch: %llu shader ticks / %llu real ticks (100 MHz) = %.1f per real tick; one-lane launch: %llu / %llu = %.1f\n",
+            ctx->h_counters[8], ctx->h_counters[9], ctx->h_counters[9] ? (double)ctx->h_counters[8] / ctx->h_counters[9] : 0.0,
+            ctx->h_counters[10], ctx->h_counters[11], ctx->h_counters[11] ? (double)ctx->h_counters[10] / ctx->h_counters[11] : 0.0);
+#endif
     float ms = 0; hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->ms_total = ms;
     ctx->ms_rk4 = 0; ctx->ms_post = 0;

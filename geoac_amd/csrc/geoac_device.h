@@ -50,6 +50,7 @@ struct GeoacDevParams {
     int     nseg;                   // spline segments = nodes - 1
     int     s_rows;                 // path rows per epoch chunk
     int     table_in_lds;
+    int     slot_lo, slot_hi;       // k_rk4 integrates the ray slots [slot_lo, slot_hi) (a fan may be split over two concurrent launches)
     int     lanes_per_ray;          // 2: Global + CalcAmp without sample capture runs the two-lanes-per-ray kernel
     int     spread;                 // grid sets: only every spread-th lane of a wave carries a ray (power of two, 1..64): a small fan is
                                     // spread over more waves so that each divergent table gather touches fewer cache lines per instruction
@@ -65,6 +66,7 @@ struct GeoacDevParams {
     double  src[3];                 // as in geoac_params
     double  freq, tweak_abs;
     double  T_o, P_o;               // SuthBass reference temperature / pressure (ground), host-evaluated from the spline
+    double  cbrt_To;                // cbrt(T_o)
     double  c000;                   // c(0,0,0) used by the 3-D travel-time integral (Q5)
     double  src_trig[2];            // Global: sin, cos of the source latitude
     double  sb_const[5];            // 10^-0.67887, 10^-0.10744, 10^-3.3979, 5/sqrt(21), sqrt(3/7) (host libm, as the reference computes them)
@@ -78,7 +80,7 @@ struct GeoacDevParams {
     const double* gz;               // [nseg+1] node z (x_min / x_max hold the z range)
     const double* gtab;             // [4 fields][nseg][gnx*gny][12]: cubics of f, df/dx, df/dy per node and vertical segment
     double        xy_lim[4];        // x_min, x_max, y_min, y_max break limits (GeoAc.Parameters.RngDep.cpp:24-28)
-    double*       dev_consts;       // [0] T_o, [1] P_o of SuthBass evaluated on the device (RngDep: medium at (0, 0, z_grnd))
+    double*       dev_consts;       // [0] T_o, [1] P_o, [2] cbrt(T_o) of SuthBass evaluated on the device (RngDep: medium at (0, 0, z_grnd))
     const int*    perm;             // slot -> ray index of the caller's order (records and samples are written in the caller's order); NULL = identity
     const double* theta_deg;        // [n_rays]
     const double* phi_deg;

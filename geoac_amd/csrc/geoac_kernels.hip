@@ -307,13 +307,21 @@ DEVINL double global_amplitude(const GeoacDevParams& P, const Medium& m, const M
 // ------------------------------------------------------------------------------------------------
 // SuthBass_Alpha (Atmo_State.Absorption.Global.cpp:12-141 / Atmo_State.Absorption.cpp:14-143); zr = altitude above sea level
 // ------------------------------------------------------------------------------------------------
-DEVINL double suthbass_alpha(const GeoacDevParams& P, double zr, double c_snd, double rho, double freq, double T_o, double P_o){
+// square root of a non-negative number through the rsq seed (<= 1 ulp, not correctly rounded; 0 -> 0)
+DEVINL double fsqrt(double x){ double r = x * frsq(x); return (x > 0.0) ? r : 0.0; }
+
+// The ~35 divisions and most square roots of the reference expression go through frcp / frsq (<= 1 ulp each): this kernel runs at
+// half the FP64 vector peak, and an IEEE division costs three times an frcp.  Kept correctly rounded: sqrt(1 + nu^2), whose
+// difference to 1 the classical term takes (catastrophic cancellation in the reference itself - the last bit of that root is
+// worth 1e-6 of a_cl at 80 km).
+DEVINL double suthbass_alpha(const GeoacDevParams& P, double zr, double c_snd, double rho, double freq, double T_o, double P_o, double cbrt_To){
     const double mu_o = 18.192E-6, S = 117.0;
     double cm = c_snd * 1000.0;
-    double T_z = cm * cm / (kRgas * kGam);
-    double P_z = rho * (cm * cm) / kGam * 1000.0;
-    double mu = mu_o * sqrt(T_z / T_o) * ((1.0 + S / T_o) / (1.0 + S / T_z));
-    double nu = (8.0 * kPi * freq * mu) / (3.0 * P_z);
+    double T_z = cm * cm * (1.0 / (kRgas * kGam));
+    double P_z = rho * (cm * cm) * (1000.0 / kGam);
+    const double iTz = frcp(T_z), iTo = frcp(T_o);
+    double mu = mu_o * fsqrt(T_z * iTo) * ((1.0 + S * iTo) * frcp(1.0 + S * iTz));
+    double nu = (8.0 * kPi * freq * mu) * frcp(3.0 * P_z);
 
     double z2 = zr * zr, z3 = z2 * zr, z4 = z2 * z2, z5 = z4 * zr;
     double X0, X1, X2, X3, X4, X5, X6;
@@ -329,25 +337,27 @@ DEVINL double suthbass_alpha(const GeoacDevParams& P, double zr, double c_snd, d
     X5 = exp10(-53.746 + (1.5439 * zr) - (1.8824E-2 * z2) + (1.1587E-4 * z3) - (3.5399E-7 * z4) + (4.2609E-10 * z5));
     X6 = (zr > 30.) ? exp10(-4.2563 + (7.6245E-2 * zr) - (2.1824E-3 * z2) - (2.3010E-6 * z3) + (2.4265E-7 * z4) - (1.2500E-09 * z5))
                     : exp10(-1.7491 + (4.4986E-2 * zr) - (6.8549E-2 * z2) + (5.4639E-3 * z3) - (1.5539E-4 * z4) + (1.5063E-06 * z5));
-    double X_ON = (X0 + X1) / 0.9903;
+    double X_ON = (X0 + X1) * (1.0 / 0.9903);
 
     double rc = rcbrt(T_z);                                  // T_z^(-1/3)
     double Zr0 = 54.1 * exp(-17.3 * rc);
     double Zr1 = 63.3 * exp(-16.7 * rc);
-    double Z_rot_ = 1.0 / ((X1 / Zr1) + (X0 / Zr0));
+    double Z_rot_ = (Zr0 * Zr1) * frcp(__builtin_fma(X1, Zr0, X0 * Zr1));      // 1 / (X1/Zr1 + X0/Zr0)
 
     const double sigma = P.sb_const[3];                      // 5/sqrt(21)
     double nn = (4.0 / 5.0) * P.sb_const[4] * Z_rot_;         // sqrt(3/7)
-    double chi = 3.0 * nn * nu / 4.0;
+    double chi = 3.0 * nn * nu * 0.25;
     double cchi = 2.36 * chi;
 
-    double w0 = 2.0 * kPi * freq / c_snd;
-    double nu2 = nu * nu, sq = sqrt(1.0 + nu2);
-    double a_cl  = w0 * sqrt(0.5 * (sq - 1.0) * (1.0 + cchi * cchi) / ((1.0 + nu2) * (1.0 + (sigma * cchi) * (sigma * cchi))));
-    double a_rot = w0 * X_ON * ((sigma * sigma - 1.0) * chi / (2 * sigma)) * sqrt(0.5 * (sq + 1.0) / ((1.0 + nu2) * (1.0 + cchi * cchi)));
+    const double ic = frcp(c_snd);
+    double w0 = 2.0 * kPi * freq * ic;
+    double nu2 = nu * nu, sq = sqrt(1.0 + nu2);              // IEEE: see above
+    const double cc2 = cchi * cchi, sc2 = (sigma * cchi) * (sigma * cchi);
+    double a_cl  = w0 * fsqrt(0.5 * (sq - 1.0) * (1.0 + cc2) * frcp((1.0 + nu2) * (1.0 + sc2)));
+    double a_rot = w0 * X_ON * ((sigma * sigma - 1.0) * chi * frcp(2 * sigma)) * fsqrt(0.5 * (sq + 1.0) * frcp((1.0 + nu2) * (1.0 + cc2)));
     double a_diff = 0.003 * a_cl;
 
-    double Tr = cbrt(T_o / T_z) - 1.0;                       // (T_z/T_o)^(-1/3) - 1
+    double Tr = __builtin_fma(cbrt_To, rc, -1.0);            // (T_z/T_o)^(-1/3) - 1 = cbrt(T_o) T_z^(-1/3) - 1
     double A1 = (X0 + X1) * 24.0 * exp(-9.16 * Tr);
     double A2 = (X4 + X5) * 2400.0;
     double B  = 40400.0 * exp(10.0 * Tr);
@@ -363,20 +373,23 @@ DEVINL double suthbass_alpha(const GeoacDevParams& P, double zr, double c_snd, d
     double L  = exp(-7.72 * Tr);
     double ZZ = H * X2 + I * (X0 + 0.5 * X4) + J * (X1 + 0.5 * X5) + K * (X6 + X3);
     double hu = 100.0 * (X3 + X6);
-    double pm = (P_z / P_o) * (mu_o / mu);
+    double pm = (P_z * mu_o) * frcp(P_o * mu);
     double fv[4] = { pm * (A1 + A2 + B * hu * (C + hu) * (D + hu)), pm * (Ee + F * X3 + G * X6), pm * ZZ, pm * (1.2E5) * L };
     const double Theta[4] = { 2239.1, 3352.0, 915.0, 1037.0 };
     const double Cp_R[4] = { 3.5, 3.5, 4.0, 4.0 }, Cv_R[4] = { 2.5, 2.5, 3.0, 3.0 };
     double Xm[4] = { X0, X1, X2, X3 };
     double a_vib = 0.0;
+    const double f2x2 = 2 * (freq * freq);
     #pragma unroll
     for(int m = 0; m < 4; m++){
-        double q = Theta[m] / T_z;
+        double q = Theta[m] * iTz;
         double ex = exp(-q);
-        double C_R = ((q * q) * ex) / ((1 - ex) * (1 - ex));
-        double A_max = (Xm[m] * (kPi / 2) * C_R) / (Cp_R[m] * (Cv_R[m] + C_R));
-        double fr = freq / fv[m];
-        a_vib += (A_max / c_snd) * ((2 * (freq * freq) / fv[m]) / (1 + fr * fr));
+        double om = 1 - ex;
+        double C_R = ((q * q) * ex) * frcp(om * om);
+        double ifv = frcp(fv[m]);
+        double fr = freq * ifv;
+        // (A_max / c) (2 f^2 / f_vib) / (1 + (f/f_vib)^2),  A_max = X (pi/2) C_R / (Cp (Cv + C_R))
+        a_vib += (Xm[m] * (kPi / 2) * C_R) * (ic * f2x2 * ifv) * frcp((Cp_R[m] * (Cv_R[m] + C_R)) * __builtin_fma(fr, fr, 1.0));
     }
     return (a_cl + a_rot + a_diff + a_vib) * P.tweak_abs * 8.685889;
 }
@@ -594,19 +607,20 @@ template <bool AMP_> struct EqGlobal {
         double sn, cs; fsincos(t, sn, cs);
         double rdt = r * dt;
         double e1 = r * cs * dp, e2 = r * sn * dp;
-        double ds_tt = sqrt(dr * dr + rdt * rdt + e1 * e1);
-        double ds_at = sqrt(dr * dr + rdt * rdt + e2 * e2);
+        double ds_tt = fsqrt(dr * dr + rdt * rdt + e1 * e1);
+        double ds_at = fsqrt(dr * dr + rdt * rdt + e2 * e2);
         double n0 = an0 + (b[3 * np] - an0) / 2.0, n1 = an1 + (b[4 * np] - an1) / 2.0, n2 = an2 + (b[5 * np] - an2) / 2.0;
-        double nu_mag = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+        double inm = frsq(n0 * n0 + n1 * n1 + n2 * n2);               // 1 / |nu|
         double xe = clampd(r, P.x_min, P.x_max);
         int k = seg_guess(P.seg, P, xe);
         Atm9 m; seg_eval<false>(P.seg, k, xe, m);
-        double c = sqrt(kGamR * m.T);
+        double qT = kGamR * m.T;
+        double c = qT * frsq(qT);
         double rho = rho_eval(P, k, xe);
-        double cp0 = c * n0 / nu_mag, cp1 = c * n1 / nu_mag + m.v, cp2 = c * n2 / nu_mag + m.u;
-        double cpm = sqrt(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
-        tt = ds_tt / cpm;
-        at = suthbass_alpha(P, r - P.r_earth, c, rho, P.freq, P.T_o, P.P_o) * ds_at;
+        double cn = c * inm;
+        double cp0 = cn * n0, cp1 = cn * n1 + m.v, cp2 = cn * n2 + m.u;
+        tt = ds_tt * frsq(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
+        at = suthbass_alpha(P, r - P.r_earth, c, rho, P.freq, P.T_o, P.P_o, P.cbrt_To) * ds_at;
     }
 };
 
@@ -660,6 +674,7 @@ template <bool AMP_, int NL_ = 1> struct Eq3DRngDep {
         double cm = g.c * 1000.0;
         P.dev_consts[0] = cm * cm / (kRgas * kGam);
         P.dev_consts[1] = g.rho * (cm * cm) / kGam * 1000.0;
+        P.dev_consts[2] = cbrt(P.dev_consts[0]);
     }
     // GeoAc_SetInitialConditions: 3DRngDep.cpp:70-136
     static DEVINL void init(const GeoacDevParams& P, double th, double ph, double* y, RayCtx& C){
@@ -771,7 +786,7 @@ template <bool AMP_, int NL_ = 1> struct Eq3DRngDep {
         double cp0 = m.c * n0 / nmag + m.u, cp1 = m.c * n1 / nmag + m.v, cp2 = m.c * n2 / nmag;
         double cpm = sqrt(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
         tt = ds / cpm;
-        at = suthbass_alpha(P, z, m.c, m.rho, P.freq, P.dev_consts[0], P.dev_consts[1]) * ds;
+        at = suthbass_alpha(P, z, m.c, m.rho, P.freq, P.dev_consts[0], P.dev_consts[1], P.dev_consts[2]) * ds;
     }
 };
 
@@ -902,7 +917,7 @@ template <bool AMP_, int NL_ = 1> struct EqGlobalRngDep {
         double cm = g.c * 1000.0;
         double T_o = cm * cm / (kRgas * kGam);
         double P_o = g.rho * (cm * cm) / kGam * 1000.0;
-        at = suthbass_alpha(P, r - P.r_earth, m.c, m.rho, P.freq, T_o, P_o) * ds_at;
+        at = suthbass_alpha(P, r - P.r_earth, m.c, m.rho, P.freq, T_o, P_o, cbrt(T_o)) * ds_at;
     }
 };
 
@@ -1026,7 +1041,7 @@ template <bool AMP_> struct Eq3D {
         double cp0 = c * nx / nu_mag + m.u, cp1 = c * ny / nu_mag + m.v, cp2 = c * nz / nu_mag;
         double cpm = sqrt(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
         tt = ds / cpm;
-        at = suthbass_alpha(P, z, c, rho, P.freq, P.T_o, P.P_o) * ds;
+        at = suthbass_alpha(P, z, c, rho, P.freq, P.T_o, P.P_o, P.cbrt_To) * ds;
     }
 };
 
@@ -1112,7 +1127,7 @@ template <bool AMP_> struct Eq2D {
         double c = sqrt(kGamR * m.T);
         double rho = rho_eval(P, k, xe);
         tt = ds / (c + m.u * cph + m.v * sph);
-        at = suthbass_alpha(P, z, c, rho, P.freq, P.T_o, P.P_o) * ds;
+        at = suthbass_alpha(P, z, c, rho, P.freq, P.T_o, P.P_o, P.cbrt_To) * ds;
     }
 };
 
@@ -1169,6 +1184,7 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
     constexpr int E = EQ::E;
     __builtin_amdgcn_s_setprio(3);      // latency-critical serial recurrence: win VALU arbitration against co-resident post-pass waves
     extern __shared__ double lds_tab[];
+    if(threadIdx.x == 0) atomicAdd(&P.counters[5], 1ull);       // this workgroup holds its CU now: k_gate releases the previous epoch's post-pass
     // ---- stage the segment table in LDS (coalesced 8 B/lane loads; 153 KiB for ToyAtmo) ----
     const double* gtab = P.seg;
     if(LDS){
@@ -1176,12 +1192,15 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
         for(int q = threadIdx.x; q < total; q += blockDim.x) lds_tab[q] = gtab[q];
         __syncthreads();
     }
+#ifdef GEOAC_DBG_CLOCK
+    const unsigned long long dbg_m0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tid0 = blockIdx.x * blockDim.x + threadIdx.x;
     if(P.spread > 1 && (tid0 & (P.spread - 1))) return;         // sparse lanes (grid sets, small fans)
     const int tid = (P.spread > 1) ? tid0 / P.spread : tid0;
-    const int slot = tid / EQ::LANES;                           // ray slot
+    const int slot = P.slot_lo + tid / EQ::LANES;               // ray slot
     const int q = tid % EQ::LANES;                              // pair kernel: which derivative system this lane carries; quad kernels: which cell corner
-    if(slot >= P.n_pad) return;
+    if(slot >= P.slot_hi) return;
     const size_t np = (size_t)P.n_pad;
     double* st = P.state + slot;
 
@@ -1350,6 +1369,11 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
     if((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1){
         atomicAdd(&P.counters[0], s);
         atomicAdd(&P.counters[1], live);
+#ifdef GEOAC_DBG_CLOCK
+        const int o = (EQ::LANES == 1) ? 6 : 4;
+        atomicMax(&P.counters[o], __builtin_amdgcn_s_memtime() - dbg_m0);
+        atomicMax(&P.counters[o + 1], __builtin_amdgcn_s_memrealtime() - dbg_r0);
+#endif
     }
 }
 
@@ -1357,7 +1381,7 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
 // k_postpass: one thread per path segment (row i -> row i+1 of one ray)
 // ------------------------------------------------------------------------------------------------
 template <class EQ>
-__global__ void __launch_bounds__(256) k_postpass(GeoacDevParams P, int rows){
+__global__ void __launch_bounds__(256, 3) k_postpass(GeoacDevParams P, int rows){
     // grid-stride sweep over (segment row i, ray slot); by default the grid covers the sweep in one pass
     const size_t np = (size_t)P.n_pad;
     const int bx = (P.n_pad + 255) / 256;                       // slot-blocks per row
@@ -1489,10 +1513,12 @@ extern "C" hipError_t geoac_launch_init(const GeoacDevParams* P, hipStream_t s){
 }
 
 template <class EQ>
-static hipError_t launch_rk4_t(const GeoacDevParams* P, int block, hipStream_t s){
+static hipError_t launch_rk4_t(const GeoacDevParams* P, int block, hipStream_t s, unsigned* n_wg){
     if(block < 64 || block > 256 || (block % 64) != 0) return hipErrorInvalidValue;   // k_rk4 carries __launch_bounds__(256)
-    const long long lanes = (long long)P->n_pad * EQ::LANES * (P->spread > 1 ? P->spread : 1);
+    if(P->slot_lo < 0 || P->slot_hi > P->n_pad || P->slot_lo >= P->slot_hi) return hipErrorInvalidValue;
+    const long long lanes = (long long)(P->slot_hi - P->slot_lo) * EQ::LANES * (P->spread > 1 ? P->spread : 1);
     dim3 b(block), g((unsigned)((lanes + block - 1) / block));
+    if(n_wg) *n_wg = g.x;
     size_t lds = P->table_in_lds ? (size_t)P->nseg * GEOAC_SEGW * sizeof(double) : 0;
     const bool smp = (P->mode & (GEOAC_MODE_WRITE_RAYS | GEOAC_MODE_WRITE_CAUSTICS)) != 0;
     #define GEOAC_RK4_LAUNCH(LDSF, SMPF) do { \
@@ -1507,10 +1533,28 @@ static hipError_t launch_rk4_t(const GeoacDevParams* P, int block, hipStream_t s
     return hipGetLastError();
 }
 
-extern "C" hipError_t geoac_launch_rk4(const GeoacDevParams* P, int block, hipStream_t s){
-    if(P->lanes_per_ray == 2 && !P->gtab) return launch_rk4_t<EqGlobalPair>(P, block, s);
-    GEOAC_DISPATCH_EQ_RK4(P, return launch_rk4_t<EQ>(P, block, s));
+extern "C" hipError_t geoac_launch_rk4(const GeoacDevParams* P, int block, hipStream_t s, unsigned* n_wg){
+    if(P->lanes_per_ray == 2 && !P->gtab) return launch_rk4_t<EqGlobalPair>(P, block, s, n_wg);
+    GEOAC_DISPATCH_EQ_RK4(P, return launch_rk4_t<EQ>(P, block, s, n_wg));
     return hipErrorNotSupported;
+}
+
+// k_gate: holds a stream until `expected` RK4 workgroups (counted from the start of the fan) have become resident.  The post-pass of
+// epoch e-1 and the RK4 launch of epoch e become runnable at the same moment; the post-pass has thousands of short workgroups that
+// refill every CU as fast as they drain, and an RK4 workgroup (a whole CU: 153 KB of LDS, 4 x 384 registers) is then not placed before
+// the post-pass grid is exhausted - the epoch degenerates to post-pass followed by RK4.  With the gate the RK4 workgroups take their CUs
+// first and the post-pass fills what is left.  Bounded spin (~40 ms): the gate always exits, a late RK4 launch only costs the ordering.
+__global__ void __launch_bounds__(64) k_gate(const unsigned long long* counter, unsigned long long expected){
+    if(threadIdx.x != 0) return;
+    for(int it = 0; it < 20000; it++){
+        if(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= expected) break;
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+
+extern "C" hipError_t geoac_launch_gate(const GeoacDevParams* P, unsigned long long expected, hipStream_t s){
+    hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, s, (const unsigned long long*)(P->counters + 5), expected);
+    return hipGetLastError();
 }
 
 extern "C" hipError_t geoac_launch_postpass(const GeoacDevParams* P, int rows, hipStream_t s){
