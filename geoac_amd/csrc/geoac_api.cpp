@@ -66,7 +66,7 @@ struct geoac_ctx {
     DevBuf path[3], contrib[3], nrows[3], legend[3], nlegend[3];   // epoch chunks, two or three in rotation (RK4 of epoch e+1 overlaps the post-pass of e)
     hipStream_t pp_stream = nullptr;                                // post-pass stream
     hipStream_t rk4b_stream = nullptr;                              // second RK4 stream (hybrid fans: the one-lane launch)
-    std::vector<hipEvent_t> evj;                                    // per epoch: the second RK4 launch has finished
+    std::vector<hipEvent_t> evj;                                    // per epoch: [2e] the second RK4 launch has finished, [2e+1] live-ray count on the host
     DevBuf ev_row[3], ev_m[3], ev_amp[3], nev[3], smp_out;          // WriteRays / WriteCaustics events and the sample list
     long long smp_cap = 4ll << 20;                                  // sample records the device list can hold (GEOAC_SMP_CAP)
     unsigned long long n_samples = 0;
@@ -534,12 +534,14 @@ int geoac_fan_launch(geoac_ctx* ctx){
     // RK4 workgroups that can be resident at once (k_rk4 runs one wave per SIMD; with the table in LDS one workgroup per CU)
     const unsigned wg_room = P.table_in_lds ? 192u : (unsigned)(768 / (block / 64));
     unsigned long long wg_seen = 0;                   // RK4 workgroups launched in the earlier epochs of this fan
-    GeoacDevParams Pprev = P; bool have_prev = false;
-    while(live > 0){
-        const size_t e = (size_t)ctx->n_epochs, eb = 4 * e;
+    GeoacDevParams Pprev = P;
+    // The host never holds the GPU up between epochs: RK4(e) is enqueued BEFORE the live-ray count of epoch e-1 is read.  When that
+    // count turns out to be zero the extra launch has found only finished rays (its workgroups return before staging the table).
+    for(size_t e = 0; ; e++){
+        const size_t eb = 4 * e;
         const int b = (int)(e % (size_t)n_chunks);
         while(ctx->evs.size() < eb + 4){ hipEvent_t ev; HIPCHK(hipEventCreate(&ev)); ctx->evs.push_back(ev); }
-        while(ctx->evj.size() < e + 1){ hipEvent_t ev; HIPCHK(hipEventCreate(&ev)); ctx->evj.push_back(ev); }
+        while(ctx->evj.size() < 2 * e + 2){ hipEvent_t ev; HIPCHK(hipEventCreate(&ev)); ctx->evj.push_back(ev); }
         GeoacDevParams Pe = P;
         Pe.path = (double*)ctx->path[b].p; Pe.contrib = (double*)ctx->contrib[b].p;
         Pe.nrows = (int*)ctx->nrows[b].p; Pe.legend = (int*)ctx->legend[b].p; Pe.nlegend = (int*)ctx->nlegend[b].p;
@@ -554,36 +556,38 @@ int geoac_fan_launch(geoac_ctx* ctx){
             P1.s_rows = std::max(8, (int)(ctx->hybrid_rows * P.s_rows));
             HIPCHK(hipStreamWaitEvent(ctx->rk4b_stream, ctx->evs[eb], 0));
             HIPCHK(geoac_launch_rk4(&P1, 256, ctx->rk4b_stream, &n_wg1));
-            HIPCHK(hipEventRecord(ctx->evj[e], ctx->rk4b_stream));
+            HIPCHK(hipEventRecord(ctx->evj[2 * e], ctx->rk4b_stream));
             Pe.slot_lo = 0; Pe.slot_hi = n_pair;
             HIPCHK(geoac_launch_rk4(&Pe, 256, s, &n_wg));
-            HIPCHK(hipStreamWaitEvent(s, ctx->evj[e], 0));
+            HIPCHK(hipStreamWaitEvent(s, ctx->evj[2 * e], 0));
             Pe.slot_hi = P.n_pad;
         } else {
             HIPCHK(geoac_launch_rk4(&Pe, block, s, &n_wg));
         }
         HIPCHK(hipEventRecord(ctx->evs[eb + 1], s));
-        HIPCHK(hipMemcpyAsync(ctx->h_counters, ctx->counters.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(ctx->h_counters + 8 * (e & 1), ctx->counters.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipEventRecord(ctx->evj[2 * e + 1], s));
         // the post-pass of the previous epoch goes behind this epoch's RK4 workgroups (see k_gate)
-        if(have_prev){ int rc = enqueue_post(Pprev, e - 1, wg_seen + std::min(n_wg + n_wg1, wg_room)); if(rc != GEOAC_OK) return rc; }
+        if(e >= 1){ int rc = enqueue_post(Pprev, e - 1, wg_seen + std::min(n_wg + n_wg1, wg_room)); if(rc != GEOAC_OK) return rc; }
         wg_seen += n_wg + n_wg1;
-        Pprev = Pe; have_prev = true;
-        HIPCHK(hipStreamSynchronize(s));
-        live = ctx->h_counters[1];
-        ctx->n_epochs++;
-        if((long long)ctx->n_epochs > max_epochs) return fail(ctx, GEOAC_E_CAPACITY, "fan_launch: epoch bound exceeded");
+        Pprev = Pe;
+        if(e >= 1){
+            HIPCHK(hipEventSynchronize(ctx->evj[2 * (e - 1) + 1]));
+            live = ctx->h_counters[8 * ((e - 1) & 1) + 1];
+            if(live == 0){ ctx->n_epochs = e; break; }
+        }
+        if((long long)e > max_epochs) return fail(ctx, GEOAC_E_CAPACITY, "fan_launch: epoch bound exceeded");
     }
-    { int rc = enqueue_post(Pprev, (size_t)ctx->n_epochs - 1, 0); if(rc != GEOAC_OK) return rc; }
     HIPCHK(hipStreamWaitEvent(s, ctx->evs[4 * (ctx->n_epochs - 1) + 3], 0));
     HIPCHK(hipEventRecord(ctx->ev1, s));
     HIPCHK(hipMemcpyAsync(ctx->h_counters + 4, ctx->counters.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     ctx->n_samples = ctx->h_counters[4 + 3];
 #ifdef GEOAC_DBG_CLOCK
-    HIPCHK(hipMemcpy(ctx->h_counters + 8, (char*)ctx->counters.p + 4 * sizeof(unsigned long long), 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ctx->h_counters + 12, (char*)ctx->counters.p + 4 * sizeof(unsigned long long), 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     fprintf(stderr, "[dbg clock] multi-lane launch: %llu shader ticks / %llu real ticks (100 MHz) = %.1f per real tick; one-lane launch: %llu / %llu = %.1f\n",
-            ctx->h_counters[8], ctx->h_counters[9], ctx->h_counters[9] ? (double)ctx->h_counters[8] / ctx->h_counters[9] : 0.0,
-            ctx->h_counters[10], ctx->h_counters[11], ctx->h_counters[11] ? (double)ctx->h_counters[10] / ctx->h_counters[11] : 0.0);
+            ctx->h_counters[12], ctx->h_counters[13], ctx->h_counters[13] ? (double)ctx->h_counters[12] / ctx->h_counters[13] : 0.0,
+            ctx->h_counters[14], ctx->h_counters[15], ctx->h_counters[15] ? (double)ctx->h_counters[14] / ctx->h_counters[15] : 0.0);
 #endif
     float ms = 0; hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->ms_total = ms;

@@ -1185,6 +1185,18 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
     __builtin_amdgcn_s_setprio(3);      // latency-critical serial recurrence: win VALU arbitration against co-resident post-pass waves
     extern __shared__ double lds_tab[];
     if(threadIdx.x == 0) atomicAdd(&P.counters[5], 1ull);       // this workgroup holds its CU now: k_gate releases the previous epoch's post-pass
+    const int tid0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tid = (P.spread > 1) ? tid0 / P.spread : tid0;
+    const int slot = P.slot_lo + tid / EQ::LANES;               // ray slot
+    const int q = tid % EQ::LANES;                              // pair kernel: which derivative system this lane carries; quad kernels: which cell corner
+    const bool mine = !(P.spread > 1 && (tid0 & (P.spread - 1))) && slot < P.slot_hi;   // spread > 1: sparse lanes (grid sets, small fans)
+    const size_t np = (size_t)P.n_pad;
+    double* st = P.state + (mine ? slot : 0);
+    bool done = mine ? (st[ST_DONE * np] != 0.0) : true;
+    if(mine && done){ P.nrows[slot] = 0; P.nlegend[slot] = 0; if(SMP) P.nev[slot] = 0; }
+    // a workgroup whose rays have all finished leaves before the table is staged (late epochs, and the launch the host
+    // enqueues ahead of knowing that the previous epoch finished the fan)
+    if(!__syncthreads_or(!done)) return;
     // ---- stage the segment table in LDS (coalesced 8 B/lane loads; 153 KiB for ToyAtmo) ----
     const double* gtab = P.seg;
     if(LDS){
@@ -1195,19 +1207,9 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
 #ifdef GEOAC_DBG_CLOCK
     const unsigned long long dbg_m0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    const int tid0 = blockIdx.x * blockDim.x + threadIdx.x;
-    if(P.spread > 1 && (tid0 & (P.spread - 1))) return;         // sparse lanes (grid sets, small fans)
-    const int tid = (P.spread > 1) ? tid0 / P.spread : tid0;
-    const int slot = P.slot_lo + tid / EQ::LANES;               // ray slot
-    const int q = tid % EQ::LANES;                              // pair kernel: which derivative system this lane carries; quad kernels: which cell corner
-    if(slot >= P.slot_hi) return;
-    const size_t np = (size_t)P.n_pad;
-    double* st = P.state + slot;
+    if(done) return;
 
     int nr = 0, nle = 0;
-    bool done = st[ST_DONE * np] != 0.0;
-    if(done){ P.nrows[slot] = 0; P.nlegend[slot] = 0; if(SMP) P.nev[slot] = 0; return; }
-
     static_assert(E <= ST_K - ST_Y0, "state block: y[] overruns ST_K");
     static_assert(!EQ::KM2 || ST_YM2 + E <= ST_DPREV, "state block: ym2[] overruns ST_DPREV");
     double y[E], ym2[EQ::KM2 ? E : 1];
