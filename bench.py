@@ -169,8 +169,10 @@ def main():
     local_steps_per_pass = ctx.total_steps()
     if rank == 0:
         value = total_steps / dt
-        # dominant kernel = k_rk4<EqGlobalPair,...>: algorithmic bytes per launch / average launch duration (HIP events on the
-        # kernel's own stream, recorded inside libgeoac_hip around every k_rk4 launch of the timed passes)
+        # dominant kernel = k_rk4: algorithmic bytes per launch / average launch duration (HIP events on the kernel's own stream,
+        # recorded inside libgeoac_hip around every k_rk4 epoch of the timed passes).  One epoch of this fan is TWO concurrent k_rk4
+        # launches of the same duration by construction (the shallow tenth of the rays on k_rk4<EqGlobalPair>, the rest on
+        # k_rk4<EqGlobal<true>> with 0.75 x the rows); "launch" below = that pair, bytes and steps are those of both.
         ach_gbs = (B_ALG_PER_STEP * local_steps_per_pass * args.steps) / (rk4_ms * 1e-3) / 1e9 if rk4_ms > 0 else 0.0
         bps, pmc_src = pmc_traffic_per_step()
         steps_per_launch = local_steps_per_pass * args.steps / max(rk4_launches, 1)
@@ -187,7 +189,7 @@ def main():
                          "frac": ach_gbs / HBM_PEAK_GBS,
                          "traffic": (bps * steps_per_launch) if bps else None, "traffic_unit": "bytes per launch",
                          "traffic_source": pmc_src, "achieved_bytes_per_launch": B_ALG_PER_STEP * steps_per_launch,
-                         "kernel": "k_rk4<EqGlobalPair,true,false>", "launches": rk4_launches,
+                         "kernel": "k_rk4<EqGlobalPair,true,false> || k_rk4<EqGlobal<true>,true,false> (one epoch)", "launches": rk4_launches,
                          "avg_launch_ms": rk4_ms / max(rk4_launches, 1),
                          "alg_bytes_per_step": B_ALG_PER_STEP,
                          "rk4_ms_per_pass": rk4_ms / args.steps, "postpass_ms_per_pass": post_ms / args.steps},

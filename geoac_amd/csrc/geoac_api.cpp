@@ -17,6 +17,7 @@
 extern "C" void geoac_natural_spline_slopes(int n, const double* x, const double* f, double* slopes);
 extern "C" hipError_t geoac_launch_init(const GeoacDevParams* P, hipStream_t s);
 extern "C" hipError_t geoac_launch_rk4(const GeoacDevParams* P, int block, hipStream_t s, unsigned* n_wg);
+extern "C" hipError_t geoac_launch_accum(const GeoacDevParams* P, hipStream_t s);
 extern "C" hipError_t geoac_launch_gate(const GeoacDevParams* P, unsigned long long expected, hipStream_t s);
 extern "C" hipError_t geoac_launch_postpass(const GeoacDevParams* P, int rows, hipStream_t s);
 
@@ -65,6 +66,8 @@ struct geoac_ctx {
     DevBuf seg, rhot, theta, phi, state, rec, counters;
     DevBuf path[3], contrib[3], nrows[3], legend[3], nlegend[3];   // epoch chunks, two or three in rotation (RK4 of epoch e+1 overlaps the post-pass of e)
     hipStream_t pp_stream = nullptr;                                // post-pass stream
+    hipStream_t acc_stream = nullptr;                               // k_accum stream
+    std::vector<hipEvent_t> evp;                                    // per epoch: k_postpass has finished (k_accum may start)
     hipStream_t rk4b_stream = nullptr;                              // second RK4 stream (hybrid fans: the one-lane launch)
     std::vector<hipEvent_t> evj;                                    // per epoch: [2e] the second RK4 launch has finished, [2e+1] live-ray count on the host
     DevBuf ev_row[3], ev_m[3], ev_amp[3], nev[3], smp_out;          // WriteRays / WriteCaustics events and the sample list
@@ -173,6 +176,7 @@ int geoac_create(geoac_ctx** out, int eqset, int device){
     if(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_hi) != hipSuccess){ delete ctx; return GEOAC_E_HIP; }
     ctx->own_stream = true;
     if(hipStreamCreateWithPriority(&ctx->pp_stream, hipStreamNonBlocking, prio_lo) != hipSuccess){ delete ctx; return GEOAC_E_HIP; }
+    if(hipStreamCreateWithPriority(&ctx->acc_stream, hipStreamNonBlocking, prio_lo) != hipSuccess){ delete ctx; return GEOAC_E_HIP; }
     if(hipStreamCreateWithPriority(&ctx->rk4b_stream, hipStreamNonBlocking, prio_hi) != hipSuccess){ delete ctx; return GEOAC_E_HIP; }
     hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
     if(hipHostMalloc((void**)&ctx->h_counters, 16 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess){
@@ -224,6 +228,8 @@ int geoac_destroy(geoac_ctx* ctx){
     if(ctx->ev1) hipEventDestroy(ctx->ev1);
     for(hipEvent_t e : ctx->evs) hipEventDestroy(e);
     for(hipEvent_t e : ctx->evj) hipEventDestroy(e);
+    for(hipEvent_t e : ctx->evp) hipEventDestroy(e);
+    if(ctx->acc_stream) hipStreamDestroy(ctx->acc_stream);
     if(ctx->rk4b_stream) hipStreamDestroy(ctx->rk4b_stream);
     if(ctx->pp_stream) hipStreamDestroy(ctx->pp_stream);
     if(ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
@@ -515,7 +521,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
     // ---- epoch pipeline: RK4 of epoch e on the context's stream, post-pass of epoch e on a second stream, chunk
     //      buffers alternate, so k_rk4(e+1) runs beside k_postpass(e)/k_accum(e).  The host only waits for the
     //      live-ray count of each RK4 launch (it must know when to stop). ----
-    hipStream_t s = ctx->stream, sp = ctx->no_overlap ? ctx->stream : ctx->pp_stream;
+    hipStream_t s = ctx->stream, sp = ctx->no_overlap ? ctx->stream : ctx->pp_stream, sa = ctx->no_overlap ? ctx->stream : ctx->acc_stream;
     HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 8 * sizeof(unsigned long long), s));
     HIPCHK(hipEventRecord(ctx->ev0, s));
     HIPCHK(geoac_launch_init(&P, s));
@@ -528,7 +534,15 @@ int geoac_fan_launch(geoac_ctx* ctx){
         if(gate_expected > 0 && sp != s && !ctx->no_gate) HIPCHK(geoac_launch_gate(&Pq, gate_expected, sp));
         HIPCHK(hipEventRecord(ctx->evs[4 * e + 2], sp));
         HIPCHK(geoac_launch_postpass(&Pq, Pq.s_rows, sp));
-        HIPCHK(hipEventRecord(ctx->evs[4 * e + 3], sp));
+        // the per-ray running sums (one thread per ray, latency-bound, 106 VGPRs: fits beside an RK4 wave) on their own stream, in
+        // epoch order, so that the next epoch's post-pass does not queue behind them
+        if(sa != sp){
+            while(ctx->evp.size() < e + 1){ hipEvent_t ev; HIPCHK(hipEventCreate(&ev)); ctx->evp.push_back(ev); }
+            HIPCHK(hipEventRecord(ctx->evp[e], sp));
+            HIPCHK(hipStreamWaitEvent(sa, ctx->evp[e], 0));
+        }
+        HIPCHK(geoac_launch_accum(&Pq, sa));
+        HIPCHK(hipEventRecord(ctx->evs[4 * e + 3], sa));
         return GEOAC_OK;
     };
     // RK4 workgroups that can be resident at once (k_rk4 runs one wave per SIMD; with the table in LDS one workgroup per CU)

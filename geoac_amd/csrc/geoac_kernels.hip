@@ -1568,7 +1568,11 @@ extern "C" hipError_t geoac_launch_postpass(const GeoacDevParams* P, int rows, h
     int nb = (int)nbl;
     dim3 b(256), g(nb);
     GEOAC_DISPATCH_EQ(P, hipLaunchKernelGGL(k_postpass<EQ>, g, b, 0, s, *P, rows));
-    dim3 g2((P->n_rays + 255) / 256);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t geoac_launch_accum(const GeoacDevParams* P, hipStream_t s){
+    dim3 b(256), g2((P->n_rays + 255) / 256);
     hipLaunchKernelGGL(k_accum, g2, b, 0, s, *P);
     return hipGetLastError();
 }
