@@ -14,8 +14,8 @@ const double kREarth = 6370.0;     // G2S_GlobalSpline1D.cpp:35
 
 bool is_global(int eqset){ return eqset == GEOAC_EQ_GLOBAL || eqset == GEOAC_EQ_GLOBAL_RNGDEP; }
 
-// wind taper towards the ground + m/s -> km/s (G2S_Spline1D.cpp:122-124); z_grnd is 0 when the mains load the profile
-double taper(double z){ return (2.0 / (1.0 + exp(-(z - 0.0) / 0.2)) - 1.0) / 1000.0; }
+// wind taper towards the ground + m/s -> km/s (G2S_Spline1D.cpp:122-124); z_grnd is 0 when the -prop mains load the profile
+double taper(double z, double z_grnd){ return (2.0 / (1.0 + exp(-(z - z_grnd) / 0.2)) - 1.0) / 1000.0; }
 }
 
 extern "C" {
@@ -32,14 +32,20 @@ int geoac_met_rows(const char* file){
 int geoac_met_from_columns(int eqset, int n, const double* z, const double* T, const double* u_ms,
                            const double* v_ms, const double* rho_in,
                            double* x, double* T_out, double* u, double* v, double* rho){
+    return geoac_met_from_columns_zg(eqset, 0.0, n, z, T, u_ms, v_ms, rho_in, x, T_out, u, v, rho);
+}
+
+int geoac_met_from_columns_zg(int eqset, double z_grnd, int n, const double* z, const double* T, const double* u_ms,
+                              const double* v_ms, const double* rho_in,
+                              double* x, double* T_out, double* u, double* v, double* rho){
     for(int i = 0; i < n; i++){
         double xi = z[i];
         double w;
         if(is_global(eqset)){
             xi += kREarth;                           // G2S_GlobalSpline1D.cpp:128
-            w = taper(xi - kREarth);                 // :129 evaluates (r - r_earth - z_grnd)
+            w = taper(xi - kREarth, z_grnd);         // :129 evaluates (r - r_earth - z_grnd)
         } else {
-            w = taper(xi);
+            w = taper(xi, z_grnd);
         }
         x[i] = xi; T_out[i] = T[i]; rho[i] = rho_in[i];
         u[i] = u_ms[i] * w;
@@ -50,6 +56,11 @@ int geoac_met_from_columns(int eqset, int n, const double* z, const double* T, c
 
 int geoac_met_load(const char* file, const char* format, int eqset, int cap,
                    double* x, double* T, double* u, double* v, double* rho){
+    return geoac_met_load_zg(file, format, eqset, 0.0, cap, x, T, u, v, rho);
+}
+
+int geoac_met_load_zg(const char* file, const char* format, int eqset, double z_grnd, int cap,
+                      double* x, double* T, double* u, double* v, double* rho){
     int fmt;
     if(strncmp(format, "zTuvdp", 6) == 0) fmt = 0;
     else if(strncmp(format, "zuvwTdp", 7) == 0) fmt = 1;
@@ -68,7 +79,7 @@ int geoac_met_load(const char* file, const char* format, int eqset, int cap,
         else        { z[i] = t[0]; uc[i] = t[1]; vc[i] = t[2]; Tc[i] = t[4]; rc[i] = t[5]; }
     }
     fclose(fp);
-    return geoac_met_from_columns(eqset, rows, z.data(), Tc.data(), uc.data(), vc.data(), rc.data(), x, T, u, v, rho);
+    return geoac_met_from_columns_zg(eqset, z_grnd, rows, z.data(), Tc.data(), uc.data(), vc.data(), rc.data(), x, T, u, v, rho);
 }
 
 int geoac_grid_dims(const char* prefix, const char* locx, const char* locy, int* nx, int* ny, int* nz){

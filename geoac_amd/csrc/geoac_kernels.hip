@@ -1236,7 +1236,9 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
 
     while(nr + 2 <= P.s_rows && !done){
         // running turning height: max over rows m < k of the height component   (GeoAcGlobal_main.cpp:294)
-        { double h = EQ::height(P, y); if(EQ::HMAX_PER_LEG && k == 0) hmax = 0.0; hmax = (hmax < h) ? h : hmax; }
+        if(EQ::PW == 2 && (P.mode & GEOAC_MODE_INTERACTIVE)){         // GeoAc2D -interactive: max over rows 1..k-1 of solution[m][2] (nu_z)
+            if(k >= 1) hmax = (hmax < y[2]) ? y[2] : hmax;
+        } else { double h = EQ::height(P, y); if(EQ::HMAX_PER_LEG && k == 0) hmax = 0.0; hmax = (hmax < h) ? h : hmax; }
 
         if(SMP && k >= 1){
             // y is row m = k (1 <= m < k_final) at chunk row nr-1: the rows the reference's post-pass loop visits

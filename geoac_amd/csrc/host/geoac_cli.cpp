@@ -47,9 +47,9 @@ static bool string2bool(const string& v){          // GeoAc.Interface.cpp:125-12
 }
 
 static void usage(){
-    cout << '\n' << "Usage: " << kName << (kRngS ? " -prop profile_prefix loc_lat.dat loc_lon.dat [parameter=value ...]" : kRng ? " -prop profile_prefix loc_x.dat loc_y.dat [parameter=value ...]" : " -prop profile.met [parameter=value ...]") << '\n'
-         << "  GPU (MI355X) build of the " << kName << " launch-angle fan; parameters, defaults and output files follow" << '\n'
-         << "  LANL-Seismoacoustics/GeoAc (see GeoAc_Manual.pdf).  Only the -prop option is provided by this build." << '\n' << '\n';
+    cout << '\n' << "Usage: " << kName << " [option] " << (kRngS ? "profile_prefix loc_lat.dat loc_lon.dat [parameter=value ...]" : kRng ? "profile_prefix loc_x.dat loc_y.dat [parameter=value ...]" : "profile.met [parameter=value ...]") << '\n'
+         << "  GPU (MI355X) build of " << kName << "; options, parameters, defaults and output files follow" << '\n'
+         << "  LANL-Seismoacoustics/GeoAc (see GeoAc_Manual.pdf): -prop, -interactive" << (kEq != GEOAC_EQ_2D ? ", -eig_search, -eig_direct" : "") << '.' << '\n' << '\n';
 }
 
 // host evaluation of the profile splines for atmo.dat only (set-up / reporting code, not the ray path)
@@ -391,6 +391,266 @@ static int run_prop(char* inputs[], int count){
     return 0;
 }
 
+// ---- -interactive (GeoAc2D_main.cpp:239-372, GeoAc3D_main.cpp:315-456, GeoAcGlobal_main.cpp:334-492, GeoAc3D.RngDep_main.cpp:336-496,
+//      GeoAcGlobal.RngDep_main.cpp:345-516): one ray per prompt through the same fan backend (a fan of one ray, WriteRays form of the
+//      sums); prompts, raypath.dat / caustics.dat and the arrival summary as the reference prints them ----
+static int run_interactive(char* inputs[], int count){
+    double src_a = 0.0, src_b = 0.0, z_src = 0.0;
+    if(kEq == GEOAC_EQ_GLOBAL){ src_a = 30.0; src_b = 0.0; }
+    double freq = 0.1;
+    bool CalcAmp = true, WriteCaustics = false;
+    const char* ProfileFormat = "zTuvdp";
+    double z_grnd = 0.0, tweak_abs = 0.3;
+    char input_check;
+    const int arg0 = kRng ? 5 : 3;
+
+    Profile prof;
+    Grid grid;
+    auto load_grid = [&](double z_taper) -> int {
+        if(geoac_grid_dims(inputs[2], inputs[3], inputs[4], &grid.nx, &grid.ny, &grid.nz)){ cout << "Error opening file, check file name" << '\n'; return 1; }
+        const size_t nn = (size_t)grid.nx * grid.ny * grid.nz;
+        grid.x.resize(grid.nx); grid.y.resize(grid.ny); grid.z.resize(grid.nz);
+        grid.T.resize(nn); grid.u.resize(nn); grid.v.resize(nn); grid.rho.resize(nn);
+        int lrc = geoac_grid_load_eq(kEq, inputs[2], inputs[3], inputs[4], ProfileFormat, z_taper, grid.nx, grid.ny, grid.nz, grid.x.data(), grid.y.data(), grid.z.data(),
+                                     grid.T.data(), grid.u.data(), grid.v.data(), grid.rho.data());
+        if(lrc == -2){ cout << "Unrecognized profile option: " << ProfileFormat << ".  Valid options are: zTuvdp and zuvwTdp" << '\n'; return 1; }
+        if(lrc){ cout << "Error opening file, check file name" << '\n'; return 1; }
+        return 0;
+    };
+    auto load_profile = [&](double z_taper) -> int {
+        prof.n = geoac_met_rows(inputs[2]);
+        if(prof.n < 3){ cout << "Error opening file, check file name" << '\n'; return 1; }
+        prof.x.resize(prof.n); prof.T.resize(prof.n); prof.u.resize(prof.n); prof.v.resize(prof.n); prof.rho.resize(prof.n);
+        prof.sl.resize(4 * (size_t)prof.n);
+        if(geoac_met_load_zg(inputs[2], ProfileFormat, kEq, z_taper, prof.n, prof.x.data(), prof.T.data(), prof.u.data(), prof.v.data(), prof.rho.data()) != prof.n){
+            cout << "Unrecognized profile option: " << ProfileFormat << ".  Valid options are: zTuvdp and zuvwTdp" << '\n';
+            return 1;
+        }
+        geoac_natural_spline_slopes(prof.n, prof.x.data(), prof.T.data(),   &prof.sl[0]);
+        geoac_natural_spline_slopes(prof.n, prof.x.data(), prof.u.data(),   &prof.sl[prof.n]);
+        geoac_natural_spline_slopes(prof.n, prof.x.data(), prof.v.data(),   &prof.sl[2 * (size_t)prof.n]);
+        geoac_natural_spline_slopes(prof.n, prof.x.data(), prof.rho.data(), &prof.sl[3 * (size_t)prof.n]);
+        return 0;
+    };
+
+    geoac_params P;
+    geoac_default_params(kEq, &P);
+
+    if(kRngS){
+        // spherical grid main: profile_format= and z_grnd= are picked up first, then the grid is loaded (taper on the parsed z_grnd) and
+        // the default source put at the centre of the grid (GeoAcGlobal.RngDep_main.cpp:350-361)
+        for(int i = arg0; i < count; i++){
+            if(strncmp(inputs[i], "profile_format=", 15) == 0) ProfileFormat = inputs[i] + 15;
+            else if(strncmp(inputs[i], "z_grnd=", 7) == 0) z_grnd = atof(inputs[i] + 7);
+        }
+        if(load_grid(z_grnd)) return 1;
+        src_a = (grid.x[0] + grid.x[(size_t)grid.nx - 1]) / 2.0 * 180.0 / Pi;
+        src_b = (grid.y[0] + grid.y[(size_t)grid.ny - 1]) / 2.0 * 180.0 / Pi;
+    } else if(!kRng){
+        for(int i = arg0; i < count; i++) if(strncmp(inputs[i], "profile_format=", 15) == 0) ProfileFormat = inputs[i] + 15;
+        if(load_profile(0.0)) return 1;                              // loaded before z_grnd= is parsed (Q9)
+        P.vert_limit = prof.x[prof.n - 1];                           // GeoAc_SetPropRegion
+    }
+
+    for(int i = arg0; i < count; i++){
+        const char* a = inputs[i];
+        if(kSph && strncmp(a, "lat_src=", 8) == 0){ src_a = atof(a + 8); }
+        else if(kSph && strncmp(a, "lon_src=", 8) == 0){ src_b = atof(a + 8); }
+        else if(kRngC && strncmp(a, "x_src=", 6) == 0){ src_a = atof(a + 6); }
+        else if(kRngC && strncmp(a, "y_src=", 6) == 0){ src_b = atof(a + 6); }
+        else if(strncmp(a, "z_src=", 6) == 0){ z_src = atof(a + 6); }
+        else if(strncmp(a, "freq=", 5) == 0){ freq = atof(a + 5); }
+        else if(strncmp(a, "abs_coeff=", 10) == 0){ tweak_abs = max(0.0, atof(a + 10)); }
+        else if(strncmp(a, "z_grnd=", 7) == 0){ z_grnd = atof(a + 7); }
+        else if(strncmp(a, "profile_format=", 15) == 0){ ProfileFormat = a + 15; }
+        else if(strncmp(a, "WriteCaustics=", 14) == 0){ WriteCaustics = string2bool(a + 14); }
+        else if(strncmp(a, "CalcAmp=", 8) == 0){ CalcAmp = string2bool(a + 8); }
+        else if(strncmp(a, "alt_max=", 8) == 0){ P.vert_limit = atof(a + 8); }
+        else if(!kRng && strncmp(a, "rng_max=", 8) == 0){ P.range_limit = atof(a + 8); }
+        else if(kRngC && (strncmp(a, "x_min=", 6) == 0 || strncmp(a, "x_max=", 6) == 0 || strncmp(a, "y_min=", 6) == 0 || strncmp(a, "y_max=", 6) == 0)){ }
+        else if(kRngS && strncmp(a, "lat_min=", 8) == 0){ P.xy_limits[0] = atof(a + 8); }
+        else if(kRngS && strncmp(a, "lat_max=", 8) == 0){ P.xy_limits[1] = atof(a + 8); }
+        else if(kRngS && strncmp(a, "lon_min=", 8) == 0){ P.xy_limits[2] = atof(a + 8); }
+        else if(kRngS && strncmp(a, "lon_max=", 8) == 0){ P.xy_limits[3] = atof(a + 8); }
+        else {
+            cout << "***WARNING*** Unrecognized parameter entry: " << a << '\n';
+            cout << "Continue? (y/n):"; cin >> input_check;
+            if(input_check != 'y' && input_check != 'Y') return 0;
+        }
+    }
+    z_src = max(z_src, z_grnd);
+    if(WriteCaustics) CalcAmp = true;
+    if(kEq == GEOAC_EQ_GLOBAL){
+        // GeoAcGlobal loads the profile a SECOND time here (GeoAcGlobal_main.cpp:367): the taper now sees the parsed z_grnd, and
+        // GeoAc_SetPropRegion inside the loader puts alt_max / rng_max back to the profile top / 1500 km
+        if(load_profile(z_grnd)) return 1;
+        geoac_params D; geoac_default_params(kEq, &D);
+        P.vert_limit = prof.x[prof.n - 1]; P.range_limit = D.range_limit;
+    }
+    if(kRngC){
+        // parsed first, loaded after, GeoAc_SetPropRegion then overwrites alt_max and the box (GeoAc3D.RngDep_main.cpp:370-372)
+        if(load_grid(z_grnd)) return 1;
+        geoac_params D; geoac_default_params(kEq, &D);
+        P.vert_limit = D.vert_limit;
+    }
+    // the range-dependent mains integrate the auxiliary equations whatever CalcAmp says (GeoAc_ConfigureCalcAmp(true)); CalcAmp
+    // then only selects what is printed
+    const bool amp_eqs = kRng ? true : CalcAmp;
+
+    geoac_ctx* ctx = nullptr;
+    int rc = geoac_create(&ctx, kEq, 0);
+    if(rc){ cout << kName << ": " << geoac_strerror(rc) << '\n'; return 2; }
+    if(kRng) rc = geoac_upload_atmo_3d(ctx, grid.nx, grid.ny, grid.nz, grid.x.data(), grid.y.data(), grid.z.data(), grid.T.data(), grid.u.data(), grid.v.data(), grid.rho.data());
+    else     rc = geoac_upload_atmo_1d(ctx, prof.n, prof.x.data(), prof.T.data(), prof.u.data(), prof.v.data(), prof.rho.data(), prof.sl.data());
+    if(rc){ cout << kName << ": " << geoac_last_error(ctx) << '\n'; return 2; }
+    P.z_grnd = z_grnd; P.tweak_abs = tweak_abs; P.freq = freq; P.calc_amp = amp_eqs ? 1 : 0;
+    P.mode = GEOAC_MODE_WRITE_RAYS | GEOAC_MODE_INTERACTIVE | (WriteCaustics ? GEOAC_MODE_WRITE_CAUSTICS : 0);
+    P.sample_stride = (kEq == GEOAC_EQ_3D || kRngS) ? 10 : 25;       // GeoAc3D_main.cpp:407, GeoAcGlobal.RngDep_main.cpp:462
+    if(kSph){ P.src[0] = z_src; P.src[1] = src_a; P.src[2] = src_b; }
+    else if(kEq == GEOAC_EQ_3D){ P.src[0] = 0.0; P.src[1] = 0.0; P.src[2] = z_src; }
+    else if(kRngC){ P.src[0] = src_a; P.src[1] = src_b; P.src[2] = z_src; }
+    else { P.src[0] = z_src; P.src[1] = 0.0; P.src[2] = 0.0; }
+
+    double theta = 0.0, phi = 0.0;
+    int bounces = 0;
+    char keepgoing = 'y';
+    ofstream raypath, caustics;                                       // one stream object each for the whole session: a setprecision sticks
+    uint64_t steps_total = 0;
+    long n_rays = 0;
+    const double r_earth = 6370.0;
+
+    while(keepgoing == 'y' || keepgoing == 'Y'){
+        raypath.open("raypath.dat");
+        if(kEq == GEOAC_EQ_GLOBAL)      raypath << "# z [km]" << '\t' << "lat [deg]" << '\t' << "lon [deg]";
+        else if(kRngS)                  raypath << "# z [km]" << '\t' << "Lat [deg]" << '\t' << "Long [deg]";
+        else if(kCart3)                 raypath << "# x [km]" << '\t' << "y [km]" << '\t' << "z [km]";
+        else                            raypath << "# r [km]" << '\t' << "z [km]";
+        raypath << '\t' << "Geo. Atten. [dB]" << '\t' << "Atmo. Atten. [dB]" << '\t' << "Travel Time [s]" << '\n';
+        if(WriteCaustics){
+            caustics.open("caustics.dat");
+            if(kEq == GEOAC_EQ_GLOBAL)  caustics << "# z [km]" << '\t' << "lat [deg]" << '\t' << "lon [deg]";
+            else if(kEq == GEOAC_EQ_2D) caustics << "# r [km]" << '\t' << "z [km]";
+            else                        caustics << "# x [km]" << '\t' << "y [km]" << '\t' << "z [km]";     // also the spherical grid main (:432-435)
+            caustics << '\t' << "Travel Time [s]" << '\n';
+        }
+
+        cout << '\t' << "Enter inclination angle [degrees]: ";  cin >> theta;
+        cout << '\t' << "Enter azimuth angle [degrees]: ";      cin >> phi;
+        cout << '\t' << "Enter number of bounces: ";            cin >> bounces;
+        if(!cin){ raypath.close(); if(WriteCaustics) caustics.close(); break; }      // end of input: leave (the reference would spin on its last answer)
+        cout << '\n';
+        cout << '\t' << "Plotting ray path w/ theta = " << theta << ", phi = " << phi << '\n';
+
+        if(bounces < 0) bounces = 0;
+        P.bounces = bounces;
+        rc = geoac_set_params(ctx, &P);
+        if(rc){ cout << kName << ": " << geoac_last_error(ctx) << '\n'; geoac_destroy(ctx); return 2; }
+        const int legs = bounces + 1;
+        vector<double> rec((size_t)legs * GEOAC_REC_STRIDE, 0.0);
+        uint64_t steps = 0;
+        rc = geoac_fan_run(ctx, 1, &theta, &phi, rec.data(), &steps);
+        if(rc){ cout << kName << ": " << geoac_last_error(ctx) << '\n'; geoac_destroy(ctx); return 2; }
+        steps_total += steps; n_rays++;
+        int64_t ns = 0;
+        geoac_fan_sample_count(ctx, &ns);
+        vector<double> smp((size_t)max<int64_t>(ns, 1) * GEOAC_SMP_STRIDE);
+        if(ns > 0 && geoac_fan_fetch_samples(ctx, smp.data(), ns)){ cout << kName << ": " << geoac_last_error(ctx) << '\n'; geoac_destroy(ctx); return 2; }
+
+        for(int64_t q = 0; q < ns; q++){
+            const double* S = &smp[(size_t)q * GEOAC_SMP_STRIDE];
+            const int kind = (int)S[GEOAC_SMP_KIND];
+            const double* v = S + GEOAC_SMP_V0;
+            if(kind == 0){
+                const double geo = CalcAmp ? v[kCart3 || kSph ? 3 : 2] : 0.0;
+                if(kSph){
+                    raypath << v[0];
+                    raypath << '\t' << setprecision(8) << v[1];
+                    raypath << '\t' << setprecision(8) << v[2];
+                    raypath << '\t' << geo << '\t' << v[4] << '\t' << v[5] << '\n';
+                } else if(kCart3){
+                    raypath << v[0] << '\t' << v[1] << '\t' << v[2] << '\t' << geo << '\t' << v[4] << '\t' << v[5] << '\n';
+                } else {
+                    raypath << v[0] << '\t' << v[1] << '\t' << geo << '\t' << v[3] << '\t' << v[4] << '\n';
+                }
+            } else if(WriteCaustics){
+                if(kEq == GEOAC_EQ_GLOBAL){                          // latitude twice, blank line after each (GeoAcGlobal_main.cpp:451-457)
+                    caustics << v[0];
+                    caustics << '\t' << setprecision(8) << v[1];
+                    caustics << '\t' << setprecision(8) << v[1];
+                    caustics << '\t' << v[3] << '\n';
+                    caustics << '\n';
+                } else if(kRngS){                                    // raw radius and radians, max(lon, 0) (GeoAcGlobal.RngDep_main.cpp:472-478)
+                    caustics << v[0] + r_earth;
+                    caustics << '\t' << v[1] * Pi / 180.0;
+                    caustics << '\t' << max(v[2] * Pi / 180.0, 0.0);
+                    caustics << '\t' << v[3] << '\n';
+                    caustics << '\n';
+                } else if(kRngC){
+                    caustics << v[0] << '\t' << v[1] << '\t' << max(v[2], 0.0) << '\t' << v[4] << '\n';
+                } else if(kEq == GEOAC_EQ_3D){
+                    caustics << v[0] << '\t' << v[1] << '\t' << v[2] << '\t' << v[3] << '\n';
+                } else {
+                    caustics << v[0] << '\t' << v[1] << '\t' << v[2] << '\n';
+                }
+            }
+        }
+
+        // arrival summary from the record of the last leg (solution[k] of the last propagation)
+        bool broke = false;
+        double z_max = 0.0;
+        for(int b = 0; b < legs; b++){
+            const double* R = &rec[(size_t)b * GEOAC_REC_STRIDE];
+            if(R[GEOAC_REC_VALID] == 0.0){ broke = true; break; }
+            z_max = max(z_max, R[GEOAC_REC_TURN]);
+        }
+        const double* R = &rec[(size_t)(legs - 1) * GEOAC_REC_STRIDE];
+        const double* yk = R + GEOAC_REC_STATE;
+        if(broke){
+            if(kRngS) cout << '\t' << '\t' << "Ray path does not return to the ground " << '\n' << '\n';
+            else      cout << '\t' << '\t' << "Ray path does not return to the ground." << '\n' << '\n';
+        } else if(kSph){
+            const double lat0 = src_a * Pi / 180.0, lon0 = src_b * Pi / 180.0;
+            const double arg1 = sin(yk[2] - lon0);
+            const double arg2 = cos(lat0) * tan(yk[1]) - sin(lat0) * cos(yk[2] - lon0);
+            const double bearing = atan2(arg1, arg2) * 180.0 / Pi;
+            cout << '\t' << '\t' << "Ray path arrived at " << yk[1] * 180.0 / Pi << " degrees latitude, " << yk[2] * 180.0 / Pi << " degrees longitude." << '\n';
+            cout << '\t' << '\t' << "Arrival range = " << R[GEOAC_REC_RANGE] << " km at azimuth " << bearing << " degrees from N." << '\n';
+            if(CalcAmp) cout << '\t' << '\t' << "Geometric attenuation = " << 20.0 * log10(R[GEOAC_REC_AMP]) << " dB." << '\n';
+            cout << '\t' << '\t' << "Atmospheric attenuation = " << -R[GEOAC_REC_ATTEN] << " dB." << '\n';
+            cout << '\t' << '\t' << "Arrival celerity = " << R[GEOAC_REC_RANGE] / R[GEOAC_REC_TTIME] << "km/sec." << '\n';
+            cout << '\t' << '\t' << "Back azimuth of the arrival = " << R[GEOAC_REC_BACKAZ] << " degrees from N. " << '\n' << '\n';
+        } else if(kCart3){
+            const double range = sqrt(yk[0] * yk[0] + yk[1] * yk[1]);
+            double back_az;
+            if(kRngC) back_az = R[GEOAC_REC_BACKAZ];
+            else { back_az = phi - 180.0; while(back_az < -180.0) back_az += 360.0; while(back_az > 180.0) back_az -= 360.0; }
+            cout << '\t' << '\t' << "Ray path arrived at " << yk[0] << " km E-W, " << yk[1] << " km N-S." << '\n';
+            cout << '\t' << '\t' << "Arrival range = " << range << " km at azimuth " << atan2(yk[1], yk[0]) * 180.0 / Pi << " degrees from N." << '\n';
+            if(CalcAmp) cout << '\t' << '\t' << "Geometric attenuation = " << 20.0 * log10(R[GEOAC_REC_AMP]) << " dB." << '\n';
+            cout << '\t' << '\t' << "Atmospheric attenuation = " << -R[GEOAC_REC_ATTEN] << " dB." << '\n';
+            cout << '\t' << '\t' << "Arrival celerity = " << range / R[GEOAC_REC_TTIME] << " km/sec." << '\n';
+            cout << '\t' << '\t' << "Turning height of the ray = " << z_max << " km." << '\n';
+            cout << '\t' << '\t' << "Back azimuth of the arrival = " << back_az << " degrees (relative to N). " << '\n' << '\n';
+        } else {
+            cout << '\t' << '\t' << "Arrival Range = " << yk[0] << '\n';
+            if(CalcAmp) cout << '\t' << '\t' << "Geometric Attenuation = " << 20.0 * log10(R[GEOAC_REC_AMP]) << " dB." << '\n';
+            cout << '\t' << '\t' << "Atmospheric Attenuation = " << -R[GEOAC_REC_ATTEN] << " dB." << '\n';
+            cout << '\t' << '\t' << "Turning Height = " << z_max << "km." << '\n';
+            cout << '\t' << '\t' << "Travel Time = " << R[GEOAC_REC_TTIME] << "sec." << '\n';
+            cout << '\t' << '\t' << "Arrival Celerity = " << yk[0] / R[GEOAC_REC_TTIME] << "km/sec." << '\n' << '\n';
+        }
+
+        raypath.close();
+        if(WriteCaustics) caustics.close();
+
+        cout << "Continue plotting other ray paths? (y/n): ";
+        if(!(cin >> keepgoing)) break;
+    }
+    geoac_destroy(ctx);
+    cerr << kName << ": " << n_rays << " rays, " << steps_total << " RK4 ray-steps on the GPU" << '\n';
+    return 0;
+}
+
 // ---- -eig_search / -eig_direct (GeoAcGlobal_main.cpp:496-660, GeoAcGlobal.RngDep_main.cpp:518-693, GeoAc3D_main.cpp:458-610,
 //      GeoAc3D.RngDep_main.cpp:497-670); the searches themselves are geoac_eig_search / geoac_eig_direct ----
 static int run_eig(char* inputs[], int count, bool direct){
@@ -587,7 +847,8 @@ int main(int argc, char* argv[]){
     if(strncmp(argv[1], "-prop", 5) == 0) return run_prop(argv, argc);
     if(kEq != GEOAC_EQ_2D && strncmp(argv[1], "-eig_search", 11) == 0) return run_eig(argv, argc, false);
     if(kEq != GEOAC_EQ_2D && strncmp(argv[1], "-eig_direct", 11) == 0) return run_eig(argv, argc, true);
-    if(strncmp(argv[1], "-interactive", 12) == 0 || strncmp(argv[1], "-eig_search", 11) == 0 || strncmp(argv[1], "-eig_direct", 11) == 0){
+    if(strncmp(argv[1], "-interactive", 12) == 0) return run_interactive(argv, argc);
+    if(strncmp(argv[1], "-eig_search", 11) == 0 || strncmp(argv[1], "-eig_direct", 11) == 0){
         cout << kName << ": option " << argv[1] << " is not part of this GPU build." << '\n';
         return 3;
     }

@@ -81,6 +81,8 @@ enum {
 /* ---- mode bits ---- */
 #define GEOAC_MODE_WRITE_RAYS      1   /* WriteRays=True: post-pass sums segments 0..k-2 (GeoAcGlobal_main.cpp:264-267), samples kept */
 #define GEOAC_MODE_WRITE_CAUSTICS  2   /* WriteCaustics=True (forces CalcAmp, GeoAcGlobal_main.cpp:166) */
+#define GEOAC_MODE_INTERACTIVE     4   /* bookkeeping of the -interactive loops: GeoAc2D's "turning height" there is the running maximum of
+                                          solution[m][2] = nu_z over rows 1..k-1 (GeoAc2D_main.cpp:332), reported in GEOAC_REC_TURN */
 
 /* ---- parameters: the reference's globals (GeoAc.Parameters*.cpp) and *_RunProp locals ---- */
 typedef struct {

@@ -22,6 +22,14 @@ int  geoac_met_rows(const char* file);
 int  geoac_met_load(const char* file, const char* format, int eqset, int cap,
                     double* x, double* T, double* u, double* v, double* rho);
 
+/* the same with the taper centred on z_grnd: GeoAcGlobal -interactive loads the profile a second time AFTER parsing z_grnd=
+ * (GeoAcGlobal_main.cpp:367), the only stratified entry point where z_grnd reaches the taper (Q9) */
+int  geoac_met_load_zg(const char* file, const char* format, int eqset, double z_grnd, int cap,
+                       double* x, double* T, double* u, double* v, double* rho);
+int  geoac_met_from_columns_zg(int eqset, double z_grnd, int n, const double* z, const double* T, const double* u_ms,
+                               const double* v_ms, const double* rho_in,
+                               double* x, double* T_out, double* u, double* v, double* rho);
+
 /* the same transformation applied to columns already in memory (z [km], T [K], u,v [m/s], rho) */
 int  geoac_met_from_columns(int eqset, int n, const double* z, const double* T, const double* u_ms,
                             const double* v_ms, const double* rho_in,

@@ -39,6 +39,51 @@ EIG_CASES = {
 }
 
 
+# -interactive sessions: (binary, args, stdin).  Two rays each (the second shows the sticky stream precision); the files are those
+# left by the LAST ray of the session, LOG.txt is the whole stdout (prompts and arrival summaries).
+IA_CASES = {
+    "ia_global": ("GeoAcGlobal", ["WriteCaustics=True", "lat_src=35", "lon_src=-100", "z_grnd=0.3", "rng_max=400", "freq=0.5"],
+                  "12.5\n-75\n1\ny\n31\n40\n0\nn\n"),
+    "ia_3d": ("GeoAc3D", ["WriteCaustics=True", "z_src=0.4", "abs_coeff=0.5"], "10\n-60\n1\ny\n44\n135\n2\nn\n"),
+    "ia_2d": ("GeoAc2D", ["WriteCaustics=True", "freq=0.2"], "6\n-80\n2\ny\n25\n70\n0\nn\n"),
+    "ia_3drd": ("GeoAc3D.RngDep", ["WriteCaustics=True", "x_src=50", "y_src=-30", "z_src=0.5", "CalcAmp=False"], "12\n-80\n1\ny\n28\n45\n0\nn\n"),
+    "ia_globalrd": ("GeoAcGlobal.RngDep", ["WriteCaustics=True", "z_src=0.5", "lon_src=1.25", "z_grnd=0.2"], "11\n-85\n1\ny\n27\n60\n0\nn\n"),
+}
+
+
+def main_ia(only):
+    for name, (binary, args, stdin) in IA_CASES.items():
+        if only and name not in only:
+            continue
+        out = os.path.join(HERE, "cli", name)
+        shutil.rmtree(out, ignore_errors=True)
+        os.makedirs(out)
+        with tempfile.TemporaryDirectory() as td:
+            if binary == "GeoAcGlobal.RngDep":
+                import rngdep_data as RD
+                RD.write_grid_global(td)
+                inputs = ["g", "loc_lat.dat", "loc_lon.dat"]
+            elif binary == "GeoAc3D.RngDep":
+                import rngdep_data as RD
+                RD.write_grid(td)
+                inputs = ["p", "loc_x.dat", "loc_y.dat"]
+            else:
+                shutil.copy(os.path.join(HERE, "ToyAtmo.met"), os.path.join(td, "ToyAtmo.met"))
+                inputs = ["ToyAtmo.met"]
+            r = subprocess.run([os.path.join(REF, binary), "-interactive"] + inputs + args, cwd=td, check=True, stdout=subprocess.PIPE,
+                               input=stdin.encode(), timeout=600)
+            with open(os.path.join(out, "LOG.txt"), "wb") as fh:
+                fh.write(r.stdout)
+            for f in ("raypath.dat", "caustics.dat"):
+                if os.path.exists(os.path.join(td, f)):
+                    shutil.copy(os.path.join(td, f), os.path.join(out, f))
+        with open(os.path.join(out, "ARGS"), "w") as fh:
+            fh.write(binary + "\n-interactive\n" + "\n".join(args) + "\n")
+        with open(os.path.join(out, "STDIN"), "w") as fh:
+            fh.write(stdin)
+        print(name, sorted(os.listdir(out)), sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)) // 1024, "KiB")
+
+
 def main_eig(only):
     for name, (binary, opt, args) in EIG_CASES.items():
         if only and name not in only:
@@ -73,8 +118,11 @@ def main():
     only = sys.argv[1:]
     if only and all(o.startswith("eig") for o in only):
         return main_eig(only)
+    if only and all(o.startswith("ia_") for o in only):
+        return main_ia(only)
     if not only:
         main_eig(only)
+        main_ia(only)
     for name, (binary, args) in CASES.items():
         if only and name not in only:
             continue

@@ -70,3 +70,50 @@ def test_cli_files_match_reference_binaries(case, tmp_path):
         same += s; tot += t
     print(f"{case}: {same}/{tot} tokens textually identical")
     assert same >= 0.995 * tot
+
+
+_NUM = __import__("re").compile(r"[-+]?(?:\d+\.?\d*|\.\d+)(?:[eE][-+]?\d+)?")
+
+
+def _compare_text(got, want, what):
+    """prompts / summaries: the text between the numbers must be identical, the numbers equal to the printed precision"""
+    assert _NUM.sub("#", got) == _NUM.sub("#", want), f"{what}: text differs\n--- got\n{got}\n--- want\n{want}"
+    gn, wn = _NUM.findall(got), _NUM.findall(want)
+    same = 0
+    for a, b in zip(gn, wn):
+        same += (a == b)
+        assert _tokens_close(a, b), f"{what}: {a!r} vs {b!r}"
+    return same, len(wn)
+
+
+@pytest.mark.parametrize("case", ["ia_global", "ia_3d", "ia_2d", "ia_3drd", "ia_globalrd"])
+def test_cli_interactive_matches_reference_binaries(case, tmp_path):
+    """-interactive sessions (two rays each): stdout (prompts, arrival summaries) and the raypath.dat / caustics.dat left by the last ray
+    against the reference binaries' (tests/golden/make_golden_cli.py: IA_CASES)"""
+    gold = os.path.join(CLI_GOLD, case)
+    args = open(os.path.join(gold, "ARGS")).read().split()
+    binary, opt, params = args[0], args[1], args[2:]
+    stdin = open(os.path.join(gold, "STDIN")).read()
+    exe = os.path.join(BIN, binary)
+    if not os.path.exists(exe):
+        import __graft_entry__
+        __graft_entry__.build()
+    if binary == "GeoAcGlobal.RngDep":
+        import rngdep_data as RD
+        RD.write_grid_global(str(tmp_path), short_paths=False)
+        inputs = ["g", "loc_lat.dat", "loc_lon.dat"]
+    elif binary.endswith("RngDep"):
+        import rngdep_data as RD
+        RD.write_grid(str(tmp_path), short_paths=False)
+        inputs = ["p", "loc_x.dat", "loc_y.dat"]
+    else:
+        shutil.copy(H.TOYATMO, tmp_path / "ToyAtmo.met")
+        inputs = ["ToyAtmo.met"]
+    r = subprocess.run([exe, opt] + inputs + params, cwd=tmp_path, check=True, stdout=subprocess.PIPE, input=stdin.encode(), timeout=600)
+    same, tot = _compare_text(r.stdout.decode(), open(os.path.join(gold, "LOG.txt")).read(), "stdout")
+    for f in ("raypath.dat", "caustics.dat"):
+        assert os.path.exists(tmp_path / f), f
+        s, t = _compare_files(tmp_path / f, os.path.join(gold, f))
+        same += s; tot += t
+    print(f"{case}: {same}/{tot} numbers textually identical")
+    assert same >= 0.99 * tot
