@@ -9,7 +9,7 @@ import numpy as np
 EQ_2D, EQ_3D, EQ_GLOBAL, EQ_3D_RNGDEP, EQ_GLOBAL_RNGDEP = 0, 1, 2, 3, 4
 REC_STRIDE = 32
 REC = dict(VALID=0, STEPS=1, BROKE=2, TTIME=3, ATTEN=4, TURN=5, INCL=6, BACKAZ=7, AMP=8, RANGE=9, JACOB=10, STATE=12)
-MODE_WRITE_RAYS, MODE_WRITE_CAUSTICS = 1, 2
+MODE_WRITE_RAYS, MODE_WRITE_CAUSTICS, MODE_INTERACTIVE = 1, 2, 4
 
 _dp = ctypes.POINTER(ctypes.c_double)
 
