@@ -159,6 +159,15 @@ class FanContext:
         """grid of profiles: fields [nx][ny][nz] (winds already tapered, km/s)"""
         x, y, z, T, u, v, rho = (_arr(a) for a in (x, y, z, T, u, v, rho))
         self._chk(self.lib.geoac_upload_atmo_3d(self._h, len(x), len(y), len(z), _p(x), _p(y), _p(z), _p(T), _p(u), _p(v), _p(rho)))
+        self._grid_dims = (len(x), len(y), len(z))
+
+    def grid_table(self):
+        """the evaluation table the last upload_atmo_3d built on the device (layout of geoac_grid_table_eq)"""
+        self.lib.geoac_grid_table_size.restype = ctypes.c_size_t
+        n = self.lib.geoac_grid_table_size(*self._grid_dims)
+        tab = np.zeros(n)
+        self._chk(self.lib.geoac_grid_table_fetch(self._h, _p(tab), ctypes.c_size_t(n)))
+        return tab
 
     def load_grid(self, prefix, locx, locy, fmt="zTuvdp", z_grnd=0.0):
         """Spline_Multi_G2S equivalent: <prefix><n>.met files + loc_x / loc_y node files"""

@@ -17,6 +17,9 @@
 extern "C" void geoac_natural_spline_slopes(int n, const double* x, const double* f, double* slopes);
 extern "C" hipError_t geoac_launch_init(const GeoacDevParams* P, hipStream_t s);
 extern "C" hipError_t geoac_launch_rk4(const GeoacDevParams* P, int block, hipStream_t s, unsigned* n_wg);
+extern "C" size_t geoac_gridbuild_work_doubles(int nx, int ny, int nz);
+extern "C" hipError_t geoac_gridbuild_launch(int glob, int nx, int ny, int nz, const double* d_x, const double* d_y, const double* d_z,
+                                             const double* d_fields, double* d_work, double* d_tab, hipStream_t s);
 extern "C" hipError_t geoac_launch_accum(const GeoacDevParams* P, hipStream_t s);
 extern "C" hipError_t geoac_launch_gate(const GeoacDevParams* P, unsigned long long expected, hipStream_t s);
 extern "C" hipError_t geoac_launch_postpass(const GeoacDevParams* P, int rows, hipStream_t s);
@@ -284,17 +287,37 @@ int geoac_upload_atmo_3d(geoac_ctx* ctx, int nx, int ny, int nz, const double* x
     for(int i = 1; i < ny; i++) if(!(y[i] > y[i - 1])) return fail(ctx, GEOAC_E_INVALID, "upload_atmo_3d: y not strictly increasing");
     for(int i = 1; i < nz; i++) if(!(z[i] > z[i - 1])) return fail(ctx, GEOAC_E_INVALID, "upload_atmo_3d: z not strictly increasing");
     HIPCHK(hipSetDevice(ctx->device));
-    // device table (geoac_rngdep.h) built on the host: vertical cubics of the node values and of the node-centred differences
-    std::vector<double> tab(geoac_grid_table_size(nx, ny, nz));
-    geoac_grid_table_eq(ctx->eqset, nx, ny, nz, x, y, z, T, u, v, rho, tab.data());
+    const size_t tab_n = geoac_grid_table_size(nx, ny, nz), nn = (size_t)nx * ny;
     HIPCHK(ctx->d_gx.ensure(sizeof(double) * nx)); HIPCHK(ctx->d_gy.ensure(sizeof(double) * ny)); HIPCHK(ctx->d_gz.ensure(sizeof(double) * nz));
-    HIPCHK(ctx->d_gtab.ensure(sizeof(double) * tab.size()));
+    HIPCHK(ctx->d_gtab.ensure(sizeof(double) * tab_n));
     HIPCHK(ctx->d_consts.ensure(sizeof(double) * 8));
     HIPCHK(hipMemcpyAsync(ctx->d_gx.p, x, sizeof(double) * nx, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_gy.p, y, sizeof(double) * ny, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_gz.p, z, sizeof(double) * nz, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_gtab.p, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const char* gb = getenv("GEOAC_GRID_BUILD");
+    if(gb && strcmp(gb, "host") == 0){
+        // the host builder (geoac_host.cpp), kept as the checker of the device builder and for A/B timing
+        std::vector<double> tab(tab_n);
+        geoac_grid_table_eq(ctx->eqset, nx, ny, nz, x, y, z, T, u, v, rho, tab.data());
+        HIPCHK(hipMemcpyAsync(ctx->d_gtab.p, tab.data(), sizeof(double) * tab_n, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    } else {
+        // device table (geoac_rngdep.h) built on the device (geoac_gridbuild.hip): 12 vertical spline systems per node + expansion;
+        // only the raw fields cross PCIe (32 B per grid point instead of 1 120 B of table per point)
+        DevBuf fields, work;
+        HIPCHK(fields.ensure(sizeof(double) * 4 * nn * nz));
+        hipError_t we = work.ensure(sizeof(double) * geoac_gridbuild_work_doubles(nx, ny, nz));
+        if(we != hipSuccess){ fields.release(); return hipfail(ctx, we, "grid table scratch"); }
+        const double* F[4] = { T, u, v, rho };
+        hipError_t e = hipSuccess;
+        for(int f = 0; f < 4 && e == hipSuccess; f++)
+            e = hipMemcpyAsync((double*)fields.p + (size_t)f * nn * nz, F[f], sizeof(double) * nn * nz, hipMemcpyHostToDevice, ctx->stream);
+        if(e == hipSuccess) e = geoac_gridbuild_launch(ctx->eqset == GEOAC_EQ_GLOBAL_RNGDEP ? 1 : 0, nx, ny, nz, (const double*)ctx->d_gx.p, (const double*)ctx->d_gy.p,
+                                                       (const double*)ctx->d_gz.p, (const double*)fields.p, (double*)work.p, (double*)ctx->d_gtab.p, ctx->stream);
+        if(e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        fields.release(); work.release();
+        if(e != hipSuccess) return hipfail(ctx, e, "grid table build");
+    }
     ctx->gnx = nx; ctx->gny = ny; ctx->n_nodes = nz;
     ctx->gx.assign(x, x + nx); ctx->gy.assign(y, y + ny); ctx->x.assign(z, z + nz);
     // GeoAc_SetPropRegion (G2S_MultiDimSpline3D.cpp:25-33)
@@ -302,6 +325,16 @@ int geoac_upload_atmo_3d(geoac_ctx* ctx, int nx, int ny, int nz, const double* x
     const double ext[4] = { x[0], x[nx - 1], y[0], y[ny - 1] };
     for(int q = 0; q < 4; q++) if(!(ctx->prm.xy_limits[q] == ctx->prm.xy_limits[q])) ctx->prm.xy_limits[q] = ext[q];
     ctx->have_grid = true; ctx->have_atmo = true;
+    return GEOAC_OK;
+}
+
+int geoac_grid_table_fetch(geoac_ctx* ctx, double* tab, size_t cap){
+    if(!ctx || !tab) return GEOAC_E_INVALID;
+    if(!ctx->have_grid) return fail(ctx, GEOAC_E_INVALID, "grid_table_fetch: no grid atmosphere uploaded");
+    const size_t n = geoac_grid_table_size(ctx->gnx, ctx->gny, ctx->n_nodes);
+    if(cap < n) return fail(ctx, GEOAC_E_CAPACITY, "grid_table_fetch: buffer too small");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpy(tab, ctx->d_gtab.p, sizeof(double) * n, hipMemcpyDeviceToHost));
     return GEOAC_OK;
 }
 

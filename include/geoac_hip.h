@@ -129,6 +129,9 @@ int  geoac_upload_atmo_1d(geoac_ctx* ctx, int n, const double* x, const double* 
  * radius [km]; xy_limits of geoac_params then hold GeoAc_lat_min/lat_max/lon_min/lon_max_limit [rad]. */
 int  geoac_upload_atmo_3d(geoac_ctx* ctx, int nx, int ny, int nz, const double* x, const double* y, const double* z,
                           const double* T, const double* u, const double* v, const double* rho);
+/* the evaluation table the upload built on the device (geoac_grid_table_size(nx, ny, nz) doubles, layout of geoac_grid_table_eq in
+ * geoac_host.h, which is the host restatement of the same construction): set-up check / diagnostics */
+int  geoac_grid_table_fetch(geoac_ctx* ctx, double* tab, size_t cap);
 
 int  geoac_set_params(geoac_ctx* ctx, const geoac_params* p);
 /* the parameters as they stand (defaults resolved: vert_limit, xy_limits after an atmosphere upload) and the equation set */

@@ -1,0 +1,77 @@
+"""GPU test of the device-side table builder of the range-dependent sets (geoac_gridbuild.hip) against the host
+restatement of the same construction (geoac_grid_table_eq in geoac_host.cpp, itself pinned to the compiled reference's scalar API by
+tests/test_host_grid.py): the natural-spline slopes are the same operations in the same order (FMA contraction off) and must agree to
+the bit; the expanded cubic coefficients (long double on the host, double-double on the device) to a few units in the last place
+relative to the size of the terms they are built from."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import geoac_amd as G
+import harness as H
+
+pytestmark = pytest.mark.gpu
+_dp = ctypes.POINTER(ctypes.c_double)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _synthetic_grid(nx, ny, nz, spherical, seed=7):
+    rng = np.random.default_rng(seed)
+    if spherical:
+        x = np.radians(25.0 + np.cumsum(0.3 + 0.4 * rng.random(nx)))          # ragged node spacing on every axis
+        y = np.radians(-5.0 + np.cumsum(0.3 + 0.4 * rng.random(ny)))
+        z = 6370.0 + np.concatenate([[0.0], np.cumsum(0.05 + 0.2 * rng.random(nz - 1))])
+    else:
+        x = -400.0 + np.cumsum(20.0 + 30.0 * rng.random(nx))
+        y = -300.0 + np.cumsum(20.0 + 30.0 * rng.random(ny))
+        z = np.concatenate([[0.0], np.cumsum(0.05 + 0.2 * rng.random(nz - 1))])
+    zz = (z - z[0])[None, None, :]
+    xx = ((x - x[0]) / (x[-1] - x[0]))[:, None, None]
+    yy = ((y - y[0]) / (y[-1] - y[0]))[None, :, None]
+    T = 288.0 - 6.5 * np.minimum(zz, 11.0) + 15.0 * np.sin(0.21 * zz + 2.0 * xx) * np.cos(1.3 * yy) + 0.5 * rng.standard_normal((nx, ny, nz))
+    u = 0.03 * np.sin(0.13 * zz + 1.7 * yy) * (1 + xx) + 1e-3 * rng.standard_normal((nx, ny, nz))
+    v = 0.02 * np.cos(0.17 * zz - 2.3 * xx) * (1 + yy) + 1e-3 * rng.standard_normal((nx, ny, nz))
+    rho = 1.2e-3 * np.exp(-zz / 7.0) * (1 + 0.05 * xx * yy) + 0.0 * xx
+    return [np.ascontiguousarray(a, dtype=np.float64) for a in (x, y, z, T, u, v, rho + 0.0 * T)]
+
+
+@pytest.mark.parametrize("eq,shape", [(G.EQ_3D_RNGDEP, (5, 5, 60)), (G.EQ_3D_RNGDEP, (13, 9, 257)), (G.EQ_GLOBAL_RNGDEP, (7, 11, 130)),
+                                      (G.EQ_GLOBAL_RNGDEP, (2, 2, 3)), (G.EQ_3D_RNGDEP, (2, 3, 1400))])
+def test_device_table_matches_host_builder(eq, shape):
+    nx, ny, nz = shape
+    x, y, z, T, u, v, rho = _synthetic_grid(nx, ny, nz, eq == G.EQ_GLOBAL_RNGDEP)
+    lib = G.load_library()
+    lib.geoac_grid_table_size.restype = ctypes.c_size_t
+    n = lib.geoac_grid_table_size(nx, ny, nz)
+    host = np.zeros(n)
+    lib.geoac_grid_table_eq.argtypes = None
+    assert lib.geoac_grid_table_eq(eq, nx, ny, nz, _p(x), _p(y), _p(z), _p(T), _p(u), _p(v), _p(rho), _p(host)) == 0
+    ctx = G.FanContext(eq, device=0)
+    ctx.upload_atmo_3d(x, y, z, T, u, v, rho)
+    dev = ctx.grid_table()
+    ctx.close()
+    assert dev.shape == host.shape
+    nseg, nn = nz - 1, nx * ny
+    main_h, main_d = host[:3 * nseg * nn * 40].reshape(3, nseg, nn, 10, 4), dev[:3 * nseg * nn * 40].reshape(3, nseg, nn, 10, 4)
+    rho_h, rho_d = host[3 * nseg * nn * 40:].reshape(nseg, nn, 4, 4), dev[3 * nseg * nn * 40:].reshape(nseg, nn, 4, 4)
+    # c0 (node values) and c1 (slopes) of the un-differenced cubics: bit-identical
+    for a, b in ((main_h[..., 0, :2], main_d[..., 0, :2]), (rho_h[..., 0, :2], rho_d[..., 0, :2])):
+        assert np.array_equal(a, b), "values / natural-spline slopes differ from the host builder"
+    if eq == G.EQ_3D_RNGDEP:                                # spherical sets fold the Q12b offset into c1 of the Vx / Vy rows
+        assert np.array_equal(main_h[..., 4, :2], main_d[..., 4, :2]) and np.array_equal(main_h[..., 7, :2], main_d[..., 7, :2])
+    # every coefficient: the differenced cubics (Dx, Dy, Dxy) subtract neighbouring columns, so a last-place difference of a base
+    # coefficient shows up divided by the node spacing: hold each to a few ulps of its BASE cubic's scale times that factor
+    IX, IY = 1.0 / np.diff(x).min(), 1.0 / np.diff(y).min()
+    unit = np.array([1.0, IX, IY, IX * IY, 1.0, IX, IX * IY, 1.0, IY, IX * IY])
+    base = np.array([0, 0, 0, 0, 4, 4, 4, 7, 7, 7])
+    for c in range(4):
+        bs = np.array([np.abs(main_h[..., b, c]).max() for b in base]) + 1e-300
+        err = np.abs(main_h[..., c] - main_d[..., c]).max(axis=(0, 1, 2)) / (bs * unit)
+        assert err.max() < 1e-14, f"coefficient c{c}: {err}"
+        bs = np.abs(rho_h[..., 0, c]).max() + 1e-300
+        err = np.abs(rho_h[..., c] - rho_d[..., c]).max(axis=(0, 1)) / (bs * unit[:4])
+        assert err.max() < 1e-14, f"rho coefficient c{c}: {err}"
