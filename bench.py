@@ -60,9 +60,27 @@ def pmc_fp64_flop_per_step():
     return None, None
 
 
+def _cpu_worker(rank, n_workers, barrier, out):
+    """one host core's share of the whole-socket baseline: its own process (the reference keeps its state in globals), two azimuth
+    slices of the metric fan"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import harness as H
+    import numpy as np
+    phis = [-180.0 + 360.0 * (rank + n_workers * j) / (2 * n_workers) for j in range(2)]
+    th = np.concatenate([H.fan_angles(phi_min=p, phi_max=p)[0] for p in phis])
+    ph = np.concatenate([H.fan_angles(phi_min=p, phi_max=p)[1] for p in phis])
+    cfg = H.make_cfg(H.EQ_GLOBAL, bounces=2, calc_amp=True, mode=0)
+    lib = H.RefShim(H.EQ_GLOBAL, MET) if H.ref_available(H.EQ_GLOBAL) else H.Oracle(H.EQ_GLOBAL, MET)
+    barrier.wait(timeout=300)
+    t0 = time.perf_counter()
+    steps, _, _, _ = lib.fan(cfg, th, ph)
+    out.put((int(steps), time.perf_counter() - t0))
+
+
 def cpu_baseline():
     """the reference's own serial loop on this box's host cores: three azimuth slices of the metric fan
-    (270 rays, ~6e6 steps, 10-20 s), compiled reference if its prebuilt shim is present, else the plain-C port."""
+    (270 rays, ~6e6 steps, 10-20 s), compiled reference if its prebuilt shim is present, else the plain-C port; then the same
+    on every core this process may use, one process per core on disjoint azimuth slices (SURVEY §8d "whole-socket figure")."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import harness as H
     th, ph = H.fan_angles(phi_min=-90.0, phi_max=90.0, phi_step=90.0)     # three azimuth slices (-90, 0, 90) of the metric fan
@@ -74,9 +92,50 @@ def cpu_baseline():
     t0 = time.perf_counter()
     steps, _, _, _ = lib.fan(cfg, th, ph)
     dt = time.perf_counter() - t0
-    return {"value": steps / dt, "unit": "RK4 ray-steps/s", "cores": 1, "kind": kind,
-            "sample": f"phi = -90, 0, 90 slices of the metric fan: {len(th)} rays, {steps} steps, {dt:.1f} s "
-                      f"({'compiled reference TUs -O2 (oracle/_ref)' if kind == 'reference' else 'plain-C restatement (oracle/)'})"}
+    res = {"value": steps / dt, "unit": "RK4 ray-steps/s", "cores": 1, "kind": kind,
+           "sample": f"phi = -90, 0, 90 slices of the metric fan: {len(th)} rays, {steps} steps, {dt:.1f} s "
+                     f"({'compiled reference TUs -O2 (oracle/_ref)' if kind == 'reference' else 'plain-C restatement (oracle/)'})"}
+    try:
+        import multiprocessing as mp
+        n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        try:                                             # a container's CPU share (cgroup quota) is what is really there
+            q = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q[0] != "max":
+                n = min(n, max(1, int(float(q[0]) / float(q[1]) + 0.5)))
+        except Exception:
+            try:
+                quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, int(quota / period + 0.5)))
+            except Exception:
+                pass
+        n = max(1, min(n, 64))
+        ctx = mp.get_context("spawn")                    # fresh interpreters: nothing of this process's GPU state is inherited
+        barrier, out = ctx.Barrier(n), ctx.Queue()
+        procs = [ctx.Process(target=_cpu_worker, args=(r, n, barrier, out)) for r in range(n)]
+        for p in procs:
+            p.start()
+        import queue
+        got, deadline = [], time.time() + 900
+        while len(got) < n and time.time() < deadline:
+            try:
+                got.append(out.get(timeout=1.0))
+            except queue.Empty:
+                if not any(p.is_alive() for p in procs) and out.empty():
+                    break
+        for p in procs:
+            p.join(timeout=5)
+            if p.is_alive():
+                p.terminate()
+        if len(got) < n:
+            raise RuntimeError(f"{n - len(got)} of {n} baseline workers did not report")
+        tot, worst = sum(g[0] for g in got), max(g[1] for g in got)
+        res["all_cores"] = {"value": tot / worst, "unit": "RK4 ray-steps/s", "cores": n, "kind": kind,
+                            "sample": f"{n} processes x 2 azimuth slices of the metric fan (180 rays each), {tot} steps, slowest {worst:.1f} s"}
+    except Exception as e:                               # a baseline, not the product: report why it is missing
+        res["all_cores"] = {"value": None, "error": repr(e)}
+    return res
 
 
 def main():
@@ -88,6 +147,12 @@ def main():
     ap.add_argument("--phi-step", type=float, default=1.0, help="azimuth step of the N=1 fan (metric: 1.0)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured path) or gloo (rehearsal of the N>1 flow on fewer GPUs than ranks)")
     args = ap.parse_args()
+
+    # CPU baseline first: its worker processes are started before this process has touched the GPU (and the host cores are idle
+    # again before the timed region starts)
+    cpu = None
+    if not args.no_cpu_baseline and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        cpu = cpu_baseline()
 
     import numpy as np
     import torch
@@ -200,8 +265,8 @@ def main():
             # the honest "how busy is the binding unit" figure beside the contract's HBM roofline
             out["roofline"]["fp64"] = {"flop_per_step": fps, "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                        "frac": tf / FP64_PEAK_TFLOPS, "source": fp_src}
-        if not args.no_cpu_baseline and n_gpus == 1:
-            out["cpu_baseline"] = cpu_baseline()
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
