@@ -697,6 +697,12 @@ int geoac_fan_sample_count(geoac_ctx* ctx, int64_t* n){
     return GEOAC_OK;
 }
 
+int geoac_fan_set_sample_capacity(geoac_ctx* ctx, int64_t rows){
+    if(!ctx || rows < 1) return GEOAC_E_INVALID;
+    ctx->smp_cap = rows;
+    return GEOAC_OK;
+}
+
 int geoac_fan_fetch_samples(geoac_ctx* ctx, double* smp_host, int64_t cap){
     if(!ctx || !ctx->ran || !smp_host) return fail(ctx, GEOAC_E_INVALID, "fan_fetch_samples: no completed launch / null buffer");
     int64_t n = (int64_t)ctx->n_samples;

@@ -19,6 +19,7 @@
 #include <iomanip>
 #include <iostream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/geoac_hip.h"
@@ -260,20 +261,6 @@ static int run_prop(char* inputs[], int count){
     if(kEq == GEOAC_EQ_2D) geoac_fan_enumerate(theta_min, theta_max, theta_step, phi_min, phi_min, 1.0, nr, th.data(), ph.data());
     else geoac_fan_enumerate(theta_min, theta_max, theta_step, phi_min, phi_max, phi_step, nr, th.data(), ph.data());
     const int legs = bounces + 1;
-    vector<double> rec((size_t)max(nr, 1L) * legs * GEOAC_REC_STRIDE, 0.0);
-    vector<double> smp;
-    uint64_t steps = 0;
-    if(nr > 0){
-        rc = geoac_fan_run(ctx, (int)nr, th.data(), ph.data(), rec.data(), &steps);
-        if(rc){ cout << kName << ": " << geoac_last_error(ctx) << '\n'; geoac_destroy(ctx); return 2; }
-        int64_t ns = 0;
-        geoac_fan_sample_count(ctx, &ns);
-        smp.resize((size_t)max<int64_t>(ns, 1) * GEOAC_SMP_STRIDE);
-        if(ns > 0 && geoac_fan_fetch_samples(ctx, smp.data(), ns)){ cout << kName << ": " << geoac_last_error(ctx) << '\n'; geoac_destroy(ctx); return 2; }
-        smp.resize((size_t)ns * GEOAC_SMP_STRIDE);
-    }
-    geoac_destroy(ctx);
-
     // ---- files, in the reference's formats ----
     ofstream results, raypath;
     sprintf(output_buffer, "%s_results.dat", file_title);
@@ -311,12 +298,14 @@ static int run_prop(char* inputs[], int count){
         }
     }
 
+    // one batch of rays [i0, i1) of the fan: rec = its records, smp = its sample rows (ray index relative to i0)
+    auto write_batch = [&](long i0, long i1, const vector<double>& rec, const vector<double>& smp){
     size_t sp = 0;
     const size_t nsmp = smp.size() / GEOAC_SMP_STRIDE;
-    for(long i = 0; i < nr; i++){
+    for(long i = i0; i < i1; i++){
         cout << "Plotting ray path w/ theta = " << th[(size_t)i] << ", phi = " << ph[(size_t)i] << (kRngC ? "." : "") << '\n';
         // raypath / caustic rows of this ray (sorted by ray, leg, m)
-        while(sp < nsmp && (long)smp[sp * GEOAC_SMP_STRIDE + GEOAC_SMP_RAY] == i){
+        while(sp < nsmp && (long)smp[sp * GEOAC_SMP_STRIDE + GEOAC_SMP_RAY] == i - i0){
             const double* S = &smp[sp * GEOAC_SMP_STRIDE];
             const int leg = (int)S[GEOAC_SMP_LEG], kind = (int)S[GEOAC_SMP_KIND];
             const double* v = S + GEOAC_SMP_V0;
@@ -349,7 +338,7 @@ static int run_prop(char* inputs[], int count){
             sp++;
         }
         for(int b = 0; b < legs; b++){
-            const double* R = &rec[((size_t)i * legs + b) * GEOAC_REC_STRIDE];
+            const double* R = &rec[((size_t)(i - i0) * legs + b) * GEOAC_REC_STRIDE];
             if(R[GEOAC_REC_VALID] == 0.0) break;                    // BreakCheck: no row for this and later legs
             results << th[(size_t)i];
             results << '\t' << ph[(size_t)i];
@@ -384,6 +373,59 @@ static int run_prop(char* inputs[], int count){
         // blank line after each azimuth in results (not in GeoAc2D)
         if(kEq != GEOAC_EQ_2D && (i + 1 == nr || ph[(size_t)i + 1] != ph[(size_t)i])) results << '\n';
     }
+    };
+
+    // ---- the fan on the GPU, the files on a writer thread.  Arrivals-only runs (WriteRays=False, no caustics) are ONE fan launch.
+    //      Runs that keep raypath / caustic rows go azimuth group by azimuth group (about 8000 rays each), so the sample list stays
+    //      bounded, and the text of group g is formatted and written while group g+1 is on the GPU (two buffers in rotation). ----
+    const bool sampling = WriteRays || WriteCaustics;
+    geoac_fan_set_sample_capacity(ctx, 16ll << 20);
+    vector<long> az_start;                                            // first ray of every azimuth (rays are phi-major)
+    for(long i = 0; i < nr; i++) if(i == 0 || ph[(size_t)i] != ph[(size_t)i - 1]) az_start.push_back(i);
+    az_start.push_back(nr);
+    const long n_az = (long)az_start.size() - 1;
+    long az_per_batch = n_az;
+    if(sampling && n_az > 0){
+        const long rays_per_az = max(1L, nr / n_az);
+        const char* rpb = getenv("GEOAC_CLI_RAYS_PER_BATCH");               // tests: force several groups on a small fan
+        az_per_batch = max(1L, ((rpb && atol(rpb) > 0) ? atol(rpb) : 8192L) / rays_per_az);
+    }
+    struct Batch { long i0 = 0, i1 = 0; vector<double> rec, smp; };
+    Batch buf[2];
+    std::thread writer;
+    uint64_t steps = 0;
+    int fail_rc = 0;
+    int nb = 0;
+    for(long a0 = 0; a0 < n_az && !fail_rc; ){
+        long a1 = min(n_az, a0 + az_per_batch);
+        Batch& B = buf[nb & 1];
+        // the buffer's previous batch (two batches ago) was handed to the writer before the last one: joined below before reuse
+        const long i0 = az_start[(size_t)a0], i1 = az_start[(size_t)a1];
+        vector<double> rec((size_t)(i1 - i0) * legs * GEOAC_REC_STRIDE, 0.0), smp;
+        uint64_t st = 0;
+        rc = geoac_fan_run(ctx, (int)(i1 - i0), th.data() + i0, ph.data() + i0, rec.data(), &st);
+        if(rc == GEOAC_E_CAPACITY && sampling){
+            int64_t need = 0;
+            geoac_fan_sample_count(ctx, &need);
+            if(need > (16ll << 20) && a1 - a0 > 1){ az_per_batch = max(1L, (a1 - a0) / 2); continue; }      // split the group
+            if(need > 0 && need <= (192ll << 20)){ geoac_fan_set_sample_capacity(ctx, need + need / 8); continue; }    // one azimuth that long: grow the list
+        }
+        if(rc){ cout << kName << ": " << geoac_last_error(ctx) << '\n'; fail_rc = 2; break; }
+        steps += st;
+        int64_t ns = 0;
+        geoac_fan_sample_count(ctx, &ns);
+        smp.resize((size_t)max<int64_t>(ns, 1) * GEOAC_SMP_STRIDE);
+        if(ns > 0 && geoac_fan_fetch_samples(ctx, smp.data(), ns)){ cout << kName << ": " << geoac_last_error(ctx) << '\n'; fail_rc = 2; break; }
+        smp.resize((size_t)ns * GEOAC_SMP_STRIDE);
+        if(writer.joinable()) writer.join();                           // batches are written in order, one at a time
+        B.i0 = i0; B.i1 = i1; B.rec.swap(rec); B.smp.swap(smp);
+        writer = std::thread([&write_batch, &B]{ write_batch(B.i0, B.i1, B.rec, B.smp); });
+        nb++;
+        a0 = a1;
+    }
+    if(writer.joinable()) writer.join();
+    geoac_destroy(ctx);
+    if(fail_rc) return fail_rc;
     if(WriteRays) raypath.close();
     results.close();
     for(auto& c : caustics) c.close();

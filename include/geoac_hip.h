@@ -158,6 +158,9 @@ int  geoac_fan_copy_records_dev(geoac_ctx* ctx, void* dst_dev);
 int  geoac_fan_fetch(geoac_ctx* ctx, double* rec_host, uint64_t* total_steps);
 /* WriteRays / WriteCaustics samples: number available, then copy (ordered by ray, leg, m) */
 int  geoac_fan_sample_count(geoac_ctx* ctx, int64_t* n);
+/* rows the device-side sample list can hold (default 4 Mi, GEOAC_SMP_STRIDE doubles each); a launch that produces more returns
+ * GEOAC_E_CAPACITY (geoac_fan_sample_count then tells how many it needed): callers split the fan or raise the capacity */
+int  geoac_fan_set_sample_capacity(geoac_ctx* ctx, int64_t rows);
 int  geoac_fan_fetch_samples(geoac_ctx* ctx, double* smp_host, int64_t cap);
 
 /* blocking convenience: set_angles + launch + sync + fetch */

@@ -40,8 +40,14 @@ def _compare_files(got, want):
     return nsame, ntok
 
 
-@pytest.mark.parametrize("case", ["global", "3d", "2d", "global_norays", "3drd", "globalrd"])
+@pytest.mark.parametrize("case", ["global", "3d", "2d", "global_norays", "3drd", "globalrd", "global+groups", "3drd+groups"])
 def test_cli_files_match_reference_binaries(case, tmp_path):
+    """"+groups": the same fan integrated one azimuth group at a time (the path large WriteRays fans take: bounded sample list, text of
+    group g written while group g+1 is on the GPU) must give the same files"""
+    env = dict(os.environ)
+    if case.endswith("+groups"):
+        case = case[:-len("+groups")]
+        env["GEOAC_CLI_RAYS_PER_BATCH"] = "2"
     gold = os.path.join(CLI_GOLD, case)
     args = open(os.path.join(gold, "ARGS")).read().split()
     binary, params = args[0], args[1:]
@@ -60,7 +66,7 @@ def test_cli_files_match_reference_binaries(case, tmp_path):
     else:
         shutil.copy(H.TOYATMO, tmp_path / "ToyAtmo.met")
         inputs = ["ToyAtmo.met"]
-    subprocess.run([exe, "-prop"] + inputs + params, cwd=tmp_path, check=True, stdout=subprocess.DEVNULL)
+    subprocess.run([exe, "-prop"] + inputs + params, cwd=tmp_path, check=True, stdout=subprocess.DEVNULL, env=env)
     want_files = sorted(f for f in os.listdir(gold) if f.endswith(".dat"))
     got_files = sorted(f for f in os.listdir(tmp_path) if f.endswith(".dat") and not f.startswith("loc_"))
     assert got_files == want_files
