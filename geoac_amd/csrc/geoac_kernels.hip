@@ -131,20 +131,36 @@ DEVINL void seg_eval(TabPtr tab, int k, double x, Atm9& a){ seg_eval_at(tab + k 
 // RK4-stage lookup: `off` = element offset (segment index * SEGW) of the segment used by the previous stage.  Rays move
 // <= 50 m per stage while nodes are ~100 m apart, so one branch-free +-1 move (two dependent LDS round trips) finds the
 // segment; the walk is the never-taken fallback for pathological (very short) segments.
+// The whole record of the segment used by the previous stage is fetched at once: the ray is still inside it in all but one
+// stage of some tens (<= 50 m per stage against ~100 m between nodes, far less for shallow rays), so the usual stage costs ONE
+// LDS round trip instead of two dependent ones (bounds, then coefficients).  seg_fetch issues the loads; the caller puts the
+// table-independent part of its right-hand side between seg_fetch and seg_resolve, which hides that round trip as well.
+template <typename TabPtr>
+DEVINL void seg_fetch(TabPtr tab, int off, double* r){
+    const auto* p = tab + off;
+    #pragma unroll
+    for(int c = 0; c < GEOAC_SEGW; c++) r[c] = p[c];
+}
+template <typename TabPtr>
+DEVINL void seg_resolve(TabPtr tab, const GeoacDevParams& P, double x, int& off, double* r, Atm9& a){
+    const int last = (P.nseg - 1) * GEOAC_SEGW;
+    const bool up = (x > r[1]) & (off < last), down = (x < r[0]) & (off > 0);
+    if(up | down){                                               // rare, divergent: step to the neighbour and fetch again
+        off += (up ? GEOAC_SEGW : 0) - (down ? GEOAC_SEGW : 0);
+        if(!P.seg_safe){                                         // wave-uniform: only for profiles with nodes closer than one step
+            const auto* p = tab + off;
+            const double x0 = p[0], x1 = p[1];
+            if(((x < x0) & (off > 0)) | ((x > x1) & (off < last))) off = seg_find(tab, P.nseg, x, off / GEOAC_SEGW) * GEOAC_SEGW;
+        }
+        seg_fetch(tab, off, r);
+    }
+    seg_eval_at(r, x, a);
+}
 template <typename TabPtr>
 DEVINL void seg_step_eval(TabPtr tab, const GeoacDevParams& P, double x, int& off, Atm9& a){
-    const int last = (P.nseg - 1) * GEOAC_SEGW;
-    {
-        const auto* p = tab + off;
-        const double x0 = p[0], x1 = p[1];
-        off += (((x > x1) & (off < last)) ? GEOAC_SEGW : 0) - (((x < x0) & (off > 0)) ? GEOAC_SEGW : 0);
-    }
-    if(!P.seg_safe){                                             // wave-uniform: only for profiles with nodes closer than one step
-        const auto* p = tab + off;
-        const double x0 = p[0], x1 = p[1];
-        if(((x < x0) & (off > 0)) | ((x > x1) & (off < last))) off = seg_find(tab, P.nseg, x, off / GEOAC_SEGW) * GEOAC_SEGW;
-    }
-    seg_eval_at(tab + off, x, a);
+    double r[GEOAC_SEGW];
+    seg_fetch(tab, off, r);
+    seg_resolve(tab, P, x, off, r, a);
 }
 
 DEVINL double clampd(double x, double lo, double hi){ double e = (hi < x) ? hi : x; return (e < lo) ? lo : e; }
@@ -169,17 +185,32 @@ DEVINL double rho_eval(const GeoacDevParams& P, int k, double x){
 // Global equation set: fused GeoAc_UpdateSources + GeoAc_EvalSrcEq (EquationSets.Global.cpp:222-442),
 // specialised for the stratified atmosphere (w = 0, every d/dlat, d/dlon of the medium = 0).
 // y: r, lat, lon, nu_r, nu_t, nu_p | R_lt(3), mu_lt(3) | R_lp(3), mu_lp(3)
-// sth/cth: sin/cos of y[1] supplied by the caller (reused by the range check).
+// sth0/cth0: sin/cos of the latitude at the start of the step, dlat: latitude increment of this stage (small-angle rotation).
 // ------------------------------------------------------------------------------------------------
 // NQ = number of launch-angle derivative systems carried in y after the 6 base components: 2 = the reference layout
 // (theta then phi), 1 = the two-lanes-per-ray kernel where each lane of a pair carries the base ray and ONE of the two systems.
 template <bool AMP, int NQ, typename TabPtr>
-DEVINL void global_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const double* y, double sth, double cth, double* dy){
+DEVINL void global_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const double* y, double sth0, double cth0, double dlat, double* dy){
     const double r = y[0];
     const double n0 = y[3], n1 = y[4], n2 = y[5];
     const double xe = clampd(r, P.x_min, P.x_max);
+    double rec[GEOAC_SEGW];
+    seg_fetch(tab, seg, rec);                                    // LDS loads in flight while the table-independent terms are formed
+    __builtin_amdgcn_sched_barrier(0);                           // (the scheduler would otherwise issue them after that arithmetic)
+    double sth, cth;
+    rot_small(sth0, cth0, dlat, sth, cth);                       // sin / cos of the stage latitude from the step's (stage 0: zero angle, exact identity)
+    // |nu|   (Global.cpp:249)
+    const double nn  = __builtin_fma(n0, n0, __builtin_fma(n1, n1, n2 * n2));
+    const double inm0 = frsq(nn);
+    double ir  = frcp(r);
+    double ico = frcp(cth);
+    double inm_ = inm0;
+    // pin these table-independent values HERE, ahead of the bounds check: left alone the compiler sinks them below the (rarely
+    // taken) re-fetch branch and the wave then sits out the LDS round trip with nothing to issue
+    asm volatile("" : "+v"(ir), "+v"(ico), "+v"(inm_), "+v"(sth), "+v"(cth));
     Atm9 a;
-    seg_step_eval(tab, P, xe, seg, a);
+    seg_resolve(tab, P, xe, seg, rec, a);
+    const double inm = inm_, numag = nn * inm;
     const double u = a.u, v = a.v, du = a.du, dv = a.dv;
 
     // c = sqrt(gamR T), c' = gamR/(2c) T'                      (G2S_GlobalSpline1D.cpp:345-356)
@@ -188,17 +219,12 @@ DEVINL void global_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const doub
     const double c   = qT * ic;
     const double hc  = (0.5 * kGamR) * ic;
     const double dc  = hc * a.dT;
-    // |nu|, group velocity c_g = c nu/|nu| + (0, v, u), |c_g|   (Global.cpp:249-255)
-    const double nn  = __builtin_fma(n0, n0, __builtin_fma(n1, n1, n2 * n2));
-    const double inm = frsq(nn);
-    const double numag = nn * inm;
+    // group velocity c_g = c nu/|nu| + (0, v, u), |c_g|   (Global.cpp:250-255)
     const double cn  = c * inm;
     const double cg0 = cn * n0;
     const double cg1 = __builtin_fma(cn, n1, v);
     const double cg2 = __builtin_fma(cn, n2, u);
     const double icg = frsq(__builtin_fma(cg0, cg0, __builtin_fma(cg1, cg1, cg2 * cg2)));
-    const double ir  = frcp(r);
-    const double ico = frcp(cth);
     const double tn  = sth * ico;
     const double u0 = cg0 * icg, u1 = cg1 * icg, u2 = cg2 * icg;       // unit group-velocity vector
     const double G1 = ir, G2 = ir * ico;                               // GeoCoeff (Global.cpp:258-260)
@@ -525,9 +551,7 @@ template <bool AMP_> struct EqGlobal {
 
     template <typename TabPtr>
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
-        double s2, c2;
-        rot_small(C.a[0], C.a[1], yt[1] - y0[1], s2, c2);          // stage 0: zero angle, exact identity
-        global_rhs<AMP, 2>(tab, P, seg, yt, s2, c2, dy);
+        global_rhs<AMP, 2>(tab, P, seg, yt, C.a[0], C.a[1], yt[1] - y0[1], dy);
     }
     // GeoAc_BreakCheck / GeoAc_GroundCheck on the new row (Global.cpp:500-522)
     static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, long long k, bool& brk, bool& gnd){
@@ -635,9 +659,7 @@ struct EqGlobalPair : EqGlobal<true> {
     static constexpr bool SPLIT = true;
     template <typename TabPtr>
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
-        double s2, c2;
-        rot_small(C.a[0], C.a[1], yt[1] - y0[1], s2, c2);          // stage 0: zero angle, exact identity
-        global_rhs<true, 1>(tab, P, seg, yt, s2, c2, dy);
+        global_rhs<true, 1>(tab, P, seg, yt, C.a[0], C.a[1], yt[1] - y0[1], dy);
     }
     // reflection of the base ray and of this lane's derivative system (Global.cpp:140-205, Q1 linear intercept)
     static DEVINL void reflect(const GeoacDevParams& P, const RayCtx& C, const double* yn, double* y, const double* ym2){
