@@ -182,7 +182,7 @@ int geoac_create(geoac_ctx** out, int eqset, int device){
     if(hipStreamCreateWithPriority(&ctx->acc_stream, hipStreamNonBlocking, prio_lo) != hipSuccess){ delete ctx; return GEOAC_E_HIP; }
     if(hipStreamCreateWithPriority(&ctx->rk4b_stream, hipStreamNonBlocking, prio_hi) != hipSuccess){ delete ctx; return GEOAC_E_HIP; }
     hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
-    if(hipHostMalloc((void**)&ctx->h_counters, 16 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess){
+    if(hipHostMalloc((void**)&ctx->h_counters, 32 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess){
         delete ctx; return GEOAC_E_HIP;
     }
     geoac_default_params(eqset, &ctx->prm);
@@ -501,7 +501,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
         P.seg_safe = (hmin >= 1.001 * ds_bound) ? 1 : 0;
     }
     P.pp_blocks = ctx->pp_blocks;
-    P.slot_lo = 0; P.slot_hi = P.n_pad;
+    P.slot_lo = 0; P.slot_hi = P.n_pad; P.live_slot = 1;
     // two lanes per ray shorten the serial chain (x1.25) at twice the lanes: only worth it while the fan leaves SIMDs idle
     P.lanes_per_ray = (is_global && p.calc_amp && !sampling && !ctx->no_pair && (long long)P.n_pad * 2 / 64 <= 1024) ? 2 : 1;
     // grid sets, small fans: four lanes per ray (one cell corner each) while that still leaves one wave per SIMD
@@ -540,7 +540,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
         n_pair = (int)(((long long)(ctx->pair_frac * ctx->n_rays) + 127) / 128 * 128);
         if(n_pair >= P.n_pad) n_pair = P.n_pad;
     }
-    const bool split = hybrid && n_pair < P.n_pad;
+    bool split = hybrid && n_pair < P.n_pad;
     if(hybrid && n_pair == 0) P.lanes_per_ray = 1;
     const int n_chunks = split ? 3 : 2;               // the post-pass of a hybrid fan may lag the RK4 by more than one epoch
     for(int b = 0; b < n_chunks; b++){
@@ -595,11 +595,13 @@ int geoac_fan_launch(geoac_ctx* ctx){
         if(sampling){ Pe.ev_row = (int*)ctx->ev_row[b].p; Pe.ev_m = (int*)ctx->ev_m[b].p; Pe.ev_amp = (double*)ctx->ev_amp[b].p; Pe.nev = (int*)ctx->nev[b].p; }
         if(e >= (size_t)n_chunks) HIPCHK(hipStreamWaitEvent(s, ctx->evs[4 * (e - n_chunks) + 3], 0));      // chunk b free again?
         HIPCHK(hipMemsetAsync((char*)ctx->counters.p + sizeof(unsigned long long), 0, sizeof(unsigned long long), s));
+        HIPCHK(hipMemsetAsync((char*)ctx->counters.p + 4 * sizeof(unsigned long long), 0, sizeof(unsigned long long), s));
+        HIPCHK(hipMemsetAsync((char*)ctx->counters.p + 6 * sizeof(unsigned long long), 0, 2 * sizeof(unsigned long long), s));
         HIPCHK(hipEventRecord(ctx->evs[eb], s));
         unsigned n_wg = 0, n_wg1 = 0;
         if(split){
             GeoacDevParams P1 = Pe;                   // one lane per ray, fewer rows: on the second RK4 stream
-            P1.lanes_per_ray = 1; P1.slot_lo = n_pair; P1.slot_hi = P.n_pad;
+            P1.lanes_per_ray = 1; P1.slot_lo = n_pair; P1.slot_hi = P.n_pad; P1.live_slot = 6;
             P1.s_rows = std::max(8, (int)(ctx->hybrid_rows * P.s_rows));
             HIPCHK(hipStreamWaitEvent(ctx->rk4b_stream, ctx->evs[eb], 0));
             HIPCHK(geoac_launch_rk4(&P1, 256, ctx->rk4b_stream, &n_wg1));
@@ -612,7 +614,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
             HIPCHK(geoac_launch_rk4(&Pe, block, s, &n_wg));
         }
         HIPCHK(hipEventRecord(ctx->evs[eb + 1], s));
-        HIPCHK(hipMemcpyAsync(ctx->h_counters + 8 * (e & 1), ctx->counters.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(ctx->h_counters + 16 * (e & 1), ctx->counters.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIPCHK(hipEventRecord(ctx->evj[2 * e + 1], s));
         // the post-pass of the previous epoch goes behind this epoch's RK4 workgroups (see k_gate)
         if(e >= 1){ int rc = enqueue_post(Pprev, e - 1, wg_seen + std::min(n_wg + n_wg1, wg_room)); if(rc != GEOAC_OK) return rc; }
@@ -620,22 +622,22 @@ int geoac_fan_launch(geoac_ctx* ctx){
         Pprev = Pe;
         if(e >= 1){
             HIPCHK(hipEventSynchronize(ctx->evj[2 * (e - 1) + 1]));
-            live = ctx->h_counters[8 * ((e - 1) & 1) + 1];
+            const unsigned long long* hc = ctx->h_counters + 16 * ((e - 1) & 1);
+            live = hc[1] + hc[6];
             if(live == 0){ ctx->n_epochs = e; break; }
+            // hybrid fan: once the rays still alive would fit on half of the SIMDs as two-lane waves (hc[4] two-lane waves alive, hc[7]
+            // one-lane waves that would become two each), or the two-lane share has finished, everything continues on the two-lane
+            // kernel, whole epochs (same state layout): whatever is still running now sets the finish time - also when the shallow
+            // rays were NOT the longest ones
+            if(split && (hc[1] == 0 || hc[4] + 2 * hc[7] <= 512)) split = false;
         }
         if((long long)e > max_epochs) return fail(ctx, GEOAC_E_CAPACITY, "fan_launch: epoch bound exceeded");
     }
     HIPCHK(hipStreamWaitEvent(s, ctx->evs[4 * (ctx->n_epochs - 1) + 3], 0));
     HIPCHK(hipEventRecord(ctx->ev1, s));
-    HIPCHK(hipMemcpyAsync(ctx->h_counters + 4, ctx->counters.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(ctx->h_counters + 8, ctx->counters.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    ctx->n_samples = ctx->h_counters[4 + 3];
-#ifdef GEOAC_DBG_CLOCK
-    HIPCHK(hipMemcpy(ctx->h_counters + 12, (char*)ctx->counters.p + 4 * sizeof(unsigned long long), 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    fprintf(stderr, "[dbg clock] multi-lane launch: %llu shader ticks / %llu real ticks (100 MHz) = %.1f per real tick; one-lane launch: %llu / %llu = %.1f\n",
-            ctx->h_counters[12], ctx->h_counters[13], ctx->h_counters[13] ? (double)ctx->h_counters[12] / ctx->h_counters[13] : 0.0,
-            ctx->h_counters[14], ctx->h_counters[15], ctx->h_counters[15] ? (double)ctx->h_counters[14] / ctx->h_counters[15] : 0.0);
-#endif
+    ctx->n_samples = ctx->h_counters[8 + 3];
     float ms = 0; hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->ms_total = ms;
     ctx->ms_rk4 = 0; ctx->ms_post = 0;
@@ -645,8 +647,8 @@ int geoac_fan_launch(geoac_ctx* ctx){
         hipEventElapsedTime(&b, ctx->evs[4 * e + 2], ctx->evs[4 * e + 3]);
         ctx->ms_rk4 += a; ctx->ms_post += b;
     }
-    ctx->total_steps = ctx->h_counters[0];
-    ctx->err_flags = ctx->h_counters[2];
+    ctx->total_steps = ctx->h_counters[8 + 0];
+    ctx->err_flags = ctx->h_counters[8 + 2];
     // algorithmic path traffic: one PATHW-wide row per step (+ leg-start / carry rows, not counted)
     ctx->path_bytes_w = ctx->total_steps * (unsigned long long)(P.pathw * sizeof(double));
     ctx->path_bytes_r = 2 * ctx->path_bytes_w;

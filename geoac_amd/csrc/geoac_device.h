@@ -50,6 +50,7 @@ struct GeoacDevParams {
     int     nseg;                   // spline segments = nodes - 1
     int     s_rows;                 // path rows per epoch chunk
     int     table_in_lds;
+    int     live_slot;              // index into counters[] of the live-ray count this launch adds to (1, or 6 for the second launch of a hybrid fan)
     int     slot_lo, slot_hi;       // k_rk4 integrates the ray slots [slot_lo, slot_hi) (a fan may be split over two concurrent launches)
     int     lanes_per_ray;          // 2: Global + CalcAmp without sample capture runs the two-lanes-per-ray kernel
     int     spread;                 // grid sets: only every spread-th lane of a wave carries a ray (power of two, 1..64): a small fan is

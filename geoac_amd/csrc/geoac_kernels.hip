@@ -1226,9 +1226,6 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
         for(int q = threadIdx.x; q < total; q += blockDim.x) lds_tab[q] = gtab[q];
         __syncthreads();
     }
-#ifdef GEOAC_DBG_CLOCK
-    const unsigned long long dbg_m0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
     if(done) return;
 
     int nr = 0, nle = 0;
@@ -1394,12 +1391,8 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
     const unsigned long long live = __popcll(__ballot(!done && q == 0));
     if((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1){
         atomicAdd(&P.counters[0], s);
-        atomicAdd(&P.counters[1], live);
-#ifdef GEOAC_DBG_CLOCK
-        const int o = (EQ::LANES == 1) ? 6 : 4;
-        atomicMax(&P.counters[o], __builtin_amdgcn_s_memtime() - dbg_m0);
-        atomicMax(&P.counters[o + 1], __builtin_amdgcn_s_memrealtime() - dbg_r0);
-#endif
+        atomicAdd(&P.counters[P.live_slot], live);
+        if(live) atomicAdd(&P.counters[P.live_slot == 1 ? 4 : 7], 1ull);     // waves that still carry a live ray
     }
 }
 
