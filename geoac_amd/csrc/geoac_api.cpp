@@ -88,6 +88,7 @@ struct geoac_ctx {
                                                   // (avg k_rk4 launch 10.9 ms vs 11.7-12.8 ms at 8192-256 blocks).
     double pair_frac = 0.10;                      // hybrid fans: share of the inclination-sorted rays that get two lanes (GEOAC_PAIR_FRAC; >= 1: all)
     double hybrid_rows = 0.75;                    // hybrid fans: rows per epoch of the one-lane launch relative to the two-lane launch (GEOAC_HYBRID_ROWS)
+    bool trace_epochs = false;                    // GEOAC_TRACE_EPOCHS=1: per-epoch live counts on stderr
     bool no_gate = false;                         // GEOAC_NO_GATE=1: post-pass not held back behind the next RK4 launch (A/B measurements)
     bool no_pair = false;                         // GEOAC_NO_PAIR=1: force one lane per ray (A/B measurements)
     std::string err;
@@ -198,6 +199,8 @@ int geoac_create(geoac_ctx** out, int eqset, int device){
     if(pf && atof(pf) >= 0.0) ctx->pair_frac = atof(pf);
     const char* hr = getenv("GEOAC_HYBRID_ROWS");
     if(hr && atof(hr) > 0.0 && atof(hr) <= 1.0) ctx->hybrid_rows = atof(hr);
+    const char* te = getenv("GEOAC_TRACE_EPOCHS");
+    if(te && atoi(te) != 0) ctx->trace_epochs = true;
     const char* ng = getenv("GEOAC_NO_GATE");
     if(ng && atoi(ng) != 0) ctx->no_gate = true;
     const char* srt = getenv("GEOAC_SORT");
@@ -559,7 +562,11 @@ int geoac_fan_launch(geoac_ctx* ctx){
     HIPCHK(hipEventRecord(ctx->ev0, s));
     HIPCHK(geoac_launch_init(&P, s));
     ctx->n_epochs = 0; ctx->path_bytes_w = 0; ctx->path_bytes_r = 0;
-    const long long max_epochs = (P.step_limit * (long long)ctx->legs) / (P.s_rows > 4 ? (P.s_rows - 3) : 1) + ctx->legs + 2;
+    // late epochs (few waves still alive) are a quarter as long: the post-pass and the serial per-ray sums of the LAST epoch are the
+    // uncovered tail of a fan, and both scale with the rows of that epoch
+    const int rows_late = (ctx->s_rows_override >= 8) ? P.s_rows : std::max(std::min(1024, P.s_rows), P.s_rows / 4);
+    int rows_now = P.s_rows;
+    const long long max_epochs = (P.step_limit * (long long)ctx->legs) / (rows_late > 4 ? (rows_late - 3) : 1) + ctx->legs + 2;
     unsigned long long live = 1;
     // post-pass of one epoch on the second stream; gate_expected > 0: only after that many RK4 workgroups of this fan are resident
     auto enqueue_post = [&](const GeoacDevParams& Pq, size_t e, unsigned long long gate_expected) -> int {
@@ -590,6 +597,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
         while(ctx->evs.size() < eb + 4){ hipEvent_t ev; HIPCHK(hipEventCreate(&ev)); ctx->evs.push_back(ev); }
         while(ctx->evj.size() < 2 * e + 2){ hipEvent_t ev; HIPCHK(hipEventCreate(&ev)); ctx->evj.push_back(ev); }
         GeoacDevParams Pe = P;
+        Pe.s_rows = rows_now;
         Pe.path = (double*)ctx->path[b].p; Pe.contrib = (double*)ctx->contrib[b].p;
         Pe.nrows = (int*)ctx->nrows[b].p; Pe.legend = (int*)ctx->legend[b].p; Pe.nlegend = (int*)ctx->nlegend[b].p;
         if(sampling){ Pe.ev_row = (int*)ctx->ev_row[b].p; Pe.ev_m = (int*)ctx->ev_m[b].p; Pe.ev_amp = (double*)ctx->ev_amp[b].p; Pe.nev = (int*)ctx->nev[b].p; }
@@ -602,7 +610,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
         if(split){
             GeoacDevParams P1 = Pe;                   // one lane per ray, fewer rows: on the second RK4 stream
             P1.lanes_per_ray = 1; P1.slot_lo = n_pair; P1.slot_hi = P.n_pad; P1.live_slot = 6;
-            P1.s_rows = std::max(8, (int)(ctx->hybrid_rows * P.s_rows));
+            P1.s_rows = std::max(8, (int)(ctx->hybrid_rows * rows_now));
             HIPCHK(hipStreamWaitEvent(ctx->rk4b_stream, ctx->evs[eb], 0));
             HIPCHK(geoac_launch_rk4(&P1, 256, ctx->rk4b_stream, &n_wg1));
             HIPCHK(hipEventRecord(ctx->evj[2 * e], ctx->rk4b_stream));
@@ -630,6 +638,8 @@ int geoac_fan_launch(geoac_ctx* ctx){
             // kernel, whole epochs (same state layout): whatever is still running now sets the finish time - also when the shallow
             // rays were NOT the longest ones
             if(split && (hc[1] == 0 || hc[4] + 2 * hc[7] <= 512)) split = false;
+            if(hc[4] + hc[7] <= 256) rows_now = rows_late;
+            if(ctx->trace_epochs) fprintf(stderr, "[epoch %zu] live rays %llu + %llu, live waves %llu + %llu, split %d, rows next %d\n", e - 1, hc[1], hc[6], hc[4], hc[7], (int)split, rows_now);
         }
         if((long long)e > max_epochs) return fail(ctx, GEOAC_E_CAPACITY, "fan_launch: epoch bound exceeded");
     }
