@@ -255,7 +255,7 @@ DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double
     GridLoc L; grid_locate(P, xe, ye, ze, kz, L);
     kz = L.kz;
     double M[3][10];                                               // T, u, v and their derivatives; one (non-inlined) evaluator call per field
-    #pragma unroll 1
+    #pragma unroll (NL == 4 ? 3 : 1)                              // four lanes per ray: one corner per lane, so the three fields' gathers fit in flight together
     for(int f = 0; f < 3; f++) grid_eval_all<AMP, false, NL>(P, f, L, M[f], cq);
     const double* T = M[0]; const double* U = M[1]; const double* V = M[2];
     const double n0 = y[3], n1 = y[4], n2 = y[5];
@@ -323,7 +323,7 @@ DEVINL void globalrd_rhs(const GeoacDevParams& P, int& kz, const double* y, doub
     GridLoc L; grid_locate(P, te, pe, re, kz, L);
     kz = L.kz;
     double M[3][10];                                               // table order: f, f_t, f_p, f_r, f_tt, f_pp, f_rr, f_tp, f_tr, f_pr
-    #pragma unroll 1
+    #pragma unroll (NL == 4 ? 3 : 1)
     for(int f = 0; f < 3; f++) grid_eval_all<AMP, true, NL>(P, f, L, M[f], cq);
     const double* T = M[0]; const double* U = M[1]; const double* V = M[2];
     // first derivatives in equation order (r, t, p) = table entries 3, 1, 2
