@@ -66,3 +66,38 @@ def test_no_cpu_fallback_without_gpu(lib):
         pytest.skip("a GPU is present")
     with pytest.raises(G.GeoAcError, match="no usable HIP device"):
         G.FanContext(G.EQ_GLOBAL)
+
+
+def test_met_load_with_ground_taper(lib):
+    """geoac_met_load_zg: the profile as GeoAcGlobal -interactive loads it the second time (taper centred on z_grnd,
+    G2S_GlobalSpline1D.cpp:128-131); z_grnd = 0 is geoac_met_load"""
+    n = lib.geoac_met_rows(H.TOYATMO.encode())
+    dp = ctypes.POINTER(ctypes.c_double)
+
+    def load(zg):
+        a = [np.zeros(n) for _ in range(5)]
+        lib.geoac_met_load_zg.argtypes = None
+        rc = lib.geoac_met_load_zg(H.TOYATMO.encode(), b"zTuvdp", H.EQ_GLOBAL, ctypes.c_double(zg), n, *[x.ctypes.data_as(dp) for x in a])
+        assert rc == n
+        return a
+    base = G.met_load(H.TOYATMO, H.EQ_GLOBAL)
+    x0, T0, u0, v0, r0 = load(0.0)
+    assert np.array_equal(u0, base["u"]) and np.array_equal(v0, base["v"]) and np.array_equal(x0, base["x"])
+    x1, T1, u1, v1, r1 = load(0.3)
+    raw = np.loadtxt(H.TOYATMO)
+    w = (2.0 / (1.0 + np.exp(-((raw[:, 0] + 6370.0) - 6370.0 - 0.3) / 0.2)) - 1.0) / 1000.0
+    assert np.allclose(u1, raw[:, 2] * w, rtol=1e-14, atol=0) and np.allclose(v1, raw[:, 3] * w, rtol=1e-14, atol=0)
+    assert np.array_equal(T1, T0) and np.array_equal(r1, r0)
+
+
+def test_drivers_print_usage_without_arguments(lib):
+    """the five host drivers exist, link against the library and print a usage text when called bare (no GPU touched)"""
+    import subprocess
+    for name in ("GeoAc2D", "GeoAc3D", "GeoAcGlobal", "GeoAc3D.RngDep", "GeoAcGlobal.RngDep"):
+        exe = os.path.join(H.ROOT, "geoac_amd", "bin", name)
+        if not os.path.exists(exe):
+            import __graft_entry__
+            __graft_entry__.build()
+        assert os.path.exists(exe), exe
+        r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+        assert r.returncode == 0 and b"Usage: " + name.encode() in r.stdout and b"-interactive" in r.stdout
