@@ -88,6 +88,7 @@ struct geoac_ctx {
                                                   // (avg k_rk4 launch 10.9 ms vs 11.7-12.8 ms at 8192-256 blocks).
     double pair_frac = 0.10;                      // hybrid fans: share of the inclination-sorted rays that get two lanes (GEOAC_PAIR_FRAC; >= 1: all)
     double hybrid_rows = 0.75;                    // hybrid fans: rows per epoch of the one-lane launch relative to the two-lane launch (GEOAC_HYBRID_ROWS)
+    bool two_chunks = false;                      // GEOAC_TWO_CHUNKS=1: two path chunks in rotation instead of three (A/B measurements)
     bool trace_epochs = false;                    // GEOAC_TRACE_EPOCHS=1: per-epoch live counts on stderr
     bool no_gate = false;                         // GEOAC_NO_GATE=1: post-pass not held back behind the next RK4 launch (A/B measurements)
     bool no_pair = false;                         // GEOAC_NO_PAIR=1: force one lane per ray (A/B measurements)
@@ -199,6 +200,8 @@ int geoac_create(geoac_ctx** out, int eqset, int device){
     if(pf && atof(pf) >= 0.0) ctx->pair_frac = atof(pf);
     const char* hr = getenv("GEOAC_HYBRID_ROWS");
     if(hr && atof(hr) > 0.0 && atof(hr) <= 1.0) ctx->hybrid_rows = atof(hr);
+    const char* tc = getenv("GEOAC_TWO_CHUNKS");
+    if(tc && atoi(tc) != 0) ctx->two_chunks = true;
     const char* te = getenv("GEOAC_TRACE_EPOCHS");
     if(te && atoi(te) != 0) ctx->trace_epochs = true;
     const char* ng = getenv("GEOAC_NO_GATE");
@@ -225,8 +228,8 @@ int geoac_destroy(geoac_ctx* ctx){
                        &ctx->path[0], &ctx->path[1], &ctx->path[2], &ctx->contrib[0], &ctx->contrib[1], &ctx->contrib[2],
                        &ctx->nrows[0], &ctx->nrows[1], &ctx->nrows[2], &ctx->legend[0], &ctx->legend[1], &ctx->legend[2],
                        &ctx->nlegend[0], &ctx->nlegend[1], &ctx->nlegend[2],
-                       &ctx->ev_row[0], &ctx->ev_row[1], &ctx->ev_m[0], &ctx->ev_m[1], &ctx->ev_amp[0], &ctx->ev_amp[1],
-                       &ctx->nev[0], &ctx->nev[1], &ctx->smp_out,
+                       &ctx->ev_row[0], &ctx->ev_row[1], &ctx->ev_row[2], &ctx->ev_m[0], &ctx->ev_m[1], &ctx->ev_m[2],
+                       &ctx->ev_amp[0], &ctx->ev_amp[1], &ctx->ev_amp[2], &ctx->nev[0], &ctx->nev[1], &ctx->nev[2], &ctx->smp_out,
                        &ctx->d_gx, &ctx->d_gy, &ctx->d_gz, &ctx->d_gtab, &ctx->d_consts };
     for(DevBuf* b : bufs) b->release();
     if(ctx->h_counters) hipHostFree(ctx->h_counters);
@@ -480,12 +483,6 @@ int geoac_fan_launch(geoac_ctx* ctx){
     P.smp_cap = sampling ? ctx->smp_cap : 0;
     if(sampling){
         HIPCHK(ctx->smp_out.ensure(sizeof(double) * GEOAC_SMP_STRIDE * (size_t)P.smp_cap));
-        for(int b = 0; b < 2; b++){
-            HIPCHK(ctx->ev_row[b].ensure(sizeof(int) * (size_t)P.ev_cap * P.n_pad));
-            HIPCHK(ctx->ev_m[b].ensure(sizeof(int) * (size_t)P.ev_cap * P.n_pad));
-            HIPCHK(ctx->ev_amp[b].ensure(sizeof(double) * (size_t)P.ev_cap * P.n_pad));
-            HIPCHK(ctx->nev[b].ensure(sizeof(int) * (size_t)P.n_pad));
-        }
         P.smp_out = (double*)ctx->smp_out.p;
     }
     HIPCHK(ctx->rec.ensure(sizeof(double) * (size_t)ctx->n_rays * ctx->legs * GEOAC_REC_STRIDE));
@@ -545,8 +542,14 @@ int geoac_fan_launch(geoac_ctx* ctx){
     }
     bool split = hybrid && n_pair < P.n_pad;
     if(hybrid && n_pair == 0) P.lanes_per_ray = 1;
-    const int n_chunks = split ? 3 : 2;               // the post-pass of a hybrid fan may lag the RK4 by more than one epoch
+    const int n_chunks = ctx->two_chunks ? 2 : 3;     // three path chunks in rotation: the post-pass may lag the RK4 by more than one epoch (measured: GeoAc3D 360 x 90 fan 212 -> 160 ms; GEOAC_TWO_CHUNKS=1 for A/B)
     for(int b = 0; b < n_chunks; b++){
+        if(sampling){                                             // per-chunk event lists of the WriteRays / WriteCaustics rows
+            HIPCHK(ctx->ev_row[b].ensure(sizeof(int) * (size_t)P.ev_cap * P.n_pad));
+            HIPCHK(ctx->ev_m[b].ensure(sizeof(int) * (size_t)P.ev_cap * P.n_pad));
+            HIPCHK(ctx->ev_amp[b].ensure(sizeof(double) * (size_t)P.ev_cap * P.n_pad));
+            HIPCHK(ctx->nev[b].ensure(sizeof(int) * (size_t)P.n_pad));
+        }
         HIPCHK(ctx->path[b].ensure(row_bytes * (size_t)P.s_rows));
         HIPCHK(ctx->contrib[b].ensure(sizeof(double) * 2 * (size_t)P.n_pad * P.s_rows));
         HIPCHK(ctx->nrows[b].ensure(sizeof(int) * (size_t)P.n_pad));

@@ -800,14 +800,14 @@ template <bool AMP_, int NL_ = 1> struct Eq3DRngDep {
     static DEVINL void segment(const GeoacDevParams& P, const double* st, size_t np, const double* a, const double* b, double& tt, double& at){
         double ax = a[0], ay = a[np], az = a[2 * np], an0 = a[3 * np], an1 = a[4 * np], an2 = a[5 * np];
         double dx = b[0] - ax, dy = b[np] - ay, dz = b[2 * np] - az;
-        double ds = sqrt(dx * dx + dy * dy + dz * dz);
+        double ds = fsqrt(dx * dx + dy * dy + dz * dz);
         double x = ax + dx / 2.0, y = ay + dy / 2.0, z = az + dz / 2.0;
         double n0 = an0 + (b[3 * np] - an0) / 2.0, n1 = an1 + (b[4 * np] - an1) / 2.0, n2 = an2 + (b[5 * np] - an2) / 2.0;
-        double nmag = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+        double inm = frsq(n0 * n0 + n1 * n1 + n2 * n2);
         Medium3 m = medium3_at<true, false>(P, x, y, z);
-        double cp0 = m.c * n0 / nmag + m.u, cp1 = m.c * n1 / nmag + m.v, cp2 = m.c * n2 / nmag;
-        double cpm = sqrt(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
-        tt = ds / cpm;
+        double cn = m.c * inm;
+        double cp0 = cn * n0 + m.u, cp1 = cn * n1 + m.v, cp2 = cn * n2;
+        tt = ds * frsq(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
         at = suthbass_alpha(P, z, m.c, m.rho, P.freq, P.dev_consts[0], P.dev_consts[1], P.dev_consts[2]) * ds;
     }
 };
@@ -927,15 +927,15 @@ template <bool AMP_, int NL_ = 1> struct EqGlobalRngDep {
         double sn, cs; fsincos(t, sn, cs);
         double rdt = r * dt;
         double e1 = r * cs * dp, e2 = r * sn * dp;
-        double ds_tt = sqrt(dr * dr + rdt * rdt + e1 * e1);
-        double ds_at = sqrt(dr * dr + rdt * rdt + e2 * e2);
+        double ds_tt = fsqrt(dr * dr + rdt * rdt + e1 * e1);
+        double ds_at = fsqrt(dr * dr + rdt * rdt + e2 * e2);
         double n0 = an0 + (b[3 * np] - an0) / 2.0, n1 = an1 + (b[4 * np] - an1) / 2.0, n2 = an2 + (b[5 * np] - an2) / 2.0;
-        double nu_mag = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+        double inm = frsq(n0 * n0 + n1 * n1 + n2 * n2);
         Medium3 m = medium3_at<true, false, true>(P, t, p, r);
         Medium3 g = medium3_at<true, false, true>(P, t, p, P.z_grnd);
-        double cp0 = m.c * n0 / nu_mag, cp1 = m.c * n1 / nu_mag + m.v, cp2 = m.c * n2 / nu_mag + m.u;
-        double cpm = sqrt(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
-        tt = ds_tt / cpm;
+        double cn = m.c * inm;
+        double cp0 = cn * n0, cp1 = cn * n1 + m.v, cp2 = cn * n2 + m.u;
+        tt = ds_tt * frsq(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
         double cm = g.c * 1000.0;
         double T_o = cm * cm / (kRgas * kGam);
         double P_o = g.rho * (cm * cm) / kGam * 1000.0;
@@ -1051,18 +1051,18 @@ template <bool AMP_> struct Eq3D {
         double nx = st[(ST_AUX0 + 0) * np], ny = st[(ST_AUX0 + 1) * np];
         double ax = a[0], ay = a[np], az = a[2 * np], anz = a[3 * np];
         double dx = b[0] - ax, dy = b[np] - ay, dz = b[2 * np] - az;
-        double ds = sqrt(dx * dx + dy * dy + dz * dz);
+        double ds = fsqrt(dx * dx + dy * dy + dz * dz);
         double z = az + dz / 2.0;
         double nz = anz + (b[3 * np] - anz) / 2.0;
         double xe = clampd(z, P.x_min, P.x_max);
         int k = seg_guess(P.seg, P, xe);
         Atm9 m; seg_eval<false>(P.seg, k, xe, m);
-        double c = sqrt(kGamR * m.T);
+        double qT = kGamR * m.T;
+        double c = qT * frsq(qT);
         double rho = rho_eval(P, k, xe);
-        double nu_mag = (P.c000 - nx * m.u - ny * m.v) / c;
-        double cp0 = c * nx / nu_mag + m.u, cp1 = c * ny / nu_mag + m.v, cp2 = c * nz / nu_mag;
-        double cpm = sqrt(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
-        tt = ds / cpm;
+        double cn = (c * c) * frcp(P.c000 - nx * m.u - ny * m.v);      // c / nu_mag, nu_mag = (c(0,0,0) - nu_x u - nu_y v) / c  (Q5)
+        double cp0 = cn * nx + m.u, cp1 = cn * ny + m.v, cp2 = cn * nz;
+        tt = ds * frsq(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
         at = suthbass_alpha(P, z, c, rho, P.freq, P.T_o, P.P_o, P.cbrt_To) * ds;
     }
 };
@@ -1142,13 +1142,14 @@ template <bool AMP_> struct Eq2D {
         double ar = a[0], az = a[np];
         double dr = b[0] - ar, dz = b[np] - az;
         double z = az + dz / 2.0;
-        double ds = sqrt(dr * dr + dz * dz);
+        double ds = fsqrt(dr * dr + dz * dz);
         double xe = clampd(z, P.x_min, P.x_max);
         int k = seg_guess(P.seg, P, xe);
         Atm9 m; seg_eval<false>(P.seg, k, xe, m);
-        double c = sqrt(kGamR * m.T);
+        double qT = kGamR * m.T;
+        double c = qT * frsq(qT);
         double rho = rho_eval(P, k, xe);
-        tt = ds / (c + m.u * cph + m.v * sph);
+        tt = ds * frcp(c + m.u * cph + m.v * sph);
         at = suthbass_alpha(P, z, c, rho, P.freq, P.T_o, P.P_o, P.cbrt_To) * ds;
     }
 };
