@@ -456,10 +456,9 @@ int geoac_fan_launch(geoac_ctx* ctx){
         }
         P.src_trig[0] = sin(p.src[1] * kPi / 180.0); P.src_trig[1] = cos(p.src[1] * kPi / 180.0);
     }
-    // ---- epoch size: 8192 rows unless a path chunk would pass 16 GiB (two chunks + two contrib buffers = 43 GiB of the 288).
-    //      Measured on the metric fan (GEOAC_S_ROWS sweep): 1024 rows 243 ms, 2048 236, 4096 228, 8192 224.5, 16384 231, 32768 243 per
-    //      pass - every epoch boundary costs a launch + host round trip + table reload + a post-pass burst against full RK4
-    //      occupancy, while very long epochs leave the last post-pass uncovered ----
+    // ---- epoch size: 8192 rows unless a path chunk would pass 16 GiB (three chunks + three contrib buffers <= 64 GiB of the 288).
+    //      Measured on the metric fan (GEOAC_S_ROWS sweep, hybrid build): 4096 rows 179 ms per pass, 8192 167, 12288 167, 16384 173 -
+    //      every epoch boundary costs a launch + table reload, while very long epochs leave the last post-pass uncovered ----
     size_t row_bytes = (size_t)P.pathw * P.n_pad * sizeof(double);
     long long s_rows = (long long)((16ull << 30) / row_bytes);
     if(s_rows > 8192) s_rows = 8192;
