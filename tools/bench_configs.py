@@ -58,12 +58,12 @@ def cfg5():
     grid = RD.write_grid_global(os.path.join(tempfile.gettempdir(), "ggb"), short_paths=False)
     ctx = G.FanContext(G.EQ_GLOBAL_RNGDEP, device=0); ctx.load_grid(*grid)
     ctx.set_params(src=(0.0, 31.0, 0.0))
-    n = 8                                           # one GPU's share of the 64-receiver ring sharded over 8 GPUs
-    az = np.arange(n) * (2.0 * np.pi / 64)
+    # one GPU's share of the 64-receiver ring sharded over 8 GPUs by receiver (geoac_amd.sharding.shard_receivers: round robin): rank 0
+    az = np.arange(0, 64, 8) * (2.0 * np.pi / 64)
     rcv = np.stack([31.0 + 2.5 * np.cos(az), 2.5 * np.sin(az) / np.cos(np.radians(31.0))], axis=1)
     t0 = time.perf_counter(); out = ctx.eig_search(rcv, bnc_min=0, bnc_max=2); dt = time.perf_counter() - t0
     st = out["stats"]
-    return dict(config="cfg5 GeoAcGlobal.RngDep -eig_search, 8 of 64 receivers on a 2.5 deg ring, bounces 0..2", rays=st["rays"], ray_steps=st["steps"],
+    return dict(config="cfg5 GeoAcGlobal.RngDep -eig_search, 8 of 64 receivers (every 8th) on a 2.5 deg ring, bounces 0..2", rays=st["rays"], ray_steps=st["steps"],
                 seconds=dt, eigenrays=int(len(out["eig"])), fan_launches=st["launches"])
 
 
