@@ -47,6 +47,37 @@ DEVINL double frsq(double x){
     double p = __builtin_fma(e, 0.375, 0.5);
     return __builtin_fma(y * e, p, y);
 }
+// exp / exp10 for the absorption integrand (k_postpass): arguments of moderate size and never NaN / inf there, so none of the library
+// routine's special-case work.  k = round(x log2 e), r = x - k ln2 (two-constant Cody-Waite, exact product through FMA), Taylor
+// polynomial of degree 13 on |r| <= ln2 / 2 (truncation 2e-17), result scaled by 2^k: < 1 ulp + the rounding of r.
+DEVINL double exp_poly(double r){
+    double p = 1.0 / 6227020800.0;
+    p = __builtin_fma(p, r, 1.0 / 479001600.0);
+    p = __builtin_fma(p, r, 1.0 / 39916800.0);
+    p = __builtin_fma(p, r, 1.0 / 3628800.0);
+    p = __builtin_fma(p, r, 1.0 / 362880.0);
+    p = __builtin_fma(p, r, 1.0 / 40320.0);
+    p = __builtin_fma(p, r, 1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_fma(p, r, 1.0);
+}
+DEVINL double fexp(double x){
+    const double k = __builtin_rint(x * 1.44269504088896338700e+00);
+    double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);
+    r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
+    return __builtin_ldexp(exp_poly(r), (int)k);
+}
+DEVINL double fexp10(double y){
+    const double k = __builtin_rint(y * 3.32192809488736218171e+00);
+    double r = __builtin_fma(-k, 3.01029995663611771306e-01, y);       // log10(2), high and low parts (fdlibm's log10_2hi / lo)
+    r = __builtin_fma(-k, 3.69423907715893078616e-13, r);
+    return __builtin_ldexp(exp_poly(r * 2.30258509299404568402e+00), (int)k);
+}
 // rotate (sin a, cos a) by a small angle d.  |d| <= ds_max / r_earth < 1e-4 for every caller (one RK4 stage or step of at most
 // 0.5 km at r >= 6370 km), so sin d = d (1 - d^2/6), cos d = 1 - d^2/2 (1 - d^2/12) are exact to < 1e-17 relative
 DEVINL void rot_small(double sa, double ca, double d, double& s, double& c){
@@ -351,23 +382,24 @@ DEVINL double suthbass_alpha(const GeoacDevParams& P, double zr, double c_snd, d
 
     double z2 = zr * zr, z3 = z2 * zr, z4 = z2 * z2, z5 = z4 * zr;
     double X0, X1, X2, X3, X4, X5, X6;
-    X0 = (zr > 90.) ? exp10(49.296 - (1.5524 * zr) + (1.8714E-2 * z2) - (1.1069E-4 * z3) + (3.199E-7 * z4) - (3.6211E-10 * z5))
+    X0 = (zr > 90.) ? fexp10(49.296 - (1.5524 * zr) + (1.8714E-2 * z2) - (1.1069E-4 * z3) + (3.199E-7 * z4) - (3.6211E-10 * z5))
                     : P.sb_const[0];          // 10^-0.67887 (host pow)
-    X1 = (zr > 76.) ? exp10((1.3972E-1) - (5.6269E-3 * zr) + (3.9407E-5 * z2) - (1.0737E-7 * z3))
+    X1 = (zr > 76.) ? fexp10((1.3972E-1) - (5.6269E-3 * zr) + (3.9407E-5 * z2) - (1.0737E-7 * z3))
                     : P.sb_const[1];          // 10^-0.10744
     X2 = P.sb_const[2];                     // 10^-3.3979
-    X3 = (zr > 80.) ? exp10(-4.234 - (3.0975E-2 * zr))
-                    : exp10(-19.027 + (1.3093 * zr) - (4.6496E-2 * z2) + (7.8543E-4 * z3) - (6.5169E-6 * z4) + (2.1343E-8 * z5));
-    X4 = (zr > 95.) ? exp10(-3.2456 + (4.6642E-2 * zr) - (2.6894E-4 * z2) + (5.264E-7 * z3))
-                    : exp10(-11.195 + (1.5408E-1 * zr) - (1.4348E-3 * z2) + (1.0166E-5 * z3));
-    X5 = exp10(-53.746 + (1.5439 * zr) - (1.8824E-2 * z2) + (1.1587E-4 * z3) - (3.5399E-7 * z4) + (4.2609E-10 * z5));
-    X6 = (zr > 30.) ? exp10(-4.2563 + (7.6245E-2 * zr) - (2.1824E-3 * z2) - (2.3010E-6 * z3) + (2.4265E-7 * z4) - (1.2500E-09 * z5))
-                    : exp10(-1.7491 + (4.4986E-2 * zr) - (6.8549E-2 * z2) + (5.4639E-3 * z3) - (1.5539E-4 * z4) + (1.5063E-06 * z5));
+    // one exponential per species: the branch of the reference's piecewise fits selects the exponent
+    X3 = fexp10((zr > 80.) ? -4.234 - (3.0975E-2 * zr)
+                           : -19.027 + (1.3093 * zr) - (4.6496E-2 * z2) + (7.8543E-4 * z3) - (6.5169E-6 * z4) + (2.1343E-8 * z5));
+    X4 = fexp10((zr > 95.) ? -3.2456 + (4.6642E-2 * zr) - (2.6894E-4 * z2) + (5.264E-7 * z3)
+                           : -11.195 + (1.5408E-1 * zr) - (1.4348E-3 * z2) + (1.0166E-5 * z3));
+    X5 = fexp10(-53.746 + (1.5439 * zr) - (1.8824E-2 * z2) + (1.1587E-4 * z3) - (3.5399E-7 * z4) + (4.2609E-10 * z5));
+    X6 = fexp10((zr > 30.) ? -4.2563 + (7.6245E-2 * zr) - (2.1824E-3 * z2) - (2.3010E-6 * z3) + (2.4265E-7 * z4) - (1.2500E-09 * z5)
+                           : -1.7491 + (4.4986E-2 * zr) - (6.8549E-2 * z2) + (5.4639E-3 * z3) - (1.5539E-4 * z4) + (1.5063E-06 * z5));
     double X_ON = (X0 + X1) * (1.0 / 0.9903);
 
     double rc = rcbrt(T_z);                                  // T_z^(-1/3)
-    double Zr0 = 54.1 * exp(-17.3 * rc);
-    double Zr1 = 63.3 * exp(-16.7 * rc);
+    double Zr0 = 54.1 * fexp(-17.3 * rc);
+    double Zr1 = 63.3 * fexp(-16.7 * rc);
     double Z_rot_ = (Zr0 * Zr1) * frcp(__builtin_fma(X1, Zr0, X0 * Zr1));      // 1 / (X1/Zr1 + X0/Zr0)
 
     const double sigma = P.sb_const[3];                      // 5/sqrt(21)
@@ -384,19 +416,19 @@ DEVINL double suthbass_alpha(const GeoacDevParams& P, double zr, double c_snd, d
     double a_diff = 0.003 * a_cl;
 
     double Tr = __builtin_fma(cbrt_To, rc, -1.0);            // (T_z/T_o)^(-1/3) - 1 = cbrt(T_o) T_z^(-1/3) - 1
-    double A1 = (X0 + X1) * 24.0 * exp(-9.16 * Tr);
+    double A1 = (X0 + X1) * 24.0 * fexp(-9.16 * Tr);
     double A2 = (X4 + X5) * 2400.0;
-    double B  = 40400.0 * exp(10.0 * Tr);
-    double C  = 0.02 * exp(-11.2 * Tr);
-    double D  = 0.391 * exp(8.41 * Tr);
-    double Ee = 9.0 * exp(-19.9 * Tr);
+    double B  = 40400.0 * fexp(10.0 * Tr);
+    double C  = 0.02 * fexp(-11.2 * Tr);
+    double D  = 0.391 * fexp(8.41 * Tr);
+    double Ee = 9.0 * fexp(-19.9 * Tr);
     double F  = 60000.0;
-    double G  = 28000.0 * exp(-4.17 * Tr);
-    double H  = 22000.0 * exp(-7.68 * Tr);
-    double I  = 15100.0 * exp(-10.4 * Tr);
-    double J  = 11500.0 * exp(-9.17 * Tr);
-    double K  = (8.48E08) * exp(9.17 * Tr);
-    double L  = exp(-7.72 * Tr);
+    double G  = 28000.0 * fexp(-4.17 * Tr);
+    double H  = 22000.0 * fexp(-7.68 * Tr);
+    double I  = 15100.0 * fexp(-10.4 * Tr);
+    double J  = 11500.0 * fexp(-9.17 * Tr);
+    double K  = (8.48E08) * fexp(9.17 * Tr);
+    double L  = fexp(-7.72 * Tr);
     double ZZ = H * X2 + I * (X0 + 0.5 * X4) + J * (X1 + 0.5 * X5) + K * (X6 + X3);
     double hu = 100.0 * (X3 + X6);
     double pm = (P_z * mu_o) * frcp(P_o * mu);
@@ -409,7 +441,7 @@ DEVINL double suthbass_alpha(const GeoacDevParams& P, double zr, double c_snd, d
     #pragma unroll
     for(int m = 0; m < 4; m++){
         double q = Theta[m] * iTz;
-        double ex = exp(-q);
+        double ex = fexp(-q);
         double om = 1 - ex;
         double C_R = ((q * q) * ex) * frcp(om * om);
         double ifv = frcp(fv[m]);
