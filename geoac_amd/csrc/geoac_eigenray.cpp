@@ -10,7 +10,9 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <iomanip>
 #include <map>
 #include <memory>
@@ -66,6 +68,45 @@ double modify_d_theta(double dr, double dr_dtheta){           // :40-44
     return d_theta_big - (d_theta_big - d_theta_small) * exp(-dr * dr / width);
 }
 
+// Deferred log: what a search task would have written to the reference's cout, kept as operations and rendered at the end
+// into ONE stream per receiver in the reference's order - the tasks of a receiver (one scan chain per bounce count, one task per
+// refinement) run concurrently, but a std::setprecision of an earlier block must still stick to the later ones, and the running
+// eigenray number is only known once the earlier blocks are complete.
+struct DLog {
+    enum Kind { TEXT, NUM, INT, PREC, COUNT, INCR };
+    struct Op { Kind k; std::string s; double d; long long i; };
+    struct Count {};                                             // prints the number of eigenrays identified so far
+    std::vector<Op> ops;
+    DLog& text(const std::string& t){ if(!ops.empty() && ops.back().k == TEXT) ops.back().s += t; else ops.push_back(Op{TEXT, t, 0.0, 0}); return *this; }
+    DLog& operator<<(const char* t){ return text(t); }
+    DLog& operator<<(const std::string& t){ return text(t); }
+    DLog& operator<<(char c){ return text(std::string(1, c)); }
+    DLog& operator<<(double d){ ops.push_back(Op{NUM, "", d, 0}); return *this; }
+    DLog& operator<<(int i){ ops.push_back(Op{INT, "", 0.0, i}); return *this; }
+    DLog& operator<<(decltype(std::setprecision(0)) pr){ ops.push_back(Op{PREC, "", 0.0, (long long)pr._M_n}); return *this; }
+    DLog& operator<<(Count){ ops.push_back(Op{COUNT, "", 0.0, 0}); return *this; }
+    void incr(){ ops.push_back(Op{INCR, "", 0.0, 0}); }
+    void render(std::ostringstream& os, int& count) const {
+        for(const Op& o : ops){
+            switch(o.k){
+                case TEXT: os << o.s; break;
+                case NUM: os << o.d; break;
+                case INT: os << o.i; break;
+                case PREC: os << std::setprecision((int)o.i); break;
+                case COUNT: os << count; break;
+                case INCR: count++; break;
+            }
+        }
+    }
+};
+
+struct Eigenray;
+struct Segment;                            // one task's output: its log and the eigenrays it identified
+thread_local DLog* tl_log = nullptr;
+thread_local std::vector<Eigenray>* tl_found = nullptr;
+#define LOG (*tl_log)
+#define FOUND (*tl_found)
+
 struct SearchBase {
     Shared* sh = nullptr;
     int eqset = GEOAC_EQ_GLOBAL;
@@ -75,12 +116,93 @@ struct SearchBase {
     double z_grnd = 0.0;
     geoac_eig_params prm{};
     bool verbose = false;
-    std::ostringstream log;                // the reference's cout for this receiver (sticky precision and all)
+    std::ostringstream log;                // the reference's cout for this receiver (sticky precision and all), rendered at the end
     std::vector<Eigenray> found;
     int eigenray_count = 0;
+    bool self_released = false;            // run_search took this thread out of Shared::active before waiting for its tasks
     virtual ~SearchBase(){}
-    virtual void run_search() = 0;
     virtual void run_direct(double theta_est, double phi_from_north, int bounces) = 0;
+    // the pieces of the reference's -eig_search loop (GeoAcGlobal_main.cpp:566-580, GeoAc3D_main.cpp:531-543) the two families differ in
+    virtual void header(int n_bnc) = 0;
+    virtual void footer() = 0;
+    virtual bool estimate(double theta_min, double theta_max, double& theta_estimate, double& phi_estimate, double& theta_next, int bounces) = 0;
+    virtual void refine(double& lt, double& lp, int bnc_cnt, int iterate_limit) = 0;
+
+    // ---- tasks.  The reference runs, per bounce count, estimate -> refine -> estimate -> ... one ray at a time.  Nothing an
+    //      estimate or a refinement computes depends on another bounce count, and a refinement depends only on the estimate it
+    //      starts from; so every bounce count is its own scan chain and every refinement its own task, all posting rays to the same
+    //      rounds (fewer, fuller fan launches), and the output is put back in the reference's order afterwards. ----
+    struct Segment { DLog log; std::vector<Eigenray> found; };
+    void task_started(int n = 1){ std::unique_lock<std::mutex> lk(sh->mu); sh->active += n; }
+    void task_ended(){ std::unique_lock<std::mutex> lk(sh->mu); sh->active--; sh->cv_work.notify_all(); }
+    static std::atomic<int>& live_tasks(){ static std::atomic<int> n{0}; return n; }
+
+    void run_search(){
+        const int nb = std::max(0, prm.bnc_max - prm.bnc_min + 1);
+        std::vector<std::deque<Segment>> segs((size_t)nb);           // per bounce count, in the reference's order: header, E1, R1, E2, R2, ...
+        std::vector<std::thread> chains;
+        task_started(nb);
+        for(int b = 0; b < nb; b++){
+            chains.emplace_back([this, b, &segs]{
+                const int n_bnc = prm.bnc_min + b;
+                std::deque<Segment>& mine = segs[(size_t)b];
+                std::vector<std::thread> refiners;
+                mine.emplace_back();
+                tl_log = &mine.back().log; tl_found = &mine.back().found;
+                header(n_bnc);
+                double theta_start = prm.theta_min, theta_next = prm.theta_max, theta_est = 0, phi_est = 0;
+                while(theta_start < prm.theta_max && !sh->failed){
+                    mine.emplace_back();
+                    tl_log = &mine.back().log; tl_found = &mine.back().found;
+                    bool ok = estimate(theta_start, prm.theta_max, theta_est, phi_est, theta_next, n_bnc);
+                    if(sh->failed) break;
+                    if(ok){
+                        mine.emplace_back();
+                        Segment* seg = &mine.back();                 // deque: the address stays valid while later segments are appended
+                        const double lt0 = theta_est, lp0 = phi_est;
+                        if(live_tasks().load() < 384){
+                            live_tasks()++;
+                            task_started();
+                            refiners.emplace_back([this, seg, lt0, lp0, n_bnc]{
+                                tl_log = &seg->log; tl_found = &seg->found;
+                                double lt = lt0, lp = lp0;
+                                refine(lt, lp, n_bnc, prm.iterations);
+                                live_tasks()--;
+                                task_ended();
+                            });
+                        } else {                                       // very many receivers: refine in line, as the reference does
+                            tl_log = &seg->log; tl_found = &seg->found;
+                            double lt = lt0, lp = lp0;
+                            refine(lt, lp, n_bnc, prm.iterations);
+                        }
+                    }
+                    theta_start = theta_next;
+                }
+                task_ended();                                          // nothing more to trace from this thread: it only waits now
+                for(auto& t : refiners) t.join();
+            });
+        }
+        task_ended();                                                  // this receiver's own thread only waits for its chains
+        self_released = true;
+        for(auto& t : chains) t.join();
+        // ---- put the output in the reference's order ----
+        for(auto& per_bnc : segs) for(Segment& g : per_bnc){
+            g.log.render(log, eigenray_count);
+            for(Eigenray& e : g.found){ e.v[GEOAC_EIG_INDEX] = (double)found.size(); found.push_back(e); }
+        }
+        Segment tail;
+        tl_log = &tail.log; tl_found = &tail.found;
+        footer();
+        tail.log.render(log, eigenray_count);
+    }
+    // -eig_direct: one refinement, on this thread
+    void direct_refine(double lt, double lp, int bounces){
+        Segment g;
+        tl_log = &g.log; tl_found = &g.found;
+        refine(lt, lp, bounces, prm.iterations);
+        g.log.render(log, eigenray_count);
+        for(Eigenray& e : g.found){ e.v[GEOAC_EIG_INDEX] = (double)found.size(); found.push_back(e); }
+    }
 
     // ---- post a request and wait for the coordinator ----
     bool trace(Request& rq){
@@ -112,13 +234,13 @@ struct Search : SearchBase {
     Geo geo{6370.0};
 
     // ---- GeoAc_EstimateEigenray: GeoAc.Eigenray.Global.cpp:46-136 ----
-    bool estimate(double theta_min, double theta_max, double& theta_estimate, double& phi_estimate, double& theta_next, int bounces){
+    bool estimate(double theta_min, double theta_max, double& theta_estimate, double& phi_estimate, double& theta_next, int bounces) override {
         const double azimuth_error_limit = prm.azimuth_err_lim;
         double GC_r_rcvr = geo.gc_distance(src[0], src[1], rcv[0], rcv[1]);
         double phi = geo.bearing(src[0], src[1], rcv[0], rcv[1]);
         if(verbose){
-            log << '\t' << "Estimating eigenray angles for source-receiver separated by great circle distance " << GC_r_rcvr << " km, and azimuth " << phi;
-            log << " degrees from N.  Inclination limits: [" << theta_min << ", " << theta_max << "]." << '\n';
+            LOG << '\t' << "Estimating eigenray angles for source-receiver separated by great circle distance " << GC_r_rcvr << " km, and azimuth " << phi;
+            LOG << " degrees from N.  Inclination limits: [" << theta_min << ", " << theta_max << "]." << '\n';
         }
         int iterations = 0;
         theta_estimate = theta_max;
@@ -149,8 +271,8 @@ struct Search : SearchBase {
                 if(BreakCheck){ r = GC_r_rcvr; r_prev = GC_r_rcvr; }
                 else r = geo.gc_distance(src[0], src[1], lat_k, lon_k);
                 if(verbose){
-                    log << '\t' << '\t' << "Ray launched at inclination=" << (theta * Pi / 180.0) * 180.0 / Pi << " degrees arrives at range " << r;
-                    log << " km after " << bounces << " bounces.  Exact arrival at " << lat_k << " degrees N latitude, " << lon_k << " degrees E longitude" << '\n';
+                    LOG << '\t' << '\t' << "Ray launched at inclination=" << (theta * Pi / 180.0) * 180.0 / Pi << " degrees arrives at range " << r;
+                    LOG << " km after " << bounces << " bounces.  Exact arrival at " << lat_k << " degrees N latitude, " << lon_k << " degrees E longitude" << '\n';
                 }
                 if((r - GC_r_rcvr) * (r_prev - GC_r_rcvr) < 0.0){
                     if(iterations == 0) theta_next = theta;
@@ -159,12 +281,12 @@ struct Search : SearchBase {
                     while(d_phi > 180.0){ d_phi -= 360.0; }
                     while(d_phi < -180.0){ d_phi += 360.0; }
                     if(fabs(d_phi) < azimuth_error_limit){
-                        if(verbose) log << '\t' << '\t' << "Azimuth deviation less than " << azimuth_error_limit << " degrees.  Estimates acceptable." << '\n' << '\n';
+                        if(verbose) LOG << '\t' << '\t' << "Azimuth deviation less than " << azimuth_error_limit << " degrees.  Estimates acceptable." << '\n' << '\n';
                         theta_estimate = theta - d_theta;
                         phi_estimate = 90.0 - phi;
                         return true;
                     } else {
-                        if(verbose) log << '\t' << '\t' << "Azimuth deviation greater than " << azimuth_error_limit << " degrees.  Compensating and searching inclinations again." << '\n' << '\n';
+                        if(verbose) LOG << '\t' << '\t' << "Azimuth deviation greater than " << azimuth_error_limit << " degrees.  Compensating and searching inclinations again." << '\n' << '\n';
                         phi += d_phi * 0.9;
                         theta_min = std::max(theta - 7.5, theta_min);
                     }
@@ -182,32 +304,32 @@ struct Search : SearchBase {
             iterations++;
             if(iterations >= 1 && iterations < 3){ d_theta = d_theta_big / 2.0; }
         }
-        if(verbose) log << '\t' << '\t' << "Reached maximum inclination angle or iteration limit." << '\n' << '\n';
+        if(verbose) LOG << '\t' << '\t' << "Reached maximum inclination angle or iteration limit." << '\n' << '\n';
         return false;
     }
 
     // ---- GeoAc_3DEigenray_LM: GeoAc.Eigenray.Global.cpp:139-319 ----
-    void refine(double& lt, double& lp, int bnc_cnt, int iterate_limit){
+    void refine(double& lt, double& lp, int bnc_cnt, int iterate_limit) override {
         double dr, dr_prev = 10000.0;
         const double tolerance = 0.1;
         const double lt_lim_step = 0.2, lp_lim_step = 0.2;
         double step_scalar = 1.0;
         long double lat, lon, d_lat, d_lon, d_lat_dlt, d_lon_dlt, d_lat_dlp, d_lon_dlp, det, dlt = 0, dlp = 0;
-        if(verbose) log << '\t' << '\t' << "Searching for exact eigenray using auxiliary parameters." << '\n';
+        if(verbose) LOG << '\t' << '\t' << "Searching for exact eigenray using auxiliary parameters." << '\n';
         for(int n = 0; n <= iterate_limit; n++){
             if(n == iterate_limit){
-                if(verbose){ log << '\t' << '\t' << '\t' << "Search for exact eigenray maxed out iterations.  No eigneray idenfied." << '\n'; }
+                if(verbose){ LOG << '\t' << '\t' << '\t' << "Search for exact eigenray maxed out iterations.  No eigneray idenfied." << '\n'; }
                 break;
             }
             Request rq; rq.bounces = bnc_cnt; rq.calc_amp = 1; rq.mode = 0;
             rq.th.push_back(lt); rq.ph.push_back(90.0 - lp);
-            if(verbose) log << '\t' << '\t' << "Plotting ray path with theta = " << lt << ", phi = " << 90.0 - lp;
+            if(verbose) LOG << '\t' << '\t' << "Plotting ray path with theta = " << lt << ", phi = " << 90.0 - lp;
             if(!trace(rq)) return;
             if(broke(rq, 0)) break;
             const double* S = &rq.rec[((size_t)bnc_cnt) * GEOAC_REC_STRIDE + GEOAC_REC_STATE];        // solution[k][*] of the last leg
             lat = S[1]; lon = S[2];
             dr = geo.gc_distance((double)(lat * 180.0 / Pi), (double)(lon * 180.0 / Pi), rcv[0], rcv[1]);
-            if(verbose) log << '\t' << '\t' << "Arrival at (" << std::setprecision(8) << (double)(lat * 180.0 / Pi) << ", " << (double)(lon * 180.0 / Pi) << "), distance to receiver = " << dr << " km." << '\n';
+            if(verbose) LOG << '\t' << '\t' << "Arrival at (" << std::setprecision(8) << (double)(lat * 180.0 / Pi) << ", " << (double)(lon * 180.0 / Pi) << "), distance to receiver = " << dr << " km." << '\n';
 
             if(dr < tolerance){
                 // the reference re-propagates and accumulates travel time / attenuation with the raypath-writing loop (:198-238):
@@ -226,7 +348,7 @@ struct Search : SearchBase {
                 double back_az_dev = back_az - bearing_back;
                 if(back_az_dev > 180.0)  back_az_dev -= 360.0;
                 if(back_az_dev < -180.0) back_az_dev += 360.0;
-                e.v[GEOAC_EIG_RCVR] = rcvr_index; e.v[GEOAC_EIG_INDEX] = eigenray_count; e.v[GEOAC_EIG_BOUNCES] = bnc_cnt;
+                e.v[GEOAC_EIG_RCVR] = rcvr_index; e.v[GEOAC_EIG_INDEX] = 0;  /* numbered when the receiver's segments are put in order */ e.v[GEOAC_EIG_BOUNCES] = bnc_cnt;
                 e.v[GEOAC_EIG_THETA] = lt; e.v[GEOAC_EIG_PHI] = 90.0 - lp;
                 e.v[GEOAC_EIG_TTIME] = travel_time;
                 e.v[GEOAC_EIG_CELERITY] = geo.gc_distance(src[0], src[1], rcv[0], rcv[1]) / travel_time;
@@ -236,28 +358,28 @@ struct Search : SearchBase {
                 e.smp = fin.smp;
                 e.v[GEOAC_EIG_NSMP] = (double)(e.smp.size() / GEOAC_SMP_STRIDE);
                 if(verbose){
-                    log << '\t' << '\t' << "Eigenray-" << eigenray_count << ".  " << bnc_cnt << " bounce(s)." << '\n';
-                    log << '\t' << '\t' << '\t' << "theta, phi = " << std::setprecision(8) << lt << ", " << 90.0 - lp << " degrees." << '\n';
-                    log << '\t' << '\t' << '\t' << "Travel Time = " << travel_time << " seconds." << '\n';
-                    log << '\t' << '\t' << '\t' << "Celerity = " << e.v[GEOAC_EIG_CELERITY] << " km/s." << '\n';
-                    log << '\t' << '\t' << '\t' << "Amplitude = " << e.v[GEOAC_EIG_AMP_DB] << " dB." << '\n';
-                    log << '\t' << '\t' << '\t' << "Atmospheric Attenuation = " << -attenuation << " dB." << '\n';
-                    log << '\t' << '\t' << '\t' << "Arrival inclination = " << arrival_incl << " degrees." << '\n';
-                    log << '\t' << '\t' << '\t' << "Bearing to source = " << bearing_back << " degrees." << '\n';
-                    log << '\t' << '\t' << '\t' << "Back azimuth of arrival = " << back_az << " degrees." << '\n';
-                    log << '\t' << '\t' << '\t' << "Azimuth Deviation = " << back_az_dev << " degrees." << '\n' << '\n';
+                    LOG << '\t' << '\t' << "Eigenray-" << DLog::Count{} << ".  " << bnc_cnt << " bounce(s)." << '\n';
+                    LOG << '\t' << '\t' << '\t' << "theta, phi = " << std::setprecision(8) << lt << ", " << 90.0 - lp << " degrees." << '\n';
+                    LOG << '\t' << '\t' << '\t' << "Travel Time = " << travel_time << " seconds." << '\n';
+                    LOG << '\t' << '\t' << '\t' << "Celerity = " << e.v[GEOAC_EIG_CELERITY] << " km/s." << '\n';
+                    LOG << '\t' << '\t' << '\t' << "Amplitude = " << e.v[GEOAC_EIG_AMP_DB] << " dB." << '\n';
+                    LOG << '\t' << '\t' << '\t' << "Atmospheric Attenuation = " << -attenuation << " dB." << '\n';
+                    LOG << '\t' << '\t' << '\t' << "Arrival inclination = " << arrival_incl << " degrees." << '\n';
+                    LOG << '\t' << '\t' << '\t' << "Bearing to source = " << bearing_back << " degrees." << '\n';
+                    LOG << '\t' << '\t' << '\t' << "Back azimuth of arrival = " << back_az << " degrees." << '\n';
+                    LOG << '\t' << '\t' << '\t' << "Azimuth Deviation = " << back_az_dev << " degrees." << '\n' << '\n';
                 } else {
-                    log << '\t' << "Eigenray identified:" << '\t' << "theta, phi = " << std::setprecision(8) << lt << ", " << 90.0 - lp << " degrees." << '\n';
+                    LOG << '\t' << "Eigenray identified:" << '\t' << "theta, phi = " << std::setprecision(8) << lt << ", " << 90.0 - lp << " degrees." << '\n';
                 }
-                found.push_back(e);
-                eigenray_count++;
+                FOUND.push_back(e);
+                LOG.incr();
                 break;
             } else if(n > 0 && dr > dr_prev){
                 lt -= dlt * step_scalar;
                 lp -= dlp * step_scalar;
                 step_scalar /= 2.0;
                 if(sqrt(dlt * dlt + dlp * dlp) * step_scalar < 1.0e-12){
-                    if(verbose) log << '\t' << '\t' << '\t' << "Step size too small, psuedo-critical ray path likely." << '\n' << '\n';
+                    if(verbose) LOG << '\t' << '\t' << '\t' << "Step size too small, psuedo-critical ray path likely." << '\n' << '\n';
                     break;
                 }
             } else {
@@ -283,25 +405,10 @@ struct Search : SearchBase {
         }
     }
 
-    // ---- the -eig_search driver loop: GeoAcGlobal_main.cpp:566-580 ----
-    void run_search() override {
-        for(int n_bnc = prm.bnc_min; n_bnc <= prm.bnc_max; n_bnc++){
-            log << "Searching for " << n_bnc << " bounce eigenrays." << '\n';
-            double theta_start = prm.theta_min, theta_next = prm.theta_max, theta_est = 0, phi_est = 0;
-            while(theta_start < prm.theta_max){
-                bool ok = estimate(theta_start, prm.theta_max, theta_est, phi_est, theta_next, n_bnc);
-                if(sh->failed) return;
-                if(ok) refine(theta_est, phi_est, n_bnc, prm.iterations);
-                if(sh->failed) return;
-                theta_start = theta_next;
-            }
-        }
-        log << "Identified " << eigenray_count << " eigenray(s)." << '\n';
-    }
-    void run_direct(double theta_est, double phi_from_north, int bounces) override {
-        double lt = theta_est, lp = 90.0 - phi_from_north;
-        refine(lt, lp, bounces, prm.iterations);
-    }
+    // ---- the text around the -eig_search driver loop: GeoAcGlobal_main.cpp:566-580 ----
+    void header(int n_bnc) override { LOG << "Searching for " << n_bnc << " bounce eigenrays." << '\n'; }
+    void footer() override { LOG << "Identified " << DLog::Count{} << " eigenray(s)." << '\n'; }
+    void run_direct(double theta_est, double phi_from_north, int bounces) override { direct_refine(theta_est, 90.0 - phi_from_north, bounces); }
 };
 
 // ================= 3-D Cartesian sets: GeoAc.Eigenray.cpp =================
@@ -315,13 +422,13 @@ struct SearchCart : SearchBase {
     double M_Comps[3] = {0, 0, 0};         // wind Mach numbers at the source (stratified set only, :130-134)
 
     // ---- GeoAc_EstimateEigenray: GeoAc.Eigenray.cpp:30-121 ----
-    bool estimate(double theta_min, double theta_max, double& theta_estimate, double& phi_estimate, double& theta_next, int bounces){
+    bool estimate(double theta_min, double theta_max, double& theta_estimate, double& phi_estimate, double& theta_next, int bounces) override {
         const double azimuth_error_limit = prm.azimuth_err_lim;
         double r_rcvr = sqrt(pow(rcv[0] - src[0], 2) + pow(rcv[1] - src[1], 2));
         double phi = 180.0 / 3.14159 * atan2(rcv[1] - src[1], rcv[0] - src[0]);
         if(verbose){
-            log << '\t' << "Estimating eigenray angles for source-receiver separated by " << r_rcvr << " km, and azimuth " << 90.0 - phi;
-            log << " degrees from N.  Inclination limits: [" << theta_min << ", " << theta_max << "]." << '\n';
+            LOG << '\t' << "Estimating eigenray angles for source-receiver separated by " << r_rcvr << " km, and azimuth " << 90.0 - phi;
+            LOG << " degrees from N.  Inclination limits: [" << theta_min << ", " << theta_max << "]." << '\n';
         }
         int iterations = 0;
         theta_estimate = theta_max;
@@ -348,8 +455,8 @@ struct SearchCart : SearchBase {
                 const double* Rk = last_row(*rq, idx);
                 const double xk = Rk[GEOAC_REC_STATE + 0], yk = Rk[GEOAC_REC_STATE + 1];
                 if(verbose){
-                    log << '\t' << '\t' << "Ray launched at " << theta << " degrees arrives at range " << sqrt(pow(xk - src[0], 2) + pow(yk - src[1], 2));
-                    log << " km after " << bounces << " reflections." << '\t' << "Exact arrival at " << xk << " km East, " << yk << " km North" << '\n';
+                    LOG << '\t' << '\t' << "Ray launched at " << theta << " degrees arrives at range " << sqrt(pow(xk - src[0], 2) + pow(yk - src[1], 2));
+                    LOG << " km after " << bounces << " reflections." << '\t' << "Exact arrival at " << xk << " km East, " << yk << " km North" << '\n';
                 }
                 if(BreakCheck){ r = r_rcvr; r_prev = r_rcvr; }
                 else { r = sqrt(pow(xk - src[0], 2) + pow(yk - src[1], 2)); }
@@ -359,12 +466,12 @@ struct SearchCart : SearchBase {
                     while(d_phi > 180.0)  d_phi -= 360.0;
                     while(d_phi < -180.0) d_phi += 360.0;
                     if(fabs(d_phi) < azimuth_error_limit){
-                        if(verbose) log << '\t' << '\t' << "Azimuth deviation = " << d_phi << ".  Less than " << azimuth_error_limit << " degrees.  Estimates acceptable." << '\n' << '\n';
+                        if(verbose) LOG << '\t' << '\t' << "Azimuth deviation = " << d_phi << ".  Less than " << azimuth_error_limit << " degrees.  Estimates acceptable." << '\n' << '\n';
                         theta_estimate = theta - d_theta;
                         phi_estimate = phi;
                         return true;
                     } else {
-                        if(verbose) log << '\t' << '\t' << "Azimuth deviation = " << d_phi << ".  Greater than " << azimuth_error_limit << " degrees.  Compensating and searching inclinations again." << '\n' << '\n';
+                        if(verbose) LOG << '\t' << '\t' << "Azimuth deviation = " << d_phi << ".  Greater than " << azimuth_error_limit << " degrees.  Compensating and searching inclinations again." << '\n' << '\n';
                         phi += d_phi * 0.9;
                         theta_min = std::max(theta - 7.5, theta_min);
                     }
@@ -380,12 +487,12 @@ struct SearchCart : SearchBase {
             iterations++;
             if(iterations >= 1 && iterations < 3){ d_theta = d_theta_big / 2.0; }
         }
-        if(verbose) log << '\t' << '\t' << "Reached maximum inclination angle or iteration limit." << '\n';
+        if(verbose) LOG << '\t' << '\t' << "Reached maximum inclination angle or iteration limit." << '\n';
         return false;
     }
 
     // ---- GeoAc_3DEigenray_LM: GeoAc.Eigenray.cpp:123-335 ----
-    void refine(double& theta, double& phi, int bnc_cnt, int iterate_limit){
+    void refine(double& theta, double& phi, int bnc_cnt, int iterate_limit) override {
         double dr, dr_prev = 10000.0;
         const double tolerance = 0.1;
         const double theta_lim_step = 0.2, phi_lim_step = 0.2;
@@ -393,10 +500,10 @@ struct SearchCart : SearchBase {
         double nu0[3], M, nu0_xy[2] = {0, 0};
         long double x, y, dx, dy, dx_dt, dy_dt, dx_dp, dy_dp;
         long double det, dt = 0, dp = 0;
-        if(verbose) log << '\t' << '\t' << "Searching for exact eigenray using auxiliary parameters." << '\n';
+        if(verbose) LOG << '\t' << '\t' << "Searching for exact eigenray using auxiliary parameters." << '\n';
         for(int n = 0; n <= iterate_limit; n++){
             if(n == iterate_limit){
-                if(verbose){ log << '\t' << '\t' << '\t' << "Search for exact eigenray maxed out iterations.  No eigneray idenfied." << '\n' << '\n'; }
+                if(verbose){ LOG << '\t' << '\t' << '\t' << "Search for exact eigenray maxed out iterations.  No eigneray idenfied." << '\n' << '\n'; }
                 break;
             }
             const double GeoAc_theta = theta * Pi / 180.0, GeoAc_phi = phi * Pi / 180.0;
@@ -410,17 +517,17 @@ struct SearchCart : SearchBase {
             }
             Request rq; rq.bounces = bnc_cnt; rq.calc_amp = 1; rq.mode = 0;
             rq.th.push_back(theta); rq.ph.push_back(90.0 - phi);
-            if(verbose) log << '\t' << '\t' << "Plotting ray path with theta = " << theta << ", phi = " << 90.0 - phi;
+            if(verbose) LOG << '\t' << '\t' << "Plotting ray path with theta = " << theta << ", phi = " << 90.0 - phi;
             if(!trace(rq)) return;
             if(broke(rq, 0)){
-                if(verbose) log << '\t' << "Ray path left propagation region." << '\n';
+                if(verbose) LOG << '\t' << "Ray path left propagation region." << '\n';
                 break;
             }
             const double* S = &rq.rec[((size_t)bnc_cnt) * GEOAC_REC_STRIDE + GEOAC_REC_STATE];
             x = S[0]; dx = rcv[0] - x;
             y = S[1]; dy = rcv[1] - y;
             dr = (double)sqrtl(dx * dx + dy * dy);
-            if(verbose) log << '\t' << '\t' << "Arrival after " << bnc_cnt << " reflections at (" << (double)x << ", " << (double)y << "), distance to receiver = " << dr << " km." << '\n';
+            if(verbose) LOG << '\t' << '\t' << "Arrival after " << bnc_cnt << " reflections at (" << (double)x << ", " << (double)y << "), distance to receiver = " << dr << " km." << '\n';
 
             if(dr < tolerance){
                 Request fin; fin.bounces = bnc_cnt; fin.calc_amp = 1; fin.mode = GEOAC_MODE_WRITE_RAYS;
@@ -438,7 +545,7 @@ struct SearchCart : SearchBase {
                 while(back_az < -180.0)     back_az += 360.0;
                 while(back_az_dev > 180.0)  back_az_dev -= 360.0;
                 while(back_az_dev < -180.0) back_az_dev += 360.0;
-                e.v[GEOAC_EIG_RCVR] = rcvr_index; e.v[GEOAC_EIG_INDEX] = eigenray_count; e.v[GEOAC_EIG_BOUNCES] = bnc_cnt;
+                e.v[GEOAC_EIG_RCVR] = rcvr_index; e.v[GEOAC_EIG_INDEX] = 0;  /* numbered when the receiver's segments are put in order */ e.v[GEOAC_EIG_BOUNCES] = bnc_cnt;
                 e.v[GEOAC_EIG_THETA] = theta; e.v[GEOAC_EIG_PHI] = 90.0 - phi;
                 e.v[GEOAC_EIG_TTIME] = travel_time;
                 e.v[GEOAC_EIG_CELERITY] = sqrt(pow(Sk[0] - src[0], 2) + pow(Sk[1] - src[1], 2)) / travel_time;
@@ -447,28 +554,28 @@ struct SearchCart : SearchBase {
                 e.v[GEOAC_EIG_INCL] = arrival_incl; e.v[GEOAC_EIG_BEARING] = az_to_src; e.v[GEOAC_EIG_BACKAZ] = back_az; e.v[GEOAC_EIG_AZDEV] = back_az_dev;
                 e.smp = fin.smp;
                 e.v[GEOAC_EIG_NSMP] = (double)(e.smp.size() / GEOAC_SMP_STRIDE);
-                if(!verbose) log << '\t' << "Eigenray identified:" << '\t' << "theta, phi = " << std::setprecision(8) << theta << ", " << 90.0 - phi << " degrees." << '\n';
+                if(!verbose) LOG << '\t' << "Eigenray identified:" << '\t' << "theta, phi = " << std::setprecision(8) << theta << ", " << 90.0 - phi << " degrees." << '\n';
                 if(verbose){
-                    log << '\t' << '\t' << "Eigenray Identified:" << '\n';
-                    log << '\t' << '\t' << '\t' << "theta, phi = " << std::setprecision(8) << theta << ", " << 90.0 - phi << " degrees." << '\n';
-                    log << '\t' << '\t' << '\t' << "Travel Time = " << travel_time << " seconds." << '\n';
-                    log << '\t' << '\t' << '\t' << "Celerity = " << e.v[GEOAC_EIG_CELERITY] << " km/s." << '\n';
-                    log << '\t' << '\t' << '\t' << "Amplitude (geometric) = " << e.v[GEOAC_EIG_AMP_DB] << " dB." << '\n';
-                    log << '\t' << '\t' << '\t' << "Atmospheric Attenuation = " << -attenuation << " dB." << '\n';
-                    log << '\t' << '\t' << '\t' << "Arrival inclination = " << arrival_incl << " degrees." << '\n';
-                    log << '\t' << '\t' << '\t' << "Azimuth to source = " << az_to_src << '\n';
-                    log << '\t' << '\t' << '\t' << "Back Azimuth of arrival = " << back_az << '\n';
-                    log << '\t' << '\t' << '\t' << "Azimuth Deviation = " << back_az_dev << " degrees." << '\n' << '\n';
+                    LOG << '\t' << '\t' << "Eigenray Identified:" << '\n';
+                    LOG << '\t' << '\t' << '\t' << "theta, phi = " << std::setprecision(8) << theta << ", " << 90.0 - phi << " degrees." << '\n';
+                    LOG << '\t' << '\t' << '\t' << "Travel Time = " << travel_time << " seconds." << '\n';
+                    LOG << '\t' << '\t' << '\t' << "Celerity = " << e.v[GEOAC_EIG_CELERITY] << " km/s." << '\n';
+                    LOG << '\t' << '\t' << '\t' << "Amplitude (geometric) = " << e.v[GEOAC_EIG_AMP_DB] << " dB." << '\n';
+                    LOG << '\t' << '\t' << '\t' << "Atmospheric Attenuation = " << -attenuation << " dB." << '\n';
+                    LOG << '\t' << '\t' << '\t' << "Arrival inclination = " << arrival_incl << " degrees." << '\n';
+                    LOG << '\t' << '\t' << '\t' << "Azimuth to source = " << az_to_src << '\n';
+                    LOG << '\t' << '\t' << '\t' << "Back Azimuth of arrival = " << back_az << '\n';
+                    LOG << '\t' << '\t' << '\t' << "Azimuth Deviation = " << back_az_dev << " degrees." << '\n' << '\n';
                 }
-                found.push_back(e);
-                eigenray_count++;
+                FOUND.push_back(e);
+                LOG.incr();
                 break;
             } else if(n > 0 && dr > dr_prev){
                 theta -= dt * step_scalar;
                 phi -= dp * step_scalar;
                 step_scalar /= 2.0;
                 if(sqrt(dt * dt + dp * dp) * step_scalar < 1.0e-12){
-                    if(verbose) log << '\t' << '\t' << '\t' << "Step size too small, psuedo-critical ray path likely." << '\n' << '\n';
+                    if(verbose) LOG << '\t' << '\t' << '\t' << "Step size too small, psuedo-critical ray path likely." << '\n' << '\n';
                     break;
                 }
             } else {
@@ -498,25 +605,10 @@ struct SearchCart : SearchBase {
         }
     }
 
-    // ---- the -eig_search driver loop: GeoAc3D_main.cpp:531-543 ----
-    void run_search() override {
-        for(int n_bnc = prm.bnc_min; n_bnc <= prm.bnc_max; n_bnc++){
-            log << "Searching for " << n_bnc << " bounce eigenray(s) between " << prm.theta_min << " and " << prm.theta_max << "." << '\n';
-            double theta_start = prm.theta_min, theta_next = prm.theta_max, theta_est = 0, phi_est = 0;
-            while(theta_start < prm.theta_max){
-                bool ok = estimate(theta_start, prm.theta_max, theta_est, phi_est, theta_next, n_bnc);
-                if(sh->failed) return;
-                if(ok) refine(theta_est, phi_est, n_bnc, prm.iterations);
-                if(sh->failed) return;
-                theta_start = theta_next;
-            }
-        }
-        log << '\t' << "Identified " << eigenray_count << " eigenray(s)." << '\n';
-    }
-    void run_direct(double theta_est, double phi_from_north, int bounces) override {
-        double theta = theta_est, phi = 90.0 - phi_from_north;
-        refine(theta, phi, bounces, prm.iterations);
-    }
+    // ---- the text around the -eig_search driver loop: GeoAc3D_main.cpp:531-543 ----
+    void header(int n_bnc) override { LOG << "Searching for " << n_bnc << " bounce eigenray(s) between " << prm.theta_min << " and " << prm.theta_max << "." << '\n'; }
+    void footer() override { LOG << '\t' << "Identified " << DLog::Count{} << " eigenray(s)." << '\n'; }
+    void run_direct(double theta_est, double phi_from_north, int bounces) override { direct_refine(theta_est, 90.0 - phi_from_north, bounces); }
 };
 
 }  // namespace
@@ -615,9 +707,11 @@ static int run_all(geoac_ctx* ctx, const geoac_eig_params* ep, int n_rcvr, const
         threads.emplace_back([&, i]{
             SearchBase& s = *S[(size_t)i];
             if(direct) s.run_direct(theta_est[i], phi_est[i], bounces); else s.run_search();
-            std::unique_lock<std::mutex> lk(sh.mu);
-            sh.active--;
-            sh.cv_work.notify_all();
+            if(!s.self_released){                                  // run_search released this thread before waiting for its tasks
+                std::unique_lock<std::mutex> lk(sh.mu);
+                sh.active--;
+                sh.cv_work.notify_all();
+            }
         });
     }
     int err = 0;
