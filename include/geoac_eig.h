@@ -8,7 +8,8 @@
  * The reference traces one ray at a time; here every decision point of every receiver's search asks for the rays it needs and the
  * requests of all receivers are integrated together as ONE fan launch per round (an inclination scan is a single launch of up to
  * (theta_max - theta_min) / d_theta rays instead of that many sequential propagations).  The decisions are then replayed on the host in
- * the reference's order, so the eigenray list and the iteration log are the reference's.
+ * the reference's order, so the eigenray list and the iteration log are the reference's.  Within a receiver every bounce count is its
+ * own scan chain and every refinement its own task (they do not depend on each other), which makes the rounds fewer and fuller.
  * Context requirements: equation set GEOAC_EQ_GLOBAL / _GLOBAL_RNGDEP (receivers = latitude, longitude [deg]) or GEOAC_EQ_3D / _3D_RNGDEP
  * (receivers = x, y [km]; GEOAC_EIG_BEARING then holds the azimuth from the receiver to the source), atmosphere uploaded, parameters set (source position,
  * z_grnd, freq, tweak_abs, limits are taken from geoac_set_params; bounces / calc_amp / mode are managed by the search and restored).
