@@ -4,6 +4,8 @@ size-independent properties plus a random sample of rays re-integrated by the or
   * eikonal (Hamiltonian) residual at every arrival: |nu| = c0 / c(ground) (winds are tapered to 0 at the ground),
   * count bookkeeping: steps of all legs add up to the device counter; a leg that broke has no later legs,
   * cumulative travel time / attenuation are non-decreasing over the legs of a ray."""
+import os
+
 import numpy as np
 import pytest
 
@@ -100,3 +102,34 @@ def test_config3_global_720x180_bounces3(G):
     rec, steps = ctx.run(th, ph)
     _properties(rec, steps, 18, slice(3, 6), c_ratio=1.0)
     _sample_vs_oracle(G, H.EQ_GLOBAL, params, th, ph, rec, E=18, n=16)
+
+
+def test_metric_fan_is_schedule_independent(G):
+    """the same fan under different launch plans - default hybrid split, a deliberately bad split (only 3 % of the rays on the
+    two-lane kernel: the merge-back rule takes over), one lane for every ray, two chunks, 4096-row epochs - gives bit-identical
+    records: which kernel variant integrates a ray, and in which epoch pattern, must not matter"""
+    th, ph = G.fan_enumerate(phi_min=-180.0, phi_max=179.0, phi_step=1.0)
+    params = dict(bounces=2, calc_amp=1, mode=0)
+
+    def run(env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            ctx = G.FanContext(G.EQ_GLOBAL, device=0)          # the knobs are read when the context is created
+            ctx.load_met(H.TOYATMO)
+            ctx.set_params(**params)
+            rec, steps = ctx.run(th, ph)
+            ctx.close()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        return rec, steps
+    ref, steps = run({})
+    assert steps == 874273730
+    for env in ({"GEOAC_PAIR_FRAC": "0.03"}, {"GEOAC_NO_PAIR": "1"}, {"GEOAC_TWO_CHUNKS": "1", "GEOAC_S_ROWS": "4096"}, {"GEOAC_PAIR_FRAC": "1.0"}):
+        rec, st = run(env)
+        assert st == steps, env
+        assert np.array_equal(rec, ref), env
