@@ -546,6 +546,7 @@ DEVINL void cart2_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCt
 // ================================================================================================
 template <bool AMP_> struct EqGlobal {
     static constexpr bool AMP = AMP_;
+    static constexpr int PP_WAVES = 3;                              // post-pass waves per SIMD (168 registers; at 128 it spills 148 B and runs 1.5 x slower)
     static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 0, LANES = 1;
     static constexpr bool SPLIT = false;                            // true: the lanes of a ray carry DIFFERENT parts of its state (EqGlobalPair)
     static constexpr bool KM2 = false, HMAX_PER_LEG = false;        // linear intercept only (Q1); turning height accumulates over legs
@@ -718,6 +719,7 @@ struct EqGlobalPair : EqGlobal<true> {
 // Range-dependent Cartesian set (GeoAc3D.RngDep): EquationSets.3DRngDep.cpp + G2S_MultiDimSpline3D.cpp
 template <bool AMP_, int NL_ = 1> struct Eq3DRngDep {
     static constexpr bool AMP = AMP_;
+    static constexpr int PP_WAVES = 3;
     static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 2, LANES = NL_;            // NL_ = 1, 2 or 4 lanes per ray, each evaluating 4/NL_ of the cell corners (identical state otherwise)
     static constexpr bool SPLIT = false;
     static constexpr bool KM2 = true, HMAX_PER_LEG = true;          // quadratic intercept; turning height per leg (Q8)
@@ -848,6 +850,7 @@ template <bool AMP_, int NL_ = 1> struct Eq3DRngDep {
 // Grid axes in table order: x = latitude, y = longitude [rad], z = geocentric radius; xy_lim = lat/lon box of the break check.
 template <bool AMP_, int NL_ = 1> struct EqGlobalRngDep {
     static constexpr bool AMP = AMP_;
+    static constexpr int PP_WAVES = 3;
     static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 0, LANES = NL_;
     static constexpr bool SPLIT = false;
     static constexpr bool KM2 = false, HMAX_PER_LEG = true;         // linear intercept (Q1, GlobalRngDep.cpp:147-148); turning height per leg (Q8)
@@ -978,6 +981,7 @@ template <bool AMP_, int NL_ = 1> struct EqGlobalRngDep {
 
 template <bool AMP_> struct Eq3D {
     static constexpr bool AMP = AMP_;
+    static constexpr int PP_WAVES = 4;                              // post-pass at four waves per SIMD (127 registers, 52 B of spill): GeoAc3D 360 x 90 fan 185 -> 168 ms
     static constexpr int E = AMP_ ? 12 : 4, PW = 4, HIDX = 2, LANES = 1;
     static constexpr bool SPLIT = false;
     static constexpr bool KM2 = true, HMAX_PER_LEG = false;                               // quadratic intercept needs row k-2
@@ -1101,6 +1105,7 @@ template <bool AMP_> struct Eq3D {
 
 template <bool AMP_> struct Eq2D {
     static constexpr bool AMP = AMP_;
+    static constexpr int PP_WAVES = 4;
     static constexpr int E = AMP_ ? 6 : 3, PW = 2, HIDX = 1, LANES = 1;
     static constexpr bool SPLIT = false;
     static constexpr bool KM2 = true, HMAX_PER_LEG = false;
@@ -1433,7 +1438,7 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
 // k_postpass: one thread per path segment (row i -> row i+1 of one ray)
 // ------------------------------------------------------------------------------------------------
 template <class EQ>
-__global__ void __launch_bounds__(256, 3) k_postpass(GeoacDevParams P, int rows){
+__global__ void __launch_bounds__(256, EQ::PP_WAVES) k_postpass(GeoacDevParams P, int rows){
     // grid-stride sweep over (segment row i, ray slot); by default the grid covers the sweep in one pass
     const size_t np = (size_t)P.n_pad;
     const int bx = (P.n_pad + 255) / 256;                       // slot-blocks per row
