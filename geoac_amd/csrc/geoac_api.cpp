@@ -502,7 +502,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
     P.pp_blocks = ctx->pp_blocks;
     P.slot_lo = 0; P.slot_hi = P.n_pad; P.live_slot = 1;
     // two lanes per ray shorten the serial chain (x1.25) at twice the lanes: only worth it while the fan leaves SIMDs idle
-    P.lanes_per_ray = (is_global && p.calc_amp && !sampling && !ctx->no_pair && (long long)P.n_pad * 2 / 64 <= 1024) ? 2 : 1;
+    P.lanes_per_ray = ((is_global || ctx->eqset == GEOAC_EQ_3D) && p.calc_amp && !sampling && !ctx->no_pair && (long long)P.n_pad * 2 / 64 <= 1024) ? 2 : 1;
     // grid sets, small fans: four lanes per ray (one cell corner each) while that still leaves one wave per SIMD
     if(is_grid && !ctx->no_quad){
         if((long long)P.n_pad * 4 / 64 <= 1024) P.lanes_per_ray = 4;

@@ -466,8 +466,8 @@ struct RayCtx {
     double t[4];      // Global: proposed sin/cos for the row under test
 };
 
-template <bool AMP, typename TabPtr>
-DEVINL void cart3_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y, double* dy){
+template <bool AMP, int NQ = 2, typename TabPtr = const double*>
+DEVINL void cart3_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y, double* dy, int q0 = 0){
     const double nz = y[3];
     const double nx = C.a[0], ny = C.a[1];
     const double xe = clampd(y[2], P.x_min, P.x_max);
@@ -492,8 +492,10 @@ DEVINL void cart3_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCt
         const double ddc = __builtin_fma(hc, a.ddT, -(dc * dc) * ic);
         const double K2  = __builtin_fma(numag, ddc, __builtin_fma(nx, a.ddu, ny * a.ddv));
         #pragma unroll
-        for(int q = 0; q < 2; q++){
-            const double mx = C.a[2 + 2 * q], my = C.a[3 + 2 * q], mz = y[7 + 4 * q], Za = y[6 + 4 * q];
+        for(int q = 0; q < NQ; q++){
+            // NQ = 1 (two-lanes-per-ray kernel): this lane carries system q0 in y[4..7]; its constant slowness derivatives sit in C.a[2 + 2 q0 ..]
+            const double mx = (NQ == 1) ? (q0 ? C.a[4] : C.a[2]) : C.a[2 + 2 * q], my = (NQ == 1) ? (q0 ? C.a[5] : C.a[3]) : C.a[3 + 2 * q];
+            const double mz = y[7 + 4 * q], Za = y[6 + 4 * q];
             const double dnu = __builtin_fma(nx, mx, __builtin_fma(ny, my, nz * mz)) * inm;
             const double al  = inm * __builtin_fma(dc, Za, -cn * dnu);
             const double dcp0 = __builtin_fma(nx, al, __builtin_fma(cn, mx, du * Za));
@@ -549,6 +551,7 @@ template <bool AMP_> struct EqGlobal {
     static constexpr int PP_WAVES = 3;                              // post-pass waves per SIMD (168 registers; at 128 it spills 148 B and runs 1.5 x slower)
     static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 0, LANES = 1;
     static constexpr bool SPLIT = false;                            // true: the lanes of a ray carry DIFFERENT parts of its state (EqGlobalPair)
+    static constexpr int NB = 6, NS = 6;                            // base-ray components, components per launch-angle derivative system
     static constexpr bool KM2 = false, HMAX_PER_LEG = false;        // linear intercept only (Q1); turning height accumulates over legs
 
     // GeoAc_SetInitialConditions: EquationSets.Global.cpp:76-136
@@ -688,6 +691,7 @@ template <bool AMP_> struct EqGlobal {
 // data (Global.cpp:273-367 is written twice, once per angle).  Halves the auxiliary work on the serial chain and puts
 // a wave on every SIMD for the 32 400-ray metric fan.  Lanes exchange values only at leg ends (arrival record).
 struct EqGlobalPair : EqGlobal<true> {
+    using Full = EqGlobal<true>;
     static constexpr int E = 12, LANES = 2;
     static constexpr bool SPLIT = true;
     template <typename TabPtr>
@@ -719,6 +723,7 @@ struct EqGlobalPair : EqGlobal<true> {
 // Range-dependent Cartesian set (GeoAc3D.RngDep): EquationSets.3DRngDep.cpp + G2S_MultiDimSpline3D.cpp
 template <bool AMP_, int NL_ = 1> struct Eq3DRngDep {
     static constexpr bool AMP = AMP_;
+    static constexpr int NB = 6, NS = 6;
     static constexpr int PP_WAVES = 3;
     static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 2, LANES = NL_;            // NL_ = 1, 2 or 4 lanes per ray, each evaluating 4/NL_ of the cell corners (identical state otherwise)
     static constexpr bool SPLIT = false;
@@ -850,6 +855,7 @@ template <bool AMP_, int NL_ = 1> struct Eq3DRngDep {
 // Grid axes in table order: x = latitude, y = longitude [rad], z = geocentric radius; xy_lim = lat/lon box of the break check.
 template <bool AMP_, int NL_ = 1> struct EqGlobalRngDep {
     static constexpr bool AMP = AMP_;
+    static constexpr int NB = 6, NS = 6;
     static constexpr int PP_WAVES = 3;
     static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 0, LANES = NL_;
     static constexpr bool SPLIT = false;
@@ -984,6 +990,7 @@ template <bool AMP_> struct Eq3D {
     static constexpr int PP_WAVES = 4;                              // post-pass at four waves per SIMD (127 registers, 52 B of spill): GeoAc3D 360 x 90 fan 185 -> 168 ms
     static constexpr int E = AMP_ ? 12 : 4, PW = 4, HIDX = 2, LANES = 1;
     static constexpr bool SPLIT = false;
+    static constexpr int NB = 4, NS = 4;
     static constexpr bool KM2 = true, HMAX_PER_LEG = false;                               // quadratic intercept needs row k-2
 
     // GeoAc_SetInitialConditions: EquationSets.3DStratified.cpp:69-131
@@ -1103,8 +1110,37 @@ template <bool AMP_> struct Eq3D {
     }
 };
 
+// Two lanes per ray for the 3-D stratified set with amplitudes: lanes 2j, 2j+1 both integrate the base ray (x, y, z, nu_z) and ONE of the
+// two launch-angle systems each (3DStratified.cpp:251-310 is the same code once per angle), as EqGlobalPair does for the spherical set.
+struct Eq3DPair : Eq3D<true> {
+    using Full = Eq3D<true>;
+    static constexpr int E = 8, LANES = 2;
+    static constexpr bool SPLIT = true;
+    template <typename TabPtr>
+    static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
+        cart3_rhs<true, 1>(tab, P, seg, C, yt, dy, (int)(threadIdx.x & 1));
+    }
+    // quadratic intercept + reflection of the base ray and of this lane's system (3DStratified.cpp:136-186)
+    static DEVINL void reflect(const GeoacDevParams& P, const RayCtx& C, const double* yn, double* y, const double* ym2){
+        double dz_k = yn[2] - y[2];
+        double dz_g = y[2] - P.ground;
+        double prev[E];
+        #pragma unroll
+        for(int e = 0; e < E; e++)
+            prev[e] = y[e] + (y[e] - yn[e]) / dz_k * dz_g + 1.0 / 2.0 * (yn[e] + ym2[e] - 2.0 * y[e]) / (dz_k * dz_k) * (dz_g * dz_g);
+        Medium mg = medium_at(P, P.z_grnd);
+        double dnuz_ds = -1.0 / mg.c * (C.c0 / mg.c * mg.dc + C.a[0] * mg.du + C.a[1] * mg.dv);
+        #pragma unroll
+        for(int e = 0; e < E; e++) y[e] = prev[e];
+        y[3] = -prev[3];
+        y[6] = -prev[6];
+        y[7] = -prev[7] + 2.0 * dnuz_ds * prev[6] / (mg.c / C.c0 * prev[3]);
+    }
+};
+
 template <bool AMP_> struct Eq2D {
     static constexpr bool AMP = AMP_;
+    static constexpr int NB = 3, NS = 3;
     static constexpr int PP_WAVES = 4;
     static constexpr int E = AMP_ ? 6 : 3, PW = 2, HIDX = 1, LANES = 1;
     static constexpr bool SPLIT = false;
@@ -1220,14 +1256,20 @@ __global__ void __launch_bounds__(256) k_init(GeoacDevParams P){
 // ------------------------------------------------------------------------------------------------
 // k_rk4: GeoAc_Propagate_RK4 (GeoAc.Solver.cpp:12-72) for one epoch, one ray per lane
 // ------------------------------------------------------------------------------------------------
+// arrival row of a leg: the pair kernels hand the assembled full row to the one-lane policy's arrival()
+template <class EQ, bool S = EQ::SPLIT> struct ArrivalOf { static DEVINL void go(const GeoacDevParams& P, const RayCtx& C, int slot, const double* y, double* R){ EQ::arrival(P, C, slot, y, R); } };
+template <class EQ> struct ArrivalOf<EQ, true> { static DEVINL void go(const GeoacDevParams& P, const RayCtx& C, int slot, const double* y, double* R){ EQ::Full::arrival(P, C, slot, y, R); } };
+template <class EQ> DEVINL void arrival_of(const GeoacDevParams& P, const RayCtx& C, int slot, const double* y, double* R){ ArrivalOf<EQ>::go(P, C, slot, y, R); }
+
 template <class EQ>
 DEVINL void write_row(const GeoacDevParams& P, int row, int slot, int q, const double* y){
     double* p = P.path + ((size_t)row * EQ::PW) * P.n_pad + slot;
     if(!EQ::SPLIT && EQ::LANES > 1 && q != 0) return;   // multi-lane grid kernels: the lanes hold the same row, lane 0 stores it
-    if(EQ::SPLIT){                    // pair kernel: lane parity 0 stores r, lat, lon; parity 1 stores nu_r, nu_t, nu_p
-        p += (size_t)(3 * q) * P.n_pad;
+    if(EQ::SPLIT){                    // pair kernels: each lane stores half of the row (Global: r, lat, lon | nu_r, nu_t, nu_p; 3D: x, y | z, nu_z)
+        constexpr int H = EQ::PW / 2;
+        p += (size_t)(H * q) * P.n_pad;
         #pragma unroll
-        for(int c = 0; c < 3; c++) p[(size_t)c * P.n_pad] = q ? y[c + 3] : y[c];
+        for(int c = 0; c < H; c++) p[(size_t)c * P.n_pad] = q ? y[c + H] : y[c];
     } else if(EQ::PW == 6){                // Global: r, lat, lon, nu_r, nu_t, nu_p
         #pragma unroll
         for(int c = 0; c < 6; c++) p[(size_t)c * P.n_pad] = y[c];
@@ -1271,10 +1313,10 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
     static_assert(!EQ::KM2 || ST_YM2 + E <= ST_DPREV, "state block: ym2[] overruns ST_DPREV");
     double y[E], ym2[EQ::KM2 ? E : 1];
     #pragma unroll
-    for(int e = 0; e < E; e++) y[e] = st[(ST_Y0 + ((EQ::SPLIT && e >= 6) ? e + 6 * q : e)) * np];
+    for(int e = 0; e < E; e++) y[e] = st[(ST_Y0 + ((EQ::SPLIT && e >= EQ::NB) ? e + EQ::NS * q : e)) * np];
     if(EQ::KM2){
         #pragma unroll
-        for(int e = 0; e < E; e++) ym2[e] = st[(ST_YM2 + e) * np];
+        for(int e = 0; e < E; e++) ym2[e] = st[(ST_YM2 + ((EQ::SPLIT && e >= EQ::NB) ? e + EQ::NS * q : e)) * np];
     }
     long long k = (long long)st[ST_K * np];
     int leg = (int)st[ST_LEG * np];
@@ -1356,29 +1398,31 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
             // the leg's last row solution[k][*] (both outcomes: arrival rows read it, and so do the eigenray scans' messages after a break)
             double yf[18];
             if(EQ::SPLIT){
-                // assemble the reference's 18-component row from the lane pair (both lanes end up with the same row
+                // assemble the reference's full row (base + both systems) from the lane pair (both lanes end up with the same row
                 // and store the same record)
                 #pragma unroll
-                for(int e = 0; e < 6; e++){
-                    yf[e] = yn[e];
-                    double mine = yn[6 + e], other = __shfl_xor(mine, 1);
-                    yf[6 + e]  = q ? other : mine;
-                    yf[12 + e] = q ? mine : other;
+                for(int e = 0; e < 18; e++) yf[e] = 0.0;
+                #pragma unroll
+                for(int e = 0; e < EQ::NB; e++) yf[e] = yn[e];
+                #pragma unroll
+                for(int e = 0; e < EQ::NS; e++){
+                    double mine = yn[EQ::NB + e], other = __shfl_xor(mine, 1);
+                    yf[EQ::NB + e]  = q ? other : mine;
+                    yf[EQ::NB + EQ::NS + e] = q ? mine : other;
                 }
             } else {
                 #pragma unroll
                 for(int e = 0; e < 18; e++) yf[e] = (e < E) ? yn[e < E ? e : 0] : 0.0;
             }
             #pragma unroll
-            for(int e = 0; e < (EQ::SPLIT ? 18 : E); e++) R[GEOAC_REC_STATE + e] = yf[e];
+            for(int e = 0; e < (EQ::SPLIT ? EQ::NB + 2 * EQ::NS : E); e++) R[GEOAC_REC_STATE + e] = yf[e];
             if(brk){
                 R[GEOAC_REC_BROKE] = 1.0;
                 done = true;
             } else {
                 R[GEOAC_REC_VALID] = 1.0;
                 R[GEOAC_REC_TURN] = hmax;
-                if(EQ::SPLIT) EqGlobal<true>::arrival(P, C, slot, yf, R);
-                else EQ::arrival(P, C, slot, yn, R);
+                arrival_of<EQ>(P, C, slot, EQ::SPLIT ? yf : yn, R);
                 if(leg >= P.bounces){
                     done = true;
                 } else {
@@ -1401,10 +1445,10 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
 
     // ---- save state (pair kernel: both lanes store the identical base ray; each stores its own derivative system) ----
     #pragma unroll
-    for(int e = 0; e < E; e++) st[(ST_Y0 + ((EQ::SPLIT && e >= 6) ? e + 6 * q : e)) * np] = y[e];
+    for(int e = 0; e < E; e++) st[(ST_Y0 + ((EQ::SPLIT && e >= EQ::NB) ? e + EQ::NS * q : e)) * np] = y[e];
     if(EQ::KM2){
         #pragma unroll
-        for(int e = 0; e < E; e++) st[(ST_YM2 + e) * np] = ym2[e];
+        for(int e = 0; e < E; e++) st[(ST_YM2 + ((EQ::SPLIT && e >= EQ::NB) ? e + EQ::NS * q : e)) * np] = ym2[e];
     }
     st[ST_K * np] = (double)k; st[ST_LEG * np] = (double)leg; st[ST_DONE * np] = done ? 1.0 : 0.0;
     st[ST_HMAX * np] = hmax; st[ST_SEG * np] = P.gtab ? (double)seg : (double)(seg / GEOAC_SEGW);
@@ -1591,7 +1635,8 @@ static hipError_t launch_rk4_t(const GeoacDevParams* P, int block, hipStream_t s
 }
 
 extern "C" hipError_t geoac_launch_rk4(const GeoacDevParams* P, int block, hipStream_t s, unsigned* n_wg){
-    if(P->lanes_per_ray == 2 && !P->gtab) return launch_rk4_t<EqGlobalPair>(P, block, s, n_wg);
+    if(P->lanes_per_ray == 2 && !P->gtab && P->eqset == GEOAC_EQ_GLOBAL) return launch_rk4_t<EqGlobalPair>(P, block, s, n_wg);
+    if(P->lanes_per_ray == 2 && !P->gtab && P->eqset == GEOAC_EQ_3D) return launch_rk4_t<Eq3DPair>(P, block, s, n_wg);
     GEOAC_DISPATCH_EQ_RK4(P, return launch_rk4_t<EQ>(P, block, s, n_wg));
     return hipErrorNotSupported;
 }

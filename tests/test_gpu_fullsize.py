@@ -104,8 +104,9 @@ def test_config3_global_720x180_bounces3(G):
     _sample_vs_oracle(G, H.EQ_GLOBAL, params, th, ph, rec, E=18, n=16)
 
 
-def test_metric_fan_is_schedule_independent(G):
-    """the same fan under different launch plans - default hybrid split, a deliberately bad split (only 3 % of the rays on the
+@pytest.mark.parametrize("eqname,total", [("EQ_GLOBAL", 874273730), ("EQ_3D", 871080426)])
+def test_full_fan_is_schedule_independent(G, eqname, total):
+    """the 360 x 90 fan of the spherical and of the 3-D stratified set under different launch plans - default hybrid split, a deliberately bad split (only 3 % of the rays on the
     two-lane kernel: the merge-back rule takes over), one lane for every ray, two chunks, 4096-row epochs - gives bit-identical
     records: which kernel variant integrates a ray, and in which epoch pattern, must not matter"""
     th, ph = G.fan_enumerate(phi_min=-180.0, phi_max=179.0, phi_step=1.0)
@@ -115,7 +116,7 @@ def test_metric_fan_is_schedule_independent(G):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
-            ctx = G.FanContext(G.EQ_GLOBAL, device=0)          # the knobs are read when the context is created
+            ctx = G.FanContext(getattr(G, eqname), device=0)   # the knobs are read when the context is created
             ctx.load_met(H.TOYATMO)
             ctx.set_params(**params)
             rec, steps = ctx.run(th, ph)
@@ -128,7 +129,7 @@ def test_metric_fan_is_schedule_independent(G):
                     os.environ[k] = v
         return rec, steps
     ref, steps = run({})
-    assert steps == 874273730
+    assert steps == total
     for env in ({"GEOAC_PAIR_FRAC": "0.03"}, {"GEOAC_NO_PAIR": "1"}, {"GEOAC_TWO_CHUNKS": "1", "GEOAC_S_ROWS": "4096"}, {"GEOAC_PAIR_FRAC": "1.0"}):
         rec, st = run(env)
         assert st == steps, env
