@@ -44,6 +44,8 @@ EIG_CASES = {
 IA_CASES = {
     "ia_global": ("GeoAcGlobal", ["WriteCaustics=True", "lat_src=35", "lon_src=-100", "z_grnd=0.3", "rng_max=400", "freq=0.5"],
                   "12.5\n-75\n1\ny\n31\n40\n0\nn\n"),
+    # CalcAmp off (6-component state, no amplitude column / line) and a ray that leaves the region ("does not return")
+    "ia_global_noamp": ("GeoAcGlobal", ["CalcAmp=False"], "60\n20\n0\ny\n20\n-90\n1\nn\n"),
     "ia_3d": ("GeoAc3D", ["WriteCaustics=True", "z_src=0.4", "abs_coeff=0.5"], "10\n-60\n1\ny\n44\n135\n2\nn\n"),
     "ia_2d": ("GeoAc2D", ["WriteCaustics=True", "freq=0.2"], "6\n-80\n2\ny\n25\n70\n0\nn\n"),
     "ia_3drd": ("GeoAc3D.RngDep", ["WriteCaustics=True", "x_src=50", "y_src=-30", "z_src=0.5", "CalcAmp=False"], "12\n-80\n1\ny\n28\n45\n0\nn\n"),
