@@ -701,39 +701,48 @@ static int run_all(geoac_ctx* ctx, const geoac_eig_params* ep, int n_rcvr, const
         sp->prm = *ep; sp->verbose = ep->verbose != 0;
         S.push_back(std::move(sp));
     }
-    sh.active = n_rcvr;
-    std::vector<std::thread> threads;
-    for(int i = 0; i < n_rcvr; i++){
-        threads.emplace_back([&, i]{
-            SearchBase& s = *S[(size_t)i];
-            if(direct) s.run_direct(theta_est[i], phi_est[i], bounces); else s.run_search();
-            if(!s.self_released){                                  // run_search released this thread before waiting for its tasks
-                std::unique_lock<std::mutex> lk(sh.mu);
-                sh.active--;
-                sh.cv_work.notify_all();
-            }
-        });
-    }
+    // receivers go through in groups of at most 96 (each receiver is a thread plus one per bounce count plus its refinement tasks, all
+    // of them only waiting for rays: the group size keeps the process well under a thousand threads whatever n_rcvr is)
     int err = 0;
-    for(;;){
-        std::vector<Request*> batch;
+    const int group = 96;
+    for(int g0 = 0; g0 < n_rcvr && !err; g0 += group){
+        const int g1 = std::min(n_rcvr, g0 + group);
         {
             std::unique_lock<std::mutex> lk(sh.mu);
-            sh.cv_work.wait(lk, [&]{ return sh.active == 0 || sh.waiting == sh.active; });
-            if(sh.active == 0) break;
-            batch.swap(sh.pending);
+            sh.active = g1 - g0; sh.waiting = 0; sh.pending.clear();
         }
-        err = serve(ctx, base, batch, res);
-        res->stats[3] += 1;
-        {
-            std::unique_lock<std::mutex> lk(sh.mu);
-            if(err) sh.failed = true;
-            for(Request* r : batch){ r->done = true; r->error = err; }
-            sh.waiting -= (int)batch.size();
-            sh.cv_done.notify_all();
+        std::vector<std::thread> threads;
+        for(int i = g0; i < g1; i++){
+            threads.emplace_back([&, i]{
+                SearchBase& s = *S[(size_t)i];
+                if(direct) s.run_direct(theta_est[i], phi_est[i], bounces); else s.run_search();
+                if(!s.self_released){                              // run_search released this thread before waiting for its tasks
+                    std::unique_lock<std::mutex> lk(sh.mu);
+                    sh.active--;
+                    sh.cv_work.notify_all();
+                }
+            });
         }
+        for(;;){
+            std::vector<Request*> batch;
+            {
+                std::unique_lock<std::mutex> lk(sh.mu);
+                sh.cv_work.wait(lk, [&]{ return sh.active == 0 || sh.waiting == sh.active; });
+                if(sh.active == 0) break;
+                batch.swap(sh.pending);
+            }
+            err = serve(ctx, base, batch, res);
+            res->stats[3] += 1;
+            {
+                std::unique_lock<std::mutex> lk(sh.mu);
+                if(err) sh.failed = true;
+                for(Request* r : batch){ r->done = true; r->error = err; }
+                sh.waiting -= (int)batch.size();
+                sh.cv_done.notify_all();
+            }
+        }
+        for(auto& t : threads) t.join();
     }
-    for(auto& t : threads) t.join();
     geoac_set_params(ctx, &base);                                  // restore the caller's bounces / calc_amp / mode
     if(err){ delete res; return err; }
     for(int i = 0; i < n_rcvr; i++){

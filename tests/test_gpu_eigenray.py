@@ -119,3 +119,26 @@ def test_batched_receivers_equal_single_receiver_searches():
     # every eigenray really reaches its receiver: arrival within the refinement's 0.1 km tolerance is implied by identification;
     # celerity = distance / travel time must be acoustic
     assert ((all_["eig"][:, G.EIG["CELERITY"]] > 0.2) & (all_["eig"][:, G.EIG["CELERITY"]] < 0.36)).all()
+
+
+def test_more_receivers_than_one_group_and_parallel_bounce_counts():
+    """100 receivers (processed in groups of 96) with bounce counts 0..1 searched concurrently: every receiver's eigenrays and log are
+    those of the same receiver searched alone"""
+    import numpy as np
+    import geoac_amd as G
+    ctx = G.FanContext(G.EQ_GLOBAL, device=0)
+    ctx.load_met(H.TOYATMO)
+    ctx.set_params(src=(0.0, 30.0, 0.0))
+    rcv = _ring(30.0, 0.0, 100)
+    all_ = ctx.eig_search(rcv, bnc_min=0, bnc_max=1, verbose=True)
+    with_rays = sorted(set(int(r) for r in all_["eig"][:, G.EIG["RCVR"]]))
+    assert len(with_rays) >= 5
+    for i in sorted(set(with_rays[:2] + [with_rays[-1], 97, 99])):
+        one = ctx.eig_search(rcv[i:i + 1], bnc_min=0, bnc_max=1, verbose=True)
+        sel = all_["eig"][all_["eig"][:, G.EIG["RCVR"]] == i]
+        assert len(sel) == len(one["eig"])
+        assert np.array_equal(sel[:, 1:G.EIG["SMP0"]], one["eig"][:, 1:G.EIG["SMP0"]])
+        assert all_["logs"][i] == one["logs"][0]
+        # eigenrays are numbered in the reference's order: by bounce count, then by inclination
+        assert list(sel[:, G.EIG["INDEX"]]) == list(range(len(sel)))
+        assert list(sel[:, G.EIG["BOUNCES"]]) == sorted(sel[:, G.EIG["BOUNCES"]])
