@@ -552,7 +552,7 @@ template <bool AMP_> struct EqGlobal {
     static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 0, LANES = 1;
     static constexpr bool SPLIT = false;                            // true: the lanes of a ray carry DIFFERENT parts of its state (EqGlobalPair)
     static constexpr int NB = 6, NS = 6;                            // base-ray components, components per launch-angle derivative system
-    static constexpr bool KM2 = false, HMAX_PER_LEG = false;        // linear intercept only (Q1); turning height accumulates over legs
+    static constexpr bool KM2 = false, KM2_MEM = false, HMAX_PER_LEG = false;        // linear intercept only (Q1); turning height accumulates over legs
 
     // GeoAc_SetInitialConditions: EquationSets.Global.cpp:76-136
     static DEVINL void init(const GeoacDevParams& P, double th, double ph, double* y, RayCtx& C){
@@ -728,6 +728,7 @@ template <bool AMP_, int NL_ = 1> struct Eq3DRngDep {
     static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 2, LANES = NL_;            // NL_ = 1, 2 or 4 lanes per ray, each evaluating 4/NL_ of the cell corners (identical state otherwise)
     static constexpr bool SPLIT = false;
     static constexpr bool KM2 = true, HMAX_PER_LEG = true;          // quadratic intercept; turning height per leg (Q8)
+    static constexpr bool KM2_MEM = true;                           // row k-2 lives in the state block, not in 36 registers: this kernel spills as it is, and the row is only read at a reflection
 
     // SuthBass reference state at (0, 0, z_grnd) (Atmo_State.Absorption.cpp:31-33), once per fan
     static DEVINL void fan_init(const GeoacDevParams& P){
@@ -859,7 +860,7 @@ template <bool AMP_, int NL_ = 1> struct EqGlobalRngDep {
     static constexpr int PP_WAVES = 3;
     static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 0, LANES = NL_;
     static constexpr bool SPLIT = false;
-    static constexpr bool KM2 = false, HMAX_PER_LEG = true;         // linear intercept (Q1, GlobalRngDep.cpp:147-148); turning height per leg (Q8)
+    static constexpr bool KM2 = false, KM2_MEM = false, HMAX_PER_LEG = true;         // linear intercept (Q1, GlobalRngDep.cpp:147-148); turning height per leg (Q8)
 
     static DEVINL Medium as_medium(const Medium3& g){ Medium m; m.c = g.c; m.dc = g.dcz; m.u = g.u; m.du = g.duz; m.v = g.v; m.dv = g.dvz; m.rho = g.rho; return m; }
     static DEVINL void fan_init(const GeoacDevParams& P){}
@@ -991,7 +992,7 @@ template <bool AMP_> struct Eq3D {
     static constexpr int E = AMP_ ? 12 : 4, PW = 4, HIDX = 2, LANES = 1;
     static constexpr bool SPLIT = false;
     static constexpr int NB = 4, NS = 4;
-    static constexpr bool KM2 = true, HMAX_PER_LEG = false;                               // quadratic intercept needs row k-2
+    static constexpr bool KM2 = true, KM2_MEM = false, HMAX_PER_LEG = false;              // quadratic intercept needs row k-2
 
     // GeoAc_SetInitialConditions: EquationSets.3DStratified.cpp:69-131
     static DEVINL void init(const GeoacDevParams& P, double th, double ph, double* y, RayCtx& C){
@@ -1144,7 +1145,7 @@ template <bool AMP_> struct Eq2D {
     static constexpr int PP_WAVES = 4;
     static constexpr int E = AMP_ ? 6 : 3, PW = 2, HIDX = 1, LANES = 1;
     static constexpr bool SPLIT = false;
-    static constexpr bool KM2 = true, HMAX_PER_LEG = false;
+    static constexpr bool KM2 = true, KM2_MEM = false, HMAX_PER_LEG = false;
 
     // GeoAc_SetInitialConditions: EquationSets.2DStratified.cpp:38-68
     static DEVINL void init(const GeoacDevParams& P, double th, double ph, double* y, RayCtx& C){
@@ -1311,10 +1312,11 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
     int nr = 0, nle = 0;
     static_assert(E <= ST_K - ST_Y0, "state block: y[] overruns ST_K");
     static_assert(!EQ::KM2 || ST_YM2 + E <= ST_DPREV, "state block: ym2[] overruns ST_DPREV");
-    double y[E], ym2[EQ::KM2 ? E : 1];
+    constexpr bool YM2_REG = EQ::KM2 && !EQ::KM2_MEM;                // row k-2 in registers (else: in the state block, read at reflections)
+    double y[E], ym2[YM2_REG ? E : 1];
     #pragma unroll
     for(int e = 0; e < E; e++) y[e] = st[(ST_Y0 + ((EQ::SPLIT && e >= EQ::NB) ? e + EQ::NS * q : e)) * np];
-    if(EQ::KM2){
+    if(YM2_REG){
         #pragma unroll
         for(int e = 0; e < E; e++) ym2[e] = st[(ST_YM2 + ((EQ::SPLIT && e >= EQ::NB) ? e + EQ::NS * q : e)) * np];
     }
@@ -1426,16 +1428,24 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
                 if(leg >= P.bounces){
                     done = true;
                 } else {
-                    EQ::reflect(P, C, yn, y, ym2);
+                    if(EQ::KM2 && EQ::KM2_MEM){
+                        double r2[E];
+                        #pragma unroll
+                        for(int e = 0; e < E; e++) r2[e] = st[(ST_YM2 + e) * np];
+                        EQ::reflect(P, C, yn, y, r2);
+                    } else EQ::reflect(P, C, yn, y, ym2);
                     leg++; k = 0;
                     EQ::restart(P, C, y);
                     write_row<EQ>(P, nr++, slot, q, y);              // leg-start row
                 }
             }
         } else {
-            if(EQ::KM2){
+            if(YM2_REG){
                 #pragma unroll
                 for(int e = 0; e < E; e++) ym2[e] = y[e];
+            } else if(EQ::KM2 && (EQ::LANES == 1 || q == 0)){       // KM2_MEM (not a split-state policy): one coalesced row per step
+                #pragma unroll
+                for(int e = 0; e < E; e++) st[(ST_YM2 + e) * np] = y[e];
             }
             #pragma unroll
             for(int e = 0; e < E; e++) y[e] = yn[e];
@@ -1446,7 +1456,7 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
     // ---- save state (pair kernel: both lanes store the identical base ray; each stores its own derivative system) ----
     #pragma unroll
     for(int e = 0; e < E; e++) st[(ST_Y0 + ((EQ::SPLIT && e >= EQ::NB) ? e + EQ::NS * q : e)) * np] = y[e];
-    if(EQ::KM2){
+    if(YM2_REG){
         #pragma unroll
         for(int e = 0; e < E; e++) st[(ST_YM2 + ((EQ::SPLIT && e >= EQ::NB) ? e + EQ::NS * q : e)) * np] = ym2[e];
     }

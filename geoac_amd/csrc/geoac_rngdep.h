@@ -138,7 +138,7 @@ DEVINL void grid_eval_all(const GeoacDevParams& P, int field, const GridLoc& L, 
     double o[10];
     #pragma unroll
     for(int i = 0; i < 10; i++) o[i] = 0.0;
-    #pragma unroll (ORDER2 ? 1 : 2)                               // geometry-only kernels have registers to keep two corners' loads in flight
+    #pragma unroll 2                                               // two corners per gather batch (one: 12 dependent batches per RHS; four: more spills than it saves)
     for(int cn = cq * (4 / NL); cn < (cq + 1) * (4 / NL); cn++){
         {
             const int a = cn >> 1, b = cn & 1;
@@ -254,8 +254,9 @@ DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double
     const double xe = clampd(y[0], P.gx[0], P.gx[P.gnx - 1]), ye = clampd(y[1], P.gy[0], P.gy[P.gny - 1]), ze = clampd(y[2], P.x_min, P.x_max);
     GridLoc L; grid_locate(P, xe, ye, ze, kz, L);
     kz = L.kz;
-    double M[3][10];                                               // T, u, v and their derivatives; one (non-inlined) evaluator call per field
-    #pragma unroll (NL == 4 ? 3 : 1)                              // four lanes per ray: one corner per lane, so the three fields' gathers fit in flight together
+    double M[3][10];                                               // T, u, v and their derivatives
+    #pragma unroll                                                // three copies of the evaluator: M[][] stays in registers (rolled, the dynamic
+                                                                  // index f put it in scratch: 240 B written and read back per stage)
     for(int f = 0; f < 3; f++) grid_eval_all<AMP, false, NL>(P, f, L, M[f], cq);
     const double* T = M[0]; const double* U = M[1]; const double* V = M[2];
     const double n0 = y[3], n1 = y[4], n2 = y[5];
@@ -323,7 +324,7 @@ DEVINL void globalrd_rhs(const GeoacDevParams& P, int& kz, const double* y, doub
     GridLoc L; grid_locate(P, te, pe, re, kz, L);
     kz = L.kz;
     double M[3][10];                                               // table order: f, f_t, f_p, f_r, f_tt, f_pp, f_rr, f_tp, f_tr, f_pr
-    #pragma unroll (NL == 4 ? 3 : 1)
+    #pragma unroll
     for(int f = 0; f < 3; f++) grid_eval_all<AMP, true, NL>(P, f, L, M[f], cq);
     const double* T = M[0]; const double* U = M[1]; const double* V = M[2];
     // first derivatives in equation order (r, t, p) = table entries 3, 1, 2
