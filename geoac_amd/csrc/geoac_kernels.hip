@@ -974,7 +974,7 @@ template <bool AMP_, int NL_ = 1> struct EqGlobalRngDep {
         double n0 = an0 + (b[3 * np] - an0) / 2.0, n1 = an1 + (b[4 * np] - an1) / 2.0, n2 = an2 + (b[5 * np] - an2) / 2.0;
         double inm = frsq(n0 * n0 + n1 * n1 + n2 * n2);
         Medium3 m = medium3_at<true, false, true>(P, t, p, r);
-        Medium3 g = medium3_at<true, false, true>(P, t, p, P.z_grnd);
+        Medium3 g = medium3_at<true, false, true, false>(P, t, p, P.z_grnd);      // reference state: c and rho only
         double cn = m.c * inm;
         double cp0 = cn * n0, cp1 = cn * n1 + m.v, cp2 = cn * n2 + m.u;
         tt = ds_tt * frsq(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);

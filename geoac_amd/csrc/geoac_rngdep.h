@@ -190,7 +190,7 @@ DEVINL double grid_eval_f(const GeoacDevParams& P, int field, const GridLoc& L){
     const double* __restrict__ base = grid_rec(P, field, L.kz, 0);
     const int stride = field < 3 ? GEOAC_GREC : GEOAC_GREC_RHO;
     double v = 0.0;
-    #pragma unroll 1
+    #pragma unroll 2
     for(int cn = 0; cn < 4; cn++){
         {
             const int a = cn >> 1, b = cn & 1;
@@ -230,14 +230,14 @@ DEVINL double grid_eval_dfdz(const GeoacDevParams& P, int field, const GridLoc& 
 // scalar medium at a point (c(), u(), v(), rho() of G2S_MultiDimSpline3D.cpp:1633-1743 / G2S_GlobalMultiDimSpline3D.cpp:1502-1611,
 // inputs clamped).  Arguments in table order: (x, y, z) Cartesian, (lat, lon, r) spherical; d*z = d/dz resp. d/dr.
 struct Medium3 { double c, u, v, rho, dcz, duz, dvz; };
-template <bool WANT_RHO, bool WANT_DZ, bool GLB = false>
+template <bool WANT_RHO, bool WANT_DZ, bool GLB = false, bool WANT_UV = true>
 DEVINL Medium3 medium3_at(const GeoacDevParams& P, double x, double y, double z){
     double xe = clampd(x, P.gx[0], P.gx[P.gnx - 1]), ye = clampd(y, P.gy[0], P.gy[P.gny - 1]), ze = clampd(z, P.x_min, P.x_max);
     GridLoc L; grid_locate(P, xe, ye, ze, -1, L);
     Medium3 m;
     m.c = sqrt(kGamR * grid_eval_f<GLB>(P, 0, L));
-    m.u = grid_eval_f<GLB>(P, 1, L);
-    m.v = grid_eval_f<GLB>(P, 2, L);
+    m.u = WANT_UV ? grid_eval_f<GLB>(P, 1, L) : 0.0;
+    m.v = WANT_UV ? grid_eval_f<GLB>(P, 2, L) : 0.0;
     m.rho = WANT_RHO ? grid_eval_f<GLB>(P, 3, L) : 0.0;
     if(WANT_DZ){
         m.dcz = kGamR / (2.0 * m.c) * grid_eval_dfdz<GLB>(P, 0, L);
