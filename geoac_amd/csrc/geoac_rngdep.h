@@ -75,8 +75,9 @@ DEVINL Cub load_cubic(const double* __restrict__ c){
     const double2 lo = q[0], hi = q[1];
     return Cub{ lo.x, lo.y, hi.x, hi.y };
 }
-DEVINL double cub_val(const Cub& c, double t, double t6){ return __builtin_fma(t, __builtin_fma(t6, __builtin_fma(t, c.e3, 3.0 * c.d2), c.c1), c.c0); }
-DEVINL double cub_d1(const Cub& c, double t, double th){ return __builtin_fma(th, __builtin_fma(t, c.e3, 2.0 * c.d2), c.c1); }
+// f = c0 + t (c1 + t/2 (d2 + t/3 e3)), f' = c1 + t (d2 + t/2 e3): three and two FMAs (t/2, t/3 are common to all cubics of an evaluation)
+DEVINL double cub_val(const Cub& c, double t, double t6){ const double th = 3.0 * t6, t3 = 2.0 * t6; return __builtin_fma(t, __builtin_fma(th, __builtin_fma(t3, c.e3, c.d2), c.c1), c.c0); }
+DEVINL double cub_d1(const Cub& c, double t, double th){ return __builtin_fma(t, __builtin_fma(th, c.e3, c.d2), c.c1); }
 DEVINL double cub_d2(const Cub& c, double t){ return __builtin_fma(t, c.e3, c.d2); }
 
 DEVINL const double* grid_rec(const GeoacDevParams& P, int field, int kz, int node){
