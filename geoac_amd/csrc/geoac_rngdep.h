@@ -32,6 +32,7 @@ struct GridLoc {
     double t;               // z - z0[kz]
     double xs, ys;          // position inside the cell, scaled to [0, 1]
     double dxs, dys;        // cell sizes (dx_scalar, dy_scalar)
+    double idxs, idys;      // and their reciprocals (frcp: < 1 ulp)
 };
 
 // locate (x, y, z) (already clamped to the grid): cell, corners, vertical segment.  kz_hint < 0: search from scratch.
@@ -54,7 +55,8 @@ DEVINL void grid_locate(const GeoacDevParams& P, double x, double y, double z, i
     L.nb[1][0] = (kx + 1) * ny + ky; L.nb[1][1] = (kx + 1) * ny + ky + 1;
     const double X1 = P.gx[kx], X2 = P.gx[kx + 1], Y1 = P.gy[ky], Y2 = P.gy[ky + 1];
     L.dxs = X2 - X1; L.dys = Y2 - Y1;
-    L.xs = (x - X1) / L.dxs; L.ys = (y - Y1) / L.dys;
+    L.idxs = frcp(L.dxs); L.idys = frcp(L.dys);
+    L.xs = (x - X1) * L.idxs; L.ys = (y - Y1) * L.idys;
 }
 
 // Hermite basis on [0,1] and its derivative: value weights h[0], h[1] and slope weights g[0], g[1] of the two cell edges
@@ -176,7 +178,7 @@ DEVINL void grid_eval_all(const GeoacDevParams& P, int field, const GridLoc& L, 
         for(int i = 0; i < (ORDER2 ? 10 : 4); i++) o[i] = (NL == 4) ? quad_sum(o[i]) : pair_sum(o[i]);
     }
     if(ORDER2 && !GLB){                                            // spherical set: left in scaled coordinates (Q12c, :1328-1338, :1374-1384, :1420-1424)
-        const double idxs = 1.0 / dxs, idys = 1.0 / dys;
+        const double idxs = L.idxs, idys = L.idys;
         o[4] *= idxs; o[8] *= idxs; o[7] *= idys; o[5] *= idys; o[9] *= idys;
     }
     #pragma unroll
