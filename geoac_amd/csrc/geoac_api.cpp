@@ -52,6 +52,7 @@ struct geoac_ctx {
     bool no_quad = false;            // GEOAC_NO_QUAD=1: never use the multi-lane grid kernels
     int  grid_lanes = 0;             // GEOAC_GRID_LANES=1|2|4: force the lanes-per-ray variant of the grid kernels (tests); 0 = by fan size
     int  spread_override = 0;        // GEOAC_SPREAD=n: force n-way lane thinning of the grid-set RK4 waves (1 = dense); 0 = automatic
+    bool grid_coop = true;           // GEOAC_GRID_COOP=0: per-lane table gathers instead of the wave-cooperative gather (A/B runs, schedule-independence test)
     hipStream_t stream = nullptr; bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> evs;                  // per-epoch markers: [4e], [4e+1] around k_rk4 (ctx stream); [4e+2], [4e+3] around the post-pass (pp stream)
@@ -214,6 +215,8 @@ int geoac_create(geoac_ctx** out, int eqset, int device){
     if(gl && (atoi(gl) == 1 || atoi(gl) == 2 || atoi(gl) == 4)) ctx->grid_lanes = atoi(gl);
     const char* nsp = getenv("GEOAC_SPREAD");
     if(nsp && atoi(nsp) > 0) ctx->spread_override = atoi(nsp);
+    const char* gc = getenv("GEOAC_GRID_COOP");
+    if(gc) ctx->grid_coop = (atoi(gc) != 0);
     const char* sc = getenv("GEOAC_SMP_CAP");
     if(sc && atoll(sc) > 0) ctx->smp_cap = atoll(sc);
     *out = ctx;
@@ -387,23 +390,28 @@ int geoac_fan_set_angles(geoac_ctx* ctx, int n_rays, const double* theta_deg, co
     HIPCHK(hipSetDevice(ctx->device));
     ctx->n_rays = n_rays;
     ctx->n_pad = (n_rays + 63) / 64 * 64;
-    HIPCHK(ctx->theta.ensure(sizeof(double) * (size_t)ctx->n_pad));
-    HIPCHK(ctx->phi.ensure(sizeof(double) * (size_t)ctx->n_pad));
     std::vector<double> ths, phs; std::vector<int> order;
     ctx->have_perm = false;
+    const double* th_up = theta_deg; const double* ph_up = phi_deg; size_t n_up = (size_t)n_rays;
     if(ctx->sort_rays){
-        order.resize((size_t)ctx->n_pad);
-        for(int i = 0; i < ctx->n_pad; i++) order[(size_t)i] = i;
-        std::stable_sort(order.begin(), order.begin() + n_rays, [&](int a, int b){ return theta_deg[a] < theta_deg[b]; });
+        std::vector<int> sorted((size_t)n_rays);
+        for(int i = 0; i < n_rays; i++) sorted[(size_t)i] = i;
+        std::stable_sort(sorted.begin(), sorted.end(), [&](int a, int b){ return theta_deg[a] < theta_deg[b]; });
+        // slot -> ray (-1: a slot without a ray: the tail padding of the last wave)
+        order.assign(sorted.begin(), sorted.end());
         ths.resize((size_t)n_rays); phs.resize((size_t)n_rays);
-        for(int i = 0; i < n_rays; i++){ ths[(size_t)i] = theta_deg[order[(size_t)i]]; phs[(size_t)i] = phi_deg[order[(size_t)i]]; }
-        theta_deg = ths.data(); phi_deg = phs.data();
+        for(int i = 0; i < n_rays; i++){ ths[(size_t)i] = theta_deg[sorted[(size_t)i]]; phs[(size_t)i] = phi_deg[sorted[(size_t)i]]; }
+        ctx->n_pad = (int)((order.size() + 63) / 64 * 64);
+        while(order.size() < (size_t)ctx->n_pad) order.push_back(-1);
+        th_up = ths.data(); ph_up = phs.data(); n_up = ths.size();
         HIPCHK(ctx->perm.ensure(sizeof(int) * (size_t)ctx->n_pad));
         HIPCHK(hipMemcpyAsync(ctx->perm.p, order.data(), sizeof(int) * (size_t)ctx->n_pad, hipMemcpyHostToDevice, ctx->stream));
         ctx->have_perm = true;
     }
-    HIPCHK(hipMemcpyAsync(ctx->theta.p, theta_deg, sizeof(double) * (size_t)n_rays, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->phi.p, phi_deg, sizeof(double) * (size_t)n_rays, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx->theta.ensure(sizeof(double) * (size_t)ctx->n_pad));
+    HIPCHK(ctx->phi.ensure(sizeof(double) * (size_t)ctx->n_pad));
+    HIPCHK(hipMemcpyAsync(ctx->theta.p, th_up, sizeof(double) * n_up, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->phi.p, ph_up, sizeof(double) * n_up, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     ctx->have_angles = true;
     return GEOAC_OK;
@@ -485,7 +493,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
         P.smp_out = (double*)ctx->smp_out.p;
     }
     HIPCHK(ctx->rec.ensure(sizeof(double) * (size_t)ctx->n_rays * ctx->legs * GEOAC_REC_STRIDE));
-    HIPCHK(ctx->counters.ensure(8 * sizeof(unsigned long long)));
+    HIPCHK(ctx->counters.ensure(16 * sizeof(unsigned long long)));
     P.seg = (const double*)ctx->seg.p; P.rho = (const double*)ctx->rhot.p;
     P.theta_deg = (const double*)ctx->theta.p; P.phi_deg = (const double*)ctx->phi.p;
     P.perm = ctx->have_perm ? (const int*)ctx->perm.p : nullptr;
@@ -525,6 +533,8 @@ int geoac_fan_launch(geoac_ctx* ctx){
         while(P.spread < 4 && (long long)P.n_pad * (P.spread * 2) / 64 <= 1024) P.spread *= 2;
         if(ctx->spread_override > 0){ P.spread = 1; while(P.spread * 2 <= ctx->spread_override && P.spread < 64) P.spread *= 2; }
     }
+    // dense one-lane-per-ray grid fans (more waves than SIMDs): the quads of a wave fetch the table records together (grid_eval3_coop)
+    P.coop = (is_grid && P.lanes_per_ray == 1 && P.spread == 1 && ctx->grid_coop) ? 1 : 0;
 
     // ---- hybrid fan (Global set, CalcAmp, inclination-sorted): the two-lane kernel shortens the serial chain of a ray by x1.25 but
     //      doubles its lanes, and with one wave on every SIMD the post-pass (168 VGPRs beside 384) cannot run next to the RK4 waves at
@@ -560,7 +570,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
     //      buffers alternate, so k_rk4(e+1) runs beside k_postpass(e)/k_accum(e).  The host only waits for the
     //      live-ray count of each RK4 launch (it must know when to stop). ----
     hipStream_t s = ctx->stream, sp = ctx->no_overlap ? ctx->stream : ctx->pp_stream, sa = ctx->no_overlap ? ctx->stream : ctx->acc_stream;
-    HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 8 * sizeof(unsigned long long), s));
+    HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 16 * sizeof(unsigned long long), s));
     HIPCHK(hipEventRecord(ctx->ev0, s));
     HIPCHK(geoac_launch_init(&P, s));
     ctx->n_epochs = 0; ctx->path_bytes_w = 0; ctx->path_bytes_r = 0;
@@ -650,6 +660,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
     HIPCHK(hipMemcpyAsync(ctx->h_counters + 8, ctx->counters.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     ctx->n_samples = ctx->h_counters[8 + 3];
+
     float ms = 0; hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->ms_total = ms;
     ctx->ms_rk4 = 0; ctx->ms_post = 0;

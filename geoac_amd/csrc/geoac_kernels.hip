@@ -548,6 +548,7 @@ DEVINL void cart2_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCt
 // ================================================================================================
 template <bool AMP_> struct EqGlobal {
     static constexpr bool AMP = AMP_;
+    static constexpr bool COOP = false;
     static constexpr int PP_WAVES = 3;                              // post-pass waves per SIMD (168 registers; at 128 it spills 148 B and runs 1.5 x slower)
     static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 0, LANES = 1;
     static constexpr bool SPLIT = false;                            // true: the lanes of a ray carry DIFFERENT parts of its state (EqGlobalPair)
@@ -721,8 +722,9 @@ struct EqGlobalPair : EqGlobal<true> {
 #include "geoac_rngdep.h"
 
 // Range-dependent Cartesian set (GeoAc3D.RngDep): EquationSets.3DRngDep.cpp + G2S_MultiDimSpline3D.cpp
-template <bool AMP_, int NL_ = 1> struct Eq3DRngDep {
+template <bool AMP_, int NL_ = 1, bool COOP_ = false> struct Eq3DRngDep {
     static constexpr bool AMP = AMP_;
+    static constexpr bool COOP = COOP_;                             // wave-cooperative record gather through LDS (grid_eval3_coop): NL_ = 1, every lane of the wave stays in the loop
     static constexpr int NB = 6, NS = 6;
     static constexpr int PP_WAVES = 3;
     static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 2, LANES = NL_;            // NL_ = 1, 2 or 4 lanes per ray, each evaluating 4/NL_ of the cell corners (identical state otherwise)
@@ -766,7 +768,7 @@ template <bool AMP_, int NL_ = 1> struct Eq3DRngDep {
     static DEVINL double above_ground(const GeoacDevParams& P, const double* y){ return y[2] - P.ground; }
     template <typename TabPtr>
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
-        rngdep_rhs<AMP, NL_>(P, seg, yt, dy, (int)(threadIdx.x & (NL_ - 1)));
+        rngdep_rhs<AMP, NL_, COOP_>(P, seg, yt, dy, (int)(threadIdx.x & (NL_ - 1)), (char*)tab);
     }
     // 3DRngDep.cpp:451-472
     static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, long long k, bool& brk, bool& gnd){
@@ -854,8 +856,9 @@ template <bool AMP_, int NL_ = 1> struct Eq3DRngDep {
 
 // Range-dependent spherical set (GeoAcGlobal.RngDep): EquationSets.GlobalRngDep.cpp + G2S_GlobalMultiDimSpline3D.cpp.
 // Grid axes in table order: x = latitude, y = longitude [rad], z = geocentric radius; xy_lim = lat/lon box of the break check.
-template <bool AMP_, int NL_ = 1> struct EqGlobalRngDep {
+template <bool AMP_, int NL_ = 1, bool COOP_ = false> struct EqGlobalRngDep {
     static constexpr bool AMP = AMP_;
+    static constexpr bool COOP = COOP_;
     static constexpr int NB = 6, NS = 6;
     static constexpr int PP_WAVES = 3;
     static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 0, LANES = NL_;
@@ -897,7 +900,7 @@ template <bool AMP_, int NL_ = 1> struct EqGlobalRngDep {
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
         double s2, c2;
         rot_small(C.a[0], C.a[1], yt[1] - y0[1], s2, c2);          // sin/cos(lat) carried along the ray, as in EqGlobal
-        globalrd_rhs<AMP, NL_>(P, seg, yt, s2, c2, dy, (int)(threadIdx.x & (NL_ - 1)));
+        globalrd_rhs<AMP, NL_, COOP_>(P, seg, yt, s2, c2, dy, (int)(threadIdx.x & (NL_ - 1)), (char*)tab);
     }
     // GeoAc_BreakCheck / GeoAc_GroundCheck: GlobalRngDep.cpp:523-545
     static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, long long k, bool& brk, bool& gnd){
@@ -988,6 +991,7 @@ template <bool AMP_, int NL_ = 1> struct EqGlobalRngDep {
 
 template <bool AMP_> struct Eq3D {
     static constexpr bool AMP = AMP_;
+    static constexpr bool COOP = false;
     static constexpr int PP_WAVES = 4;                              // post-pass at four waves per SIMD (127 registers, 52 B of spill): GeoAc3D 360 x 90 fan 185 -> 168 ms
     static constexpr int E = AMP_ ? 12 : 4, PW = 4, HIDX = 2, LANES = 1;
     static constexpr bool SPLIT = false;
@@ -1141,6 +1145,7 @@ struct Eq3DPair : Eq3D<true> {
 
 template <bool AMP_> struct Eq2D {
     static constexpr bool AMP = AMP_;
+    static constexpr bool COOP = false;
     static constexpr int NB = 3, NS = 3;
     static constexpr int PP_WAVES = 4;
     static constexpr int E = AMP_ ? 6 : 3, PW = 2, HIDX = 1, LANES = 1;
@@ -1239,7 +1244,8 @@ __global__ void __launch_bounds__(256) k_init(GeoacDevParams P){
     double* st = P.state + i;
     const size_t np = (size_t)P.n_pad;
     for(int f = 0; f < ST_NSTATE; f++) st[f * np] = 0.0;
-    if(i >= P.n_rays){ st[ST_DONE * np] = 1.0; return; }          // padding lanes: finished from the start
+    const int ray = P.perm ? P.perm[i] : (i < P.n_rays ? i : -1);   // slots without a ray (tail padding, quad alignment of the grid sets): finished from the start
+    if(ray < 0){ st[ST_DONE * np] = 1.0; return; }
     const double th = P.theta_deg[i] * kPi / 180.0;               // GeoAcGlobal_main.cpp:244
     const double ph = kPi / 2.0 - P.phi_deg[i] * kPi / 180.0;     // :245
     double y[GEOAC_MAXE];
@@ -1250,7 +1256,7 @@ __global__ void __launch_bounds__(256) k_init(GeoacDevParams P){
     st[ST_C0 * np] = C.c0; st[ST_NU0 * np] = C.nu0;
     for(int q = 0; q < 6; q++) st[(ST_AUX0 + q) * np] = C.a[q];
     st[ST_SEG * np] = P.gtab ? -1.0 : (double)seg_guess(P.seg, P, clampd(y[EQ::HIDX], P.x_min, P.x_max));   // grid sets: search from scratch
-    double* R = P.rec + (size_t)i * (P.bounces + 1) * GEOAC_REC_STRIDE;
+    double* R = P.rec + (size_t)ray * (P.bounces + 1) * GEOAC_REC_STRIDE;
     for(int q = 0; q < (P.bounces + 1) * GEOAC_REC_STRIDE; q++) R[q] = 0.0;
 }
 
@@ -1283,7 +1289,7 @@ DEVINL void write_row(const GeoacDevParams& P, int row, int slot, int q, const d
 }
 
 template <class EQ, bool LDS, bool SMP>
-__global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
+__global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAVES : 1) k_rk4(GeoacDevParams P){
     constexpr int E = EQ::E;
     __builtin_amdgcn_s_setprio(3);      // latency-critical serial recurrence: win VALU arbitration against co-resident post-pass waves
     extern __shared__ double lds_tab[];
@@ -1307,7 +1313,15 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
         for(int q = threadIdx.x; q < total; q += blockDim.x) lds_tab[q] = gtab[q];
         __syncthreads();
     }
-    if(done) return;
+    // cooperative-gather policies keep every lane of the wave in the step loop: a lane whose ray has finished (or a padding lane) goes on
+    // fetching table records for its quad mates (grid_eval3_coop); all its own side effects are switched off
+    const bool idle0 = done;                                     // finished before this epoch: nothing of this lane's is written
+    if(!EQ::COOP && done) return;
+    // per wave: the 64 x 176 B exchange buffer of the cooperative gather, then y[E][64] and yn[E][64]
+    constexpr int COOP_WAVE_BYTES = 64 * GEOAC_COOP_SLOT + 2 * GEOAC_MAXE * 64 * (int)sizeof(double);
+    char* const ldsw = EQ::COOP ? (char*)lds_tab + (threadIdx.x >> 6) * COOP_WAVE_BYTES : nullptr;
+    double* const ly = EQ::COOP ? (double*)(ldsw + 64 * GEOAC_COOP_SLOT) + (threadIdx.x & 63) : nullptr;
+    double* const lyn = EQ::COOP ? ly + GEOAC_MAXE * 64 : nullptr;
 
     int nr = 0, nle = 0;
     static_assert(E <= ST_K - ST_Y0, "state block: y[] overruns ST_K");
@@ -1333,9 +1347,13 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
     double dprev = SMP ? st[ST_DPREV * np] : 0.0;               // Jacobian of the previous row (caustic detection)
     const bool want_rays = SMP && (P.mode & GEOAC_MODE_WRITE_RAYS), want_caus = SMP && EQ::AMP && (P.mode & GEOAC_MODE_WRITE_CAUSTICS);
 
-    write_row<EQ>(P, nr++, slot, q, y);                            // carry row: chunk row 0 = current state
+    if(!EQ::COOP || !idle0) write_row<EQ>(P, nr++, slot, q, y);    // carry row: chunk row 0 = current state
 
-    while(nr + 2 <= P.s_rows && !done){
+    while(true){
+        const bool act = (nr + 2 <= P.s_rows) && !done;
+        if(EQ::COOP ? !__any(act) : !act) break;                  // COOP: wave-uniform exit, `act` predicates this lane's own work
+        double ds = P.ds_min;
+        if(!EQ::COOP || act){
         // running turning height: max over rows m < k of the height component   (GeoAcGlobal_main.cpp:294)
         if(EQ::PW == 2 && (P.mode & GEOAC_MODE_INTERACTIVE)){         // GeoAc2D -interactive: max over rows 1..k-1 of solution[m][2] (nu_z)
             if(k >= 1) hmax = (hmax < y[2]) ? y[2] : hmax;
@@ -1363,27 +1381,48 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
         }
 
         // ---- GeoAc_Set_ds (Global.cpp:210-217 and twins) ----
-        double ds = 0.05 - 0.049 * exp(-EQ::above_ground(P, y) / 0.75);
+        ds = 0.05 - 0.049 * exp(-EQ::above_ground(P, y) / 0.75);
         ds = (P.ds_max < ds) ? P.ds_max : ds;
         ds = (ds < P.ds_min) ? P.ds_min : ds;
+        }
 
         // ---- the four RK4 stages as ONE rolled loop (a single copy of the RHS keeps the live set < 256 VGPRs):
         //      k_s = ds f(y + a_s k_{s-1}), a = {0, 1/2, 1/2, 1};  y' = y + k1/6 + k2/3 + k3/3 + k4/6  (Solver.cpp:33-54)
         double dy[E], yt[E], yn[E];
         #pragma unroll
         for(int e = 0; e < E; e++){ yt[e] = y[e]; yn[e] = y[e]; }
+        if(EQ::COOP){
+            // the step's base row y and the accumulating new row yn live in LDS ([component][lane], conflict free) while the four stages
+            // run: 72 registers less under the table evaluation, which is what spilled (416 B of scratch per lane before)
+            #pragma unroll
+            for(int e = 0; e < E; e++){ ly[e * 64] = y[e]; lyn[e * 64] = y[e]; }
+        }
         #pragma unroll 1
         for(int stage = 0; stage < 4; stage++){
-            if(LDS) EQ::rhs(lds_tab, P, seg, C, y, yt, stage, dy); else EQ::rhs(gtab, P, seg, C, y, yt, stage, dy);
+            if(EQ::COOP) EQ::rhs((double*)ldsw, P, seg, C, y, yt, stage, dy);
+            else if(LDS) EQ::rhs(lds_tab, P, seg, C, y, yt, stage, dy); else EQ::rhs(gtab, P, seg, C, y, yt, stage, dy);
             const double wa = ((stage == 2) ? 1.0 : 0.5) * ds;
             const double wb = ((stage == 0 || stage == 3) ? (1.0 / 6.0) : (1.0 / 3.0)) * ds;
-            #pragma unroll
-            for(int e = 0; e < E; e++){
-                yn[e] = __builtin_fma(dy[e], wb, yn[e]);
-                yt[e] = __builtin_fma(dy[e], wa, y[e]);
+            if(EQ::COOP){
+                #pragma unroll
+                for(int e = 0; e < E; e++){
+                    lyn[e * 64] = __builtin_fma(dy[e], wb, lyn[e * 64]);
+                    yt[e] = __builtin_fma(dy[e], wa, ly[e * 64]);
+                }
+            } else {
+                #pragma unroll
+                for(int e = 0; e < E; e++){
+                    yn[e] = __builtin_fma(dy[e], wb, yn[e]);
+                    yt[e] = __builtin_fma(dy[e], wa, y[e]);
+                }
             }
         }
+        if(EQ::COOP){
+            #pragma unroll
+            for(int e = 0; e < E; e++){ y[e] = ly[e * 64]; yn[e] = lyn[e * 64]; }
+        }
 
+        if(!EQ::COOP || act){                                     // (a helper lane has nothing of its own to advance)
         k++; steps_here++;
         write_row<EQ>(P, nr++, slot, q, yn);
 
@@ -1451,9 +1490,11 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
             for(int e = 0; e < E; e++) y[e] = yn[e];
             EQ::accept(C);
         }
+        }
     }
 
     // ---- save state (pair kernel: both lanes store the identical base ray; each stores its own derivative system) ----
+    if(!(EQ::COOP && idle0)){
     #pragma unroll
     for(int e = 0; e < E; e++) st[(ST_Y0 + ((EQ::SPLIT && e >= EQ::NB) ? e + EQ::NS * q : e)) * np] = y[e];
     if(YM2_REG){
@@ -1469,6 +1510,7 @@ __global__ void __launch_bounds__(256, 1) k_rk4(GeoacDevParams P){
         st[ST_DPREV * np] = dprev;
         P.nev[slot] = nev < P.ev_cap ? nev : P.ev_cap;
         if(nev > P.ev_cap) atomicOr(&P.counters[2], 2ull);
+    }
     }
 
     // ---- step count and live-ray count: lanes of finished rays have already returned, so reduce over the
@@ -1517,9 +1559,9 @@ __global__ void __launch_bounds__(256, EQ::PP_WAVES) k_postpass(GeoacDevParams P
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_accum(GeoacDevParams P){
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if(slot >= P.n_rays) return;
+    if(slot >= P.n_pad) return;
     const size_t np = (size_t)P.n_pad;
-    const int nr = P.nrows[slot];
+    const int nr = P.nrows[slot];                               // 0 for slots without a ray
     if(nr < 2) return;
     double* st = P.state + slot;
     double tt = st[ST_TT * np], at = st[ST_AT * np];           // cumulative over the ray
@@ -1585,6 +1627,7 @@ __global__ void __launch_bounds__(256) k_accum(GeoacDevParams P){
 // ------------------------------------------------------------------------------------------------
 // host-callable launchers (called from geoac_api.cpp)
 // ------------------------------------------------------------------------------------------------
+#ifndef GEOAC_NO_LAUNCHERS          // tools/dev_kernel.sh compiles single instantiations of the kernels above
 #define GEOAC_DISPATCH_EQ(P, CALL) \
     switch((P)->eqset * 2 + ((P)->calc_amp ? 1 : 0)){ \
         case GEOAC_EQ_GLOBAL * 2 + 1: { using EQ = EqGlobal<true>;  CALL; } break; \
@@ -1615,6 +1658,13 @@ __global__ void __launch_bounds__(256) k_accum(GeoacDevParams P){
             case GEOAC_EQ_GLOBAL_RNGDEP * 2 + 1: { using EQ = EqGlobalRngDep<true, 2>;  CALL; } break; \
             case GEOAC_EQ_GLOBAL_RNGDEP * 2 + 0: { using EQ = EqGlobalRngDep<false, 2>; CALL; } break; \
             default: return hipErrorNotSupported; } \
+    } else if((P)->coop && (P)->gtab && (P)->lanes_per_ray == 1 && (P)->spread <= 1){ \
+        switch((P)->eqset * 2 + ((P)->calc_amp ? 1 : 0)){ \
+            case GEOAC_EQ_3D_RNGDEP * 2 + 1: { using EQ = Eq3DRngDep<true, 1, true>;  CALL; } break; \
+            case GEOAC_EQ_3D_RNGDEP * 2 + 0: { using EQ = Eq3DRngDep<false, 1, true>; CALL; } break; \
+            case GEOAC_EQ_GLOBAL_RNGDEP * 2 + 1: { using EQ = EqGlobalRngDep<true, 1, true>;  CALL; } break; \
+            case GEOAC_EQ_GLOBAL_RNGDEP * 2 + 0: { using EQ = EqGlobalRngDep<false, 1, true>; CALL; } break; \
+            default: return hipErrorNotSupported; } \
     } else GEOAC_DISPATCH_EQ(P, CALL)
 
 extern "C" hipError_t geoac_launch_init(const GeoacDevParams* P, hipStream_t s){
@@ -1631,6 +1681,7 @@ static hipError_t launch_rk4_t(const GeoacDevParams* P, int block, hipStream_t s
     dim3 b(block), g((unsigned)((lanes + block - 1) / block));
     if(n_wg) *n_wg = g.x;
     size_t lds = P->table_in_lds ? (size_t)P->nseg * GEOAC_SEGW * sizeof(double) : 0;
+    if(EQ::COOP) lds = (size_t)(block / 64) * (64 * GEOAC_COOP_SLOT + 2 * GEOAC_MAXE * 64 * sizeof(double));   // per wave: exchange buffer + y, yn rows (k_rk4)
     const bool smp = (P->mode & (GEOAC_MODE_WRITE_RAYS | GEOAC_MODE_WRITE_CAUSTICS)) != 0;
     #define GEOAC_RK4_LAUNCH(LDSF, SMPF) do { \
         if(lds > 65536){ \
@@ -1682,7 +1733,8 @@ extern "C" hipError_t geoac_launch_postpass(const GeoacDevParams* P, int rows, h
 }
 
 extern "C" hipError_t geoac_launch_accum(const GeoacDevParams* P, hipStream_t s){
-    dim3 b(256), g2((P->n_rays + 255) / 256);
+    dim3 b(256), g2((P->n_pad + 255) / 256);
     hipLaunchKernelGGL(k_accum, g2, b, 0, s, *P);
     return hipGetLastError();
 }
+#endif  // GEOAC_NO_LAUNCHERS

@@ -185,6 +185,127 @@ DEVINL void grid_eval_all(const GeoacDevParams& P, int field, const GridLoc& L, 
     for(int i = 0; i < (ORDER2 ? 10 : 4); i++) out[i] = o[i];
 }
 
+// ---- wave-cooperative record gather (one ray per lane, large fans) --------------------------------------------------------------
+// With one record per lane every global_load_dwordx4 of a wave touches 64 different cache lines and the CU's texture-address / L1 path
+// is busy 48 cycles per wave-instruction, against 17-23 when lanes read contiguous bytes (tools/ubench_gather.hip; 240 such loads per
+// RK4 stage).  Here the four lanes of a QUAD fetch 64 contiguous bytes per instruction (16 pieces per instruction instead of 64 lines):
+// a quad walks through the half-records (160 B: five cubics) of its four lanes back to back, 10 loads for 4 x 160 B, and the chunks are
+// handed to their owners through LDS: every lane stores what it loaded at slot[owner][chunk] and then reads its own 10 chunks.  Slots are
+// 176 B apart (160 B + 16 B pad): the ds_read_b128 of a wave are bank-conflict free (bank group (11 slot + chunk) mod 16 is distinct over
+// each 16-lane access group), the ds_write_b128 too except the two of ten that straddle two owners (2-way).
+// All 64 lanes of the wave take part, also lanes whose ray has finished (they fetch for their quad mates): the caller keeps the wave
+// converged around this function.  LDS: 64 x 176 B = 11 KiB per wave.  The next half-record's loads are in flight while one is evaluated.
+// Same operations in the same order as grid_eval_all: a ray's numbers do not depend on which of the two gathers served it.
+// Measured (config-4 share, MI355X): texture-path busy cycles -32 %, L1 accesses -38 %; 5x5x1400 grid (38 MB table) 2.94 -> 2.50 s,
+// 5x5x350 grid (9.6 MB) 2.16 -> 2.14 s: with one wave per SIMD the 480 LDS instructions per stage (ds_write_b128: 13 issue cycles)
+// cost the wave what the gathers cost the texture path.  Tried and dropped: fetching only the (at most two) DISTINCT records of a quad -
+// neighbouring rays fall out of step after their first ground reflection, 20 % of the lanes then need a third record.
+#define GEOAC_COOP_SLOT 176
+#ifndef GEOAC_COOP_WAVES
+#define GEOAC_COOP_WAVES 1            // waves per SIMD the cooperative kernels are compiled for
+#endif
+typedef double geoac_d2 __attribute__((ext_vector_type(2)));       // one 16-byte chunk (native vector: stays in registers)
+template <int O> DEVINL unsigned quad_bcast_u32(unsigned v){ return (unsigned)__builtin_amdgcn_mov_dpp((int)v, O * 0x55, 0xF, 0xF, true); }
+
+template <bool ORDER2, bool GLB>
+DEVINL void grid_eval3_coop(const GeoacDevParams& P, const GridLoc& L, double (*M)[10], char* ldsw){
+    const unsigned lane = threadIdx.x & 63u, r = lane & 3u;
+    const bool hi2 = r >= 2u;                                                         // the upper lane pair of the quad (loads that straddle two owners)
+    const unsigned nn = (unsigned)(P.gnx * P.gny);
+    const Herm hx = hermite(L.xs), hy = hermite(L.ys);
+    const double dxs = L.dxs, dys = L.dys, dxy = dxs * dys;
+    const double t = L.t, th = 0.5 * t, t6 = t * (1.0 / 6.0);
+    const size_t fstride = (size_t)P.nseg * nn * (GEOAC_GREC * sizeof(double));       // bytes per field block of the table
+    // the quad's 40 chunks of a half-record round are numbered g = 10 owner + chunk; load j of lane r fetches g = 4 j + r:
+    //   global address = field block + [off_owner - 160 owner + 16 r] + 64 j + 160 half     LDS address = [176 quad + 16 r] + 16 owner + 64 j
+    //   (16 chunk = 64 j + 16 r - 160 owner;  slot = 176 (quad + owner) + 16 chunk).  The - 160 owner term is kept non-negative by a bias
+    //   of 480 that the base pointer takes back: the offsets stay unsigned 32-bit.
+    const char* __restrict__ tabb = (const char*)P.gtab - 480;
+    const unsigned rb = 16u * r + 480u;
+    char* const wq = ldsw + (lane & ~3u) * GEOAC_COOP_SLOT + 16u * r;
+    const char* const rslot = ldsw + lane * GEOAC_COOP_SLOT;
+    #pragma unroll
+    for(int f = 0; f < 3; f++){
+        #pragma unroll
+        for(int i = 0; i < 10; i++) M[f][i] = 0.0;
+    }
+    // owner of load j: j = 0, 1 -> 0; 2 -> 0 | 1; 3, 4 -> 1; 5, 6 -> 2; 7 -> 2 | 3; 8, 9 -> 3
+    #define GEOAC_COOP_OWNER(j, B) ((j) < 2 ? B[0] : (j) == 2 ? (hi2 ? B[1] : B[0]) : (j) < 5 ? B[1] : (j) < 7 ? B[2] : (j) == 7 ? (hi2 ? B[3] : B[2]) : B[3])
+    unsigned gb[4];                                                                   // global bases of the quad's owners for the corner being fetched
+    const unsigned wb[4] = { 0u, 16u, 32u, 48u };
+    {
+        const unsigned off = ((unsigned)L.kz * nn + (unsigned)L.nb[0][0]) * (unsigned)(GEOAC_GREC * sizeof(double));
+        gb[0] = quad_bcast_u32<0>(off) + rb; gb[1] = quad_bcast_u32<1>(off) + (rb - 160u); gb[2] = quad_bcast_u32<2>(off) + (rb - 320u); gb[3] = quad_bcast_u32<3>(off) + (rb - 480u);
+    }
+    geoac_d2 v[10];                                                                   // in flight: the NEXT half-record's chunks
+    #pragma unroll
+    for(int j = 0; j < 10; j++) v[j] = *(const geoac_d2*)(tabb + GEOAC_COOP_OWNER(j, gb) + 64 * j);
+    double cF1 = 0, cF2 = 0, cF3 = 0, cFz = 0, cVxz = 0, cFxyz = 0;                   // carried from the first half of a record to the second
+    #pragma unroll
+    for(int h = 0; h < 24; h++){
+        const int n = h >> 1, part = h & 1, cn = n / 3, f = n % 3, a = cn >> 1, b = cn & 1;
+        #pragma unroll
+        for(int j = 0; j < 10; j++) *(geoac_d2*)(wq + GEOAC_COOP_OWNER(j, wb) + 64 * j) = v[j];
+        if(h + 1 < 24){
+            const int n1 = (h + 1) >> 1, part1 = (h + 1) & 1, cn1 = n1 / 3, f1 = n1 % 3;
+            if(part1 == 0 && f1 == 0){                                                // first half-record of the next corner: its owners' bases
+                const unsigned off = ((unsigned)L.kz * nn + (unsigned)L.nb[cn1 >> 1][cn1 & 1]) * (unsigned)(GEOAC_GREC * sizeof(double));
+                gb[0] = quad_bcast_u32<0>(off) + rb; gb[1] = quad_bcast_u32<1>(off) + (rb - 160u); gb[2] = quad_bcast_u32<2>(off) + (rb - 320u); gb[3] = quad_bcast_u32<3>(off) + (rb - 480u);
+            }
+            const char* __restrict__ fb = tabb + (size_t)f1 * fstride + 160 * part1;
+            #pragma unroll
+            for(int j = 0; j < 10; j++) v[j] = *(const geoac_d2*)(fb + GEOAC_COOP_OWNER(j, gb) + 64 * j);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        Cub c[5];
+        #pragma unroll
+        for(int i = 0; i < 5; i++){
+            const geoac_d2 lo = *(const geoac_d2*)(rslot + 32 * i), hi = *(const geoac_d2*)(rslot + 32 * i + 16);
+            c[i] = Cub{ lo.x, lo.y, hi.x, hi.y };
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");              // the next half-record's stores stay behind these reads
+        __builtin_amdgcn_wave_barrier();
+        CornerW w = corner_weights<ORDER2, ORDER2>(hx, hy, a, b);
+        const double Wq = w.W[2] * (GLB ? dys : dxs);                                 // Cartesian: Q11 row of the f_zz patch (y row scaled by dx)
+        w.W[1] *= dxs; w.W[2] *= dys; w.W[3] *= dxy;
+        if(ORDER2){ w.D[1] *= dxs; w.D[2] *= dys; w.D[3] *= dxy; w.E[1] *= dxs; w.E[2] *= dys; w.E[3] *= dxy; }
+        double* o = M[f];
+        if(part == 0){                                                                // F, DxF, DyF, DxyF, Vx
+            const double F = cub_val(c[GC_F], t, t6), DxF = cub_val(c[GC_DXF], t, t6), DyF = cub_val(c[GC_DYF], t, t6), DxyF = cub_val(c[GC_DXYF], t, t6);
+            const double Fz = cub_d1(c[GC_F], t, th), Vxz = cub_d1(c[GC_VX], t, th), DxyFz = cub_d1(c[GC_DXYF], t, th);
+            o[0] = dot4(w.W, F, DxF, DyF, DxyF, o[0]);
+            if(ORDER2){
+                const double Fzz = cub_d2(c[GC_F], t), DxFzz = cub_d2(c[GC_DXF], t), DyFzz = cub_d2(c[GC_DYF], t), DxyFzz = cub_d2(c[GC_DXYF], t);
+                o[6] = __builtin_fma(w.W[0], Fzz, __builtin_fma(w.W[1], DxFzz, __builtin_fma(Wq, DyFzz, __builtin_fma(w.W[3], DxyFzz, o[6]))));
+            }
+            cF1 = DxF; cF2 = DyF; cF3 = DxyF; cFz = Fz; cVxz = Vxz; cFxyz = DxyFz;
+        } else {                                                                      // DxVx, DxyVx, Vy, DyVy, DxyVy
+            const double DxVx = cub_val(c[GC_DXVX - 5], t, t6), DxyVx = cub_val(c[GC_DXYVX - 5], t, t6);
+            const double DyVy = cub_val(c[GC_DYVY - 5], t, t6), DxyVy = cub_val(c[GC_DXYVY - 5], t, t6);
+            const double Vyz = cub_d1(c[GC_VY - 5], t, th);
+            const double DxF = cF1, DyF = cF2, DxyF = cF3, Fz = cFz, Vxz = cVxz, DxyFz = cFxyz;
+            o[1] = dot4(w.W, DxF, DxVx, DxyF, DxyVx, o[1]);
+            o[2] = dot4(w.W, DyF, DxyF, DyVy, DxyVy, o[2]);
+            o[3] = dot4(w.W, Fz, Vxz, Vyz, DxyFz, o[3]);
+            if(ORDER2){
+                o[4] = dot4(w.D, DxF, DxVx, DxyF, DxyVx, o[4]);
+                o[7] = dot4(w.E, DxF, DxVx, DxyF, DxyVx, o[7]);
+                o[5] = dot4(w.E, DyF, DxyF, DyVy, DxyVy, o[5]);
+                o[8] = dot4(w.D, Fz, Vxz, Vyz, DxyFz, o[8]);
+                o[9] = dot4(w.E, Fz, Vxz, Vyz, DxyFz, o[9]);
+            }
+        }
+    }
+    #undef GEOAC_COOP_OWNER
+    if(ORDER2 && !GLB){                                                               // spherical set: left in scaled coordinates (Q12c)
+        const double idxs = L.idxs, idys = L.idys;
+        #pragma unroll
+        for(int f = 0; f < 3; f++){ M[f][4] *= idxs; M[f][8] *= idxs; M[f][7] *= idys; M[f][5] *= idys; M[f][9] *= idys; }
+    }
+}
+
 // Eval_Spline_f (:806-863): scalar value, y rows scaled by dx_scalar (Q11; the spherical twin :755-807 uses dp_scalar)
 template <bool GLB>
 DEVINL double grid_eval_f(const GeoacDevParams& P, int field, const GridLoc& L){
@@ -252,15 +373,18 @@ DEVINL Medium3 medium3_at(const GeoacDevParams& P, double x, double y, double z)
 
 // fused GeoAc_UpdateSources + GeoAc_EvalSrcEq of the range-dependent Cartesian set (EquationSets.3DRngDep.cpp:218-393)
 // y: x, y, z, nu_x, nu_y, nu_z | X_th(3), mu_th(3) | X_ph(3), mu_ph(3)
-template <bool AMP, int NL = 1>
-DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double* dy, int cq = 0){
+template <bool AMP, int NL = 1, bool COOP = false>
+DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double* dy, int cq = 0, char* ldsw = nullptr){
     const double xe = clampd(y[0], P.gx[0], P.gx[P.gnx - 1]), ye = clampd(y[1], P.gy[0], P.gy[P.gny - 1]), ze = clampd(y[2], P.x_min, P.x_max);
     GridLoc L; grid_locate(P, xe, ye, ze, kz, L);
     kz = L.kz;
     double M[3][10];                                               // T, u, v and their derivatives
-    #pragma unroll                                                // three copies of the evaluator: M[][] stays in registers (rolled, the dynamic
-                                                                  // index f put it in scratch: 240 B written and read back per stage)
-    for(int f = 0; f < 3; f++) grid_eval_all<AMP, false, NL>(P, f, L, M[f], cq);
+    // three copies of the evaluator: M[][] stays in registers (rolled, the dynamic index f put it in scratch: 240 B written and read back per stage)
+    if(COOP) grid_eval3_coop<AMP, false>(P, L, M, ldsw);
+    else {
+        #pragma unroll
+        for(int f = 0; f < 3; f++) grid_eval_all<AMP, false, NL>(P, f, L, M[f], cq);
+    }
     const double* T = M[0]; const double* U = M[1]; const double* V = M[2];
     const double n0 = y[3], n1 = y[4], n2 = y[5];
     const double qT = kGamR * T[0];
@@ -320,15 +444,18 @@ DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double
 // fused GeoAc_UpdateSources + GeoAc_EvalSrcEq of the range-dependent spherical set (EquationSets.GlobalRngDep.cpp:226-458):
 // the algebra of global_rhs (geoac_kernels.hip) with the full gradient and second-derivative matrices of c, u, v (w = 0).
 // y: r, lat, lon, nu_r, nu_t, nu_p | R_lt(3), mu_lt(3) | R_lp(3), mu_lp(3);  sth/cth = sin/cos(lat) from the caller.
-template <bool AMP, int NL = 1>
-DEVINL void globalrd_rhs(const GeoacDevParams& P, int& kz, const double* y, double sth, double cth, double* dy, int cq = 0){
+template <bool AMP, int NL = 1, bool COOP = false>
+DEVINL void globalrd_rhs(const GeoacDevParams& P, int& kz, const double* y, double sth, double cth, double* dy, int cq = 0, char* ldsw = nullptr){
     const double r = y[0];
     const double te = clampd(y[1], P.gx[0], P.gx[P.gnx - 1]), pe = clampd(y[2], P.gy[0], P.gy[P.gny - 1]), re = clampd(r, P.x_min, P.x_max);
     GridLoc L; grid_locate(P, te, pe, re, kz, L);
     kz = L.kz;
     double M[3][10];                                               // table order: f, f_t, f_p, f_r, f_tt, f_pp, f_rr, f_tp, f_tr, f_pr
-    #pragma unroll
-    for(int f = 0; f < 3; f++) grid_eval_all<AMP, true, NL>(P, f, L, M[f], cq);
+    if(COOP) grid_eval3_coop<AMP, true>(P, L, M, ldsw);
+    else {
+        #pragma unroll
+        for(int f = 0; f < 3; f++) grid_eval_all<AMP, true, NL>(P, f, L, M[f], cq);
+    }
     const double* T = M[0]; const double* U = M[1]; const double* V = M[2];
     // first derivatives in equation order (r, t, p) = table entries 3, 1, 2
     const int fi[3] = { 3, 1, 2 };

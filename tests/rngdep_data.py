@@ -12,9 +12,9 @@ Y_NODES = np.array([-800.0, -400.0, 0.0, 400.0, 800.0])
 THIN = 4                      # keep every 4th ToyAtmo row: 350 nodes, dz = 0.4 km
 
 
-def grid_columns():
+def grid_columns(thin=THIN):
     """returns z [nz], and T, u, v, rho as [nx][ny][nz] (raw .met units: K, m/s, m/s, g/cm^3)"""
-    raw = np.loadtxt(H.TOYATMO)[::THIN]
+    raw = np.loadtxt(H.TOYATMO)[::thin]
     z = raw[:, 0]
     nx, ny = len(X_NODES), len(Y_NODES)
     T = np.zeros((nx, ny, len(z))); u = np.zeros_like(T); v = np.zeros_like(T); rho = np.zeros_like(T)
@@ -29,25 +29,31 @@ def grid_columns():
 
 
 GRID_NPZ = os.path.join(H.GOLDEN_DIR, "rngdep_grid.npz")
+GRID_NPZ_FULL = os.path.join(H.GOLDEN_DIR, "rngdep_grid_1400.npz")       # thin = 1: the 5x5x1400 grid of BASELINE config 4
 
 
-def save_grid_npz():
+def _grid_npz(thin):
+    assert thin in (THIN, 1)
+    return GRID_NPZ if thin == THIN else GRID_NPZ_FULL
+
+
+def save_grid_npz(thin=THIN):
     """(make_golden.py) evaluates the analytic perturbation once and stores the columns, so that the files written at
     test time are the same bytes on every machine"""
-    z, T, u, v, rho, p = grid_columns()
-    np.savez_compressed(GRID_NPZ, z=z, T=T, u=u, v=v, rho=rho, p=p, x=X_NODES, y=Y_NODES)
+    z, T, u, v, rho, p = grid_columns(thin)
+    np.savez_compressed(_grid_npz(thin), z=z, T=T, u=u, v=v, rho=rho, p=p, x=X_NODES, y=Y_NODES)
 
 
-def load_grid_columns():
-    g = np.load(GRID_NPZ)
+def load_grid_columns(thin=THIN):
+    g = np.load(_grid_npz(thin))
     return g["z"], g["T"], g["u"], g["v"], g["rho"], g["p"]
 
 
-def write_grid(dirpath, short_paths=True):
+def write_grid(dirpath, short_paths=True, thin=THIN):
     """writes the files; returns (prefix, locx, locy).  Paths must stay short: the reference formats file names into a
     50-byte buffer (G2S_MultiDimSpline3D.cpp:112,154)."""
     os.makedirs(dirpath, exist_ok=True)
-    z, T, u, v, rho, p = load_grid_columns()
+    z, T, u, v, rho, p = load_grid_columns(thin)
     prefix = os.path.join(dirpath, "p")
     assert len(prefix) < 40 or not short_paths     # only the reference needs short names
     for i in range(len(X_NODES)):

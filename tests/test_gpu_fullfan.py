@@ -1,0 +1,70 @@
+"""BASELINE.json's configurations at FULL size against fixtures made by the compiled reference (tests/golden/make_golden_full.py,
+oracle/_ref/libref_*.so run here, 6 processes): every (ray, leg) of the GPU fan must reproduce the reference's
+GeoAc_Propagate_RK4 step count and its VALID / BROKE outcome exactly, and travel time, attenuation, turning height, arrival
+inclination, back azimuth, amplitude and range within 1e-6 relative (tests/parity.py).
+
+  metric   GeoAcGlobal 360 az x 90 incl, bounces=2, CalcAmp=True: all 32 400 rays x 3 legs, values for all
+  cfg2     GeoAc3D, same fan: all rays, values for all
+  cfg3     GeoAcGlobal 720 az x 180 incl, bounces=3: counts for all 129 600 rays x 4 legs, values for every 4th azimuth
+  cfg4     GeoAc3D.RngDep, 5x5x1400 grid, the rank-0 share (125 azimuths x 1000 inclinations = 124 000 rays) of the 1000 x 1000 fan:
+           the GPU integrates the whole share; the reference's lattice of 2000 of its rays (every 8th azimuth x every 8th inclination)
+  cfg5     GeoAcGlobal.RngDep -eig_search, the rank-0 receivers of the 64-ring: tests/test_gpu_eig_ring.py
+"""
+import os
+
+import numpy as np
+import pytest
+
+import harness as H
+from parity import compare_compact
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import geoac_amd
+    geoac_amd.load_library()
+    return geoac_amd
+
+
+def _gold(name):
+    return np.load(os.path.join(H.GOLDEN_DIR, f"full_{name}.npz"))
+
+
+def _fan_kwargs(g):
+    return {str(k): float(v) for k, v in g["fan"]}
+
+
+@pytest.mark.parametrize("name,eqname", [("metric", "EQ_GLOBAL"), ("cfg2", "EQ_3D"), ("cfg3", "EQ_GLOBAL")])
+def test_stratified_fan_every_ray_vs_reference(G, name, eqname):
+    g = _gold(name)
+    th, ph = G.fan_enumerate(**_fan_kwargs(g))
+    assert len(th) == int(g["n_rays"])
+    ctx = G.FanContext(getattr(G, eqname), device=0)
+    ctx.load_met(H.TOYATMO)
+    ctx.set_params(bounces=int(g["bounces"]), calc_amp=1, mode=0)
+    rec, steps = ctx.run(th, ph)
+    assert steps == int(g["total_steps"])                 # the reference's own sum of GeoAc_Propagate_RK4 return values
+    err = compare_compact(rec, g)
+    print(name, "ray-steps", steps, "max rel err", {k: f"{v:.2e}" for k, v in err.items()})
+    if name == "metric":
+        assert steps == 874273730
+
+
+def test_config4_share_on_5x5x1400_grid_vs_reference(G, tmp_path):
+    import rngdep_data as RD
+    g = _gold("cfg4")
+    grid = RD.write_grid(str(tmp_path), short_paths=False, thin=1)
+    ctx = G.FanContext(G.EQ_3D_RNGDEP, device=0)
+    ctx.load_grid(*grid)
+    ctx.set_params(bounces=int(g["bounces"]), calc_amp=1, mode=0, src=(0.0, 0.0, 0.0))
+    th, ph = G.fan_enumerate(theta_min=0.05, theta_max=50.0, theta_step=0.05, phi_min=-180.0, phi_max=-180.0 + 124 * 0.36, phi_step=0.36)
+    assert len(th) == int(g["n_rays"]) == 124000
+    sel = g["sel"]
+    assert np.array_equal(th[sel], g["theta"]) and np.array_equal(ph[sel], g["phi"])
+    rec, steps = ctx.run(th, ph)
+    assert int(rec[..., H.REC["STEPS"]].sum()) == steps
+    gold = {k: g[k] for k in ("steps", "flags", "vals", "val_fields")}
+    err = compare_compact(rec, gold, idx=sel)
+    print("cfg4 share:", steps, "ray-steps;", len(sel), "rays vs reference, max rel err", {k: f"{v:.2e}" for k, v in err.items()})

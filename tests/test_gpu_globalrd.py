@@ -68,9 +68,16 @@ def test_globalrd_write_rays_caustics_vs_golden(gold, grid):
             assert (d / scale).max() <= 1e-6, (col, (d / scale).max())
 
 
-@pytest.mark.parametrize("lanes", [1, 2, 4])
+@pytest.mark.parametrize("lanes", [1, 2, 4, "coop", "dense"])
 def test_every_lanes_per_ray_variant_vs_golden(gold, grid, lanes, monkeypatch):
-    monkeypatch.setenv("GEOAC_GRID_LANES", str(lanes))
+    if lanes in ("coop", "dense"):
+        # one lane per ray without lane thinning, as a large fan runs: "coop" = wave-cooperative table gather through LDS (58 of the
+        # wave's 64 lanes are helpers without a ray here), "dense" = the same launch with per-lane gathers
+        monkeypatch.setenv("GEOAC_GRID_LANES", "1")
+        monkeypatch.setenv("GEOAC_SPREAD", "1")
+        monkeypatch.setenv("GEOAC_GRID_COOP", "1" if lanes == "coop" else "0")
+    else:
+        monkeypatch.setenv("GEOAC_GRID_LANES", str(lanes))
     ctx = _ctx(grid, bounces=1, calc_amp=1, mode=3, src=(0.0, 31.0, 0.0))
     rec, steps = ctx.run(gold["theta"], gold["phi"])
     assert steps == int(gold["steps_amp1_mode3"])

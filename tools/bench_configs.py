@@ -42,15 +42,21 @@ def cfg3():
     return dict(config="cfg3 GeoAcGlobal 720 az x 180 incl, bounces=3, CalcAmp=True", rays=len(th), ray_steps=steps, seconds=dt)
 
 
-def cfg4():
+def cfg4(thin=1):
     import rngdep_data as RD
-    grid = RD.write_grid(os.path.join(tempfile.gettempdir(), "gdb"), short_paths=False)
+    grid = RD.write_grid(os.path.join(tempfile.gettempdir(), f"gdb{thin}"), short_paths=False, thin=thin)
     ctx = G.FanContext(G.EQ_3D_RNGDEP, device=0); ctx.load_grid(*grid)
     ctx.set_params(bounces=1, calc_amp=1, mode=0, src=(0.0, 0.0, 0.0))
     # one GPU's share of the 1000 az x 1000 incl fan sharded over 8 GPUs: 125 azimuths
     th, ph = G.fan_enumerate(theta_min=0.05, theta_max=50.0, theta_step=0.05, phi_min=-180.0, phi_max=-180.0 + 124 * 0.36, phi_step=0.36)
     steps, dt = run_fan(ctx, th, ph, reps=1)
-    return dict(config="cfg4 GeoAc3D.RngDep 5x5 grid, 1/8 of 1000 az x 1000 incl (125 az), bounces=1, CalcAmp=True", rays=len(th), ray_steps=steps, seconds=dt)
+    nz = 1400 // thin
+    return dict(config=f"cfg4 GeoAc3D.RngDep 5x5x{nz} grid, 1/8 of 1000 az x 1000 incl (125 az), bounces=1, CalcAmp=True", rays=len(th), ray_steps=steps, seconds=dt)
+
+
+def cfg4_350():
+    """the same fan on the thinned 5x5x350 grid of the small parity fixtures (table 9.6 MB instead of 38 MB)"""
+    return cfg4(thin=4)
 
 
 def cfg5():
