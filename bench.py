@@ -4,17 +4,25 @@
 One "step" of this bench = one full pass of the hot path over the metric fan:
     GeoAcGlobal -prop ToyAtmo.met phi_min=-180 phi_max=179 phi_step=1  (theta 0.5..45/0.5, bounces=2,
     CalcAmp=True, WriteRays=False, lat_src=30 lon_src=0, rng_max=1500)   -> 360 az x 90 incl = 32 400 rays
-(BASELINE.json metric / SURVEY.md §8d item 3).  Profile tables and launch angles are resident in HBM before
-the timed region; the timed region covers RK4 + post-pass kernels, and for N > 1 the RCCL gather of arrivals.
+(BASELINE.json metric / SURVEY.md §8d item 3).  The profile tables are resident in HBM before the timed region (atmosphere upload
+excluded); a timed pass is what geoac_fan_run does: launch angles host -> device, every kernel of the fan (RK4 epochs,
+post-pass, sums), arrival records device -> host - and for N > 1 the RCCL gather of the arrival tables in between.
+`launch_only` repeats the figure without the two copies (HIP events around the kernels).
 
-N > 1 (one process per GPU, torch.distributed/RCCL): weak scaling by azimuth - the fan has N x 360 azimuths
-(phi step 1/N degree), rank r integrates azimuth indices r, r+N, ...; arrival records are all-gathered over xGMI
-and the step counts all-reduced.  value = all ranks' RK4 ray-steps / max-over-ranks time.
+Parity gate before timing: the warm-up pass's records are compared with tests/golden/full_metric.npz, the fan as the COMPILED
+REFERENCE integrated it (tests/golden/make_golden_full.py): step count and outcome of every (ray, leg) exact, travel time /
+attenuation / turning height / arrival angles / amplitude / range within 1e-6.  A failed gate aborts the bench.
+
+N > 1 (one process per GPU, torch.distributed/RCCL).  `--scaling weak` (default; the line's `value`): the fan has N x 360 azimuths
+(phi step 1/N degree), rank r integrates azimuth indices r, r+N, ... - per-GPU work fixed.  `--scaling strong`: the metric fan itself,
+360 azimuths dealt round-robin to the ranks.  Whatever the line is, the other flavour and the strong-scaling run of BASELINE's
+config 4 (GeoAc3D.RngDep, 5x5x1400 grid, 1000 az x 1000 incl = 1 M rays sharded by azimuth) are measured in the same run and
+reported under "other_scalings" (skip with --no-extras).  Arrival records are all-gathered over xGMI and the step counts all-reduced.
+value = all ranks' RK4 ray-steps / max-over-ranks time.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -26,38 +34,22 @@ MET = os.path.join(ROOT, "tests", "golden", "ToyAtmo.met")
 
 B_ALG_PER_STEP = 144          # 8 B x E(=18) state row per accepted RK4 step (Global, CalcAmp on)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
-
-
-def pmc_traffic_per_step():
-    """HBM bytes per ray-step of the dominant kernel from the newest committed rocprofv3 PMC summary
-    (profiles/rNN_*_pmc_traffic.json: separate FETCH_SIZE / WRITE_SIZE passes of this same command); None if absent."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-    if not files:
-        return None, None
-    try:
-        with open(files[-1]) as fh:
-            return float(json.load(fh)["k_rk4_hbm_bytes_per_ray_step"]), os.path.basename(files[-1])
-    except Exception:
-        return None, None
-
-
 FP64_PEAK_TFLOPS = 78.6       # MI355X FP64 vector peak (SURVEY §8d)
 
 
-def pmc_fp64_flop_per_step():
-    """executed FP64 lane-flops per ray-step of the dominant kernel, from the SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 pass of the
-    newest committed PMC summary (the binding resource of this path is FP64 VALU, not HBM); None if absent."""
+def newest_pmc():
+    """per-ray-step figures of the dominant kernel from the newest committed rocprofv3 PMC summary (profiles/rNN_*_pmc_traffic.json:
+    separate FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU_*_F64 passes of this same command, tools/profile_round.sh); {} if absent."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
         try:
             with open(f) as fh:
-                v = json.load(fh).get("k_rk4_fp64_flop_per_ray_step")
-            if v:
-                return float(v), os.path.basename(f)
+                d = json.load(fh)
+            d["_source"] = os.path.basename(f)
+            return d
         except Exception:
             pass
-    return None, None
+    return {}
 
 
 def _cpu_worker(rank, n_workers, barrier, out):
@@ -138,13 +130,94 @@ def cpu_baseline():
     return res
 
 
+class FanRun:
+    """one azimuth-sharded fan on this rank's GPU: pass() = angles H2D + all kernels + (N > 1: RCCL gather) + records D2H"""
+
+    def __init__(self, G, eq, load, params, th_all, ph_all, n_theta, rank, world, dev, coll_dev, stream, legs):
+        import numpy as np
+        import torch
+        from geoac_amd.sharding import shard_by_azimuth
+        self.G, self.world, self.rank, self.dev, self.coll_dev, self.legs = G, world, rank, dev, coll_dev, legs
+        self.n_theta, self.n_az = n_theta, len(th_all) // n_theta
+        self.theta, self.phi, self.idx = shard_by_azimuth(th_all, ph_all, n_theta, rank, world)
+        self.ctx = G.FanContext(eq, device=dev.index, stream=stream)
+        load(self.ctx)
+        self.ctx.set_params(**params)
+        self.rec_local = torch.empty((len(self.theta), legs, G.REC_STRIDE), dtype=torch.float64, device=dev) if world > 1 else None
+        self.steps_t = torch.zeros(1, dtype=torch.int64, device=coll_dev)
+        self.rec = None            # rank 0: the whole fan's records on the host after a pass
+        self.np, self.torch = np, torch
+
+    def one_pass(self):
+        import torch.distributed as dist
+        from geoac_amd.sharding import gather_records
+        ctx = self.ctx
+        if self.world == 1:
+            self.rec, steps = ctx.run(self.theta, self.phi)             # set_angles + launch + fetch (geoac_fan_run)
+            return steps
+        ctx.set_angles(self.theta, self.phi)
+        ctx.launch()
+        ctx.copy_records_to(self.rec_local.data_ptr())                  # D2D on the context's (= torch's current) stream
+        full = gather_records(self.rec_local if self.coll_dev == self.dev else self.rec_local.cpu(), self.n_az, self.n_theta)
+        self.steps_t[0] = ctx.total_steps()
+        dist.all_reduce(self.steps_t)
+        if self.rank == 0:
+            self.rec = full.cpu().numpy()                               # arrivals of the whole fan on the host
+        return int(self.steps_t.item())
+
+    def timed(self, n_pass):
+        """barrier + sync, n_pass passes, sync + barrier; returns (ray-steps, max-over-ranks seconds, kernel-event sums)"""
+        import torch.distributed as dist
+        torch = self.torch
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        total = 0
+        ev = {"ms_total": 0.0, "ms_rk4": 0.0, "ms_post": 0.0, "epochs": 0}
+        for _ in range(n_pass):
+            total += self.one_pass()
+            tm = self.ctx.timing()
+            for k in ev:
+                ev[k] += tm[k]
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if self.world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=self.coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return total, dt, ev
+
+
+def parity_gate(rec, phi_step_mult):
+    """rank 0: the fan's records against the reference-made fixture of the metric fan; with N x 360 azimuths every N-th one is a
+    fixture azimuth.  Returns a dict for the JSON line; raises on a mismatch."""
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "full_metric.npz")
+    if not os.path.exists(path):
+        return {"status": "skipped", "why": "tests/golden/full_metric.npz not present"}
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from parity import compare_compact
+    g = np.load(path)
+    n_theta = 90
+    az = np.arange(360) * phi_step_mult
+    idx = (az[:, None] * n_theta + np.arange(n_theta)[None, :]).reshape(-1)
+    err = compare_compact(rec, g, idx=idx)
+    return {"status": "pass", "fixture": "tests/golden/full_metric.npz (compiled reference, every ray of the 360 x 90 fan)",
+            "rays_checked": int(len(idx)), "legs_checked": int(len(idx) * 3), "counts": "exact",
+            "max_rel_err": {k: v for k, v in err.items()}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--phi-step", type=float, default=1.0, help="azimuth step of the N=1 fan (metric: 1.0)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak", help="which N > 1 fan the line's value is measured on")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other-scaling and config-4 measurements")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured path) or gloo (rehearsal of the N>1 flow on fewer GPUs than ranks)")
     args = ap.parse_args()
 
@@ -176,95 +249,110 @@ def main():
     n_gpus = world
     dev = torch.device("cuda", dev_index)
     coll_dev = dev if args.backend == "nccl" else torch.device("cpu")
+    stream = torch.cuda.current_stream(dev).cuda_stream
 
-    # ---- the fan: 360*N azimuths x 90 inclinations, this rank's azimuth shard ----
-    phi_step = args.phi_step / n_gpus
-    th_all, ph_all = G.fan_enumerate(phi_min=-180.0, phi_max=180.0 - phi_step * 0.999999, phi_step=phi_step)
-    n_theta = 90
-    n_az = len(th_all) // n_theta
-    from geoac_amd.sharding import gather_records, shard_by_azimuth
-    theta, phi, _ = shard_by_azimuth(th_all, ph_all, n_theta, rank, n_gpus)
+    def metric_fan(scaling):
+        """(theta, phi, multiple of the fixture's azimuth step) of the whole fan for N ranks"""
+        mult = n_gpus if scaling == "weak" else 1
+        step = 1.0 / mult
+        th, ph = G.fan_enumerate(phi_min=-180.0, phi_max=180.0 - step * 0.999999, phi_step=step)
+        return th, ph, mult
 
-    stream = torch.cuda.current_stream(dev)
-    ctx = G.FanContext(G.EQ_GLOBAL, device=dev.index, stream=stream.cuda_stream)
-    ctx.load_met(MET)
-    ctx.set_params(bounces=2, calc_amp=1, mode=0)
-    ctx.set_angles(theta, phi)                                 # inputs resident in HBM before timing
-    legs = 3
-    rec_local = torch.empty((len(theta), legs, G.REC_STRIDE), dtype=torch.float64, device=dev)
-    steps_t = torch.zeros(1, dtype=torch.int64, device=coll_dev)
-    gathered = {}
+    def metric_run(scaling):
+        th, ph, mult = metric_fan(scaling)
+        run = FanRun(G, G.EQ_GLOBAL, lambda c: c.load_met(MET), dict(bounces=2, calc_amp=1, mode=0), th, ph, 90, rank, world, dev, coll_dev, stream, 3)
+        return run, mult
 
-    def one_pass():
-        ctx.launch()
-        if world > 1:
-            ctx.copy_records_to(rec_local.data_ptr())          # D2D on the context's (= torch's current) stream
-            # gather of the arrival records of the whole fan: RCCL all_gather over xGMI (gloo: host rehearsal)
-            gathered["rec"] = gather_records(rec_local if coll_dev == dev else rec_local.cpu(), n_az, n_theta)
-            steps_t[0] = ctx.total_steps()
-            dist.all_reduce(steps_t)
-            return int(steps_t.item())
-        return ctx.total_steps()
+    # ---- the line's fan ----
+    run, mult = metric_run(args.scaling)
+    gate = {"status": "skipped", "why": "--warmup 0 (profiler passes): the gate runs on the first untimed pass"}
+    for w in range(args.warmup):
+        run.one_pass()
+        if w == 0 and rank == 0:
+            gate = parity_gate(run.rec, mult)                          # raises AssertionError on a mismatch: no timing without parity
+    total_steps, dt, ev = run.timed(args.steps)
+    local_steps_per_pass = run.ctx.total_steps()
 
-    for _ in range(args.warmup):
-        one_pass()
+    extras = {}
+    if not args.no_extras:
+        try:
+            other = "strong" if args.scaling == "weak" else "weak"
+            if world > 1:
+                r2, m2 = metric_run(other)
+                r2.one_pass()
+                if rank == 0:
+                    parity_gate(r2.rec, m2)
+                s2, t2, _ = r2.timed(max(1, min(args.steps, 3)))
+                extras[f"metric_fan_{other}"] = {"value": s2 / t2, "unit": "RK4 ray-steps/s", "ms_per_pass": t2 / max(1, min(args.steps, 3)) * 1e3,
+                                                 "rays": int(r2.n_az * r2.n_theta), "rays_per_gpu": int(len(r2.theta)), "scaling": other,
+                                                 "note": "a fan lasts as long as its longest ray (54 130 steps x the step latency): sharding the fixed 32 400-ray fan does not shorten it" if other == "strong" else "N x 360 azimuths"}
+                del r2
+            # BASELINE config 4: GeoAc3D.RngDep, 5x5x1400 grid, 1000 az x 1000 incl, strong scaling by azimuth
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import tempfile
+            import rngdep_data as RD
+            grid = RD.write_grid(os.path.join(tempfile.gettempdir(), f"bench_grid_{rank}"), short_paths=False, thin=1)
+            th4, ph4 = G.fan_enumerate(theta_min=0.05, theta_max=50.0, theta_step=0.05, phi_min=-180.0, phi_max=-180.0 + 999 * 0.36, phi_step=0.36)
+            n_th4 = int(np.sum(ph4 == ph4[0]))
+            r4 = FanRun(G, G.EQ_3D_RNGDEP, lambda c: c.load_grid(*grid), dict(bounces=1, calc_amp=1, mode=0, src=(0.0, 0.0, 0.0)),
+                        th4, ph4, n_th4, rank, world, dev, coll_dev, stream, 2)
+            s4, t4, _ = r4.timed(1)
+            extras["config4_fan_strong"] = {"value": s4 / t4, "unit": "RK4 ray-steps/s", "seconds_per_pass": t4, "rays": int(len(th4)), "rays_per_gpu": int(len(r4.theta)),
+                                            "scaling": "strong", "workload": "GeoAc3D.RngDep 5x5x1400 grid, 1000 az x 1000 incl, bounces=1, CalcAmp=True, azimuth-sharded; one pass, first-touch allocations included",
+                                            "parity": "tests/test_gpu_fullfan.py::test_config4_share_on_5x5x1400_grid_vs_reference"}
+            del r4
+        except Exception as e:                                          # the extras never take the line down
+            extras["error"] = repr(e)
 
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    total_steps = 0
-    rk4_ms = post_ms = 0.0
-    rk4_launches = 0
-    for _ in range(args.steps):
-        total_steps += one_pass()
-        tm = ctx.timing()
-        rk4_ms += tm["ms_rk4"]; post_ms += tm["ms_post"]; rk4_launches += tm["epochs"]
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        # every leg that produced a row somewhere must be present in the gathered table
-        assert gathered["rec"].shape[0] == n_az * n_theta
-
-    local_steps_per_pass = ctx.total_steps()
     if rank == 0:
         value = total_steps / dt
+        rk4_ms, post_ms, rk4_launches = ev["ms_rk4"], ev["ms_post"], ev["epochs"]
         # dominant kernel = k_rk4: algorithmic bytes per launch / average launch duration (HIP events on the kernel's own stream,
         # recorded inside libgeoac_hip around every k_rk4 epoch of the timed passes).  One epoch of this fan is TWO concurrent k_rk4
         # launches of the same duration by construction (the shallow tenth of the rays on k_rk4<EqGlobalPair>, the rest on
         # k_rk4<EqGlobal<true>> with 0.75 x the rows); "launch" below = that pair, bytes and steps are those of both.
         ach_gbs = (B_ALG_PER_STEP * local_steps_per_pass * args.steps) / (rk4_ms * 1e-3) / 1e9 if rk4_ms > 0 else 0.0
-        bps, pmc_src = pmc_traffic_per_step()
+        pmc = newest_pmc()
+        bps = pmc.get("k_rk4_hbm_bytes_per_ray_step")
         steps_per_launch = local_steps_per_pass * args.steps / max(rk4_launches, 1)
+        n_az, n_theta = run.n_az, run.n_theta
         out = {
             "metric": "RK4 ray-steps/sec, GeoAcGlobal 360x90 ToyAtmo fan; arrivals within 1e-6 of ref",
             "value": value, "unit": "RK4 ray-steps/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"GeoAcGlobal -prop ToyAtmo.met, {n_az} az x {n_theta} incl = {n_az * n_theta} rays "
-                                   f"(phi step {phi_step:g} deg), bounces=2, CalcAmp=True, WriteRays=False, rng_max=1500",
-                       "rays_per_gpu": int(len(theta)), "ray_steps_per_pass": int(total_steps // args.steps),
+                                   f"(phi step {1.0 / mult:g} deg), bounces=2, CalcAmp=True, WriteRays=False, rng_max=1500",
+                       "rays_per_gpu": int(len(run.theta)), "ray_steps_per_pass": int(total_steps // args.steps),
+                       "timed_region": "launch angles H2D + RK4 / post-pass / sum kernels + " + ("RCCL all_gather of arrivals + " if world > 1 else "") + "arrival records D2H (geoac_fan_run); atmosphere tables resident",
                        "parallelism": f"azimuth-sharded x{n_gpus}" + (f", {'RCCL' if args.backend == 'nccl' else args.backend} all_gather of arrivals" if world > 1 else "")},
-            "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "parity_gate": gate,
+            "launch_only": {"value": local_steps_per_pass * args.steps * (n_gpus if args.scaling == "weak" else 1) / (ev["ms_total"] * 1e-3) if ev["ms_total"] > 0 and world == 1 else None,
+                            "ms_per_step": ev["ms_total"] / args.steps, "what": "HIP events around the kernels of a pass on this rank, no copies"},
+            "roofline": {"bound": "fp64_valu_latency",
+                         "bound_note": "a register-resident FP64 ODE recurrence: the pass lasts as long as the serial integration of its longest ray; "
+                                       "`achieved`/`frac` are the SURVEY 8(d) contract figure (144 B per step against HBM peak), `hbm_measured` the counter bytes, `fp64` the issue-side figure",
+                         "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS,
                          "traffic": (bps * steps_per_launch) if bps else None, "traffic_unit": "bytes per launch",
-                         "traffic_source": pmc_src, "achieved_bytes_per_launch": B_ALG_PER_STEP * steps_per_launch,
+                         "traffic_source": pmc.get("_source"), "achieved_bytes_per_launch": B_ALG_PER_STEP * steps_per_launch,
                          "kernel": "k_rk4<EqGlobalPair,true,false> || k_rk4<EqGlobal<true>,true,false> (one epoch)", "launches": rk4_launches,
                          "avg_launch_ms": rk4_ms / max(rk4_launches, 1),
                          "alg_bytes_per_step": B_ALG_PER_STEP,
                          "rk4_ms_per_pass": rk4_ms / args.steps, "postpass_ms_per_pass": post_ms / args.steps},
         }
-        fps, fp_src = pmc_fp64_flop_per_step()
+        if bps and rk4_ms > 0:
+            mg = bps * local_steps_per_pass * args.steps / (rk4_ms * 1e-3) / 1e9
+            out["roofline"]["hbm_measured"] = {"bytes_per_step": bps, "achieved": mg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": mg / HBM_PEAK_GBS,
+                                               "source": pmc.get("_source")}
+        fps = pmc.get("k_rk4_fp64_flop_per_ray_step")
         if fps and rk4_ms > 0:
             tf = fps * local_steps_per_pass * args.steps / (rk4_ms * 1e-3) / 1e12
             # the honest "how busy is the binding unit" figure beside the contract's HBM roofline (SURVEY §8d)
             out["roofline"]["fp64"] = {"flop_per_step": fps, "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                       "frac": tf / FP64_PEAK_TFLOPS, "source": fp_src}
+                                       "frac": tf / FP64_PEAK_TFLOPS, "source": pmc.get("_source")}
+        if extras:
+            out["other_scalings"] = extras
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

@@ -233,6 +233,25 @@ class FanContext:
         """async D2D copy of the record table into a caller-owned device buffer (ordered on the context's stream)"""
         self._chk(self.lib.geoac_fan_copy_records_dev(self._h, ctypes.c_void_p(dev_ptr)))
 
+    # ---- device-function probes (include/geoac_probe.h): need one completed launch ----
+    def probe_atmo_1d(self, x):
+        x = _arr(x); n = len(x)
+        o9 = np.zeros((n, 9)); rho = np.zeros(n)
+        self._chk(self.lib.geoac_probe_atmo_1d(self._h, n, _p(x), _p(o9), _p(rho)))
+        return o9, rho
+
+    def probe_absorption(self, x, freq):
+        x = _arr(x); f = _arr(freq); n = len(x)
+        out = np.zeros(n)
+        self._chk(self.lib.geoac_probe_absorption(self._h, n, _p(x), _p(f), _p(out)))
+        return out
+
+    def probe_grid(self, a0, a1, a2, coop=False):
+        a0, a1, a2 = _arr(a0), _arr(a1), _arr(a2); n = len(a0)
+        o30 = np.zeros((n, 30)); a7 = np.zeros((n, 7))
+        self._chk(self.lib.geoac_probe_grid(self._h, n, _p(a0), _p(a1), _p(a2), 1 if coop else 0, _p(o30), _p(a7)))
+        return o30, a7
+
     def total_steps(self):
         steps = ctypes.c_uint64(0)
         self._chk(self.lib.geoac_fan_fetch(self._h, None, ctypes.byref(steps)))

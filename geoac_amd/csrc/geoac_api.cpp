@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/geoac_hip.h"
+#include "../../include/geoac_probe.h"
 #include "../../include/geoac_host.h"
 #include "geoac_device.h"
 
@@ -21,6 +22,10 @@ extern "C" size_t geoac_gridbuild_work_doubles(int nx, int ny, int nz);
 extern "C" hipError_t geoac_gridbuild_launch(int glob, int nx, int ny, int nz, const double* d_x, const double* d_y, const double* d_z,
                                              const double* d_fields, double* d_work, double* d_tab, hipStream_t s);
 extern "C" hipError_t geoac_launch_accum(const GeoacDevParams* P, hipStream_t s);
+extern "C" hipError_t geoac_launch_probe_atmo1d(const GeoacDevParams* P, int n, const double* x, double* out9, double* rho, hipStream_t s);
+extern "C" hipError_t geoac_launch_probe_absorption(const GeoacDevParams* P, int n, const double* x, const double* f, double* out, hipStream_t s);
+extern "C" hipError_t geoac_launch_probe_grid(const GeoacDevParams* P, int n, const double* a0, const double* a1, const double* a2, int coop,
+                                              double* out30, double* api7, hipStream_t s);
 extern "C" hipError_t geoac_launch_gate(const GeoacDevParams* P, unsigned long long expected, hipStream_t s);
 extern "C" hipError_t geoac_launch_postpass(const GeoacDevParams* P, int rows, hipStream_t s);
 
@@ -45,6 +50,7 @@ struct DevBuf {
 
 struct geoac_ctx {
     int eqset = 0, device = 0;
+    GeoacDevParams lastP{};          // parameter block of the last completed launch (device-function probes, include/geoac_probe.h)
     bool sort_rays = true;           // integrate the rays in order of launch inclination, results in caller order (GEOAC_SORT=0: caller order).
                                      // Ray length is mostly a function of inclination (ground-hugging rays take 1 m steps), so whole waves finish early
                                      // instead of every wave waiting for its one long ray: the post-pass then lands on idle SIMDs (metric fan +13 %)
@@ -676,6 +682,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
     ctx->path_bytes_w = ctx->total_steps * (unsigned long long)(P.pathw * sizeof(double));
     ctx->path_bytes_r = 2 * ctx->path_bytes_w;
     ctx->ran = true;
+    ctx->lastP = P;
     if(ctx->err_flags & 2ull) return fail(ctx, GEOAC_E_CAPACITY, "per-epoch sample/caustic event list overflowed");
     if(sampling && ctx->n_samples > (unsigned long long)P.smp_cap)
         return fail(ctx, GEOAC_E_CAPACITY, "sample list overflowed: raise GEOAC_SMP_CAP (needed " + std::to_string(ctx->n_samples) + ")");
@@ -758,6 +765,56 @@ int geoac_fan_run(geoac_ctx* ctx, int n_rays, const double* theta_deg, const dou
     rc = geoac_fan_launch(ctx);
     if(rc) return rc;
     return geoac_fan_fetch(ctx, rec_host, total_steps);
+}
+
+// ---- device-function probes (include/geoac_probe.h) ----
+namespace {
+struct ProbeBufs {
+    std::vector<void*> d;
+    ~ProbeBufs(){ for(void* p : d) if(p) hipFree(p); }
+    double* in(const double* h, size_t n){ void* p = nullptr; if(hipMalloc(&p, n * sizeof(double)) != hipSuccess) return nullptr; d.push_back(p);
+                                           if(hipMemcpy(p, h, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return nullptr; return (double*)p; }
+    double* out(size_t n){ void* p = nullptr; if(hipMalloc(&p, n * sizeof(double)) != hipSuccess) return nullptr; d.push_back(p); return (double*)p; }
+};
+}
+
+int geoac_probe_atmo_1d(geoac_ctx* ctx, int n, const double* x, double* out9, double* rho){
+    if(!ctx || n <= 0 || !x || !out9 || !rho) return fail(ctx, GEOAC_E_INVALID, "probe_atmo_1d: bad arguments");
+    if(!ctx->ran || ctx->have_grid) return fail(ctx, GEOAC_E_INVALID, "probe_atmo_1d: needs a 1-D equation set and a completed launch");
+    HIPCHK(hipSetDevice(ctx->device));
+    ProbeBufs B; double* dx = B.in(x, (size_t)n); double* d9 = B.out((size_t)9 * n); double* dr = B.out((size_t)n);
+    if(!dx || !d9 || !dr) return fail(ctx, GEOAC_E_NOMEM, "probe: device allocation failed");
+    HIPCHK(geoac_launch_probe_atmo1d(&ctx->lastP, n, dx, d9, dr, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(out9, d9, sizeof(double) * 9 * (size_t)n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(rho, dr, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+    return GEOAC_OK;
+}
+
+int geoac_probe_absorption(geoac_ctx* ctx, int n, const double* x, const double* freq, double* alpha){
+    if(!ctx || n <= 0 || !x || !freq || !alpha) return fail(ctx, GEOAC_E_INVALID, "probe_absorption: bad arguments");
+    if(!ctx->ran || ctx->have_grid) return fail(ctx, GEOAC_E_INVALID, "probe_absorption: needs a 1-D equation set and a completed launch");
+    HIPCHK(hipSetDevice(ctx->device));
+    ProbeBufs B; double* dx = B.in(x, (size_t)n); double* df = B.in(freq, (size_t)n); double* da = B.out((size_t)n);
+    if(!dx || !df || !da) return fail(ctx, GEOAC_E_NOMEM, "probe: device allocation failed");
+    HIPCHK(geoac_launch_probe_absorption(&ctx->lastP, n, dx, df, da, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(alpha, da, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+    return GEOAC_OK;
+}
+
+int geoac_probe_grid(geoac_ctx* ctx, int n, const double* a0, const double* a1, const double* a2, int coop, double* out30, double* api7){
+    if(!ctx || n <= 0 || !a0 || !a1 || !a2 || !out30 || !api7) return fail(ctx, GEOAC_E_INVALID, "probe_grid: bad arguments");
+    if(!ctx->ran || !ctx->have_grid) return fail(ctx, GEOAC_E_INVALID, "probe_grid: needs a grid equation set and a completed launch");
+    HIPCHK(hipSetDevice(ctx->device));
+    ProbeBufs B; double* d0 = B.in(a0, (size_t)n); double* d1 = B.in(a1, (size_t)n); double* d2 = B.in(a2, (size_t)n);
+    double* do30 = B.out((size_t)30 * n); double* da7 = B.out((size_t)7 * n);
+    if(!d0 || !d1 || !d2 || !do30 || !da7) return fail(ctx, GEOAC_E_NOMEM, "probe: device allocation failed");
+    HIPCHK(geoac_launch_probe_grid(&ctx->lastP, n, d0, d1, d2, coop ? 1 : 0, do30, da7, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(out30, do30, sizeof(double) * 30 * (size_t)n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(api7, da7, sizeof(double) * 7 * (size_t)n, hipMemcpyDeviceToHost));
+    return GEOAC_OK;
 }
 
 int geoac_last_timing(geoac_ctx* ctx, double ms[3], uint64_t stats[3]){

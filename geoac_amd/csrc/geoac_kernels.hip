@@ -1625,6 +1625,67 @@ __global__ void __launch_bounds__(256) k_accum(GeoacDevParams P){
 }
 
 // ------------------------------------------------------------------------------------------------
+// device-function probes (include/geoac_probe.h): one thread per point through the very functions the RK4 and post-pass kernels call,
+// so that the table lookups and the absorption model have parity tests of their own (not only through fan integrals)
+// ------------------------------------------------------------------------------------------------
+// c, c', c'', u, u', u'', v, v', v'' and rho of the 1-D atmosphere at abscissa x: seg_guess + seg_eval (the RHS's lookup) and the sound-speed
+// algebra of global_rhs / cart3_rhs (rsq-based c, c' = gamR/(2c) T', c'' = gamR/(2c) T'' - c'^2/c)
+__global__ void __launch_bounds__(256) k_probe_atmo1d(GeoacDevParams P, int n, const double* __restrict__ x, double* __restrict__ out9, double* __restrict__ rho){
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n) return;
+    const double xe = clampd(x[i], P.x_min, P.x_max);
+    const int k = seg_guess(P.seg, P, xe);
+    Atm9 a; seg_eval<true>(P.seg, k, xe, a);
+    const double qT = kGamR * a.T;
+    const double ic = frsq(qT);
+    const double c = qT * ic;
+    const double hc = (0.5 * kGamR) * ic;
+    const double dc = hc * a.dT;
+    const double ddc = __builtin_fma(hc, a.ddT, -(dc * dc) * ic);
+    double* o = out9 + (size_t)9 * i;
+    o[0] = c; o[1] = dc; o[2] = ddc; o[3] = a.u; o[4] = a.du; o[5] = a.ddu; o[6] = a.v; o[7] = a.dv; o[8] = a.ddv;
+    rho[i] = rho_eval(P, k, xe);
+}
+
+// SuthBass_Alpha at abscissa x[i] (geocentric radius for the spherical sets) and frequency f[i]: medium_at + suthbass_alpha as the
+// post-pass calls them (1-D sets; reference state T_o, P_o from the launch parameters)
+__global__ void __launch_bounds__(256) k_probe_absorption(GeoacDevParams P, int n, const double* __restrict__ x, const double* __restrict__ f, double* __restrict__ out){
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n) return;
+    const Medium m = medium_at(P, x[i]);
+    out[i] = suthbass_alpha(P, x[i] - P.r_earth, m.c, m.rho, f[i], P.T_o, P.P_o, P.cbrt_To);
+}
+
+// grid interpolant at (a0, a1, a2) in table order ((x, y, z) Cartesian, (lat, lon, r) spherical): out30 = the ten outputs of
+// grid_eval_all / grid_eval3_coop for T, u, v (table order of geoac_rngdep.h); api7 = c, rho, u, v, dc/dz, du/dz, dv/dz of medium3_at.
+// coop != 0: whole waves through the cooperative gather (blocks of 64, LDS exchange buffer; n is padded by repeating the last point)
+template <bool GLB>
+__global__ void __launch_bounds__(64) k_probe_grid(GeoacDevParams P, int n, const double* __restrict__ a0, const double* __restrict__ a1, const double* __restrict__ a2,
+                                                   int coop, double* __restrict__ out30, double* __restrict__ api7){
+    extern __shared__ double lds_tab[];
+    const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = i0 < n ? i0 : n - 1;
+    const double x = clampd(a0[i], P.gx[0], P.gx[P.gnx - 1]), y = clampd(a1[i], P.gy[0], P.gy[P.gny - 1]), z = clampd(a2[i], P.x_min, P.x_max);
+    GridLoc L; grid_locate(P, x, y, z, -1, L);
+    double M[3][10];
+    if(coop) grid_eval3_coop<true, GLB>(P, L, M, (char*)lds_tab);
+    else {
+        grid_eval_all<true, GLB, 1>(P, 0, L, M[0], 0);
+        grid_eval_all<true, GLB, 1>(P, 1, L, M[1], 0);
+        grid_eval_all<true, GLB, 1>(P, 2, L, M[2], 0);
+    }
+    if(i0 >= n) return;
+    #pragma unroll
+    for(int f = 0; f < 3; f++){
+        #pragma unroll
+        for(int q = 0; q < 10; q++) out30[(size_t)30 * i + 10 * f + q] = M[f][q];
+    }
+    const Medium3 m = medium3_at<true, true, GLB>(P, a0[i], a1[i], a2[i]);
+    double* a = api7 + (size_t)7 * i;
+    a[0] = m.c; a[1] = m.rho; a[2] = m.u; a[3] = m.v; a[4] = m.dcz; a[5] = m.duz; a[6] = m.dvz;
+}
+
+// ------------------------------------------------------------------------------------------------
 // host-callable launchers (called from geoac_api.cpp)
 // ------------------------------------------------------------------------------------------------
 #ifndef GEOAC_NO_LAUNCHERS          // tools/dev_kernel.sh compiles single instantiations of the kernels above
@@ -1729,6 +1790,22 @@ extern "C" hipError_t geoac_launch_postpass(const GeoacDevParams* P, int rows, h
     int nb = (int)nbl;
     dim3 b(256), g(nb);
     GEOAC_DISPATCH_EQ(P, hipLaunchKernelGGL(k_postpass<EQ>, g, b, 0, s, *P, rows));
+    return hipGetLastError();
+}
+
+extern "C" hipError_t geoac_launch_probe_atmo1d(const GeoacDevParams* P, int n, const double* x, double* out9, double* rho, hipStream_t s){
+    hipLaunchKernelGGL(k_probe_atmo1d, dim3((n + 255) / 256), dim3(256), 0, s, *P, n, x, out9, rho);
+    return hipGetLastError();
+}
+extern "C" hipError_t geoac_launch_probe_absorption(const GeoacDevParams* P, int n, const double* x, const double* f, double* out, hipStream_t s){
+    hipLaunchKernelGGL(k_probe_absorption, dim3((n + 255) / 256), dim3(256), 0, s, *P, n, x, f, out);
+    return hipGetLastError();
+}
+extern "C" hipError_t geoac_launch_probe_grid(const GeoacDevParams* P, int n, const double* a0, const double* a1, const double* a2, int coop,
+                                              double* out30, double* api7, hipStream_t s){
+    const size_t lds = coop ? (size_t)64 * GEOAC_COOP_SLOT : 0;
+    if(P->eqset == GEOAC_EQ_GLOBAL_RNGDEP) hipLaunchKernelGGL(k_probe_grid<true>, dim3((n + 63) / 64), dim3(64), lds, s, *P, n, a0, a1, a2, coop, out30, api7);
+    else                                   hipLaunchKernelGGL(k_probe_grid<false>, dim3((n + 63) / 64), dim3(64), lds, s, *P, n, a0, a1, a2, coop, out30, api7);
     return hipGetLastError();
 }
 

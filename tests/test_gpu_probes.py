@@ -1,0 +1,108 @@
+"""Device-function probes (include/geoac_probe.h) against the reference's own function values (golden vectors made by the compiled
+reference, tests/golden/make_golden.py): the 1-D spline accessors, SuthBass_Alpha over 0.01 - 10 Hz (a13) and the
+grid interpolants of the two range-dependent sets (a7, a8; per-lane gathers and the wave-cooperative gather) are checked point by point,
+through the very device functions the RK4 and post-pass kernels call - not only through whole-fan integrals."""
+import numpy as np
+import pytest
+
+import harness as H
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6
+
+
+def _colwise(got, want, floor=1e-6, field_scale=None):
+    """max over points of |got - want| / max(|want|, floor x column scale): 1e-6 relative, a value that passes through zero judged
+    against 1e-6 of its column's scale.  field_scale (per column: the magnitude of the FIELD the column is a derivative of): a
+    derivative that vanishes identically for the synthetic atmosphere (u_xx of a wind that is linear in x: 1e-20 of rounding noise in
+    the reference and here) is judged against 1e-7 of its field (absolute error 1e-13 x the field) instead of against its own noise."""
+    scale = np.maximum(np.abs(want).max(axis=0, keepdims=True), 1e-300)
+    den = np.maximum(np.abs(want), floor * scale)
+    if field_scale is not None:
+        den = np.maximum(den, 1e-7 * np.asarray(field_scale)[None, :])
+    return (np.abs(got - want) / den).max(axis=0)
+
+
+def _field_scales(want30):
+    return np.repeat(np.abs(want30[:, [0, 10, 20]]).max(axis=0), 10)
+
+
+def _ctx_1d(eq):
+    import geoac_amd as G
+    ctx = G.FanContext(eq, device=0)
+    ctx.load_met(H.TOYATMO)
+    ctx.set_params(bounces=0, calc_amp=1, mode=0)
+    ctx.run(np.array([20.0]), np.array([-90.0]))                 # the probes use the parameter block of a completed launch
+    return ctx
+
+
+@pytest.mark.parametrize("eq", [H.EQ_GLOBAL, H.EQ_3D, H.EQ_2D])
+def test_spline_accessors_vs_reference(eq):
+    """c, c', c'', u, u', u'', v, v', v'', rho at 1000 abscissae (nodes, both ends, beyond both ends): G2S_GlobalSpline1D.cpp:216-295,
+    332-428 / G2S_Spline1D.cpp:245-281, 321-416"""
+    g = np.load(f"{H.GOLDEN_DIR}/{H.EQ_NAMES[eq]}_small.npz")
+    ctx = _ctx_1d(eq)
+    o9, rho = ctx.probe_atmo_1d(g["probe_x"])
+    e = _colwise(o9, g["probe_out9"])
+    er = _colwise(rho[:, None], g["probe_rho"][:, None])
+    print(H.EQ_NAMES[eq], "out9 max rel err per column", [f"{v:.1e}" for v in e], "rho", f"{er[0]:.1e}")
+    assert e.max() <= RTOL and er.max() <= RTOL
+
+
+@pytest.mark.parametrize("eq", [H.EQ_GLOBAL, H.EQ_3D, H.EQ_2D])
+def test_absorption_vs_reference(eq):
+    """SuthBass_Alpha at 200 (altitude, frequency) pairs, 0.01 - 10 Hz (Atmo_State.Absorption{,.Global}.cpp:12-141): the most heavily
+    rewritten function of the device code (reciprocal / rsq forms, own exp / exp10), on its own"""
+    g = np.load(f"{H.GOLDEN_DIR}/{H.EQ_NAMES[eq]}_small.npz")
+    ctx = _ctx_1d(eq)
+    a = ctx.probe_absorption(g["abs_x"], g["abs_f"])
+    want = g["abs_alpha"]
+    rel = np.abs(a - want) / np.abs(want)
+    print(H.EQ_NAMES[eq], "alpha: f range", g["abs_f"].min(), g["abs_f"].max(), "max rel err", rel.max())
+    assert (want > 0).all() and rel.max() <= RTOL
+
+
+@pytest.mark.parametrize("coop", [False, True])
+def test_cartesian_grid_interpolant_vs_reference(coop, tmp_path):
+    """Eval_Spline_AllOrder2 of T, u, v (30 values) and the scalar API at 400 points of the 5x5 grid (Q11 included):
+    G2S_MultiDimSpline3D.cpp:1341-1593, 1633-1743"""
+    import geoac_amd as G
+    import rngdep_data as RD
+    g = np.load(f"{H.GOLDEN_DIR}/3drd_small.npz")
+    ctx = G.FanContext(G.EQ_3D_RNGDEP, device=0)
+    ctx.load_grid(*RD.write_grid(str(tmp_path), short_paths=False))
+    ctx.set_params(bounces=0, calc_amp=1, mode=0, src=(0.0, 0.0, 0.0))
+    ctx.run(np.array([20.0]), np.array([-90.0]))
+    o30, a7 = ctx.probe_grid(g["probe_x"], g["probe_y"], g["probe_z"], coop=coop)
+    e = _colwise(o30, g["probe_out30"], field_scale=_field_scales(g["probe_out30"]))
+    ea = _colwise(a7, g["probe_api8"][:, :7])
+    print("3drd coop" if coop else "3drd", "AllOrder2 max rel err", f"{e.max():.1e}", "scalar API", [f"{v:.1e}" for v in ea])
+    assert e.max() <= RTOL and ea.max() <= RTOL
+
+
+@pytest.mark.parametrize("coop", [False, True])
+def test_spherical_grid_interpolant_vs_reference(coop, tmp_path):
+    """the spherical twin with its quirks Q12: G2S_GlobalMultiDimSpline3D.cpp:1224-1461, 1502-1611.  The reference orders its outputs
+    f, r, t, p, rr, tt, pp, rt, rp, tp; the device table order is (lat, lon, r)"""
+    import geoac_amd as G
+    import rngdep_data as RD
+    g = np.load(f"{H.GOLDEN_DIR}/globalrd_small.npz")
+    ctx = G.FanContext(G.EQ_GLOBAL_RNGDEP, device=0)
+    ctx.load_grid(*RD.write_grid_global(str(tmp_path), short_paths=False))
+    ctx.set_params(bounces=0, calc_amp=1, mode=0, src=(0.0, 31.0, 0.0))
+    ctx.run(np.array([20.0]), np.array([-90.0]))
+    o30, a7 = ctx.probe_grid(g["probe_lat"], g["probe_lon"], g["probe_r"], coop=coop)
+    dev_of_ref = [0, 3, 1, 2, 6, 4, 5, 8, 9, 7]                  # reference slot q <- device slot
+    got = np.concatenate([o30[:, 10 * f + np.array(dev_of_ref)] for f in range(3)], axis=1)
+    # the first six probe points sit exactly on grid nodes in all three coordinates: the patch is C1 there, but the reference's mixed
+    # second derivatives (left in scaled cell coordinates, Q12) jump from cell to cell, and which cell the reference takes at an exact
+    # node depends on the history of its search cursor (Q13) - those six points are compared on value and gradient only
+    want = g["probe_out30"]
+    second = np.array([q >= 4 for q in range(10)] * 3)
+    e = _colwise(got[6:], want[6:], field_scale=_field_scales(want))
+    e_nodes = _colwise(got[:6][:, ~second], want[:6][:, ~second], field_scale=_field_scales(want)[~second])
+    e = np.concatenate([e, e_nodes])
+    ea = _colwise(a7, g["probe_api8"][:, :7])
+    print("globalrd coop" if coop else "globalrd", "AllOrder2 max rel err", f"{e.max():.1e}", "scalar API", [f"{v:.1e}" for v in ea])
+    print("   per column", [f"{v:.0e}" for v in e])
+    assert e.max() <= RTOL and ea.max() <= RTOL

@@ -2,10 +2,10 @@ set -e
 R=$GRAFT_REPO_ROOT; TAG=${1:-r1x}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R && timeout -k 10 400 python bench.py --steps 3 --warmup 1 > $O/bench.json 2> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats -o $TAG --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats -o $TAG --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/bench_under_rocprof.json 2> $O/stats.err
 for set in "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64" "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS" "FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $set | cut -d' ' -f1); mkdir -p $O/pmc/$tag
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set -d $O/pmc/$tag --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc/$tag.json 2> $O/pmc/$tag.err
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set -d $O/pmc/$tag --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $O/pmc/$tag.json 2> $O/pmc/$tag.err
   echo "pmc pass $tag done"
 done
 cd $R && python3 tools/pmc_summary.py $O/pmc_summary.json $O/pmc/SQ_INSTS_VALU_ADD_F64 $O/pmc/SQ_INSTS_VALU $O/pmc/FETCH_SIZE $O/pmc/WRITE_SIZE > $O/pmc_summary.txt
