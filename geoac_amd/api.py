@@ -308,3 +308,79 @@ class FanContext:
         self.lib.geoac_eig_free.argtypes = [ctypes.c_void_p]
         self.lib.geoac_eig_free(res)
         return out
+
+
+# ---------------- several GPUs from one process (include/geoac_multi.h) ----------------
+class FanPool:
+    """geoac_pool: one context per listed device, azimuth groups from a shared queue, records gathered into the caller's table."""
+
+    def __init__(self, eqset, devices):
+        self.lib = load_library()
+        self.eqset = eqset
+        self.devices = [int(d) for d in devices]
+        self._h = ctypes.c_void_p()
+        arr = (ctypes.c_int * len(self.devices))(*self.devices)
+        rc = self.lib.geoac_pool_create(ctypes.byref(self._h), eqset, len(self.devices), arr)
+        if rc:
+            raise GeoAcError(f"geoac_pool_create: {self.lib.geoac_strerror(rc).decode()}")
+        self.lib.geoac_pool_last_error.restype = ctypes.c_char_p
+        self.params = default_params(eqset)
+
+    def _chk(self, rc):
+        if rc:
+            msg = self.lib.geoac_pool_last_error(self._h)
+            raise GeoAcError(f"{self.lib.geoac_strerror(rc).decode()}: {msg.decode() if msg else ''}")
+
+    def close(self):
+        if self._h:
+            self.lib.geoac_pool_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_met(self, path, fmt="zTuvdp"):
+        a = met_load(path, self.eqset, fmt)
+        x, T, u, v, rho = (_arr(a[k]) for k in ("x", "T", "u", "v", "rho"))
+        sl = _arr(np.concatenate([natural_spline_slopes(x, f) for f in (T, u, v, rho)]))
+        self._chk(self.lib.geoac_pool_upload_atmo_1d(self._h, len(x), _p(x), _p(T), _p(u), _p(v), _p(rho), _p(sl)))
+
+    def load_grid(self, prefix, locx, locy, fmt="zTuvdp", z_grnd=0.0):
+        nx, ny, nz = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        if self.lib.geoac_grid_dims(prefix.encode(), locx.encode(), locy.encode(), ctypes.byref(nx), ctypes.byref(ny), ctypes.byref(nz)):
+            raise GeoAcError(f"cannot read grid {prefix}")
+        nx, ny, nz = nx.value, ny.value, nz.value
+        x, y, z = np.zeros(nx), np.zeros(ny), np.zeros(nz)
+        F = [np.zeros((nx, ny, nz)) for _ in range(4)]
+        rc = self.lib.geoac_grid_load_eq(self.eqset, prefix.encode(), locx.encode(), locy.encode(), fmt.encode(), ctypes.c_double(z_grnd),
+                                      nx, ny, nz, _p(x), _p(y), _p(z), *[_p(f) for f in F])
+        if rc:
+            raise GeoAcError(f"geoac_grid_load_eq -> {rc}")
+        self._chk(self.lib.geoac_pool_upload_atmo_3d(self._h, nx, ny, nz, _p(x), _p(y), _p(z), *[_p(f) for f in F]))
+
+    def set_params(self, **kw):
+        for k, val in kw.items():
+            if k == "src":
+                self.params.src = (ctypes.c_double * 3)(*val)
+            elif k == "xy_limits":
+                self.params.xy_limits = (ctypes.c_double * 4)(*val)
+            else:
+                setattr(self.params, k, val)
+        self._chk(self.lib.geoac_pool_set_params(self._h, ctypes.byref(self.params)))
+
+    def run(self, theta_deg, phi_deg, rays_per_group=0):
+        th, ph = _arr(theta_deg), _arr(phi_deg)
+        rec = np.zeros((len(th), self.params.bounces + 1, REC_STRIDE))
+        steps = ctypes.c_uint64(0)
+        self._chk(self.lib.geoac_pool_fan_run(self._h, len(th), _p(th), _p(ph), int(rays_per_group), _p(rec), ctypes.byref(steps)))
+        return rec, int(steps.value)
+
+    def shares(self):
+        n = len(self.devices)
+        r, s, g = ((ctypes.c_uint64 * n)() for _ in range(3))
+        self._chk(self.lib.geoac_pool_last_shares(self._h, r, s, g))
+        return dict(rays=list(r), steps=list(s), groups=list(g))
+

@@ -9,7 +9,10 @@
 //   GeoAcGlobal_RngDep_RunProp  Code/GeoAcGlobal.RngDep_main.cpp:122-343 (`-prop prefix loc_lat loc_lon [parameter=value ...]`)
 //   GeoAcGlobal_RunEigSearch / RunEigDirect (+ the .RngDep twins)  Code/GeoAcGlobal_main.cpp:496-660, Code/GeoAcGlobal.RngDep_main.cpp:518-693
 //     (spherical mains only; the searches themselves are geoac_eig_search / geoac_eig_direct, include/geoac_eig.h)
-// Not provided here (out of the accelerated path): -interactive.
+//   -interactive of the five mains: run_interactive below.
+// Environment (not part of the reference's surface): GEOAC_DEVICES=0,1,... integrates an arrivals-only -prop fan (WriteRays=False, no
+// caustics) on several GPUs of the node through geoac_pool_fan_run (include/geoac_multi.h); GEOAC_STATS=<file> writes a JSON
+// summary of the run (rays, RK4 ray-steps, seconds on the GPU, per-device shares).
 #include <strings.h>
 #include <cmath>
 #include <cstdio>
@@ -25,6 +28,8 @@
 #include "../../../include/geoac_hip.h"
 #include "../../../include/geoac_host.h"
 #include "../../../include/geoac_eig.h"
+#include "../../../include/geoac_multi.h"
+#include <chrono>
 
 #ifndef GEOAC_CLI_SET
 #define GEOAC_CLI_SET 2
@@ -45,6 +50,39 @@ static const bool kSph = (GEOAC_CLI_SET == 2 || GEOAC_CLI_SET == 4);     // z, l
 
 static bool string2bool(const string& v){          // GeoAc.Interface.cpp:125-128
     return !v.empty() && (strcasecmp(v.c_str(), "true") == 0 || atoi(v.c_str()) != 0);
+}
+
+// GEOAC_DEVICES=0,1,2,...: the HIP devices a -prop fan may use (default: device 0)
+static vector<int> device_list(){
+    vector<int> d;
+    const char* e = getenv("GEOAC_DEVICES");
+    if(e){
+        const char* q = e;
+        while(*q){
+            char* end = nullptr;
+            long v = strtol(q, &end, 10);
+            if(end == q) break;
+            if(v >= 0) d.push_back((int)v);
+            q = (*end == ',') ? end + 1 : end;
+            if(*end != ',' ) break;
+        }
+    }
+    if(d.empty()) d.push_back(0);
+    return d;
+}
+
+static void write_stats(const char* mode, long rays, uint64_t steps, double seconds, const vector<int>& devs,
+                        const vector<uint64_t>& d_rays, const vector<uint64_t>& d_steps, const vector<uint64_t>& d_groups){
+    const char* path = getenv("GEOAC_STATS");
+    if(!path || !*path) return;
+    ofstream js(path);
+    js << "{\"program\": \"" << kName << "\", \"mode\": \"" << mode << "\", \"rays\": " << rays << ", \"rk4_ray_steps\": " << steps
+       << ", \"gpu_seconds\": " << setprecision(9) << seconds << ", \"ray_steps_per_s\": " << (seconds > 0 ? steps / seconds : 0.0) << ", \"devices\": [";
+    for(size_t i = 0; i < devs.size(); i++) js << (i ? ", " : "") << devs[i];
+    js << "], \"per_device\": [";
+    for(size_t i = 0; i < d_rays.size(); i++)
+        js << (i ? ", " : "") << "{\"rays\": " << d_rays[i] << ", \"rk4_ray_steps\": " << d_steps[i] << ", \"groups\": " << d_groups[i] << "}";
+    js << "]}" << '\n';
 }
 
 static void usage(){
@@ -237,21 +275,34 @@ static int run_prop(char* inputs[], int count){
         else      write_profile_grid(grid, "atmo.dat", src_a, src_b, 90.0 - phi_min);
     }
 
-    // ---- the fan on the GPU ----
+    // ---- the fan on the GPU(s) ----
+    const vector<int> devs = device_list();
+    const bool multi = devs.size() > 1 && !(WriteRays || WriteCaustics);      // several devices: arrivals-only fans (sample capture is per context)
     geoac_ctx* ctx = nullptr;
-    int rc = geoac_create(&ctx, kEq, 0);
+    geoac_pool* pool = nullptr;
+    int rc;
+    if(multi){
+        rc = geoac_pool_create(&pool, kEq, (int)devs.size(), devs.data());
+        if(rc){ cout << kName << ": " << geoac_strerror(rc) << '\n'; return 2; }
+        if(kRng) rc = geoac_pool_upload_atmo_3d(pool, grid.nx, grid.ny, grid.nz, grid.x.data(), grid.y.data(), grid.z.data(), grid.T.data(), grid.u.data(), grid.v.data(), grid.rho.data());
+        else     rc = geoac_pool_upload_atmo_1d(pool, prof.n, prof.x.data(), prof.T.data(), prof.u.data(), prof.v.data(), prof.rho.data(), prof.sl.data());
+        if(rc){ cout << kName << ": " << geoac_pool_last_error(pool) << '\n'; return 2; }
+        ctx = geoac_pool_ctx(pool, 0);
+    } else {
+    rc = geoac_create(&ctx, kEq, devs[0]);
     if(rc){ cout << kName << ": " << geoac_strerror(rc) << '\n'; return 2; }
     if(kRng) rc = geoac_upload_atmo_3d(ctx, grid.nx, grid.ny, grid.nz, grid.x.data(), grid.y.data(), grid.z.data(), grid.T.data(), grid.u.data(), grid.v.data(), grid.rho.data());
     else     rc = geoac_upload_atmo_1d(ctx, prof.n, prof.x.data(), prof.T.data(), prof.u.data(), prof.v.data(), prof.rho.data(), prof.sl.data());
     if(rc){ cout << kName << ": " << geoac_last_error(ctx) << '\n'; return 2; }
+    }
     P.z_grnd = z_grnd; P.tweak_abs = tweak_abs; P.freq = freq; P.bounces = bounces; P.calc_amp = CalcAmp ? 1 : 0;
     P.mode = (WriteRays ? GEOAC_MODE_WRITE_RAYS : 0) | (WriteCaustics ? GEOAC_MODE_WRITE_CAUSTICS : 0);
     if(kSph){ P.src[0] = z_src; P.src[1] = src_a; P.src[2] = src_b; }
     else if(kEq == GEOAC_EQ_3D){ P.src[0] = 0.0; P.src[1] = 0.0; P.src[2] = z_src; }
     else if(kRngC){ P.src[0] = src_a; P.src[1] = src_b; P.src[2] = z_src; }
     else { P.src[0] = z_src; P.src[1] = 0.0; P.src[2] = 0.0; }
-    rc = geoac_set_params(ctx, &P);
-    if(rc){ cout << kName << ": " << geoac_last_error(ctx) << '\n'; return 2; }
+    rc = multi ? geoac_pool_set_params(pool, &P) : geoac_set_params(ctx, &P);
+    if(rc){ cout << kName << ": " << (multi ? geoac_pool_last_error(pool) : geoac_last_error(ctx)) << '\n'; return 2; }
 
     long nr;
     if(kEq == GEOAC_EQ_2D) nr = geoac_fan_enumerate(theta_min, theta_max, theta_step, phi_min, phi_min, 1.0, 0, nullptr, nullptr);
@@ -379,7 +430,8 @@ static int run_prop(char* inputs[], int count){
     //      Runs that keep raypath / caustic rows go azimuth group by azimuth group (about 8000 rays each), so the sample list stays
     //      bounded, and the text of group g is formatted and written while group g+1 is on the GPU (two buffers in rotation). ----
     const bool sampling = WriteRays || WriteCaustics;
-    geoac_fan_set_sample_capacity(ctx, 16ll << 20);
+    int64_t sample_cap = 16ll << 20;
+    if(!multi) geoac_fan_set_sample_capacity(ctx, sample_cap);
     vector<long> az_start;                                            // first ray of every azimuth (rays are phi-major)
     for(long i = 0; i < nr; i++) if(i == 0 || ph[(size_t)i] != ph[(size_t)i - 1]) az_start.push_back(i);
     az_start.push_back(nr);
@@ -396,6 +448,25 @@ static int run_prop(char* inputs[], int count){
     uint64_t steps = 0;
     int fail_rc = 0;
     int nb = 0;
+    int capacity_retries = 0;
+    const auto t_gpu0 = std::chrono::steady_clock::now();
+    if(multi){
+        // arrivals-only fan over the pool's devices: azimuth groups from a shared queue, records straight into the fan's table
+        vector<double> rec((size_t)nr * legs * GEOAC_REC_STRIDE, 0.0), smp;
+        rc = geoac_pool_fan_run(pool, (int)nr, th.data(), ph.data(), 0, rec.data(), &steps);
+        if(rc){ cout << kName << ": " << geoac_pool_last_error(pool) << '\n'; geoac_pool_destroy(pool); return 2; }
+        const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_gpu0).count();
+        write_batch(0, nr, rec, smp);
+        vector<uint64_t> dr(devs.size()), ds(devs.size()), dg(devs.size());
+        geoac_pool_last_shares(pool, dr.data(), ds.data(), dg.data());
+        write_stats("-prop", nr, steps, secs, devs, dr, ds, dg);
+        geoac_pool_destroy(pool);
+        results.close();
+        cerr << kName << ": " << nr << " rays, " << steps << " RK4 ray-steps on " << devs.size() << " GPUs (";
+        for(size_t i = 0; i < devs.size(); i++) cerr << (i ? ", " : "") << "device " << devs[i] << ": " << dr[i] << " rays";
+        cerr << ")" << '\n';
+        return 0;
+    }
     for(long a0 = 0; a0 < n_az && !fail_rc; ){
         long a1 = min(n_az, a0 + az_per_batch);
         Batch& B = buf[nb & 1];
@@ -404,11 +475,17 @@ static int run_prop(char* inputs[], int count){
         vector<double> rec((size_t)(i1 - i0) * legs * GEOAC_REC_STRIDE, 0.0), smp;
         uint64_t st = 0;
         rc = geoac_fan_run(ctx, (int)(i1 - i0), th.data() + i0, ph.data() + i0, rec.data(), &st);
-        if(rc == GEOAC_E_CAPACITY && sampling){
+        if(rc == GEOAC_E_CAPACITY && sampling && capacity_retries < 8){
+            // GEOAC_E_CAPACITY has three causes; only a sample list that was too small is cured by splitting the group or growing the
+            // list (need > current capacity).  A ray at step_limit or an overflow of the per-epoch event list come back with
+            // need <= capacity: retrying those would launch the same fan again and again - report them instead.
             int64_t need = 0;
             geoac_fan_sample_count(ctx, &need);
-            if(need > (16ll << 20) && a1 - a0 > 1){ az_per_batch = max(1L, (a1 - a0) / 2); continue; }      // split the group
-            if(need > 0 && need <= (192ll << 20)){ geoac_fan_set_sample_capacity(ctx, need + need / 8); continue; }    // one azimuth that long: grow the list
+            if(need > sample_cap){
+                capacity_retries++;
+                if(need > (16ll << 20) && a1 - a0 > 1){ az_per_batch = max(1L, (a1 - a0) / 2); continue; }      // split the group
+                if(need <= (192ll << 20)){ sample_cap = need + need / 8; geoac_fan_set_sample_capacity(ctx, sample_cap); continue; }    // one azimuth that long: grow the list
+            }
         }
         if(rc){ cout << kName << ": " << geoac_last_error(ctx) << '\n'; fail_rc = 2; break; }
         steps += st;
@@ -429,6 +506,8 @@ static int run_prop(char* inputs[], int count){
     if(WriteRays) raypath.close();
     results.close();
     for(auto& c : caustics) c.close();
+    write_stats("-prop", nr, steps, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_gpu0).count(), vector<int>(1, devs[0]),
+                vector<uint64_t>(1, (uint64_t)nr), vector<uint64_t>(1, steps), vector<uint64_t>(1, (uint64_t)nb));
     cerr << kName << ": " << nr << " rays, " << steps << " RK4 ray-steps on the GPU" << '\n';
     return 0;
 }
