@@ -185,14 +185,16 @@ int geoac_create(geoac_ctx** out, int eqset, int device){
     // moment and its short workgroups would otherwise occupy the CUs the RK4 workgroups (153 KB of LDS each) need
     int prio_lo = 0, prio_hi = 0;
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);          // lo = least urgent (numerically largest)
-    if(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_hi) != hipSuccess){ delete ctx; return GEOAC_E_HIP; }
+    // (a failure part-way leaves streams / events behind: geoac_destroy releases whatever exists)
+    if(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_hi) != hipSuccess){ ctx->stream = nullptr; geoac_destroy(ctx); return GEOAC_E_HIP; }
     ctx->own_stream = true;
-    if(hipStreamCreateWithPriority(&ctx->pp_stream, hipStreamNonBlocking, prio_lo) != hipSuccess){ delete ctx; return GEOAC_E_HIP; }
-    if(hipStreamCreateWithPriority(&ctx->acc_stream, hipStreamNonBlocking, prio_lo) != hipSuccess){ delete ctx; return GEOAC_E_HIP; }
-    if(hipStreamCreateWithPriority(&ctx->rk4b_stream, hipStreamNonBlocking, prio_hi) != hipSuccess){ delete ctx; return GEOAC_E_HIP; }
-    hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
+    if(hipStreamCreateWithPriority(&ctx->pp_stream, hipStreamNonBlocking, prio_lo) != hipSuccess){ ctx->pp_stream = nullptr; geoac_destroy(ctx); return GEOAC_E_HIP; }
+    if(hipStreamCreateWithPriority(&ctx->acc_stream, hipStreamNonBlocking, prio_lo) != hipSuccess){ ctx->acc_stream = nullptr; geoac_destroy(ctx); return GEOAC_E_HIP; }
+    if(hipStreamCreateWithPriority(&ctx->rk4b_stream, hipStreamNonBlocking, prio_hi) != hipSuccess){ ctx->rk4b_stream = nullptr; geoac_destroy(ctx); return GEOAC_E_HIP; }
+    if(hipEventCreate(&ctx->ev0) != hipSuccess){ ctx->ev0 = nullptr; geoac_destroy(ctx); return GEOAC_E_HIP; }
+    if(hipEventCreate(&ctx->ev1) != hipSuccess){ ctx->ev1 = nullptr; geoac_destroy(ctx); return GEOAC_E_HIP; }
     if(hipHostMalloc((void**)&ctx->h_counters, 32 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess){
-        delete ctx; return GEOAC_E_HIP;
+        ctx->h_counters = nullptr; geoac_destroy(ctx); return GEOAC_E_HIP;
     }
     geoac_default_params(eqset, &ctx->prm);
     const char* sr = getenv("GEOAC_S_ROWS");
@@ -478,6 +480,21 @@ int geoac_fan_launch(geoac_ctx* ctx){
     if(s_rows > 8192) s_rows = 8192;
     if(s_rows < 64) s_rows = 64;
     if(ctx->s_rows_override >= 8) s_rows = ctx->s_rows_override;
+    {   // the chunks must fit in what the device has left (another context, torch tensors, RCCL buffers may share it): shorter epochs
+        // rather than an out-of-memory failure.  Budget: 80 % of the free memory plus what this context's chunks already hold.
+        size_t free_b = 0, total_b = 0;
+        if(hipMemGetInfo(&free_b, &total_b) == hipSuccess){
+            size_t held = 0;
+            for(int b = 0; b < 3; b++) held += ctx->path[b].bytes + ctx->contrib[b].bytes;
+            const size_t per_row = (size_t)(ctx->two_chunks ? 2 : 3) * (row_bytes + 2 * (size_t)P.n_pad * sizeof(double));
+            const double budget = 0.8 * (double)(free_b + held);
+            if((double)per_row * (double)s_rows > budget){
+                long long fit = (long long)(budget / (double)per_row);
+                if(fit < 16) return fail(ctx, GEOAC_E_NOMEM, "fan_launch: not enough free device memory for the path chunks of this fan (" + std::to_string(free_b >> 20) + " MiB free)");
+                s_rows = fit;
+            }
+        }
+    }
     P.s_rows = (int)s_rows;
     size_t lds_need = (size_t)P.nseg * GEOAC_SEGW * sizeof(double);
     P.table_in_lds = (!is_grid && lds_need <= 160 * 1024) ? 1 : 0;
@@ -555,7 +572,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
         n_pair = (int)(((long long)(ctx->pair_frac * ctx->n_rays) + 127) / 128 * 128);
         if(n_pair >= P.n_pad) n_pair = P.n_pad;
     }
-    bool split = hybrid && n_pair < P.n_pad;
+    bool split = hybrid && n_pair > 0 && n_pair < P.n_pad;      // n_pair == 0 (GEOAC_PAIR_FRAC=0): everything on the one-lane kernel, one launch
     if(hybrid && n_pair == 0) P.lanes_per_ray = 1;
     const int n_chunks = ctx->two_chunks ? 2 : 3;     // three path chunks in rotation: the post-pass may lag the RK4 by more than one epoch (measured: GeoAc3D 360 x 90 fan 212 -> 160 ms; GEOAC_TWO_CHUNKS=1 for A/B)
     for(int b = 0; b < n_chunks; b++){
@@ -686,7 +703,15 @@ int geoac_fan_launch(geoac_ctx* ctx){
     if(ctx->err_flags & 2ull) return fail(ctx, GEOAC_E_CAPACITY, "per-epoch sample/caustic event list overflowed");
     if(sampling && ctx->n_samples > (unsigned long long)P.smp_cap)
         return fail(ctx, GEOAC_E_CAPACITY, "sample list overflowed: raise GEOAC_SMP_CAP (needed " + std::to_string(ctx->n_samples) + ")");
-    if(ctx->err_flags & 1ull) return fail(ctx, GEOAC_E_CAPACITY, "a ray reached step_limit (GeoAc.Solver.cpp:14) without leaving the region or reaching the ground");
+    // a ray that exhausts step_limit is an ordinary leg end for the reference (GeoAc_Propagate_RK4 returns step_limit with check = false
+    // and the mains write the row): the fan is complete and valid, the condition is reported through geoac_fan_status
+    if(ctx->err_flags & 1ull) ctx->err = "warning: a ray reached step_limit (GeoAc.Solver.cpp:14) without leaving the region or reaching the ground";
+    return GEOAC_OK;
+}
+
+int geoac_fan_status(geoac_ctx* ctx, uint64_t* flags){
+    if(!ctx || !flags || !ctx->ran) return GEOAC_E_INVALID;
+    *flags = (uint64_t)ctx->err_flags;
     return GEOAC_OK;
 }
 

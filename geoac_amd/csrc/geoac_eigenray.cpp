@@ -45,7 +45,7 @@ struct Shared {
     std::vector<Request*> pending;
     int active = 0;                        // searches still running
     int waiting = 0;                       // searches blocked in trace()
-    bool failed = false;
+    std::atomic<bool> failed{false};     // written by the coordinator under the mutex, read by the scan-chain threads without it
 };
 
 struct Geo {                               // spherical helpers of GeoAc.Eigenray.Global.cpp:25-43
@@ -83,7 +83,8 @@ struct DLog {
     DLog& operator<<(char c){ return text(std::string(1, c)); }
     DLog& operator<<(double d){ ops.push_back(Op{NUM, "", d, 0}); return *this; }
     DLog& operator<<(int i){ ops.push_back(Op{INT, "", 0.0, i}); return *this; }
-    DLog& operator<<(decltype(std::setprecision(0)) pr){ ops.push_back(Op{PREC, "", 0.0, (long long)pr._M_n}); return *this; }
+    struct Prec { int n; };                                      // the log's own setprecision (std::setprecision's return type hides its argument)
+    DLog& operator<<(Prec pr){ ops.push_back(Op{PREC, "", 0.0, (long long)pr.n}); return *this; }
     DLog& operator<<(Count){ ops.push_back(Op{COUNT, "", 0.0, 0}); return *this; }
     void incr(){ ops.push_back(Op{INCR, "", 0.0, 0}); }
     void render(std::ostringstream& os, int& count) const {
@@ -329,7 +330,7 @@ struct Search : SearchBase {
             const double* S = &rq.rec[((size_t)bnc_cnt) * GEOAC_REC_STRIDE + GEOAC_REC_STATE];        // solution[k][*] of the last leg
             lat = S[1]; lon = S[2];
             dr = geo.gc_distance((double)(lat * 180.0 / Pi), (double)(lon * 180.0 / Pi), rcv[0], rcv[1]);
-            if(verbose) LOG << '\t' << '\t' << "Arrival at (" << std::setprecision(8) << (double)(lat * 180.0 / Pi) << ", " << (double)(lon * 180.0 / Pi) << "), distance to receiver = " << dr << " km." << '\n';
+            if(verbose) LOG << '\t' << '\t' << "Arrival at (" << DLog::Prec{8} << (double)(lat * 180.0 / Pi) << ", " << (double)(lon * 180.0 / Pi) << "), distance to receiver = " << dr << " km." << '\n';
 
             if(dr < tolerance){
                 // the reference re-propagates and accumulates travel time / attenuation with the raypath-writing loop (:198-238):
@@ -359,7 +360,7 @@ struct Search : SearchBase {
                 e.v[GEOAC_EIG_NSMP] = (double)(e.smp.size() / GEOAC_SMP_STRIDE);
                 if(verbose){
                     LOG << '\t' << '\t' << "Eigenray-" << DLog::Count{} << ".  " << bnc_cnt << " bounce(s)." << '\n';
-                    LOG << '\t' << '\t' << '\t' << "theta, phi = " << std::setprecision(8) << lt << ", " << 90.0 - lp << " degrees." << '\n';
+                    LOG << '\t' << '\t' << '\t' << "theta, phi = " << DLog::Prec{8} << lt << ", " << 90.0 - lp << " degrees." << '\n';
                     LOG << '\t' << '\t' << '\t' << "Travel Time = " << travel_time << " seconds." << '\n';
                     LOG << '\t' << '\t' << '\t' << "Celerity = " << e.v[GEOAC_EIG_CELERITY] << " km/s." << '\n';
                     LOG << '\t' << '\t' << '\t' << "Amplitude = " << e.v[GEOAC_EIG_AMP_DB] << " dB." << '\n';
@@ -369,7 +370,7 @@ struct Search : SearchBase {
                     LOG << '\t' << '\t' << '\t' << "Back azimuth of arrival = " << back_az << " degrees." << '\n';
                     LOG << '\t' << '\t' << '\t' << "Azimuth Deviation = " << back_az_dev << " degrees." << '\n' << '\n';
                 } else {
-                    LOG << '\t' << "Eigenray identified:" << '\t' << "theta, phi = " << std::setprecision(8) << lt << ", " << 90.0 - lp << " degrees." << '\n';
+                    LOG << '\t' << "Eigenray identified:" << '\t' << "theta, phi = " << DLog::Prec{8} << lt << ", " << 90.0 - lp << " degrees." << '\n';
                 }
                 FOUND.push_back(e);
                 LOG.incr();
@@ -554,10 +555,10 @@ struct SearchCart : SearchBase {
                 e.v[GEOAC_EIG_INCL] = arrival_incl; e.v[GEOAC_EIG_BEARING] = az_to_src; e.v[GEOAC_EIG_BACKAZ] = back_az; e.v[GEOAC_EIG_AZDEV] = back_az_dev;
                 e.smp = fin.smp;
                 e.v[GEOAC_EIG_NSMP] = (double)(e.smp.size() / GEOAC_SMP_STRIDE);
-                if(!verbose) LOG << '\t' << "Eigenray identified:" << '\t' << "theta, phi = " << std::setprecision(8) << theta << ", " << 90.0 - phi << " degrees." << '\n';
+                if(!verbose) LOG << '\t' << "Eigenray identified:" << '\t' << "theta, phi = " << DLog::Prec{8} << theta << ", " << 90.0 - phi << " degrees." << '\n';
                 if(verbose){
                     LOG << '\t' << '\t' << "Eigenray Identified:" << '\n';
-                    LOG << '\t' << '\t' << '\t' << "theta, phi = " << std::setprecision(8) << theta << ", " << 90.0 - phi << " degrees." << '\n';
+                    LOG << '\t' << '\t' << '\t' << "theta, phi = " << DLog::Prec{8} << theta << ", " << 90.0 - phi << " degrees." << '\n';
                     LOG << '\t' << '\t' << '\t' << "Travel Time = " << travel_time << " seconds." << '\n';
                     LOG << '\t' << '\t' << '\t' << "Celerity = " << e.v[GEOAC_EIG_CELERITY] << " km/s." << '\n';
                     LOG << '\t' << '\t' << '\t' << "Amplitude (geometric) = " << e.v[GEOAC_EIG_AMP_DB] << " dB." << '\n';

@@ -1433,7 +1433,7 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
         if(brk || gnd || lim){
             // ---- leg end: record (GeoAcGlobal_main.cpp:293-317 and twins) ----
             double* R = P.rec + ((size_t)(P.perm ? P.perm[slot] : slot) * (P.bounces + 1) + leg) * GEOAC_REC_STRIDE;
-            R[GEOAC_REC_STEPS] = (double)k;
+            R[GEOAC_REC_STEPS] = (double)((lim && !brk && !gnd) ? k + 1 : k);   // exhausted loop: the reference returns step_limit (= k + 1), Solver.cpp:70
             P.legend[(size_t)nle * np + slot] = nr - 1; nle++;
             if(lim && !brk && !gnd) atomicOr(&P.counters[2], 1ull);
             // the leg's last row solution[k][*] (both outcomes: arrival rows read it, and so do the eigenray scans' messages after a break)

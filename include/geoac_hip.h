@@ -147,6 +147,13 @@ int  geoac_fan_set_angles(geoac_ctx* ctx, int n_rays, const double* theta_deg, c
  * epochs (it needs the live-ray count to stop), so the call returns when every ray has finished. */
 int  geoac_fan_launch(geoac_ctx* ctx);
 int  geoac_fan_sync(geoac_ctx* ctx);
+/* condition flags of the last completed launch.  GEOAC_FAN_STEP_LIMIT: some ray exhausted step_limit = ray_limit * int(1 / (10 ds_min))
+ * (GeoAc.Solver.cpp:14) before leaving the region or reaching the ground.  The reference treats that as an ordinary leg end
+ * (GeoAc_Propagate_RK4 returns step_limit with check = false and the row is written), so the launch succeeds and the leg's record is
+ * kept: GEOAC_REC_STEPS = step_limit as the reference returns it (step_limit - 1 steps were taken; the reference's post-pass then
+ * reads one row it never wrote - here the sums end at the last integrated row). */
+#define GEOAC_FAN_STEP_LIMIT 1
+int  geoac_fan_status(geoac_ctx* ctx, uint64_t* flags);
 
 /* device pointer to the record table [n_rays][bounces+1][GEOAC_REC_STRIDE] f64 (valid after launch,
  * ordered on the context's stream) - what a multi-GPU caller hands to its gather collective */
