@@ -1,0 +1,67 @@
+"""BASELINE config 5 on the GPU against the reference binary itself: GeoAcGlobal.RngDep -eig_search, bounces 0..2, to the receivers
+rank 0 of an 8-GPU run takes from the 64-receiver ring of 2.5 degrees around the source (every 8th; geoac_amd.sharding.shard_receivers).
+The fixtures (tests/golden/cli/cfg5_r<k>/, tests/golden/make_golden_full.py cfg5) are the reference's verbose iteration log and its
+result files, one process per receiver.  Here the eight searches run as ONE batched geoac_eig_search (the decision rounds of all
+receivers share fan launches): every receiver's log must be the reference's line for line, and its eigenray list the reference's
+(launch angles, travel time, celerity, amplitude, attenuation, arrival angles to their printed 8 digits)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import harness as H
+from test_gpu_eigenray import _compare_logs
+
+pytestmark = pytest.mark.gpu
+CLI_GOLD = os.path.join(H.GOLDEN_DIR, "cli")
+
+
+def _ring(n=64, every=8, lat0=31.0, lon0=0.0, radius_deg=2.5):
+    az = np.arange(0, n, every) * (2.0 * np.pi / n)
+    return np.stack([lat0 + radius_deg * np.cos(az), lon0 + radius_deg * np.sin(az) / np.cos(np.radians(lat0))], axis=1)
+
+
+def _parse_results(path):
+    """[(bounces, {field: value})] from a reference <title>_results.dat"""
+    out = []
+    for block in open(path).read().split("Eigenray-")[1:]:
+        nums = lambda key: [float(x) for x in re.findall(r"[-+]?\d+\.?\d*(?:[eE][-+]?\d+)?", block.split(key)[1].split("\n")[0])]
+        out.append(dict(bounces=int(re.search(r"(\d+) bounce", block).group(1)),
+                        theta=nums("theta, phi =")[0], phi=nums("theta, phi =")[1], ttime=nums("Travel Time =")[0], celerity=nums("Celerity =")[0],
+                        amp=nums("Amplitude (geometric) =")[0], atten=nums("Atmospheric attenuation =")[0], incl=nums("Arrival inclination =")[0],
+                        bearing=nums("Bearing to source =")[0], backaz=nums("Back azimuth of arrival =")[0], azdev=nums("Azimuth deviation =")[0]))
+    return out
+
+
+def test_config5_rank0_receivers_vs_reference_binary(tmp_path):
+    import geoac_amd as G
+    import rngdep_data as RD
+    rcv = _ring()
+    # the receivers the fixtures were made for (ARGS hold the exact decimal strings the reference parsed)
+    for k in range(len(rcv)):
+        args = open(os.path.join(CLI_GOLD, f"cfg5_r{k}", "ARGS")).read().split()
+        kv = dict(a.split("=") for a in args if "=" in a)
+        assert float(kv["lat_rcvr"]) == rcv[k, 0] and float(kv["lon_rcvr"]) == rcv[k, 1]
+    ctx = G.FanContext(G.EQ_GLOBAL_RNGDEP, device=0)
+    ctx.load_grid(*RD.write_grid_global(str(tmp_path), short_paths=False))
+    ctx.set_params(src=(0.0, 31.0, 0.0))
+    out = ctx.eig_search(rcv, bnc_min=0, bnc_max=2, verbose=True)
+    print("config 5, 8 receivers:", out["stats"], len(out["eig"]), "eigenrays")
+    E = G.EIG
+    n_ref = 0
+    for k in range(len(rcv)):
+        gold = os.path.join(CLI_GOLD, f"cfg5_r{k}")
+        _compare_logs(out["logs"][k], open(os.path.join(gold, "LOG.txt")).read())
+        want = _parse_results(os.path.join(gold, "g_results.dat"))
+        got = out["eig"][out["eig"][:, E["RCVR"]] == k]
+        assert len(got) == len(want), f"receiver {k}: {len(got)} eigenrays vs {len(want)}"
+        n_ref += len(want)
+        for g, w in zip(got, want):
+            assert int(g[E["BOUNCES"]]) == w["bounces"]
+            for f, col in (("theta", "THETA"), ("phi", "PHI"), ("ttime", "TTIME"), ("celerity", "CELERITY"), ("amp", "AMP_DB"), ("atten", "ATTEN_DB"),
+                           ("incl", "INCL"), ("bearing", "BEARING"), ("backaz", "BACKAZ"), ("azdev", "AZDEV")):
+                x, y = float(g[E[col]]), w[f]
+                # 8 printed digits; the deviation is a difference of nearly equal bearings: absolute on the scale of a degree
+                assert abs(x - y) <= 2e-7 * max(abs(x), abs(y)) + (2e-6 if f in ("azdev", "phi", "backaz", "bearing") else 1e-12), (k, f, x, y)
+    assert n_ref >= 5
