@@ -22,6 +22,7 @@ extern "C" size_t geoac_gridbuild_work_doubles(int nx, int ny, int nz);
 extern "C" hipError_t geoac_gridbuild_launch(int glob, int nx, int ny, int nz, const double* d_x, const double* d_y, const double* d_z,
                                              const double* d_fields, double* d_work, double* d_tab, hipStream_t s);
 extern "C" hipError_t geoac_launch_accum(const GeoacDevParams* P, hipStream_t s);
+extern "C" hipError_t geoac_launch_compact(const GeoacDevParams* P, const int* cur, const int* n_cur, int n_first, int* next, int* n_next, hipStream_t s);
 extern "C" hipError_t geoac_launch_probe_atmo1d(const GeoacDevParams* P, int n, const double* x, double* out9, double* rho, hipStream_t s);
 extern "C" hipError_t geoac_launch_probe_absorption(const GeoacDevParams* P, int n, const double* x, const double* f, double* out, hipStream_t s);
 extern "C" hipError_t geoac_launch_probe_grid(const GeoacDevParams* P, int n, const double* a0, const double* a1, const double* a2, int coop,
@@ -58,6 +59,8 @@ struct geoac_ctx {
     bool no_quad = false;            // GEOAC_NO_QUAD=1: never use the multi-lane grid kernels
     int  grid_lanes = 0;             // GEOAC_GRID_LANES=1|2|4: force the lanes-per-ray variant of the grid kernels (tests); 0 = by fan size
     int  spread_override = 0;        // GEOAC_SPREAD=n: force n-way lane thinning of the grid-set RK4 waves (1 = dense); 0 = automatic
+    bool compact = true;             // GEOAC_COMPACT=0: every epoch runs over all slots (no live-ray compaction between epochs)
+    DevBuf colmap[3], ncols;         // per chunk: column -> slot list of the rays alive at the start of that epoch; their counts (3 ints)
     bool grid_coop = true;           // GEOAC_GRID_COOP=0: per-lane table gathers instead of the wave-cooperative gather (A/B runs, schedule-independence test)
     hipStream_t stream = nullptr; bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -223,6 +226,8 @@ int geoac_create(geoac_ctx** out, int eqset, int device){
     if(gl && (atoi(gl) == 1 || atoi(gl) == 2 || atoi(gl) == 4)) ctx->grid_lanes = atoi(gl);
     const char* nsp = getenv("GEOAC_SPREAD");
     if(nsp && atoi(nsp) > 0) ctx->spread_override = atoi(nsp);
+    const char* cp = getenv("GEOAC_COMPACT");
+    if(cp) ctx->compact = (atoi(cp) != 0);
     const char* gc = getenv("GEOAC_GRID_COOP");
     if(gc) ctx->grid_coop = (atoi(gc) != 0);
     const char* sc = getenv("GEOAC_SMP_CAP");
@@ -241,7 +246,7 @@ int geoac_destroy(geoac_ctx* ctx){
                        &ctx->nlegend[0], &ctx->nlegend[1], &ctx->nlegend[2],
                        &ctx->ev_row[0], &ctx->ev_row[1], &ctx->ev_row[2], &ctx->ev_m[0], &ctx->ev_m[1], &ctx->ev_m[2],
                        &ctx->ev_amp[0], &ctx->ev_amp[1], &ctx->ev_amp[2], &ctx->nev[0], &ctx->nev[1], &ctx->nev[2], &ctx->smp_out,
-                       &ctx->d_gx, &ctx->d_gy, &ctx->d_gz, &ctx->d_gtab, &ctx->d_consts };
+                       &ctx->d_gx, &ctx->d_gy, &ctx->d_gz, &ctx->d_gtab, &ctx->d_consts, &ctx->colmap[0], &ctx->colmap[1], &ctx->colmap[2], &ctx->ncols };
     for(DevBuf* b : bufs) b->release();
     if(ctx->h_counters) hipHostFree(ctx->h_counters);
     if(ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -574,6 +579,14 @@ int geoac_fan_launch(geoac_ctx* ctx){
     }
     bool split = hybrid && n_pair > 0 && n_pair < P.n_pad;      // n_pair == 0 (GEOAC_PAIR_FRAC=0): everything on the one-lane kernel, one launch
     if(hybrid && n_pair == 0) P.lanes_per_ray = 1;
+    // live-ray compaction between epochs (single-launch fans; a hybrid fan assigns its two kernels by slot range): epoch e > 0 runs
+    // over the dense list of the rays alive after epoch e-1, built on the device (k_compact) right before its RK4 launch
+    const bool compact = ctx->compact && !hybrid;
+    if(compact){
+        for(int b = 0; b < 3; b++) HIPCHK(ctx->colmap[b].ensure(sizeof(int) * (size_t)P.n_pad));
+        HIPCHK(ctx->ncols.ensure(4 * sizeof(int)));
+    }
+    P.n_cols_bound = P.n_pad;
     const int n_chunks = ctx->two_chunks ? 2 : 3;     // three path chunks in rotation: the post-pass may lag the RK4 by more than one epoch (measured: GeoAc3D 360 x 90 fan 212 -> 160 ms; GEOAC_TWO_CHUNKS=1 for A/B)
     for(int b = 0; b < n_chunks; b++){
         if(sampling){                                             // per-chunk event lists of the WriteRays / WriteCaustics rows
@@ -602,7 +615,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
     const int rows_late = (ctx->s_rows_override >= 8) ? P.s_rows : std::max(std::min(1024, P.s_rows), P.s_rows / 4);
     int rows_now = P.s_rows;
     const long long max_epochs = (P.step_limit * (long long)ctx->legs) / (rows_late > 4 ? (rows_late - 3) : 1) + ctx->legs + 2;
-    unsigned long long live = 1;
+    unsigned long long live = 1, live_bound = (unsigned long long)P.n_pad;
     // post-pass of one epoch on the second stream; gate_expected > 0: only after that many RK4 workgroups of this fan are resident
     auto enqueue_post = [&](const GeoacDevParams& Pq, size_t e, unsigned long long gate_expected) -> int {
         HIPCHK(hipStreamWaitEvent(sp, ctx->evs[4 * e + 1], 0));
@@ -637,6 +650,17 @@ int geoac_fan_launch(geoac_ctx* ctx){
         Pe.nrows = (int*)ctx->nrows[b].p; Pe.legend = (int*)ctx->legend[b].p; Pe.nlegend = (int*)ctx->nlegend[b].p;
         if(sampling){ Pe.ev_row = (int*)ctx->ev_row[b].p; Pe.ev_m = (int*)ctx->ev_m[b].p; Pe.ev_amp = (double*)ctx->ev_amp[b].p; Pe.nev = (int*)ctx->nev[b].p; }
         if(e >= (size_t)n_chunks) HIPCHK(hipStreamWaitEvent(s, ctx->evs[4 * (e - n_chunks) + 3], 0));      // chunk b free again?
+        if(compact && e >= 1){
+            // columns of this epoch = rays alive after the previous one; the launch is sized by the newest live count the host has
+            // (after epoch e-2: an upper bound), lanes beyond the device-side count leave at once
+            const int pb = (int)((e - 1) % (size_t)n_chunks);
+            HIPCHK(geoac_launch_compact(&P, e == 1 ? nullptr : (const int*)ctx->colmap[pb].p, (const int*)ctx->ncols.p + pb, P.n_pad,
+                                        (int*)ctx->colmap[b].p, (int*)ctx->ncols.p + b, s));
+            Pe.colmap = (const int*)ctx->colmap[b].p; Pe.n_cols = (const int*)ctx->ncols.p + b;
+            Pe.n_cols_bound = (int)std::min<unsigned long long>((unsigned long long)P.n_pad, (live_bound + 63ull) / 64ull * 64ull);
+            if(Pe.n_cols_bound < 64) Pe.n_cols_bound = 64;
+            Pe.slot_lo = 0; Pe.slot_hi = Pe.n_cols_bound;
+        }
         HIPCHK(hipMemsetAsync((char*)ctx->counters.p + sizeof(unsigned long long), 0, sizeof(unsigned long long), s));
         HIPCHK(hipMemsetAsync((char*)ctx->counters.p + 4 * sizeof(unsigned long long), 0, sizeof(unsigned long long), s));
         HIPCHK(hipMemsetAsync((char*)ctx->counters.p + 6 * sizeof(unsigned long long), 0, 2 * sizeof(unsigned long long), s));
@@ -667,6 +691,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
             HIPCHK(hipEventSynchronize(ctx->evj[2 * (e - 1) + 1]));
             const unsigned long long* hc = ctx->h_counters + 16 * ((e - 1) & 1);
             live = hc[1] + hc[6];
+            live_bound = live;
             if(live == 0){ ctx->n_epochs = e; break; }
             // hybrid fan: once the rays still alive would fit on half of the SIMDs as two-lane waves (hc[4] two-lane waves alive, hc[7]
             // one-lane waves that would become two each), or the two-lane share has finished, everything continues on the two-lane

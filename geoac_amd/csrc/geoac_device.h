@@ -83,6 +83,9 @@ struct GeoacDevParams {
     const double* gtab;             // [4 fields][nseg][gnx*gny][12]: cubics of f, df/dx, df/dy per node and vertical segment
     double        xy_lim[4];        // x_min, x_max, y_min, y_max break limits (GeoAc.Parameters.RngDep.cpp:24-28)
     double*       dev_consts;       // [0] T_o, [1] P_o, [2] cbrt(T_o) of SuthBass evaluated on the device (RngDep: medium at (0, 0, z_grnd))
+    const int*    colmap;           // live-ray compaction: column of this epoch's chunk -> ray slot (NULL: identity, column = slot)
+    const int*    n_cols;           // device: number of valid columns of colmap
+    int           n_cols_bound;     // host-side upper bound of the columns in use this epoch (launch sizes of the post-pass / sum kernels); n_pad without compaction
     const int*    perm;             // slot -> ray index of the caller's order (records and samples are written in the caller's order); NULL = identity
     const double* theta_deg;        // [n_rays]
     const double* phi_deg;

@@ -548,7 +548,7 @@ DEVINL void cart2_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCt
 // ================================================================================================
 template <bool AMP_> struct EqGlobal {
     static constexpr bool AMP = AMP_;
-    static constexpr bool COOP = false;
+    static constexpr bool COOP = false; static constexpr bool LDS_STATE = false;
     static constexpr int PP_WAVES = 3;                              // post-pass waves per SIMD (168 registers; at 128 it spills 148 B and runs 1.5 x slower)
     static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 0, LANES = 1;
     static constexpr bool SPLIT = false;                            // true: the lanes of a ray carry DIFFERENT parts of its state (EqGlobalPair)
@@ -725,6 +725,7 @@ struct EqGlobalPair : EqGlobal<true> {
 template <bool AMP_, int NL_ = 1, bool COOP_ = false> struct Eq3DRngDep {
     static constexpr bool AMP = AMP_;
     static constexpr bool COOP = COOP_;                             // wave-cooperative record gather through LDS (grid_eval3_coop): NL_ = 1, every lane of the wave stays in the loop
+    static constexpr bool LDS_STATE = true;                         // the step's rows y and yn live in LDS while the four stages run (the grid kernels use no LDS otherwise)
     static constexpr int NB = 6, NS = 6;
     static constexpr int PP_WAVES = 3;
     static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 2, LANES = NL_;            // NL_ = 1, 2 or 4 lanes per ray, each evaluating 4/NL_ of the cell corners (identical state otherwise)
@@ -859,6 +860,7 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false> struct Eq3DRngDep {
 template <bool AMP_, int NL_ = 1, bool COOP_ = false> struct EqGlobalRngDep {
     static constexpr bool AMP = AMP_;
     static constexpr bool COOP = COOP_;
+    static constexpr bool LDS_STATE = true;
     static constexpr int NB = 6, NS = 6;
     static constexpr int PP_WAVES = 3;
     static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 0, LANES = NL_;
@@ -991,7 +993,7 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false> struct EqGlobalRngDep {
 
 template <bool AMP_> struct Eq3D {
     static constexpr bool AMP = AMP_;
-    static constexpr bool COOP = false;
+    static constexpr bool COOP = false; static constexpr bool LDS_STATE = false;
     static constexpr int PP_WAVES = 4;                              // post-pass at four waves per SIMD (127 registers, 52 B of spill): GeoAc3D 360 x 90 fan 185 -> 168 ms
     static constexpr int E = AMP_ ? 12 : 4, PW = 4, HIDX = 2, LANES = 1;
     static constexpr bool SPLIT = false;
@@ -1145,7 +1147,7 @@ struct Eq3DPair : Eq3D<true> {
 
 template <bool AMP_> struct Eq2D {
     static constexpr bool AMP = AMP_;
-    static constexpr bool COOP = false;
+    static constexpr bool COOP = false; static constexpr bool LDS_STATE = false;
     static constexpr int NB = 3, NS = 3;
     static constexpr int PP_WAVES = 4;
     static constexpr int E = AMP_ ? 6 : 3, PW = 2, HIDX = 1, LANES = 1;
@@ -1269,8 +1271,8 @@ template <class EQ> struct ArrivalOf<EQ, true> { static DEVINL void go(const Geo
 template <class EQ> DEVINL void arrival_of(const GeoacDevParams& P, const RayCtx& C, int slot, const double* y, double* R){ ArrivalOf<EQ>::go(P, C, slot, y, R); }
 
 template <class EQ>
-DEVINL void write_row(const GeoacDevParams& P, int row, int slot, int q, const double* y){
-    double* p = P.path + ((size_t)row * EQ::PW) * P.n_pad + slot;
+DEVINL void write_row(const GeoacDevParams& P, int row, int col, int q, const double* y){
+    double* p = P.path + ((size_t)row * EQ::PW) * P.n_pad + col;
     if(!EQ::SPLIT && EQ::LANES > 1 && q != 0) return;   // multi-lane grid kernels: the lanes hold the same row, lane 0 stores it
     if(EQ::SPLIT){                    // pair kernels: each lane stores half of the row (Global: r, lat, lon | nu_r, nu_t, nu_p; 3D: x, y | z, nu_z)
         constexpr int H = EQ::PW / 2;
@@ -1296,13 +1298,18 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
     if(threadIdx.x == 0) atomicAdd(&P.counters[5], 1ull);       // this workgroup holds its CU now: k_gate releases the previous epoch's post-pass
     const int tid0 = blockIdx.x * blockDim.x + threadIdx.x;
     const int tid = (P.spread > 1) ? tid0 / P.spread : tid0;
-    const int slot = P.slot_lo + tid / EQ::LANES;               // ray slot
+    // `col` = this ray's column in the epoch's chunk buffers (path, contrib, row counts, leg-end and sample events); `slot` = its row in the
+    // fan-long state block.  Without compaction they are the same number.  With it (P.colmap) the epoch runs over the dense list of the
+    // rays that were still alive after the previous epoch (k_compact): column p integrates slot colmap[p], finished rays hold no lane.
+    const int col = P.slot_lo + tid / EQ::LANES;
     const int q = tid % EQ::LANES;                              // pair kernel: which derivative system this lane carries; quad kernels: which cell corner
-    const bool mine = !(P.spread > 1 && (tid0 & (P.spread - 1))) && slot < P.slot_hi;   // spread > 1: sparse lanes (grid sets, small fans)
+    const int col_hi = P.colmap ? min(P.slot_hi, *P.n_cols) : P.slot_hi;
+    const bool mine = !(P.spread > 1 && (tid0 & (P.spread - 1))) && col < col_hi;   // spread > 1: sparse lanes (grid sets, small fans)
+    const int slot = (P.colmap && mine) ? P.colmap[col] : col;  // ray slot
     const size_t np = (size_t)P.n_pad;
     double* st = P.state + (mine ? slot : 0);
     bool done = mine ? (st[ST_DONE * np] != 0.0) : true;
-    if(mine && done){ P.nrows[slot] = 0; P.nlegend[slot] = 0; if(SMP) P.nev[slot] = 0; }
+    if(mine && done){ P.nrows[col] = 0; P.nlegend[col] = 0; if(SMP) P.nev[col] = 0; }
     // a workgroup whose rays have all finished leaves before the table is staged (late epochs, and the launch the host
     // enqueues ahead of knowing that the previous epoch finished the fan)
     if(!__syncthreads_or(!done)) return;
@@ -1317,11 +1324,12 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
     // fetching table records for its quad mates (grid_eval3_coop); all its own side effects are switched off
     const bool idle0 = done;                                     // finished before this epoch: nothing of this lane's is written
     if(!EQ::COOP && done) return;
-    // per wave: the 64 x 176 B exchange buffer of the cooperative gather, then y[E][64] and yn[E][64]
-    constexpr int COOP_WAVE_BYTES = 64 * GEOAC_COOP_SLOT + 2 * GEOAC_MAXE * 64 * (int)sizeof(double);
-    char* const ldsw = EQ::COOP ? (char*)lds_tab + (threadIdx.x >> 6) * COOP_WAVE_BYTES : nullptr;
-    double* const ly = EQ::COOP ? (double*)(ldsw + 64 * GEOAC_COOP_SLOT) + (threadIdx.x & 63) : nullptr;
-    double* const lyn = EQ::COOP ? ly + GEOAC_MAXE * 64 : nullptr;
+    // per wave: (COOP) the 64 x 176 B exchange buffer of the cooperative gather, then (LDS_STATE) y[E][64] and yn[E][64]
+    constexpr int LDS_XCHG_BYTES = EQ::COOP ? 64 * GEOAC_COOP_SLOT : 0;
+    constexpr int LDS_WAVE_BYTES = LDS_XCHG_BYTES + (EQ::LDS_STATE ? 2 * GEOAC_MAXE * 64 * (int)sizeof(double) : 0);
+    char* const ldsw = (char*)lds_tab + (threadIdx.x >> 6) * LDS_WAVE_BYTES;
+    double* const ly = (double*)(ldsw + LDS_XCHG_BYTES) + (threadIdx.x & 63);
+    double* const lyn = ly + GEOAC_MAXE * 64;
 
     int nr = 0, nle = 0;
     static_assert(E <= ST_K - ST_Y0, "state block: y[] overruns ST_K");
@@ -1347,7 +1355,7 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
     double dprev = SMP ? st[ST_DPREV * np] : 0.0;               // Jacobian of the previous row (caustic detection)
     const bool want_rays = SMP && (P.mode & GEOAC_MODE_WRITE_RAYS), want_caus = SMP && EQ::AMP && (P.mode & GEOAC_MODE_WRITE_CAUSTICS);
 
-    if(!EQ::COOP || !idle0) write_row<EQ>(P, nr++, slot, q, y);    // carry row: chunk row 0 = current state
+    if(!EQ::COOP || !idle0) write_row<EQ>(P, nr++, col, q, y);     // carry row: chunk row 0 = current state
 
     while(true){
         const bool act = (nr + 2 <= P.s_rows) && !done;
@@ -1367,12 +1375,12 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
                 double amp = 0.0, D = 0.0;
                 if(EQ::AMP) EQ::amp_jac(P, C, slot, y, amp, D);
                 if(smp_row){
-                    if(nev < P.ev_cap){ P.ev_row[(size_t)nev * np + slot] = nr - 1; P.ev_m[(size_t)nev * np + slot] = (int)k; P.ev_amp[(size_t)nev * np + slot] = amp; }
+                    if(nev < P.ev_cap){ P.ev_row[(size_t)nev * np + col] = nr - 1; P.ev_m[(size_t)nev * np + col] = (int)k; P.ev_amp[(size_t)nev * np + col] = amp; }
                     nev++;
                 }
                 if(want_caus){
                     if(k > 1 && D * dprev < 0.0){
-                        if(nev < P.ev_cap){ P.ev_row[(size_t)nev * np + slot] = nr - 1; P.ev_m[(size_t)nev * np + slot] = (int)k | (1 << 30); P.ev_amp[(size_t)nev * np + slot] = 0.0; }
+                        if(nev < P.ev_cap){ P.ev_row[(size_t)nev * np + col] = nr - 1; P.ev_m[(size_t)nev * np + col] = (int)k | (1 << 30); P.ev_amp[(size_t)nev * np + col] = 0.0; }
                         nev++;
                     }
                     dprev = D;
@@ -1391,7 +1399,7 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
         double dy[E], yt[E], yn[E];
         #pragma unroll
         for(int e = 0; e < E; e++){ yt[e] = y[e]; yn[e] = y[e]; }
-        if(EQ::COOP){
+        if(EQ::LDS_STATE){
             // the step's base row y and the accumulating new row yn live in LDS ([component][lane], conflict free) while the four stages
             // run: 72 registers less under the table evaluation, which is what spilled (416 B of scratch per lane before)
             #pragma unroll
@@ -1403,7 +1411,7 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
             else if(LDS) EQ::rhs(lds_tab, P, seg, C, y, yt, stage, dy); else EQ::rhs(gtab, P, seg, C, y, yt, stage, dy);
             const double wa = ((stage == 2) ? 1.0 : 0.5) * ds;
             const double wb = ((stage == 0 || stage == 3) ? (1.0 / 6.0) : (1.0 / 3.0)) * ds;
-            if(EQ::COOP){
+            if(EQ::LDS_STATE){
                 #pragma unroll
                 for(int e = 0; e < E; e++){
                     lyn[e * 64] = __builtin_fma(dy[e], wb, lyn[e * 64]);
@@ -1417,14 +1425,14 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
                 }
             }
         }
-        if(EQ::COOP){
+        if(EQ::LDS_STATE){
             #pragma unroll
             for(int e = 0; e < E; e++){ y[e] = ly[e * 64]; yn[e] = lyn[e * 64]; }
         }
 
         if(!EQ::COOP || act){                                     // (a helper lane has nothing of its own to advance)
         k++; steps_here++;
-        write_row<EQ>(P, nr++, slot, q, yn);
+        write_row<EQ>(P, nr++, col, q, yn);
 
         bool brk, gnd;
         EQ::checks(P, C, y, yn, k, brk, gnd);
@@ -1434,7 +1442,7 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
             // ---- leg end: record (GeoAcGlobal_main.cpp:293-317 and twins) ----
             double* R = P.rec + ((size_t)(P.perm ? P.perm[slot] : slot) * (P.bounces + 1) + leg) * GEOAC_REC_STRIDE;
             R[GEOAC_REC_STEPS] = (double)((lim && !brk && !gnd) ? k + 1 : k);   // exhausted loop: the reference returns step_limit (= k + 1), Solver.cpp:70
-            P.legend[(size_t)nle * np + slot] = nr - 1; nle++;
+            P.legend[(size_t)nle * np + col] = nr - 1; nle++;
             if(lim && !brk && !gnd) atomicOr(&P.counters[2], 1ull);
             // the leg's last row solution[k][*] (both outcomes: arrival rows read it, and so do the eigenray scans' messages after a break)
             double yf[18];
@@ -1475,7 +1483,7 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
                     } else EQ::reflect(P, C, yn, y, ym2);
                     leg++; k = 0;
                     EQ::restart(P, C, y);
-                    write_row<EQ>(P, nr++, slot, q, y);              // leg-start row
+                    write_row<EQ>(P, nr++, col, q, y);               // leg-start row
                 }
             }
         } else {
@@ -1505,10 +1513,10 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
     st[ST_HMAX * np] = hmax; st[ST_SEG * np] = P.gtab ? (double)seg : (double)(seg / GEOAC_SEGW);
     #pragma unroll
     for(int q = 0; q < 4; q++) st[(ST_AUX0 + q) * np] = C.a[q];
-    P.nrows[slot] = nr; P.nlegend[slot] = nle;
+    P.nrows[col] = nr; P.nlegend[col] = nle;
     if(SMP){
         st[ST_DPREV * np] = dprev;
-        P.nev[slot] = nev < P.ev_cap ? nev : P.ev_cap;
+        P.nev[col] = nev < P.ev_cap ? nev : P.ev_cap;
         if(nev > P.ev_cap) atomicOr(&P.counters[2], 2ull);
     }
     }
@@ -1537,18 +1545,19 @@ template <class EQ>
 __global__ void __launch_bounds__(256, EQ::PP_WAVES) k_postpass(GeoacDevParams P, int rows){
     // grid-stride sweep over (segment row i, ray slot); by default the grid covers the sweep in one pass
     const size_t np = (size_t)P.n_pad;
-    const int bx = (P.n_pad + 255) / 256;                       // slot-blocks per row
+    const int bx = (P.n_cols_bound + 255) / 256;                // column-blocks per row
     const long long total = (long long)bx * (rows - 1);
     for(long long w = blockIdx.x; w < total; w += gridDim.x){
         const int i = (int)(w / bx);
-        const int slot = (int)(w % bx) * 256 + threadIdx.x;
-        if(slot >= P.n_pad) continue;
-        if(i + 1 >= P.nrows[slot]) continue;
-        const double* a = P.path + ((size_t)i * EQ::PW) * np + slot;
+        const int col = (int)(w % bx) * 256 + threadIdx.x;
+        if(col >= (P.colmap ? *P.n_cols : P.n_pad)) continue;
+        if(i + 1 >= P.nrows[col]) continue;
+        const int slot = P.colmap ? P.colmap[col] : col;
+        const double* a = P.path + ((size_t)i * EQ::PW) * np + col;
         const double* b = a + (size_t)EQ::PW * np;
         double tt, at;
         EQ::segment(P, P.state + slot, np, a, b, tt, at);
-        double* o = P.contrib + ((size_t)i * 2) * np + slot;
+        double* o = P.contrib + ((size_t)i * 2) * np + col;
         o[0]  = tt;
         o[np] = at;
     }
@@ -1558,32 +1567,33 @@ __global__ void __launch_bounds__(256, EQ::PP_WAVES) k_postpass(GeoacDevParams P
 // k_accum: in-order summation per ray, leg bookkeeping (GeoAcGlobal_main.cpp:256-291, Q7)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_accum(GeoacDevParams P){
-    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if(slot >= P.n_pad) return;
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if(col >= (P.colmap ? *P.n_cols : P.n_pad)) return;
     const size_t np = (size_t)P.n_pad;
-    const int nr = P.nrows[slot];                               // 0 for slots without a ray
+    const int nr = P.nrows[col];                                // 0 for slots without a ray
     if(nr < 2) return;
+    const int slot = P.colmap ? P.colmap[col] : col;
     double* st = P.state + slot;
     double tt = st[ST_TT * np], at = st[ST_AT * np];           // cumulative over the ray
     double ltt = st[ST_LTT * np], lat = st[ST_LAT * np];   // per-leg partial sums (arrivals-only form)
     int leg = (int)st[ST_PLEG * np];
-    const int ne = P.nlegend[slot];
+    const int ne = P.nlegend[col];
     int e = 0;
-    int next_end = (e < ne) ? P.legend[(size_t)e * np + slot] : 0x7fffffff;
+    int next_end = (e < ne) ? P.legend[(size_t)e * np + col] : 0x7fffffff;
     int cur_end = -1;
     const bool rays_form = P.rays_form != 0;      // WriteRays/WriteCaustics form of Q7; GeoAc2D always uses it (GeoAc2D_main.cpp:190-192)
-    const int nev = P.ev_cap > 0 ? P.nev[slot] : 0;
+    const int nev = P.ev_cap > 0 ? P.nev[col] : 0;
     int ev = 0;
     auto emit_events = [&](int crow){
-        while(ev < nev && P.ev_row[(size_t)ev * np + slot] == crow){
-        const int mm = P.ev_m[(size_t)ev * np + slot];
+        while(ev < nev && P.ev_row[(size_t)ev * np + col] == crow){
+        const int mm = P.ev_m[(size_t)ev * np + col];
         const int kind = (mm >> 30) & 1, m = mm & 0x3fffffff;
         unsigned long long o = atomicAdd(&P.counters[3], 1ull);
         if(o < (unsigned long long)P.smp_cap){
             double* S = P.smp_out + o * GEOAC_SMP_STRIDE;
-            const double* row = P.path + ((size_t)crow * P.pathw) * np + slot;
+            const double* row = P.path + ((size_t)crow * P.pathw) * np + col;
             S[GEOAC_SMP_RAY] = (double)(P.perm ? P.perm[slot] : slot); S[GEOAC_SMP_LEG] = (double)leg; S[GEOAC_SMP_M] = (double)m; S[GEOAC_SMP_KIND] = (double)kind;
-            double amp = P.ev_amp[(size_t)ev * np + slot];
+            double amp = P.ev_amp[(size_t)ev * np + col];
             double amp_db = P.calc_amp ? 20.0 * log10(amp) : 0.0;
             double v[6] = {0, 0, 0, 0, 0, 0};
             int np3;                                                   // number of position columns
@@ -1603,7 +1613,7 @@ __global__ void __launch_bounds__(256) k_accum(GeoacDevParams P){
     emit_events(0);             // events on the carry row (the row a previous epoch ended on)
     for(int i = 0; i + 1 < nr; i++){
         if(i == cur_end) continue;                              // (leg-end row -> next leg's start row): not a segment
-        const double* cpt = P.contrib + ((size_t)i * 2) * np + slot;
+        const double* cpt = P.contrib + ((size_t)i * 2) * np + col;
         const bool last = (i + 1 == next_end);
         if(rays_form){
             if(!last){ tt += cpt[0]; at += cpt[np]; }           // segments 0..k-2 only (GeoAcGlobal_main.cpp:264-267)
@@ -1617,11 +1627,43 @@ __global__ void __launch_bounds__(256) k_accum(GeoacDevParams P){
             R[GEOAC_REC_TTIME] = tt;
             R[GEOAC_REC_ATTEN] = at;
             leg++; cur_end = i + 1; e++;
-            next_end = (e < ne) ? P.legend[(size_t)e * np + slot] : 0x7fffffff;
+            next_end = (e < ne) ? P.legend[(size_t)e * np + col] : 0x7fffffff;
         }
     }
     st[ST_TT * np] = tt; st[ST_AT * np] = at; st[ST_PLEG * np] = (double)leg;
     st[ST_LTT * np] = ltt; st[ST_LAT * np] = lat;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_compact: the dense, order-preserving list of the rays still alive after an epoch (north_star: "wavefront ballot for ground-bounce /
+// termination compaction").  One workgroup walks the previous list in tiles of 1024 columns: a wave ballot of the live flags, the
+// popcount below each lane and a running offset give every live ray its column of the next epoch.  The order of the list (launch
+// inclination) is kept, so the next epoch's waves are again made of neighbouring rays.  n <= ~1e6 columns: 10-200 us per epoch.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_compact(GeoacDevParams P, const int* __restrict__ cur, const int* __restrict__ n_cur, int n_first,
+                                                  int* __restrict__ next, int* __restrict__ n_next){
+    __shared__ int wave_cnt[16];
+    __shared__ int base_s;
+    const int n = cur ? *n_cur : n_first;                       // cur == NULL: the first epoch ran over the identity list 0..n_first-1
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t np = (size_t)P.n_pad;
+    if(threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    for(int t0 = 0; t0 < n; t0 += 1024){
+        const int c = t0 + threadIdx.x;
+        const int slot = (c < n) ? (cur ? cur[c] : c) : -1;
+        const bool live = slot >= 0 && P.state[ST_DONE * np + slot] == 0.0;
+        const unsigned long long m = __ballot(live);
+        if(lane == 0) wave_cnt[wv] = __popcll(m);
+        __syncthreads();
+        int off = base_s;
+        for(int w = 0; w < wv; w++) off += wave_cnt[w];
+        if(live) next[off + __popcll(m & ((1ull << lane) - 1ull))] = slot;
+        __syncthreads();
+        if(threadIdx.x == 0){ int tot = 0; for(int w = 0; w < 16; w++) tot += wave_cnt[w]; base_s += tot; }
+        __syncthreads();
+    }
+    if(threadIdx.x == 0) *n_next = base_s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1742,7 +1784,7 @@ static hipError_t launch_rk4_t(const GeoacDevParams* P, int block, hipStream_t s
     dim3 b(block), g((unsigned)((lanes + block - 1) / block));
     if(n_wg) *n_wg = g.x;
     size_t lds = P->table_in_lds ? (size_t)P->nseg * GEOAC_SEGW * sizeof(double) : 0;
-    if(EQ::COOP) lds = (size_t)(block / 64) * (64 * GEOAC_COOP_SLOT + 2 * GEOAC_MAXE * 64 * sizeof(double));   // per wave: exchange buffer + y, yn rows (k_rk4)
+    if(EQ::LDS_STATE) lds = (size_t)(block / 64) * ((EQ::COOP ? 64 * GEOAC_COOP_SLOT : 0) + 2 * GEOAC_MAXE * 64 * sizeof(double));   // per wave: exchange buffer, y and yn rows (k_rk4)
     const bool smp = (P->mode & (GEOAC_MODE_WRITE_RAYS | GEOAC_MODE_WRITE_CAUSTICS)) != 0;
     #define GEOAC_RK4_LAUNCH(LDSF, SMPF) do { \
         if(lds > 65536){ \
@@ -1783,7 +1825,7 @@ extern "C" hipError_t geoac_launch_gate(const GeoacDevParams* P, unsigned long l
 
 extern "C" hipError_t geoac_launch_postpass(const GeoacDevParams* P, int rows, hipStream_t s){
     if(rows < 2) return hipSuccess;
-    long long total = (long long)((P->n_pad + 255) / 256) * (rows - 1);
+    long long total = (long long)((P->n_cols_bound + 255) / 256) * (rows - 1);
     long long nbl = P->pp_blocks > 0 ? P->pp_blocks : total;
     if(total < nbl) nbl = total;
     if(nbl > 0x7fffffffLL) nbl = 0x7fffffffLL;
@@ -1809,8 +1851,13 @@ extern "C" hipError_t geoac_launch_probe_grid(const GeoacDevParams* P, int n, co
     return hipGetLastError();
 }
 
+extern "C" hipError_t geoac_launch_compact(const GeoacDevParams* P, const int* cur, const int* n_cur, int n_first, int* next, int* n_next, hipStream_t s){
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, s, *P, cur, n_cur, n_first, next, n_next);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t geoac_launch_accum(const GeoacDevParams* P, hipStream_t s){
-    dim3 b(256), g2((P->n_pad + 255) / 256);
+    dim3 b(256), g2((P->n_cols_bound + 255) / 256);
     hipLaunchKernelGGL(k_accum, g2, b, 0, s, *P);
     return hipGetLastError();
 }

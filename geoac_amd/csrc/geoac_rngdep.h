@@ -28,7 +28,8 @@ enum { GC_F = 0, GC_DXF, GC_DYF, GC_DXYF, GC_VX, GC_DXVX, GC_DXYVX, GC_VY, GC_DY
 
 struct GridLoc {
     int kz;                 // vertical segment
-    int nb[2][2];           // node index (ix*ny + iy) of the cell corners, [a][b], a <-> x edge, b <-> y edge
+    int n00, n01, n10, n11; // node index (ix*ny + iy) of the cell corners n<a><b>, a <-> x edge, b <-> y edge (scalars, not an array: a rolled
+                            // corner loop would index an array dynamically and put it in scratch)
     double t;               // z - z0[kz]
     double xs, ys;          // position inside the cell, scaled to [0, 1]
     double dxs, dys;        // cell sizes (dx_scalar, dy_scalar)
@@ -51,8 +52,8 @@ DEVINL void grid_locate(const GeoacDevParams& P, double x, double y, double z, i
     while(kz < P.nseg - 1 && z > P.gz[kz + 1]) kz++;
     L.kz = kz;
     L.t = z - P.gz[kz];
-    L.nb[0][0] = kx * ny + ky;       L.nb[0][1] = kx * ny + ky + 1;
-    L.nb[1][0] = (kx + 1) * ny + ky; L.nb[1][1] = (kx + 1) * ny + ky + 1;
+    L.n00 = kx * ny + ky;       L.n01 = kx * ny + ky + 1;
+    L.n10 = (kx + 1) * ny + ky; L.n11 = (kx + 1) * ny + ky + 1;
     const double X1 = P.gx[kx], X2 = P.gx[kx + 1], Y1 = P.gy[ky], Y2 = P.gy[ky + 1];
     L.dxs = X2 - X1; L.dys = Y2 - Y1;
     L.idxs = frcp(L.dxs); L.idys = frcp(L.dys);
@@ -102,7 +103,7 @@ DEVINL CornerW corner_weights(const Herm& hx, const Herm& hy, int a, int b){
     if(WANT_E){ w.E[0] = xh * ydh; w.E[1] = xg * ydh; w.E[2] = xh * ydg; w.E[3] = xg * ydg; }
     return w;
 }
-DEVINL int corner_node(const GridLoc& L, int a, int b){ return a ? (b ? L.nb[1][1] : L.nb[1][0]) : (b ? L.nb[0][1] : L.nb[0][0]); }
+DEVINL int corner_node(const GridLoc& L, int a, int b){ return a ? (b ? L.n11 : L.n10) : (b ? L.n01 : L.n00); }
 DEVINL double dot4(const double* w, double F, double FX, double FY, double FXY, double acc){
     return __builtin_fma(w[0], F, __builtin_fma(w[1], FX, __builtin_fma(w[2], FY, __builtin_fma(w[3], FXY, acc))));
 }
@@ -234,7 +235,7 @@ DEVINL void grid_eval3_coop(const GeoacDevParams& P, const GridLoc& L, double (*
     unsigned gb[4];                                                                   // global bases of the quad's owners for the corner being fetched
     const unsigned wb[4] = { 0u, 16u, 32u, 48u };
     {
-        const unsigned off = ((unsigned)L.kz * nn + (unsigned)L.nb[0][0]) * (unsigned)(GEOAC_GREC * sizeof(double));
+        const unsigned off = ((unsigned)L.kz * nn + (unsigned)corner_node(L, 0, 0)) * (unsigned)(GEOAC_GREC * sizeof(double));
         gb[0] = quad_bcast_u32<0>(off) + rb; gb[1] = quad_bcast_u32<1>(off) + (rb - 160u); gb[2] = quad_bcast_u32<2>(off) + (rb - 320u); gb[3] = quad_bcast_u32<3>(off) + (rb - 480u);
     }
     geoac_d2 v[10];                                                                   // in flight: the NEXT half-record's chunks
@@ -249,7 +250,7 @@ DEVINL void grid_eval3_coop(const GeoacDevParams& P, const GridLoc& L, double (*
         if(h + 1 < 24){
             const int n1 = (h + 1) >> 1, part1 = (h + 1) & 1, cn1 = n1 / 3, f1 = n1 % 3;
             if(part1 == 0 && f1 == 0){                                                // first half-record of the next corner: its owners' bases
-                const unsigned off = ((unsigned)L.kz * nn + (unsigned)L.nb[cn1 >> 1][cn1 & 1]) * (unsigned)(GEOAC_GREC * sizeof(double));
+                const unsigned off = ((unsigned)L.kz * nn + (unsigned)corner_node(L, cn1 >> 1, cn1 & 1)) * (unsigned)(GEOAC_GREC * sizeof(double));
                 gb[0] = quad_bcast_u32<0>(off) + rb; gb[1] = quad_bcast_u32<1>(off) + (rb - 160u); gb[2] = quad_bcast_u32<2>(off) + (rb - 320u); gb[3] = quad_bcast_u32<3>(off) + (rb - 480u);
             }
             const char* __restrict__ fb = tabb + (size_t)f1 * fstride + 160 * part1;

@@ -107,7 +107,7 @@ def test_config3_global_720x180_bounces3(G):
 @pytest.mark.parametrize("eqname,total", [("EQ_GLOBAL", 874273730), ("EQ_3D", 871080426)])
 def test_full_fan_is_schedule_independent(G, eqname, total):
     """the 360 x 90 fan of the spherical and of the 3-D stratified set under different launch plans - default hybrid split, a deliberately bad split (only 3 % of the rays on the
-    two-lane kernel: the merge-back rule takes over), one lane for every ray, two chunks, 4096-row epochs - gives bit-identical
+    two-lane kernel: the merge-back rule takes over), one lane for every ray with and without live-ray compaction between epochs, two chunks, 4096-row epochs - gives bit-identical
     records: which kernel variant integrates a ray, and in which epoch pattern, must not matter"""
     th, ph = G.fan_enumerate(phi_min=-180.0, phi_max=179.0, phi_step=1.0)
     params = dict(bounces=2, calc_amp=1, mode=0)
@@ -130,7 +130,9 @@ def test_full_fan_is_schedule_independent(G, eqname, total):
         return rec, steps
     ref, steps = run({})
     assert steps == total
-    for env in ({"GEOAC_PAIR_FRAC": "0.03"}, {"GEOAC_NO_PAIR": "1"}, {"GEOAC_TWO_CHUNKS": "1", "GEOAC_S_ROWS": "4096"}, {"GEOAC_PAIR_FRAC": "1.0"}):
+    # GEOAC_NO_PAIR: one launch per epoch, which runs over the compacted list of live rays (k_compact); with GEOAC_COMPACT=0 over all slots
+    for env in ({"GEOAC_PAIR_FRAC": "0.03"}, {"GEOAC_NO_PAIR": "1"}, {"GEOAC_NO_PAIR": "1", "GEOAC_COMPACT": "0"},
+                {"GEOAC_TWO_CHUNKS": "1", "GEOAC_S_ROWS": "4096"}, {"GEOAC_PAIR_FRAC": "1.0"}, {"GEOAC_PAIR_FRAC": "0"}):
         rec, st = run(env)
         assert st == steps, env
         assert np.array_equal(rec, ref), env
