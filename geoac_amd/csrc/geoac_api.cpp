@@ -61,6 +61,7 @@ struct geoac_ctx {
     int  spread_override = 0;        // GEOAC_SPREAD=n: force n-way lane thinning of the grid-set RK4 waves (1 = dense); 0 = automatic
     bool compact = true;             // GEOAC_COMPACT=0: every epoch runs over all slots (no live-ray compaction between epochs)
     DevBuf colmap[3], ncols;         // per chunk: column -> slot list of the rays alive at the start of that epoch; their counts (3 ints)
+    bool quad_cache = true;          // GEOAC_QUAD_CACHE=0: four-lane grid kernels without the per-lane record cache (A/B)
     bool grid_coop = true;           // GEOAC_GRID_COOP=0: per-lane table gathers instead of the wave-cooperative gather (A/B runs, schedule-independence test)
     hipStream_t stream = nullptr; bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -228,6 +229,8 @@ int geoac_create(geoac_ctx** out, int eqset, int device){
     if(nsp && atoi(nsp) > 0) ctx->spread_override = atoi(nsp);
     const char* cp = getenv("GEOAC_COMPACT");
     if(cp) ctx->compact = (atoi(cp) != 0);
+    const char* qc = getenv("GEOAC_QUAD_CACHE");
+    if(qc) ctx->quad_cache = (atoi(qc) != 0);
     const char* gc = getenv("GEOAC_GRID_COOP");
     if(gc) ctx->grid_coop = (atoi(gc) != 0);
     const char* sc = getenv("GEOAC_SMP_CAP");
@@ -561,6 +564,9 @@ int geoac_fan_launch(geoac_ctx* ctx){
         while(P.spread < 4 && (long long)P.n_pad * (P.spread * 2) / 64 <= 1024) P.spread *= 2;
         if(ctx->spread_override > 0){ P.spread = 1; while(P.spread * 2 <= ctx->spread_override && P.spread < 64) P.spread *= 2; }
     }
+    // small four-lane fans (at most one wave per CU): records and z nodes cached in LDS, the stage latency is what such a fan costs
+    P.quad_cache = (is_grid && P.lanes_per_ray == 4 && ctx->quad_cache && (long long)P.n_pad * 4 / 64 <= 256 &&
+                    2 * GEOAC_MAXE * 64 * sizeof(double) + 64 * 976 + (size_t)(P.nseg + 1) * sizeof(double) <= 160 * 1024) ? 1 : 0;
     // dense one-lane-per-ray grid fans (more waves than SIMDs): the quads of a wave fetch the table records together (grid_eval3_coop)
     P.coop = (is_grid && P.lanes_per_ray == 1 && P.spread == 1 && ctx->grid_coop) ? 1 : 0;
 

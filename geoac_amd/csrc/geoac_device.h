@@ -55,6 +55,7 @@ struct GeoacDevParams {
     int     lanes_per_ray;          // 2: Global + CalcAmp without sample capture runs the two-lanes-per-ray kernel
     int     spread;                 // grid sets: only every spread-th lane of a wave carries a ray (power of two, 1..64): a small fan is
                                     // spread over more waves so that each divergent table gather touches fewer cache lines per instruction
+    int     quad_cache;             // grid sets, four lanes per ray, at most 256 waves: per-lane record cache and z nodes in LDS (grid_cache_fill)
     int     coop;                   // grid sets, one lane per ray: wave-cooperative record gather through LDS (grid_eval3_coop)
     int     seg_safe;               // 1: every spline segment is longer than the largest RK4 step => the +-1 segment move is exact
     int     pp_blocks;              // grid size of the persistent post-pass kernel

@@ -464,6 +464,7 @@ struct RayCtx {
     double a[6];      // Global: sin/cos(lat), sin/cos(lon - lon_src) carried along the ray
                       // 3D: nu_x, nu_y, mu_x_th, mu_y_th, mu_x_ph, mu_y_ph ; 2D: cos(phi), sin(phi), cos(theta), sin(theta)
     double t[4];      // Global: proposed sin/cos for the row under test
+    mutable int ckey; // record-cache kernels: (segment, node) key of the records this lane holds in LDS (-1: none)
 };
 
 template <bool AMP, int NQ = 2, typename TabPtr = const double*>
@@ -548,7 +549,7 @@ DEVINL void cart2_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCt
 // ================================================================================================
 template <bool AMP_> struct EqGlobal {
     static constexpr bool AMP = AMP_;
-    static constexpr bool COOP = false; static constexpr bool LDS_STATE = false;
+    static constexpr bool COOP = false; static constexpr bool CACHE = false; static constexpr bool LDS_STATE = false;
     static constexpr int PP_WAVES = 3;                              // post-pass waves per SIMD (168 registers; at 128 it spills 148 B and runs 1.5 x slower)
     static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 0, LANES = 1;
     static constexpr bool SPLIT = false;                            // true: the lanes of a ray carry DIFFERENT parts of its state (EqGlobalPair)
@@ -722,7 +723,8 @@ struct EqGlobalPair : EqGlobal<true> {
 #include "geoac_rngdep.h"
 
 // Range-dependent Cartesian set (GeoAc3D.RngDep): EquationSets.3DRngDep.cpp + G2S_MultiDimSpline3D.cpp
-template <bool AMP_, int NL_ = 1, bool COOP_ = false> struct Eq3DRngDep {
+template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struct Eq3DRngDep {
+    static constexpr bool CACHE = CACHE_;                           // NL_ = 4, small fans: per-lane record cache and z nodes in LDS (grid_cache_fill)
     static constexpr bool AMP = AMP_;
     static constexpr bool COOP = COOP_;                             // wave-cooperative record gather through LDS (grid_eval3_coop): NL_ = 1, every lane of the wave stays in the loop
     static constexpr bool LDS_STATE = true;                         // the step's rows y and yn live in LDS while the four stages run (the grid kernels use no LDS otherwise)
@@ -769,7 +771,7 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false> struct Eq3DRngDep {
     static DEVINL double above_ground(const GeoacDevParams& P, const double* y){ return y[2] - P.ground; }
     template <typename TabPtr>
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
-        rngdep_rhs<AMP, NL_, COOP_>(P, seg, yt, dy, (int)(threadIdx.x & (NL_ - 1)), (char*)tab);
+        rngdep_rhs<AMP, NL_, COOP_, CACHE_>(P, seg, yt, dy, (int)(threadIdx.x & (NL_ - 1)), (char*)tab, &C.ckey);
     }
     // 3DRngDep.cpp:451-472
     static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, long long k, bool& brk, bool& gnd){
@@ -857,7 +859,8 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false> struct Eq3DRngDep {
 
 // Range-dependent spherical set (GeoAcGlobal.RngDep): EquationSets.GlobalRngDep.cpp + G2S_GlobalMultiDimSpline3D.cpp.
 // Grid axes in table order: x = latitude, y = longitude [rad], z = geocentric radius; xy_lim = lat/lon box of the break check.
-template <bool AMP_, int NL_ = 1, bool COOP_ = false> struct EqGlobalRngDep {
+template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struct EqGlobalRngDep {
+    static constexpr bool CACHE = CACHE_;
     static constexpr bool AMP = AMP_;
     static constexpr bool COOP = COOP_;
     static constexpr bool LDS_STATE = true;
@@ -902,7 +905,7 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false> struct EqGlobalRngDep {
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
         double s2, c2;
         rot_small(C.a[0], C.a[1], yt[1] - y0[1], s2, c2);          // sin/cos(lat) carried along the ray, as in EqGlobal
-        globalrd_rhs<AMP, NL_, COOP_>(P, seg, yt, s2, c2, dy, (int)(threadIdx.x & (NL_ - 1)), (char*)tab);
+        globalrd_rhs<AMP, NL_, COOP_, CACHE_>(P, seg, yt, s2, c2, dy, (int)(threadIdx.x & (NL_ - 1)), (char*)tab, &C.ckey);
     }
     // GeoAc_BreakCheck / GeoAc_GroundCheck: GlobalRngDep.cpp:523-545
     static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, long long k, bool& brk, bool& gnd){
@@ -993,7 +996,7 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false> struct EqGlobalRngDep {
 
 template <bool AMP_> struct Eq3D {
     static constexpr bool AMP = AMP_;
-    static constexpr bool COOP = false; static constexpr bool LDS_STATE = false;
+    static constexpr bool COOP = false; static constexpr bool CACHE = false; static constexpr bool LDS_STATE = false;
     static constexpr int PP_WAVES = 4;                              // post-pass at four waves per SIMD (127 registers, 52 B of spill): GeoAc3D 360 x 90 fan 185 -> 168 ms
     static constexpr int E = AMP_ ? 12 : 4, PW = 4, HIDX = 2, LANES = 1;
     static constexpr bool SPLIT = false;
@@ -1147,7 +1150,7 @@ struct Eq3DPair : Eq3D<true> {
 
 template <bool AMP_> struct Eq2D {
     static constexpr bool AMP = AMP_;
-    static constexpr bool COOP = false; static constexpr bool LDS_STATE = false;
+    static constexpr bool COOP = false; static constexpr bool CACHE = false; static constexpr bool LDS_STATE = false;
     static constexpr int NB = 3, NS = 3;
     static constexpr int PP_WAVES = 4;
     static constexpr int E = AMP_ ? 6 : 3, PW = 2, HIDX = 1, LANES = 1;
@@ -1323,6 +1326,17 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
     // cooperative-gather policies keep every lane of the wave in the step loop: a lane whose ray has finished (or a padding lane) goes on
     // fetching table records for its quad mates (grid_eval3_coop); all its own side effects are switched off
     const bool idle0 = done;                                     // finished before this epoch: nothing of this lane's is written
+    // record-cache kernels (one wave per workgroup): behind the state rows, 64 x 976 B of per-lane records, then a copy of the z nodes,
+    // staged by ALL 64 lanes before the lanes without a live ray leave
+    constexpr int LDS_STATE_BYTES = (EQ::COOP ? 64 * GEOAC_COOP_SLOT : 0) + (EQ::LDS_STATE ? 2 * GEOAC_MAXE * 64 * (int)sizeof(double) : 0);
+    char* const ldsc = (char*)lds_tab + (threadIdx.x >> 6) * LDS_STATE_BYTES + LDS_STATE_BYTES;
+    if(EQ::CACHE){
+        double* gzl = (double*)(ldsc + GEOAC_CACHE_BYTES);
+        for(int i = threadIdx.x & 63; i <= P.nseg; i += 64) gzl[i] = P.gz[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");          // every lane reads entries other lanes wrote
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    }
     if(!EQ::COOP && done) return;
     // per wave: (COOP) the 64 x 176 B exchange buffer of the cooperative gather, then (LDS_STATE) y[E][64] and yn[E][64]
     constexpr int LDS_XCHG_BYTES = EQ::COOP ? 64 * GEOAC_COOP_SLOT : 0;
@@ -1346,6 +1360,7 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
     int leg = (int)st[ST_LEG * np];
     double hmax = st[ST_HMAX * np];
     RayCtx C;
+    C.ckey = -1;
     C.c0 = st[ST_C0 * np]; C.nu0 = st[ST_NU0 * np];
     #pragma unroll
     for(int q = 0; q < 6; q++) C.a[q] = st[(ST_AUX0 + q) * np];
@@ -1408,6 +1423,7 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
         #pragma unroll 1
         for(int stage = 0; stage < 4; stage++){
             if(EQ::COOP) EQ::rhs((double*)ldsw, P, seg, C, y, yt, stage, dy);
+            else if(EQ::CACHE) EQ::rhs((double*)ldsc, P, seg, C, y, yt, stage, dy);
             else if(LDS) EQ::rhs(lds_tab, P, seg, C, y, yt, stage, dy); else EQ::rhs(gtab, P, seg, C, y, yt, stage, dy);
             const double wa = ((stage == 2) ? 1.0 : 0.5) * ds;
             const double wb = ((stage == 0 || stage == 3) ? (1.0 / 6.0) : (1.0 / 3.0)) * ds;
@@ -1747,7 +1763,14 @@ __global__ void __launch_bounds__(64) k_probe_grid(GeoacDevParams P, int n, cons
 
 // RK4 only: the grid sets have four-lanes-per-ray variants (small fans)
 #define GEOAC_DISPATCH_EQ_RK4(P, CALL) \
-    if((P)->lanes_per_ray == 4){ \
+    if((P)->lanes_per_ray == 4 && (P)->quad_cache){ \
+        switch((P)->eqset * 2 + ((P)->calc_amp ? 1 : 0)){ \
+            case GEOAC_EQ_3D_RNGDEP * 2 + 1: { using EQ = Eq3DRngDep<true, 4, false, true>;  CALL; } break; \
+            case GEOAC_EQ_3D_RNGDEP * 2 + 0: { using EQ = Eq3DRngDep<false, 4, false, true>; CALL; } break; \
+            case GEOAC_EQ_GLOBAL_RNGDEP * 2 + 1: { using EQ = EqGlobalRngDep<true, 4, false, true>;  CALL; } break; \
+            case GEOAC_EQ_GLOBAL_RNGDEP * 2 + 0: { using EQ = EqGlobalRngDep<false, 4, false, true>; CALL; } break; \
+            default: return hipErrorNotSupported; } \
+    } else if((P)->lanes_per_ray == 4){ \
         switch((P)->eqset * 2 + ((P)->calc_amp ? 1 : 0)){ \
             case GEOAC_EQ_3D_RNGDEP * 2 + 1: { using EQ = Eq3DRngDep<true, 4>;  CALL; } break; \
             case GEOAC_EQ_3D_RNGDEP * 2 + 0: { using EQ = Eq3DRngDep<false, 4>; CALL; } break; \
@@ -1785,6 +1808,10 @@ static hipError_t launch_rk4_t(const GeoacDevParams* P, int block, hipStream_t s
     if(n_wg) *n_wg = g.x;
     size_t lds = P->table_in_lds ? (size_t)P->nseg * GEOAC_SEGW * sizeof(double) : 0;
     if(EQ::LDS_STATE) lds = (size_t)(block / 64) * ((EQ::COOP ? 64 * GEOAC_COOP_SLOT : 0) + 2 * GEOAC_MAXE * 64 * sizeof(double));   // per wave: exchange buffer, y and yn rows (k_rk4)
+    if(EQ::CACHE){
+        if(block != 64) return hipErrorInvalidValue;
+        lds += GEOAC_CACHE_BYTES + (size_t)(P->nseg + 1) * sizeof(double);                 // per-lane records, z nodes
+    }
     const bool smp = (P->mode & (GEOAC_MODE_WRITE_RAYS | GEOAC_MODE_WRITE_CAUSTICS)) != 0;
     #define GEOAC_RK4_LAUNCH(LDSF, SMPF) do { \
         if(lds > 65536){ \

@@ -37,7 +37,8 @@ struct GridLoc {
 };
 
 // locate (x, y, z) (already clamped to the grid): cell, corners, vertical segment.  kz_hint < 0: search from scratch.
-DEVINL void grid_locate(const GeoacDevParams& P, double x, double y, double z, int kz_hint, GridLoc& L){
+DEVINL void grid_locate(const GeoacDevParams& P, double x, double y, double z, int kz_hint, GridLoc& L, const double* __restrict__ gzp = nullptr){
+    const double* __restrict__ gz = gzp ? gzp : P.gz;              // the z nodes: global table, or the kernel's LDS copy (record-cache kernels)
     const int nx = P.gnx, ny = P.gny;
     int kx = 0, ky = 0;
     for(int i = 1; i < nx - 1; i++) kx += (x >= P.gx[i]) ? 1 : 0;       // last i with x >= X[i], capped at nx-2 (branch-free scan)
@@ -48,10 +49,10 @@ DEVINL void grid_locate(const GeoacDevParams& P, double x, double y, double z, i
         kz = (int)((z - P.x_min) / span * (double)P.nseg);
         kz = kz < 0 ? 0 : (kz > P.nseg - 1 ? P.nseg - 1 : kz);
     } else kz = kz_hint;
-    while(kz > 0 && z < P.gz[kz]) kz--;
-    while(kz < P.nseg - 1 && z > P.gz[kz + 1]) kz++;
+    while(kz > 0 && z < gz[kz]) kz--;
+    while(kz < P.nseg - 1 && z > gz[kz + 1]) kz++;
     L.kz = kz;
-    L.t = z - P.gz[kz];
+    L.t = z - gz[kz];
     L.n00 = kx * ny + ky;       L.n01 = kx * ny + ky + 1;
     L.n10 = (kx + 1) * ny + ky; L.n11 = (kx + 1) * ny + ky + 1;
     const double X1 = P.gx[kx], X2 = P.gx[kx + 1], Y1 = P.gy[ky], Y2 = P.gy[ky + 1];
@@ -73,9 +74,10 @@ DEVINL Herm hermite(double s){
 
 // one vertical cubic (c0, c1, 2 c2, 6 c3), 32-byte aligned: two 16-byte loads
 struct Cub { double c0, c1, d2, e3; };
-DEVINL Cub load_cubic(const double* __restrict__ c){
-    const double2* q = (const double2*)__builtin_assume_aligned(c, 16);
-    const double2 lo = q[0], hi = q[1];
+typedef double geoac_d2 __attribute__((ext_vector_type(2)));       // one 16-byte chunk (native vector: stays in registers)
+DEVINL Cub load_cubic(const double* c){
+    const geoac_d2* q = (const geoac_d2*)__builtin_assume_aligned(c, 16);
+    const geoac_d2 lo = q[0], hi = q[1];
     return Cub{ lo.x, lo.y, hi.x, hi.y };
 }
 // f = c0 + t (c1 + t/2 (d2 + t/3 e3)), f' = c1 + t (d2 + t/2 e3): three and two FMAs (t/2, t/3 are common to all cubics of an evaluation)
@@ -133,8 +135,9 @@ DEVINL double pair_sum(double v){
 
 // NL = 2 or 4 lanes per ray (small fans).  Lane cq of the group evaluates 4/NL of the cell corners and the partial sums are added
 // across the group: 3 (NL = 4) or 6 (NL = 2) dependent gather batches per RHS instead of 12 (the kernel is bound by their latency).
+// rec_lds (four-lane kernels with a record cache): this lane's record of `field` for its corner, already in LDS
 template <bool ORDER2, bool GLB, int NL = 1>
-DEVINL void grid_eval_all(const GeoacDevParams& P, int field, const GridLoc& L, double* out, int cq = 0){
+DEVINL void grid_eval_all(const GeoacDevParams& P, int field, const GridLoc& L, double* out, int cq = 0, const double* rec_lds = nullptr){
     const Herm hx = hermite(L.xs), hy = hermite(L.ys);
     const double dxs = L.dxs, dys = L.dys, dxy = dxs * dys;
     const double t = L.t, th = 0.5 * t, t6 = t * (1.0 / 6.0);
@@ -146,7 +149,7 @@ DEVINL void grid_eval_all(const GeoacDevParams& P, int field, const GridLoc& L, 
     for(int cn = cq * (4 / NL); cn < (cq + 1) * (4 / NL); cn++){
         {
             const int a = cn >> 1, b = cn & 1;
-            const double* __restrict__ r = base + (size_t)corner_node(L, a, b) * GEOAC_GREC;
+            const double* r = rec_lds ? rec_lds : base + (size_t)corner_node(L, a, b) * GEOAC_GREC;
             Cub c[10];                                             // all 20 loads of the corner in flight before the first use
             #pragma unroll
             for(int i = 0; i < 10; i++) c[i] = load_cubic(r + 4 * i);
@@ -205,7 +208,6 @@ DEVINL void grid_eval_all(const GeoacDevParams& P, int field, const GridLoc& L, 
 #ifndef GEOAC_COOP_WAVES
 #define GEOAC_COOP_WAVES 1            // waves per SIMD the cooperative kernels are compiled for
 #endif
-typedef double geoac_d2 __attribute__((ext_vector_type(2)));       // one 16-byte chunk (native vector: stays in registers)
 template <int O> DEVINL unsigned quad_bcast_u32(unsigned v){ return (unsigned)__builtin_amdgcn_mov_dpp((int)v, O * 0x55, 0xF, 0xF, true); }
 
 template <bool ORDER2, bool GLB>
@@ -307,6 +309,35 @@ DEVINL void grid_eval3_coop(const GeoacDevParams& P, const GridLoc& L, double (*
     }
 }
 
+// ---- per-lane record cache (four lanes per ray, small fans: eigenray rounds, -interactive) ---------------------------------------
+// A small fan leaves most of the chip idle and lasts as long as its longest ray: what counts is the latency of one RK4 stage, and that
+// was two dependent trips to memory (z nodes, then the table records) in front of the arithmetic.  A ray stays in one cell and one
+// vertical segment for tens of stages, so each lane keeps the three records (T, u, v) of ITS corner in LDS - 976 B per lane (960 B +
+// 16 B pad: the ds_read_b128 / ds_write_b128 of a wave are bank-conflict free), filled from the table only when (segment, node)
+// changes - and the kernel keeps a copy of the z nodes behind it.  One wave per CU (92 KB of LDS): for fans of at most 256 waves.
+#define GEOAC_CACHE_SLOT 976
+#define GEOAC_CACHE_BYTES (64 * GEOAC_CACHE_SLOT)
+DEVINL const double* grid_cache_fill(const GeoacDevParams& P, const GridLoc& L, int cq, char* cache, int* ckey){
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned nn = (unsigned)(P.gnx * P.gny);
+    const int key = L.kz * (int)nn + corner_node(L, cq >> 1, cq & 1);
+    char* mine = cache + lane * GEOAC_CACHE_SLOT;
+    if(key != *ckey){                                              // (the four lanes of a ray change cell / segment together)
+        const size_t fstride = (size_t)P.nseg * nn * (GEOAC_GREC * sizeof(double));
+        const char* __restrict__ src = (const char*)P.gtab + (size_t)key * (GEOAC_GREC * sizeof(double));
+        geoac_d2 v[20];
+        #pragma unroll
+        for(int f = 0; f < 3; f++){
+            #pragma unroll
+            for(int j = 0; j < 20; j++) v[j] = *(const geoac_d2*)(src + f * fstride + 16 * j);
+            #pragma unroll
+            for(int j = 0; j < 20; j++) *(geoac_d2*)(mine + f * (GEOAC_GREC * (int)sizeof(double)) + 16 * j) = v[j];
+        }
+        *ckey = key;
+    }
+    return (const double*)mine;
+}
+
 // Eval_Spline_f (:806-863): scalar value, y rows scaled by dx_scalar (Q11; the spherical twin :755-807 uses dp_scalar)
 template <bool GLB>
 DEVINL double grid_eval_f(const GeoacDevParams& P, int field, const GridLoc& L){
@@ -374,15 +405,19 @@ DEVINL Medium3 medium3_at(const GeoacDevParams& P, double x, double y, double z)
 
 // fused GeoAc_UpdateSources + GeoAc_EvalSrcEq of the range-dependent Cartesian set (EquationSets.3DRngDep.cpp:218-393)
 // y: x, y, z, nu_x, nu_y, nu_z | X_th(3), mu_th(3) | X_ph(3), mu_ph(3)
-template <bool AMP, int NL = 1, bool COOP = false>
-DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double* dy, int cq = 0, char* ldsw = nullptr){
+template <bool AMP, int NL = 1, bool COOP = false, bool CACHE = false>
+DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double* dy, int cq = 0, char* ldsw = nullptr, int* ckey = nullptr){
     const double xe = clampd(y[0], P.gx[0], P.gx[P.gnx - 1]), ye = clampd(y[1], P.gy[0], P.gy[P.gny - 1]), ze = clampd(y[2], P.x_min, P.x_max);
-    GridLoc L; grid_locate(P, xe, ye, ze, kz, L);
+    GridLoc L; grid_locate(P, xe, ye, ze, kz, L, CACHE ? (const double*)(ldsw + GEOAC_CACHE_BYTES) : nullptr);
     kz = L.kz;
     double M[3][10];                                               // T, u, v and their derivatives
     // three copies of the evaluator: M[][] stays in registers (rolled, the dynamic index f put it in scratch: 240 B written and read back per stage)
     if(COOP) grid_eval3_coop<AMP, false>(P, L, M, ldsw);
-    else {
+    else if(CACHE){
+        const double* rec = grid_cache_fill(P, L, cq, ldsw, ckey);
+        #pragma unroll
+        for(int f = 0; f < 3; f++) grid_eval_all<AMP, false, NL>(P, f, L, M[f], cq, rec + f * GEOAC_GREC);
+    } else {
         #pragma unroll
         for(int f = 0; f < 3; f++) grid_eval_all<AMP, false, NL>(P, f, L, M[f], cq);
     }
@@ -445,15 +480,19 @@ DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double
 // fused GeoAc_UpdateSources + GeoAc_EvalSrcEq of the range-dependent spherical set (EquationSets.GlobalRngDep.cpp:226-458):
 // the algebra of global_rhs (geoac_kernels.hip) with the full gradient and second-derivative matrices of c, u, v (w = 0).
 // y: r, lat, lon, nu_r, nu_t, nu_p | R_lt(3), mu_lt(3) | R_lp(3), mu_lp(3);  sth/cth = sin/cos(lat) from the caller.
-template <bool AMP, int NL = 1, bool COOP = false>
-DEVINL void globalrd_rhs(const GeoacDevParams& P, int& kz, const double* y, double sth, double cth, double* dy, int cq = 0, char* ldsw = nullptr){
+template <bool AMP, int NL = 1, bool COOP = false, bool CACHE = false>
+DEVINL void globalrd_rhs(const GeoacDevParams& P, int& kz, const double* y, double sth, double cth, double* dy, int cq = 0, char* ldsw = nullptr, int* ckey = nullptr){
     const double r = y[0];
     const double te = clampd(y[1], P.gx[0], P.gx[P.gnx - 1]), pe = clampd(y[2], P.gy[0], P.gy[P.gny - 1]), re = clampd(r, P.x_min, P.x_max);
-    GridLoc L; grid_locate(P, te, pe, re, kz, L);
+    GridLoc L; grid_locate(P, te, pe, re, kz, L, CACHE ? (const double*)(ldsw + GEOAC_CACHE_BYTES) : nullptr);
     kz = L.kz;
     double M[3][10];                                               // table order: f, f_t, f_p, f_r, f_tt, f_pp, f_rr, f_tp, f_tr, f_pr
     if(COOP) grid_eval3_coop<AMP, true>(P, L, M, ldsw);
-    else {
+    else if(CACHE){
+        const double* rec = grid_cache_fill(P, L, cq, ldsw, ckey);
+        #pragma unroll
+        for(int f = 0; f < 3; f++) grid_eval_all<AMP, true, NL>(P, f, L, M[f], cq, rec + f * GEOAC_GREC);
+    } else {
         #pragma unroll
         for(int f = 0; f < 3; f++) grid_eval_all<AMP, true, NL>(P, f, L, M[f], cq);
     }

@@ -8,14 +8,42 @@ import geoac_amd as G
 import harness as H
 
 
+LAST = {}
+
+
 def run_fan(ctx, th, ph, reps=2):
     ctx.set_angles(th, ph)
     ctx.launch()                                   # warm-up (allocations, first-touch)
     t0 = time.perf_counter()
+    ms_rk4 = 0.0; epochs = 0
     for _ in range(reps):
         ctx.launch()
+        tm = ctx.timing(); ms_rk4 += tm["ms_rk4"]; epochs += tm["epochs"]
     dt = (time.perf_counter() - t0) / reps
+    LAST.update(ms_rk4=ms_rk4 / reps, epochs=epochs / reps)
     return ctx.total_steps(), dt
+
+
+HBM_PEAK, L1_PEAK = 8000.0, 64.0 * 256 * 2.4        # GB/s: HBM3E; vector L1: 64 B/clk/CU x 256 CUs x 2.4 GHz (MI355X_MICROARCH.md)
+
+
+def roofline(r, grid_gather=False):
+    """per-configuration roofline object (bench.py's conventions): the dominant kernel is k_rk4; duration = HIP events around its
+    launches (inside libgeoac_hip).  Stratified sets: the SURVEY 8(d) contract figure, 8 B x E per step against HBM peak (the kernels are
+    FP64-latency bound).  Grid sets: the binding resource is the per-lane gather of table records through the texture /
+    L1 path: 4 stages x 3 fields x 4 corners x 320 B = 15 360 B per ray-step, against 64 B/clk/CU."""
+    steps, ms = r["ray_steps"], LAST.get("ms_rk4", 0.0)
+    if ms <= 0:
+        return None
+    E = r.get("E", 18)
+    hbm = 8.0 * E * steps / (ms * 1e-3) / 1e9
+    out = {"kernel": r.get("kernel", "k_rk4"), "rk4_ms_per_pass": ms, "launches_per_pass": LAST.get("epochs"), "alg_bytes_per_step": 8 * E,
+           "bound": "fp64_valu_latency", "achieved": hbm, "peak": HBM_PEAK, "unit": "GB/s", "frac": hbm / HBM_PEAK, "traffic": None}
+    if grid_gather:
+        g = 15360.0 * steps / (ms * 1e-3) / 1e9
+        out.update({"bound": "l1_gather", "achieved": g, "peak": L1_PEAK, "frac": g / L1_PEAK, "alg_bytes_per_step": 15360,
+                    "hbm_contract": {"achieved": hbm, "peak": HBM_PEAK, "frac": hbm / HBM_PEAK, "alg_bytes_per_step": 8 * E}})
+    return out
 
 
 def cfg1():
@@ -31,7 +59,8 @@ def cfg2():
     ctx.set_params(bounces=2, calc_amp=1, mode=0)
     th, ph = G.fan_enumerate(phi_min=-180.0, phi_max=179.0, phi_step=1.0)
     steps, dt = run_fan(ctx, th, ph)
-    return dict(config="cfg2 GeoAc3D 360 az x 90 incl, bounces=2, CalcAmp=True", rays=len(th), ray_steps=steps, seconds=dt)
+    return dict(config="cfg2 GeoAc3D 360 az x 90 incl, bounces=2, CalcAmp=True", rays=len(th), ray_steps=steps, seconds=dt, E=12,
+                kernel="k_rk4<Eq3DPair,true,false> || k_rk4<Eq3D<true>,true,false>")
 
 
 def cfg3():
@@ -39,7 +68,8 @@ def cfg3():
     ctx.set_params(bounces=3, calc_amp=1, mode=0, src=(0.0, 30.0, 0.0))
     th, ph = G.fan_enumerate(theta_min=0.25, theta_max=45.0, theta_step=0.25, phi_min=-180.0, phi_max=179.5, phi_step=0.5)
     steps, dt = run_fan(ctx, th, ph, reps=1)
-    return dict(config="cfg3 GeoAcGlobal 720 az x 180 incl, bounces=3, CalcAmp=True", rays=len(th), ray_steps=steps, seconds=dt)
+    return dict(config="cfg3 GeoAcGlobal 720 az x 180 incl, bounces=3, CalcAmp=True", rays=len(th), ray_steps=steps, seconds=dt, E=18,
+                kernel="k_rk4<EqGlobal<true>,true,false>")
 
 
 def cfg4(thin=1):
@@ -51,7 +81,8 @@ def cfg4(thin=1):
     th, ph = G.fan_enumerate(theta_min=0.05, theta_max=50.0, theta_step=0.05, phi_min=-180.0, phi_max=-180.0 + 124 * 0.36, phi_step=0.36)
     steps, dt = run_fan(ctx, th, ph, reps=1)
     nz = 1400 // thin
-    return dict(config=f"cfg4 GeoAc3D.RngDep 5x5x{nz} grid, 1/8 of 1000 az x 1000 incl (125 az), bounces=1, CalcAmp=True", rays=len(th), ray_steps=steps, seconds=dt)
+    return dict(config=f"cfg4 GeoAc3D.RngDep 5x5x{nz} grid, 1/8 of 1000 az x 1000 incl (125 az), bounces=1, CalcAmp=True", rays=len(th), ray_steps=steps, seconds=dt,
+                E=18, kernel="k_rk4<Eq3DRngDep<true,1,true>,false,false>", grid=True)
 
 
 def cfg4_350():
@@ -76,6 +107,11 @@ def cfg5():
 if __name__ == "__main__":
     which = sys.argv[1:] or ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"]
     for w in which:
+        LAST.clear()
         r = globals()[w]()
         r["ray_steps_per_s"] = r["ray_steps"] / r["seconds"]
+        rf = roofline(r, grid_gather=bool(r.pop("grid", False))) if w not in ("cfg1", "cfg5") else None
+        r.pop("E", None); r.pop("kernel", None)
+        if rf:
+            r["roofline"] = rf
         print(json.dumps(r), flush=True)
