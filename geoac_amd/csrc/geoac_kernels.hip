@@ -1372,9 +1372,10 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
 
     if(!EQ::COOP || !idle0) write_row<EQ>(P, nr++, col, q, y);     // carry row: chunk row 0 = current state
 
-    while(true){
-        const bool act = (nr + 2 <= P.s_rows) && !done;
-        if(EQ::COOP ? !__any(act) : !act) break;                  // COOP: wave-uniform exit, `act` predicates this lane's own work
+    // COOP: wave-uniform loop (every lane stays while any lane of the wave has work; `act` predicates this lane's own work).
+    // Other policies: the plain per-lane loop (kept in this form: the latency-bound stratified kernels are sensitive to how the loop is laid out)
+    while(EQ::COOP ? (bool)__any((nr + 2 <= P.s_rows) && !done) : ((nr + 2 <= P.s_rows) && !done)){
+        const bool act = EQ::COOP ? ((nr + 2 <= P.s_rows) && !done) : true;
         double ds = P.ds_min;
         if(!EQ::COOP || act){
         // running turning height: max over rows m < k of the height component   (GeoAcGlobal_main.cpp:294)

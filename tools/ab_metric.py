@@ -1,0 +1,28 @@
+"""A/B of two builds of libgeoac_hip.so on the metric fan, same box, same process order: usage ab_metric.py <libA.so> <libB.so> [passes]"""
+import ctypes, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import geoac_amd.api as A
+import harness as H
+
+
+def run(lib_path, passes):
+    A._lib = None
+    A.library_path = lambda: lib_path
+    import geoac_amd as G
+    th, ph = A.fan_enumerate(phi_min=-180.0, phi_max=179.0, phi_step=1.0)
+    ctx = A.FanContext(A.EQ_GLOBAL, device=0); ctx.load_met(H.TOYATMO); ctx.set_params(bounces=2, calc_amp=1, mode=0)
+    ctx.set_angles(th, ph); ctx.launch(); ctx.launch()
+    ts = []
+    for _ in range(passes):
+        t0 = time.perf_counter(); ctx.launch(); ts.append((time.perf_counter() - t0) * 1e3)
+    tm = ctx.timing()
+    print(os.path.basename(lib_path), "ms per pass: min %.2f median %.2f" % (min(ts), float(np.median(ts))), "rk4 %.2f epochs %d" % (tm["ms_rk4"], tm["epochs"]), flush=True)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+    for p in (sys.argv[1], sys.argv[2], sys.argv[1], sys.argv[2]):
+        run(os.path.abspath(p), n)
