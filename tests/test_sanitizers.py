@@ -1,0 +1,30 @@
+"""CPU suite: AddressSanitizer + UndefinedBehaviorSanitizer builds of the host-side code (no GPU involved, GPU sanitizers are not
+available on this pool): the set-up helpers of libgeoac_hip (geoac_host.cpp: .met and grid readers, spline slopes, fan enumeration,
+grid table) and the plain-C oracle, each run over the fixtures and their error paths by a small driver (tests/sanitize/)."""
+import os
+import subprocess
+
+import pytest
+
+import harness as H
+import rngdep_data as RD
+
+SAN = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer"]
+ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+
+
+def test_host_helpers_under_asan_ubsan(tmp_path):
+    exe = str(tmp_path / "san_host")
+    subprocess.check_call(["g++", "-std=c++17"] + SAN + ["-o", exe, os.path.join(H.ROOT, "tests", "sanitize", "san_host_driver.cpp"),
+                                                         os.path.join(H.ROOT, "geoac_amd", "csrc", "geoac_host.cpp")])
+    grid = RD.write_grid(str(tmp_path / "g"), short_paths=False)
+    r = subprocess.run([exe, H.TOYATMO, *grid], env=ENV, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0 and b"san_host_driver ok" in r.stdout, r.stdout.decode()[-3000:]
+
+
+def test_oracle_under_asan_ubsan(tmp_path):
+    exe = str(tmp_path / "san_oracle")
+    subprocess.check_call(["gcc", "-std=c99"] + SAN + ["-ffp-contract=off", "-o", exe, os.path.join(H.ROOT, "tests", "sanitize", "san_oracle_driver.c"),
+                                                       os.path.join(H.ROOT, "oracle", "geoac_oracle.c"), "-lm"])
+    r = subprocess.run([exe, H.TOYATMO], env=ENV, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0 and b"san_oracle_driver ok" in r.stdout, r.stdout.decode()[-3000:]
