@@ -144,8 +144,11 @@ class FanRun:
         load(self.ctx)
         self.ctx.set_params(**params)
         self.rec_local = torch.empty((len(self.theta), legs, G.REC_STRIDE), dtype=torch.float64, device=dev) if world > 1 else None
+        # the arrivals' landing place on the host: pinned, so the device -> host copy runs at link speed
+        self.rec_host = torch.empty((len(self.theta), legs, G.REC_STRIDE), dtype=torch.float64, pin_memory=True)
         self.steps_t = torch.zeros(1, dtype=torch.int64, device=coll_dev)
-        self.rec = None            # rank 0: the whole fan's records on the host after a pass
+        self.rec = None            # N = 1: this pass's records; N > 1, rank 0, when want_full: the whole fan's gathered table (parity gate)
+        self.want_full = False
         self.np, self.torch = np, torch
 
     def one_pass(self):
@@ -153,16 +156,21 @@ class FanRun:
         from geoac_amd.sharding import gather_records
         ctx = self.ctx
         if self.world == 1:
-            self.rec, steps = ctx.run(self.theta, self.phi)             # set_angles + launch + fetch (geoac_fan_run)
+            self.rec, steps = ctx.run(self.theta, self.phi, out=self.rec_host.numpy())    # set_angles + launch + fetch (geoac_fan_run)
             return steps
         ctx.set_angles(self.theta, self.phi)
         ctx.launch()
         ctx.copy_records_to(self.rec_local.data_ptr())                  # D2D on the context's (= torch's current) stream
+        # the whole fan's table on every GPU: RCCL all_gather over xGMI (gloo: host rehearsal)
         full = gather_records(self.rec_local if self.coll_dev == self.dev else self.rec_local.cpu(), self.n_az, self.n_theta)
         self.steps_t[0] = ctx.total_steps()
         dist.all_reduce(self.steps_t)
-        if self.rank == 0:
-            self.rec = full.cpu().numpy()                               # arrivals of the whole fan on the host
+        # arrivals device -> host: every rank lands its own share (the N processes' pinned buffers together hold the fan, as the one
+        # buffer does at N = 1); the gathered table goes to the host only for the parity gate
+        self.rec_host.copy_(self.rec_local, non_blocking=True)
+        self.torch.cuda.current_stream().synchronize()
+        if self.rank == 0 and self.want_full:
+            self.rec = full.cpu().numpy()
         return int(self.steps_t.item())
 
     def timed(self, n_pass):
@@ -267,9 +275,11 @@ def main():
     run, mult = metric_run(args.scaling)
     gate = {"status": "skipped", "why": "--warmup 0 (profiler passes): the gate runs on the first untimed pass"}
     for w in range(args.warmup):
+        run.want_full = (w == 0)
         run.one_pass()
         if w == 0 and rank == 0:
             gate = parity_gate(run.rec, mult)                          # raises AssertionError on a mismatch: no timing without parity
+    run.want_full = False
     total_steps, dt, ev = run.timed(args.steps)
     local_steps_per_pass = run.ctx.total_steps()
 
@@ -279,7 +289,9 @@ def main():
             other = "strong" if args.scaling == "weak" else "weak"
             if world > 1:
                 r2, m2 = metric_run(other)
+                r2.want_full = True
                 r2.one_pass()
+                r2.want_full = False
                 if rank == 0:
                     parity_gate(r2.rec, m2)
                 s2, t2, _ = r2.timed(max(1, min(args.steps, 3)))
@@ -324,7 +336,7 @@ def main():
             "config": {"workload": f"GeoAcGlobal -prop ToyAtmo.met, {n_az} az x {n_theta} incl = {n_az * n_theta} rays "
                                    f"(phi step {1.0 / mult:g} deg), bounces=2, CalcAmp=True, WriteRays=False, rng_max=1500",
                        "rays_per_gpu": int(len(run.theta)), "ray_steps_per_pass": int(total_steps // args.steps),
-                       "timed_region": "launch angles H2D + RK4 / post-pass / sum kernels + " + ("RCCL all_gather of arrivals + " if world > 1 else "") + "arrival records D2H (geoac_fan_run); atmosphere tables resident",
+                       "timed_region": "launch angles H2D + RK4 / post-pass / sum kernels + " + ("RCCL all_gather of the arrival tables + every rank's own arrivals D2H" if world > 1 else "arrival records D2H (geoac_fan_run)") + "; atmosphere tables resident",
                        "parallelism": f"azimuth-sharded x{n_gpus}" + (f", {'RCCL' if args.backend == 'nccl' else args.backend} all_gather of arrivals" if world > 1 else "")},
             "parity_gate": gate,
             "launch_only": {"value": local_steps_per_pass * args.steps * (n_gpus if args.scaling == "weak" else 1) / (ev["ms_total"] * 1e-3) if ev["ms_total"] > 0 and world == 1 else None,

@@ -208,9 +208,15 @@ class FanContext:
     def launch(self):
         self._chk(self.lib.geoac_fan_launch(self._h))
 
-    def fetch(self):
+    def fetch(self, out=None):
+        """records of the last launch; `out`: caller-owned C-contiguous float64 array [n_rays][legs][32] (e.g. the numpy view of a pinned
+        torch tensor) to copy into instead of a fresh array"""
         legs = self.params.bounces + 1
-        rec = np.zeros((self.n_rays, legs, REC_STRIDE))
+        if out is None:
+            rec = np.empty((self.n_rays, legs, REC_STRIDE))
+        else:
+            rec = out
+            assert rec.dtype == np.float64 and rec.flags.c_contiguous and rec.shape == (self.n_rays, legs, REC_STRIDE)
         steps = ctypes.c_uint64(0)
         self._chk(self.lib.geoac_fan_fetch(self._h, _p(rec), ctypes.byref(steps)))
         return rec, int(steps.value)
@@ -257,10 +263,10 @@ class FanContext:
         self._chk(self.lib.geoac_fan_fetch(self._h, None, ctypes.byref(steps)))
         return int(steps.value)
 
-    def run(self, theta_deg, phi_deg):
+    def run(self, theta_deg, phi_deg, out=None):
         self.set_angles(theta_deg, phi_deg)
         self.launch()
-        return self.fetch()
+        return self.fetch(out)
 
     def timing(self):
         ms = (ctypes.c_double * 3)(); st = (ctypes.c_uint64 * 3)()
