@@ -1,4 +1,4 @@
-"""CPU suite: AddressSanitizer + UndefinedBehaviorSanitizer builds of the host-side code (no GPU involved, GPU sanitizers are not
+"""CPU suite: AddressSanitizer + UndefinedBehaviorSanitizer builds of the host-side code, ThreadSanitizer over the eigenray scheduler (no GPU involved, GPU sanitizers are not
 available on this pool): the set-up helpers of libgeoac_hip (geoac_host.cpp: .met and grid readers, spline slopes, fan enumeration,
 grid table) and the plain-C oracle, each run over the fixtures and their error paths by a small driver (tests/sanitize/)."""
 import os
@@ -28,3 +28,14 @@ def test_oracle_under_asan_ubsan(tmp_path):
                                                        os.path.join(H.ROOT, "oracle", "geoac_oracle.c"), "-lm"])
     r = subprocess.run([exe, H.TOYATMO], env=ENV, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0 and b"san_oracle_driver ok" in r.stdout, r.stdout.decode()[-3000:]
+
+
+def test_eigenray_scheduler_under_tsan(tmp_path):
+    """the search threads / round coordinator of geoac_eigenray.cpp under ThreadSanitizer, on a closed-form stub of the fan ABI
+    (tests/sanitize/tsan_eig_driver.cpp): 12 receivers x 2 bounce counts, scans and refinements running concurrently"""
+    exe = str(tmp_path / "tsan_eig")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread", "-o", exe,
+                           os.path.join(H.ROOT, "tests", "sanitize", "tsan_eig_driver.cpp"), os.path.join(H.ROOT, "geoac_amd", "csrc", "geoac_eigenray.cpp")])
+    r = subprocess.run([exe], env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "tsan_eig_driver ok" in out and "ThreadSanitizer" not in out, out[-3000:]
