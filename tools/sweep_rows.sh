@@ -1,0 +1,6 @@
+#!/bin/bash
+# epoch-length sweep of one tools/bench_configs.py configuration: usage tools/sweep_rows.sh cfg4 1443 2886 5772
+c=$1; shift
+for r in "$@"; do
+  GEOAC_S_ROWS=$r python tools/bench_configs.py $c 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('rows $r:', round(d['seconds'],3), 's', '%.3e' % d['ray_steps_per_s'], 'launches', d.get('roofline',{}).get('launches_per_pass'))"
+done
