@@ -480,11 +480,11 @@ int geoac_fan_launch(geoac_ctx* ctx){
         }
         P.src_trig[0] = sin(p.src[1] * kPi / 180.0); P.src_trig[1] = cos(p.src[1] * kPi / 180.0);
     }
-    // ---- epoch size: 8192 rows unless a path chunk would pass 16 GiB (three chunks + three contrib buffers <= 64 GiB of the 288).
+    // ---- epoch size: 8192 rows unless a path chunk would pass 40 GiB (three chunks + three contrib buffers <= 160 GiB of the 288).
     //      Measured on the metric fan (GEOAC_S_ROWS sweep, hybrid build): 4096 rows 179 ms per pass, 8192 167, 12288 167, 16384 173 -
     //      every epoch boundary costs a launch + table reload, while very long epochs leave the last post-pass uncovered ----
     size_t row_bytes = (size_t)P.pathw * P.n_pad * sizeof(double);
-    long long s_rows = (long long)((16ull << 30) / row_bytes);
+    long long s_rows = (long long)((40ull << 30) / row_bytes);      // round 2: 40 GiB per chunk (config 3: 2760 -> 6900 rows, 21 -> 9 epochs, +8 %); the free-memory clamp below still applies
     if(s_rows > 8192) s_rows = 8192;
     if(s_rows < 64) s_rows = 64;
     if(ctx->s_rows_override >= 8) s_rows = ctx->s_rows_override;
