@@ -641,6 +641,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
     };
     // RK4 workgroups that can be resident at once (k_rk4 runs one wave per SIMD; with the table in LDS one workgroup per CU)
     const unsigned wg_room = P.table_in_lds ? 192u : (unsigned)(768 / (block / 64));
+    unsigned waves_launched_prev = 0, waves_launched_cur = 0;      // (GEOAC_TRACE_EPOCHS)
     unsigned long long wg_seen = 0;                   // RK4 workgroups launched in the earlier epochs of this fan
     GeoacDevParams Pprev = P;
     // The host never holds the GPU up between epochs: RK4(e) is enqueued BEFORE the live-ray count of epoch e-1 is read.  When that
@@ -692,6 +693,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
         // the post-pass of the previous epoch goes behind this epoch's RK4 workgroups (see k_gate)
         if(e >= 1){ int rc = enqueue_post(Pprev, e - 1, wg_seen + std::min(n_wg + n_wg1, wg_room)); if(rc != GEOAC_OK) return rc; }
         wg_seen += n_wg + n_wg1;
+        waves_launched_prev = waves_launched_cur; waves_launched_cur = (n_wg + n_wg1) * (unsigned)((split ? 256 : block) / 64);
         Pprev = Pe;
         if(e >= 1){
             HIPCHK(hipEventSynchronize(ctx->evj[2 * (e - 1) + 1]));
@@ -705,7 +707,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
             // rays were NOT the longest ones
             if(split && (hc[1] == 0 || hc[4] + 2 * hc[7] <= 512)) split = false;
             if(hc[4] + hc[7] <= 256) rows_now = rows_late;
-            if(ctx->trace_epochs) fprintf(stderr, "[epoch %zu] live rays %llu + %llu, live waves %llu + %llu, split %d, rows next %d\n", e - 1, hc[1], hc[6], hc[4], hc[7], (int)split, rows_now);
+            if(ctx->trace_epochs) fprintf(stderr, "[epoch %zu] waves launched %u, after it: live rays %llu + %llu in %llu + %llu waves, split %d, rows next %d\n", e - 1, waves_launched_prev, hc[1], hc[6], hc[4], hc[7], (int)split, rows_now);
         }
         if((long long)e > max_epochs) return fail(ctx, GEOAC_E_CAPACITY, "fan_launch: epoch bound exceeded");
     }
