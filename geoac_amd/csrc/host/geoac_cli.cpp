@@ -878,6 +878,7 @@ static int run_eig(char* inputs[], int count, bool direct){
 
     geoac_eig_result* res = nullptr;
     ofstream results;
+    const auto t_eig0 = std::chrono::steady_clock::now();
     if(direct){
         if(kSph){       // bearing to the receiver unless phi_est= was given (GeoAcGlobal_main.cpp:636-643)
             double term1 = sin((Receiver_Loc[1] - Source_Loc[1]) * Pi / 180.0);
@@ -958,6 +959,8 @@ static int run_eig(char* inputs[], int count, bool direct){
     if(!direct) results.close();
     uint64_t st[4]; geoac_eig_stats(res, st);
     cerr << kName << ": " << st[1] << " rays in " << st[0] << " fan launches (" << st[3] << " rounds), " << st[2] << " RK4 ray-steps on the GPU" << '\n';
+    write_stats(direct ? "-eig_direct" : "-eig_search", (long)st[1], st[2], std::chrono::duration<double>(std::chrono::steady_clock::now() - t_eig0).count(),
+                vector<int>(1, 0), vector<uint64_t>(1, st[1]), vector<uint64_t>(1, st[2]), vector<uint64_t>(1, st[0]));
     geoac_eig_free(res);
     geoac_destroy(ctx);
     return 0;
