@@ -19,6 +19,9 @@ extern "C" void geoac_natural_spline_slopes(int n, const double* x, const double
 extern "C" hipError_t geoac_launch_init(const GeoacDevParams* P, hipStream_t s);
 extern "C" hipError_t geoac_launch_rk4(const GeoacDevParams* P, int block, hipStream_t s, unsigned* n_wg);
 extern "C" size_t geoac_gridbuild_work_doubles(int nx, int ny, int nz);
+extern "C" size_t geoac_gridpack_doubles(int nx, int ny, int nz);
+extern "C" hipError_t geoac_gridpack_launch(int nx, int ny, int nz, const double* d_tab, double* d_tab8, hipStream_t s);
+extern "C" int geoac_kernels_cart_rec(void);
 extern "C" hipError_t geoac_gridbuild_launch(int glob, int nx, int ny, int nz, const double* d_x, const double* d_y, const double* d_z,
                                              const double* d_fields, double* d_work, double* d_tab, hipStream_t s);
 extern "C" hipError_t geoac_launch_accum(const GeoacDevParams* P, hipStream_t s);
@@ -74,7 +77,8 @@ struct geoac_ctx {
     // range-dependent grid
     int gnx = 0, gny = 0;
     std::vector<double> gx, gy;
-    DevBuf d_gx, d_gy, d_gz, d_gtab, d_consts;
+    DevBuf d_gx, d_gy, d_gz, d_gtab, d_gtab8, d_consts;      // d_gtab8: packed records the Cartesian kernels read (geoac_rngdep.h); d_gtab: the full table
+    size_t gtab_bytes = 0;           // of the table the kernels read
     bool have_grid = false;
     // device
     DevBuf seg, rhot, theta, phi, state, rec, counters;
@@ -249,7 +253,7 @@ int geoac_destroy(geoac_ctx* ctx){
                        &ctx->nlegend[0], &ctx->nlegend[1], &ctx->nlegend[2],
                        &ctx->ev_row[0], &ctx->ev_row[1], &ctx->ev_row[2], &ctx->ev_m[0], &ctx->ev_m[1], &ctx->ev_m[2],
                        &ctx->ev_amp[0], &ctx->ev_amp[1], &ctx->ev_amp[2], &ctx->nev[0], &ctx->nev[1], &ctx->nev[2], &ctx->smp_out,
-                       &ctx->d_gx, &ctx->d_gy, &ctx->d_gz, &ctx->d_gtab, &ctx->d_consts, &ctx->colmap[0], &ctx->colmap[1], &ctx->colmap[2], &ctx->ncols };
+                       &ctx->d_gx, &ctx->d_gy, &ctx->d_gz, &ctx->d_gtab, &ctx->d_gtab8, &ctx->d_consts, &ctx->colmap[0], &ctx->colmap[1], &ctx->colmap[2], &ctx->ncols };
     for(DevBuf* b : bufs) b->release();
     if(ctx->h_counters) hipHostFree(ctx->h_counters);
     if(ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -343,6 +347,14 @@ int geoac_upload_atmo_3d(geoac_ctx* ctx, int nx, int ny, int nz, const double* x
         fields.release(); work.release();
         if(e != hipSuccess) return hipfail(ctx, e, "grid table build");
     }
+    ctx->gtab_bytes = sizeof(double) * tab_n;
+    if(ctx->eqset == GEOAC_EQ_3D_RNGDEP && geoac_kernels_cart_rec() == 32){
+        // Cartesian kernels read 256-byte line-aligned records (eight cubics: V_x = D_x F, V_y = D_y F are not stored twice)
+        ctx->gtab_bytes = sizeof(double) * geoac_gridpack_doubles(nx, ny, nz);
+        HIPCHK(ctx->d_gtab8.ensure(ctx->gtab_bytes));
+        HIPCHK(geoac_gridpack_launch(nx, ny, nz, (const double*)ctx->d_gtab.p, (double*)ctx->d_gtab8.p, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    } else ctx->d_gtab8.release();
     ctx->gnx = nx; ctx->gny = ny; ctx->n_nodes = nz;
     ctx->gx.assign(x, x + nx); ctx->gy.assign(y, y + ny); ctx->x.assign(z, z + nz);
     // GeoAc_SetPropRegion (G2S_MultiDimSpline3D.cpp:25-33)
@@ -509,7 +521,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
     if(is_grid){
         P.gnx = ctx->gnx; P.gny = ctx->gny;
         P.gx = (const double*)ctx->d_gx.p; P.gy = (const double*)ctx->d_gy.p; P.gz = (const double*)ctx->d_gz.p;
-        P.gtab = (const double*)ctx->d_gtab.p; P.dev_consts = (double*)ctx->d_consts.p;
+        P.gtab = (const double*)(ctx->d_gtab8.p ? ctx->d_gtab8.p : ctx->d_gtab.p); P.dev_consts = (double*)ctx->d_consts.p;
         for(int q = 0; q < 4; q++) P.xy_lim[q] = p.xy_limits[q];
     }
     ctx->legs = p.bounces + 1;
@@ -568,7 +580,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
     P.quad_cache = (is_grid && P.lanes_per_ray == 4 && ctx->quad_cache && (long long)P.n_pad * 4 / 64 <= 256 &&
                     2 * GEOAC_MAXE * 64 * sizeof(double) + 64 * 976 + (size_t)(P.nseg + 1) * sizeof(double) <= 160 * 1024) ? 1 : 0;
     // dense one-lane-per-ray grid fans (more waves than SIMDs): the quads of a wave fetch the table records together (grid_eval3_coop)
-    P.coop = (is_grid && P.lanes_per_ray == 1 && P.spread == 1 && ctx->grid_coop) ? 1 : 0;
+    P.coop = (is_grid && P.lanes_per_ray == 1 && P.spread == 1 && ctx->grid_coop && ctx->gtab_bytes < (4ull << 30)) ? 1 : 0;   // (32-bit record offsets)
 
     // ---- hybrid fan (Global set, CalcAmp, inclination-sorted): the two-lane kernel shortens the serial chain of a ray by x1.25 but
     //      doubles its lanes, and with one wave on every SIMD the post-pass (168 VGPRs beside 384) cannot run next to the RK4 waves at

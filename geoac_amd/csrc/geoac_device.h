@@ -81,7 +81,7 @@ struct GeoacDevParams {
     const double* gx;               // [gnx] node x
     const double* gy;               // [gny] node y
     const double* gz;               // [nseg+1] node z (x_min / x_max hold the z range)
-    const double* gtab;             // [4 fields][nseg][gnx*gny][12]: cubics of f, df/dx, df/dy per node and vertical segment
+    const double* gtab;             // grid sets: T, u, v [3][nseg][gnx*gny][40 | 32 packed, Cartesian] then rho [nseg][gnx*gny][16] (geoac_rngdep.h)
     double        xy_lim[4];        // x_min, x_max, y_min, y_max break limits (GeoAc.Parameters.RngDep.cpp:24-28)
     double*       dev_consts;       // [0] T_o, [1] P_o, [2] cbrt(T_o) of SuthBass evaluated on the device (RngDep: medium at (0, 0, z_grnd))
     const int*    colmap;           // live-ray compaction: column of this epoch's chunk -> ray slot (NULL: identity, column = slot)

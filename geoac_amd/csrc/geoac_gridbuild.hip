@@ -166,7 +166,35 @@ __global__ void __launch_bounds__(256) k_gb_assemble(GbParams P, double* out, in
     }
 }
 
+// Cartesian set: V_x = S_fx and V_y = S_fy are splines of centred differences of the node values, D_x F and D_y F are the same
+// differences of the spline coefficients - the same cubics up to rounding (the spline systems are linear and share the z grid; measured
+// < 1e-10 of the coefficient scale).  The kernels read the packed form: eight cubics  F, DxF, DyF, DxyF | DxVx, DxyVx, DyVy, DxyVy  per
+// (field, kz, node), 256 bytes = two cache lines, line-aligned.  One thread per 16-byte chunk.
+__global__ void k_gb_pack8(const double* __restrict__ t40, double* __restrict__ t8, long long n_rec){
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n_rec * 16) return;
+    const long long rec = i >> 4; const int ch = (int)(i & 15);
+    const int cub = ch >> 1;
+    const int src = cub < 4 ? cub : (cub < 6 ? cub + 1 : cub + 2);         // 4, 5 <- DxVx, DxyVx (5, 6);  6, 7 <- DyVy, DxyVy (8, 9)
+    const double2 v = *(const double2*)(t40 + rec * 40 + 4 * src + 2 * (ch & 1));
+    *(double2*)(t8 + rec * 32 + 2 * ch) = v;
+}
+
 }  // namespace
+
+// packed Cartesian table (3 n_seg n_node records of 32 doubles, then the rho block unchanged) from the full one
+extern "C" size_t geoac_gridpack_doubles(int nx, int ny, int nz){
+    const size_t nn = (size_t)nx * ny, nseg = (size_t)(nz - 1);
+    return 3 * nseg * nn * 32 + nseg * nn * 16;
+}
+extern "C" hipError_t geoac_gridpack_launch(int nx, int ny, int nz, const double* d_tab, double* d_tab8, hipStream_t s){
+    const size_t nn = (size_t)nx * ny, nseg = (size_t)(nz - 1);
+    const long long n_rec = (long long)(3 * nseg * nn);
+    hipLaunchKernelGGL(k_gb_pack8, dim3((unsigned)((n_rec * 16 + 255) / 256)), dim3(256), 0, s, d_tab, d_tab8, n_rec);
+    hipError_t e = hipGetLastError();
+    if(e != hipSuccess) return e;
+    return hipMemcpyAsync(d_tab8 + (size_t)n_rec * 32, d_tab + (size_t)n_rec * 40, sizeof(double) * nseg * nn * 16, hipMemcpyDeviceToDevice, s);
+}
 
 // Builds the whole table (geoac_grid_table_size doubles at d_tab) from the device copies of the node coordinates and of the four
 // fields ([4][nx][ny][nz]: T, u, v, rho).  d_work: scratch of geoac_gridbuild_work_doubles(nx, ny, nz) doubles.

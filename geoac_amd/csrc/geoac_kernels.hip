@@ -1727,7 +1727,10 @@ __global__ void __launch_bounds__(64) k_probe_grid(GeoacDevParams P, int n, cons
     const double x = clampd(a0[i], P.gx[0], P.gx[P.gnx - 1]), y = clampd(a1[i], P.gy[0], P.gy[P.gny - 1]), z = clampd(a2[i], P.x_min, P.x_max);
     GridLoc L; grid_locate(P, x, y, z, -1, L);
     double M[3][10];
-    if(coop) grid_eval3_coop<true, GLB>(P, L, M, (char*)lds_tab);
+    if(coop){
+        if constexpr (GRec<GLB>::PACKED) grid_eval3_coop8<true>(P, L, M, (char*)lds_tab);
+        else grid_eval3_coop<true, GLB>(P, L, M, (char*)lds_tab);
+    }
     else {
         grid_eval_all<true, GLB, 1>(P, 0, L, M[0], 0);
         grid_eval_all<true, GLB, 1>(P, 1, L, M[1], 0);
@@ -1871,6 +1874,7 @@ extern "C" hipError_t geoac_launch_probe_absorption(const GeoacDevParams* P, int
     hipLaunchKernelGGL(k_probe_absorption, dim3((n + 255) / 256), dim3(256), 0, s, *P, n, x, f, out);
     return hipGetLastError();
 }
+extern "C" int geoac_kernels_cart_rec(void){ return GRec<false>::N; }     // doubles per record of the table the Cartesian grid kernels read
 extern "C" hipError_t geoac_launch_probe_grid(const GeoacDevParams* P, int n, const double* a0, const double* a1, const double* a2, int coop,
                                               double* out30, double* api7, hipStream_t s){
     const size_t lds = coop ? (size_t)64 * GEOAC_COOP_SLOT : 0;

@@ -25,6 +25,19 @@
 #define GEOAC_GREC 40        // doubles per (field, kz, node) record of T, u, v: ten cubics
 #define GEOAC_GREC_RHO 16    // rho: F, DxF, DyF, DxyF only (scalar evaluator)
 enum { GC_F = 0, GC_DXF, GC_DYF, GC_DXYF, GC_VX, GC_DXVX, GC_DXYVX, GC_VY, GC_DYVY, GC_DXYVY };
+// Cartesian set: Vx and DxF (Vy and DyF) are the same cubic up to rounding - the natural-spline systems are linear and every node has
+// the same z grid, so the spline of the differences is the difference of the splines (< 1e-10 of the coefficient scale, k_gb_pack8) -
+// and the kernels read a PACKED table of eight cubics  F, DxF, DyF, DxyF | DxVx, DxyVx, DyVy, DxyVy:  256 bytes, line-aligned, two
+// cache lines per record instead of 320 bytes over three or four.  (The spherical set's S_fx / S_fy carry the Q12 terms: ten cubics.)
+#ifndef GEOAC_GREC_CART
+#define GEOAC_GREC_CART 32   // 40: the Cartesian kernels read the full records as well (A/B builds)
+#endif
+template <bool GLB> struct GRec {
+    static constexpr bool PACKED = !GLB && GEOAC_GREC_CART == 32;
+    static constexpr int  N = PACKED ? 32 : GEOAC_GREC, NCUB = N / 4;
+    static constexpr int  VX = PACKED ? (int)GC_DXF : (int)GC_VX, VY = PACKED ? (int)GC_DYF : (int)GC_VY;
+    static constexpr int  DXVX = PACKED ? 4 : (int)GC_DXVX, DXYVX = PACKED ? 5 : (int)GC_DXYVX, DYVY = PACKED ? 6 : (int)GC_DYVY, DXYVY = PACKED ? 7 : (int)GC_DXYVY;
+};
 
 struct GridLoc {
     int kz;                 // vertical segment
@@ -85,10 +98,11 @@ DEVINL double cub_val(const Cub& c, double t, double t6){ const double th = 3.0 
 DEVINL double cub_d1(const Cub& c, double t, double th){ return __builtin_fma(t, __builtin_fma(th, c.e3, c.d2), c.c1); }
 DEVINL double cub_d2(const Cub& c, double t){ return __builtin_fma(t, c.e3, c.d2); }
 
+template <bool GLB>
 DEVINL const double* grid_rec(const GeoacDevParams& P, int field, int kz, int node){
     const size_t nn = (size_t)(P.gnx * P.gny);
-    if(field < 3) return P.gtab + (((size_t)field * P.nseg + kz) * nn + node) * GEOAC_GREC;
-    return P.gtab + (size_t)3 * P.nseg * nn * GEOAC_GREC + ((size_t)kz * nn + node) * GEOAC_GREC_RHO;
+    if(field < 3) return P.gtab + (((size_t)field * P.nseg + kz) * nn + node) * GRec<GLB>::N;
+    return P.gtab + (size_t)3 * P.nseg * nn * GRec<GLB>::N + ((size_t)kz * nn + node) * GEOAC_GREC_RHO;
 }
 
 // tensor Hermite weights of corner (a, b): value (W), d/dxs (D), d/dys (E); index hh, gh, hg, gg <-> F, FX, FY, FXY
@@ -141,7 +155,8 @@ DEVINL void grid_eval_all(const GeoacDevParams& P, int field, const GridLoc& L, 
     const Herm hx = hermite(L.xs), hy = hermite(L.ys);
     const double dxs = L.dxs, dys = L.dys, dxy = dxs * dys;
     const double t = L.t, th = 0.5 * t, t6 = t * (1.0 / 6.0);
-    const double* __restrict__ base = grid_rec(P, field, L.kz, 0);
+    typedef GRec<GLB> R;
+    const double* __restrict__ base = grid_rec<GLB>(P, field, L.kz, 0);
     double o[10];
     #pragma unroll
     for(int i = 0; i < 10; i++) o[i] = 0.0;
@@ -149,19 +164,19 @@ DEVINL void grid_eval_all(const GeoacDevParams& P, int field, const GridLoc& L, 
     for(int cn = cq * (4 / NL); cn < (cq + 1) * (4 / NL); cn++){
         {
             const int a = cn >> 1, b = cn & 1;
-            const double* r = rec_lds ? rec_lds : base + (size_t)corner_node(L, a, b) * GEOAC_GREC;
-            Cub c[10];                                             // all 20 loads of the corner in flight before the first use
+            const double* r = rec_lds ? rec_lds : base + (size_t)corner_node(L, a, b) * R::N;
+            Cub c[R::NCUB];                                        // all loads of the corner in flight before the first use
             #pragma unroll
-            for(int i = 0; i < 10; i++) c[i] = load_cubic(r + 4 * i);
+            for(int i = 0; i < R::NCUB; i++) c[i] = load_cubic(r + 4 * i);
             CornerW w = corner_weights<ORDER2, ORDER2>(hx, hy, a, b);
             // fold the cell-size factors of the FX / FY / FXY rows into the weights
             const double Wq = w.W[2] * (GLB ? dys : dxs);          // Cartesian: Q11 row of the f_zz patch (y row scaled by dx)
             w.W[1] *= dxs; w.W[2] *= dys; w.W[3] *= dxy;
             if(ORDER2){ w.D[1] *= dxs; w.D[2] *= dys; w.D[3] *= dxy; w.E[1] *= dxs; w.E[2] *= dys; w.E[3] *= dxy; }
             const double F = cub_val(c[GC_F], t, t6), DxF = cub_val(c[GC_DXF], t, t6), DyF = cub_val(c[GC_DYF], t, t6), DxyF = cub_val(c[GC_DXYF], t, t6);
-            const double DxVx = cub_val(c[GC_DXVX], t, t6), DxyVx = cub_val(c[GC_DXYVX], t, t6);
-            const double DyVy = cub_val(c[GC_DYVY], t, t6), DxyVy = cub_val(c[GC_DXYVY], t, t6);
-            const double Fz = cub_d1(c[GC_F], t, th), Vxz = cub_d1(c[GC_VX], t, th), Vyz = cub_d1(c[GC_VY], t, th), DxyFz = cub_d1(c[GC_DXYF], t, th);
+            const double DxVx = cub_val(c[R::DXVX], t, t6), DxyVx = cub_val(c[R::DXYVX], t, t6);
+            const double DyVy = cub_val(c[R::DYVY], t, t6), DxyVy = cub_val(c[R::DXYVY], t, t6);
+            const double Fz = cub_d1(c[GC_F], t, th), Vxz = cub_d1(c[R::VX], t, th), Vyz = cub_d1(c[R::VY], t, th), DxyFz = cub_d1(c[GC_DXYF], t, th);
             o[0] = dot4(w.W, F, DxF, DyF, DxyF, o[0]);
             o[1] = dot4(w.W, DxF, DxVx, DxyF, DxyVx, o[1]);
             o[2] = dot4(w.W, DyF, DxyF, DyVy, DxyVy, o[2]);
@@ -309,6 +324,99 @@ DEVINL void grid_eval3_coop(const GeoacDevParams& P, const GridLoc& L, double (*
     }
 }
 
+// The same gather over the PACKED Cartesian records (256 B, line-aligned): half-records of four cubics = one 128-byte cache line.  A quad
+// walks through the four half-records of its lanes in 8 loads (load j: owner j >> 1, chunks 4 (j & 1) + r; every quad-load is 64 bytes
+// inside ONE line), LDS slots 144 B apart (128 B + 16 B pad: reads and writes of a wave bank-conflict free), 8 loads / 8 ds_write /
+// 8 ds_read per half-record instead of 10 / 10 / 10.  First half: F, DxF, DyF, DxyF -> f, f_z, f_zz, f_xz, f_yz; second half:
+// DxVx, DxyVx, DyVy, DxyVy -> f_x, f_y, f_xx, f_xy, f_yy.  Offsets are unsigned 32-bit: the launch takes this kernel for tables < 4 GiB.
+#define GEOAC_COOP8_SLOT 144
+template <bool ORDER2>
+DEVINL void grid_eval3_coop8(const GeoacDevParams& P, const GridLoc& L, double (*M)[10], char* ldsw){
+    const unsigned lane = threadIdx.x & 63u, r = lane & 3u;
+    const unsigned nn = (unsigned)(P.gnx * P.gny);
+    const Herm hx = hermite(L.xs), hy = hermite(L.ys);
+    const double dxs = L.dxs, dys = L.dys, dxy = dxs * dys;
+    const double t = L.t, th = 0.5 * t, t6 = t * (1.0 / 6.0);
+    const size_t fstride = (size_t)P.nseg * nn * 256u;                                // bytes per field block of the table
+    const char* __restrict__ tabb = (const char*)P.gtab;
+    char* const wq = ldsw + (lane & ~3u) * GEOAC_COOP8_SLOT + 16u * r;
+    const char* const rslot = ldsw + lane * GEOAC_COOP8_SLOT;
+    #pragma unroll
+    for(int f = 0; f < 3; f++){
+        #pragma unroll
+        for(int i = 0; i < 10; i++) M[f][i] = 0.0;
+    }
+    unsigned gb[4];                                                                   // byte offsets of the quad's owners' records (+ this lane's 16 r)
+    {
+        const unsigned off = ((unsigned)L.kz * nn + (unsigned)corner_node(L, 0, 0)) * 256u;
+        gb[0] = quad_bcast_u32<0>(off) + 16u * r; gb[1] = quad_bcast_u32<1>(off) + 16u * r; gb[2] = quad_bcast_u32<2>(off) + 16u * r; gb[3] = quad_bcast_u32<3>(off) + 16u * r;
+    }
+    geoac_d2 v[8];                                                                    // in flight: the NEXT half-record's chunks
+    #pragma unroll
+    for(int j = 0; j < 8; j++) v[j] = *(const geoac_d2*)(tabb + gb[j >> 1] + 64 * (j & 1));
+    double cDxF = 0, cDyF = 0, cDxyF = 0;                                             // carried from the first half of a record to the second
+    #pragma unroll
+    for(int h = 0; h < 24; h++){
+        const int n = h >> 1, part = h & 1, cn = n / 3, f = n % 3, a = cn >> 1, b = cn & 1;
+        #pragma unroll
+        for(int j = 0; j < 8; j++) *(geoac_d2*)(wq + GEOAC_COOP8_SLOT * (j >> 1) + 64 * (j & 1)) = v[j];
+        if(h + 1 < 24){
+            const int n1 = (h + 1) >> 1, part1 = (h + 1) & 1, cn1 = n1 / 3, f1 = n1 % 3;
+            if(part1 == 0 && f1 == 0){                                                // first half-record of the next corner: its owners' offsets
+                const unsigned off = ((unsigned)L.kz * nn + (unsigned)corner_node(L, cn1 >> 1, cn1 & 1)) * 256u;
+                gb[0] = quad_bcast_u32<0>(off) + 16u * r; gb[1] = quad_bcast_u32<1>(off) + 16u * r; gb[2] = quad_bcast_u32<2>(off) + 16u * r; gb[3] = quad_bcast_u32<3>(off) + 16u * r;
+            }
+            const char* __restrict__ fb = tabb + (size_t)f1 * fstride + 128 * part1;
+            #pragma unroll
+            for(int j = 0; j < 8; j++) v[j] = *(const geoac_d2*)(fb + gb[j >> 1] + 64 * (j & 1));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        Cub c[4];
+        #pragma unroll
+        for(int i = 0; i < 4; i++){
+            const geoac_d2 lo = *(const geoac_d2*)(rslot + 32 * i), hi = *(const geoac_d2*)(rslot + 32 * i + 16);
+            c[i] = Cub{ lo.x, lo.y, hi.x, hi.y };
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");              // the next half-record's stores stay behind these reads
+        __builtin_amdgcn_wave_barrier();
+        CornerW w = corner_weights<ORDER2, ORDER2>(hx, hy, a, b);
+        const double Wq = w.W[2] * dxs;                                               // Q11 row of the f_zz patch (y row scaled by dx)
+        w.W[1] *= dxs; w.W[2] *= dys; w.W[3] *= dxy;
+        if(ORDER2){ w.D[1] *= dxs; w.D[2] *= dys; w.D[3] *= dxy; w.E[1] *= dxs; w.E[2] *= dys; w.E[3] *= dxy; }
+        double* o = M[f];
+        if(part == 0){                                                                // F, DxF, DyF, DxyF
+            const double F = cub_val(c[GC_F], t, t6), DxF = cub_val(c[GC_DXF], t, t6), DyF = cub_val(c[GC_DYF], t, t6), DxyF = cub_val(c[GC_DXYF], t, t6);
+            const double Fz = cub_d1(c[GC_F], t, th), Vxz = cub_d1(c[GC_DXF], t, th), Vyz = cub_d1(c[GC_DYF], t, th), DxyFz = cub_d1(c[GC_DXYF], t, th);
+            o[0] = dot4(w.W, F, DxF, DyF, DxyF, o[0]);
+            o[3] = dot4(w.W, Fz, Vxz, Vyz, DxyFz, o[3]);
+            if(ORDER2){
+                o[8] = dot4(w.D, Fz, Vxz, Vyz, DxyFz, o[8]);
+                o[9] = dot4(w.E, Fz, Vxz, Vyz, DxyFz, o[9]);
+                const double Fzz = cub_d2(c[GC_F], t), DxFzz = cub_d2(c[GC_DXF], t), DyFzz = cub_d2(c[GC_DYF], t), DxyFzz = cub_d2(c[GC_DXYF], t);
+                o[6] = __builtin_fma(w.W[0], Fzz, __builtin_fma(w.W[1], DxFzz, __builtin_fma(Wq, DyFzz, __builtin_fma(w.W[3], DxyFzz, o[6]))));
+            }
+            cDxF = DxF; cDyF = DyF; cDxyF = DxyF;
+        } else {                                                                      // DxVx, DxyVx, DyVy, DxyVy
+            const double DxVx = cub_val(c[0], t, t6), DxyVx = cub_val(c[1], t, t6), DyVy = cub_val(c[2], t, t6), DxyVy = cub_val(c[3], t, t6);
+            const double DxF = cDxF, DyF = cDyF, DxyF = cDxyF;
+            o[1] = dot4(w.W, DxF, DxVx, DxyF, DxyVx, o[1]);
+            o[2] = dot4(w.W, DyF, DxyF, DyVy, DxyVy, o[2]);
+            if(ORDER2){
+                o[4] = dot4(w.D, DxF, DxVx, DxyF, DxyVx, o[4]);
+                o[7] = dot4(w.E, DxF, DxVx, DxyF, DxyVx, o[7]);
+                o[5] = dot4(w.E, DyF, DxyF, DyVy, DxyVy, o[5]);
+            }
+        }
+    }
+    if(ORDER2){
+        const double idxs = L.idxs, idys = L.idys;
+        #pragma unroll
+        for(int f = 0; f < 3; f++){ M[f][4] *= idxs; M[f][8] *= idxs; M[f][7] *= idys; M[f][5] *= idys; M[f][9] *= idys; }
+    }
+}
+
 // ---- per-lane record cache (four lanes per ray, small fans: eigenray rounds, -interactive) ---------------------------------------
 // A small fan leaves most of the chip idle and lasts as long as its longest ray: what counts is the latency of one RK4 stage, and that
 // was two dependent trips to memory (z nodes, then the table records) in front of the arithmetic.  A ray stays in one cell and one
@@ -317,21 +425,33 @@ DEVINL void grid_eval3_coop(const GeoacDevParams& P, const GridLoc& L, double (*
 // changes - and the kernel keeps a copy of the z nodes behind it.  One wave per CU (92 KB of LDS): for fans of at most 256 waves.
 #define GEOAC_CACHE_SLOT 976
 #define GEOAC_CACHE_BYTES (64 * GEOAC_CACHE_SLOT)
+template <bool GLB>
 DEVINL const double* grid_cache_fill(const GeoacDevParams& P, const GridLoc& L, int cq, char* cache, int* ckey){
+    constexpr int RB = GRec<GLB>::N * (int)sizeof(double), NCH = RB / 16;             // bytes and 16-byte chunks per record
     const unsigned lane = threadIdx.x & 63u;
     const unsigned nn = (unsigned)(P.gnx * P.gny);
     const int key = L.kz * (int)nn + corner_node(L, cq >> 1, cq & 1);
     char* mine = cache + lane * GEOAC_CACHE_SLOT;
     if(key != *ckey){                                              // (the four lanes of a ray change cell / segment together)
-        const size_t fstride = (size_t)P.nseg * nn * (GEOAC_GREC * sizeof(double));
-        const char* __restrict__ src = (const char*)P.gtab + (size_t)key * (GEOAC_GREC * sizeof(double));
-        geoac_d2 v[20];
-        #pragma unroll
-        for(int f = 0; f < 3; f++){
+        const size_t fstride = (size_t)P.nseg * nn * RB;
+        const char* __restrict__ src = (const char*)P.gtab + (size_t)key * RB;
+        geoac_d2 v[NCH];
+        if constexpr (GLB){
             #pragma unroll
-            for(int j = 0; j < 20; j++) v[j] = *(const geoac_d2*)(src + f * fstride + 16 * j);
-            #pragma unroll
-            for(int j = 0; j < 20; j++) *(geoac_d2*)(mine + f * (GEOAC_GREC * (int)sizeof(double)) + 16 * j) = v[j];
+            for(int f = 0; f < 3; f++){
+                #pragma unroll
+                for(int j = 0; j < NCH; j++) v[j] = *(const geoac_d2*)(src + f * fstride + 16 * j);
+                #pragma unroll
+                for(int j = 0; j < NCH; j++) *(geoac_d2*)(mine + f * RB + 16 * j) = v[j];
+            }
+        } else {
+            #pragma unroll 1                                       // (Cartesian kernel: unrolled, the compiler spills 189 registers around it)
+            for(int f = 0; f < 3; f++){
+                #pragma unroll
+                for(int j = 0; j < NCH; j++) v[j] = *(const geoac_d2*)(src + f * fstride + 16 * j);
+                #pragma unroll
+                for(int j = 0; j < NCH; j++) *(geoac_d2*)(mine + f * RB + 16 * j) = v[j];
+            }
         }
         *ckey = key;
     }
@@ -343,8 +463,8 @@ template <bool GLB>
 DEVINL double grid_eval_f(const GeoacDevParams& P, int field, const GridLoc& L){
     const Herm hx = hermite(L.xs), hy = hermite(L.ys);
     const double t = L.t, t6 = t * (1.0 / 6.0);
-    const double* __restrict__ base = grid_rec(P, field, L.kz, 0);
-    const int stride = field < 3 ? GEOAC_GREC : GEOAC_GREC_RHO;
+    const double* __restrict__ base = grid_rec<GLB>(P, field, L.kz, 0);
+    const int stride = field < 3 ? GRec<GLB>::N : GEOAC_GREC_RHO;
     double v = 0.0;
     #pragma unroll 2
     for(int cn = 0; cn < 4; cn++){
@@ -367,14 +487,14 @@ template <bool GLB>
 DEVINL double grid_eval_dfdz(const GeoacDevParams& P, int field, const GridLoc& L){
     const Herm hx = hermite(L.xs), hy = hermite(L.ys);
     const double t = L.t, th = 0.5 * t;
-    const double* __restrict__ base = grid_rec(P, field, L.kz, 0);
+    const double* __restrict__ base = grid_rec<GLB>(P, field, L.kz, 0);
     double v = 0.0;
     #pragma unroll 1
     for(int cn = 0; cn < 4; cn++){
         {
             const int a = cn >> 1, b = cn & 1;
-            const double* __restrict__ r = base + (size_t)corner_node(L, a, b) * GEOAC_GREC;
-            const Cub cF = load_cubic(r + 4 * GC_F), cXY = load_cubic(r + 4 * GC_DXYF), cX = load_cubic(r + 4 * GC_VX), cY = load_cubic(r + 4 * GC_VY);
+            const double* __restrict__ r = base + (size_t)corner_node(L, a, b) * GRec<GLB>::N;
+            const Cub cF = load_cubic(r + 4 * GC_F), cXY = load_cubic(r + 4 * GC_DXYF), cX = load_cubic(r + 4 * GRec<GLB>::VX), cY = load_cubic(r + 4 * GRec<GLB>::VY);
             CornerW w = corner_weights<false, false>(hx, hy, a, b);
             w.W[1] *= L.dxs; w.W[2] *= (GLB ? L.dys : L.dxs); w.W[3] *= L.dxs * L.dys;
             v = dot4(w.W, cub_d1(cF, t, th), cub_d1(cX, t, th), cub_d1(cY, t, th), cub_d1(cXY, t, th), v);
@@ -412,11 +532,13 @@ DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double
     kz = L.kz;
     double M[3][10];                                               // T, u, v and their derivatives
     // three copies of the evaluator: M[][] stays in registers (rolled, the dynamic index f put it in scratch: 240 B written and read back per stage)
-    if(COOP) grid_eval3_coop<AMP, false>(P, L, M, ldsw);
-    else if(CACHE){
-        const double* rec = grid_cache_fill(P, L, cq, ldsw, ckey);
+    if(COOP){
+        if constexpr (GRec<false>::PACKED) grid_eval3_coop8<AMP>(P, L, M, ldsw);
+        else grid_eval3_coop<AMP, false>(P, L, M, ldsw);
+    } else if(CACHE){
+        const double* rec = grid_cache_fill<false>(P, L, cq, ldsw, ckey);
         #pragma unroll
-        for(int f = 0; f < 3; f++) grid_eval_all<AMP, false, NL>(P, f, L, M[f], cq, rec + f * GEOAC_GREC);
+        for(int f = 0; f < 3; f++) grid_eval_all<AMP, false, NL>(P, f, L, M[f], cq, rec + f * GRec<false>::N);
     } else {
         #pragma unroll
         for(int f = 0; f < 3; f++) grid_eval_all<AMP, false, NL>(P, f, L, M[f], cq);
@@ -489,9 +611,9 @@ DEVINL void globalrd_rhs(const GeoacDevParams& P, int& kz, const double* y, doub
     double M[3][10];                                               // table order: f, f_t, f_p, f_r, f_tt, f_pp, f_rr, f_tp, f_tr, f_pr
     if(COOP) grid_eval3_coop<AMP, true>(P, L, M, ldsw);
     else if(CACHE){
-        const double* rec = grid_cache_fill(P, L, cq, ldsw, ckey);
+        const double* rec = grid_cache_fill<true>(P, L, cq, ldsw, ckey);
         #pragma unroll
-        for(int f = 0; f < 3; f++) grid_eval_all<AMP, true, NL>(P, f, L, M[f], cq, rec + f * GEOAC_GREC);
+        for(int f = 0; f < 3; f++) grid_eval_all<AMP, true, NL>(P, f, L, M[f], cq, rec + f * GRec<true>::N);
     } else {
         #pragma unroll
         for(int f = 0; f < 3; f++) grid_eval_all<AMP, true, NL>(P, f, L, M[f], cq);

@@ -31,7 +31,7 @@ def roofline(r, grid_gather=False):
     """per-configuration roofline object (bench.py's conventions): the dominant kernel is k_rk4; duration = HIP events around its
     launches (inside libgeoac_hip).  Stratified sets: the SURVEY 8(d) contract figure, 8 B x E per step against HBM peak (the kernels are
     FP64-latency bound).  Grid sets: the binding resource is the per-lane gather of table records through the texture /
-    L1 path: 4 stages x 3 fields x 4 corners x 320 B = 15 360 B per ray-step, against 64 B/clk/CU."""
+    L1 path: 4 stages x 3 fields x 4 corners x 256 B (packed Cartesian records) = 12 288 B per ray-step, against 64 B/clk/CU."""
     steps, ms = r["ray_steps"], LAST.get("ms_rk4", 0.0)
     if ms <= 0:
         return None
@@ -40,8 +40,8 @@ def roofline(r, grid_gather=False):
     out = {"kernel": r.get("kernel", "k_rk4"), "rk4_ms_per_pass": ms, "launches_per_pass": LAST.get("epochs"), "alg_bytes_per_step": 8 * E,
            "bound": "fp64_valu_latency", "achieved": hbm, "peak": HBM_PEAK, "unit": "GB/s", "frac": hbm / HBM_PEAK, "traffic": None}
     if grid_gather:
-        g = 15360.0 * steps / (ms * 1e-3) / 1e9
-        out.update({"bound": "l1_gather", "achieved": g, "peak": L1_PEAK, "frac": g / L1_PEAK, "alg_bytes_per_step": 15360,
+        g = 12288.0 * steps / (ms * 1e-3) / 1e9
+        out.update({"bound": "l1_gather", "achieved": g, "peak": L1_PEAK, "frac": g / L1_PEAK, "alg_bytes_per_step": 12288,
                     "hbm_contract": {"achieved": hbm, "peak": HBM_PEAK, "frac": hbm / HBM_PEAK, "alg_bytes_per_step": 8 * E}})
     return out
 
