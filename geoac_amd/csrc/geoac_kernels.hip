@@ -549,7 +549,7 @@ DEVINL void cart2_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCt
 // ================================================================================================
 template <bool AMP_> struct EqGlobal {
     static constexpr bool AMP = AMP_;
-    static constexpr bool COOP = false; static constexpr bool CACHE = false; static constexpr bool LDS_STATE = false;
+    static constexpr bool COOP = false; static constexpr bool CACHE = false; static constexpr bool LDS_STATE = false; static constexpr int XCHG_BYTES = 0;
     static constexpr int PP_WAVES = 3;                              // post-pass waves per SIMD (168 registers; at 128 it spills 148 B and runs 1.5 x slower)
     static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 0, LANES = 1;
     static constexpr bool SPLIT = false;                            // true: the lanes of a ray carry DIFFERENT parts of its state (EqGlobalPair)
@@ -726,7 +726,8 @@ struct EqGlobalPair : EqGlobal<true> {
 template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struct Eq3DRngDep {
     static constexpr bool CACHE = CACHE_;                           // NL_ = 4, small fans: per-lane record cache and z nodes in LDS (grid_cache_fill)
     static constexpr bool AMP = AMP_;
-    static constexpr bool COOP = COOP_;                             // wave-cooperative record gather through LDS (grid_eval3_coop): NL_ = 1, every lane of the wave stays in the loop
+    static constexpr bool COOP = COOP_;                             // wave-cooperative record gather through LDS (grid_eval3_glds / _coop8): NL_ = 1, every lane of the wave stays in the loop
+    static constexpr int XCHG_BYTES = (GRec<false>::PACKED && GEOAC_COOP_GLDS) ? GEOAC_GLDS_BYTES : 64 * GEOAC_COOP_SLOT;   // per wave: LDS-DMA ring / exchange slots
     static constexpr bool LDS_STATE = true;                         // the step's rows y and yn live in LDS while the four stages run (the grid kernels use no LDS otherwise)
     static constexpr int NB = 6, NS = 6;
     static constexpr int PP_WAVES = 3;
@@ -863,6 +864,7 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
     static constexpr bool CACHE = CACHE_;
     static constexpr bool AMP = AMP_;
     static constexpr bool COOP = COOP_;
+    static constexpr int XCHG_BYTES = 64 * GEOAC_COOP_SLOT;
     static constexpr bool LDS_STATE = true;
     static constexpr int NB = 6, NS = 6;
     static constexpr int PP_WAVES = 3;
@@ -996,7 +998,7 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
 
 template <bool AMP_> struct Eq3D {
     static constexpr bool AMP = AMP_;
-    static constexpr bool COOP = false; static constexpr bool CACHE = false; static constexpr bool LDS_STATE = false;
+    static constexpr bool COOP = false; static constexpr bool CACHE = false; static constexpr bool LDS_STATE = false; static constexpr int XCHG_BYTES = 0;
     static constexpr int PP_WAVES = 4;                              // post-pass at four waves per SIMD (127 registers, 52 B of spill): GeoAc3D 360 x 90 fan 185 -> 168 ms
     static constexpr int E = AMP_ ? 12 : 4, PW = 4, HIDX = 2, LANES = 1;
     static constexpr bool SPLIT = false;
@@ -1150,7 +1152,7 @@ struct Eq3DPair : Eq3D<true> {
 
 template <bool AMP_> struct Eq2D {
     static constexpr bool AMP = AMP_;
-    static constexpr bool COOP = false; static constexpr bool CACHE = false; static constexpr bool LDS_STATE = false;
+    static constexpr bool COOP = false; static constexpr bool CACHE = false; static constexpr bool LDS_STATE = false; static constexpr int XCHG_BYTES = 0;
     static constexpr int NB = 3, NS = 3;
     static constexpr int PP_WAVES = 4;
     static constexpr int E = AMP_ ? 6 : 3, PW = 2, HIDX = 1, LANES = 1;
@@ -1328,7 +1330,7 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
     const bool idle0 = done;                                     // finished before this epoch: nothing of this lane's is written
     // record-cache kernels (one wave per workgroup): behind the state rows, 64 x 976 B of per-lane records, then a copy of the z nodes,
     // staged by ALL 64 lanes before the lanes without a live ray leave
-    constexpr int LDS_STATE_BYTES = (EQ::COOP ? 64 * GEOAC_COOP_SLOT : 0) + (EQ::LDS_STATE ? 2 * GEOAC_MAXE * 64 * (int)sizeof(double) : 0);
+    constexpr int LDS_STATE_BYTES = (EQ::COOP ? EQ::XCHG_BYTES : 0) + (EQ::LDS_STATE ? 2 * GEOAC_MAXE * 64 * (int)sizeof(double) : 0);
     char* const ldsc = (char*)lds_tab + (threadIdx.x >> 6) * LDS_STATE_BYTES + LDS_STATE_BYTES;
     if(EQ::CACHE){
         double* gzl = (double*)(ldsc + GEOAC_CACHE_BYTES);
@@ -1339,7 +1341,7 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
     }
     if(!EQ::COOP && done) return;
     // per wave: (COOP) the 64 x 176 B exchange buffer of the cooperative gather, then (LDS_STATE) y[E][64] and yn[E][64]
-    constexpr int LDS_XCHG_BYTES = EQ::COOP ? 64 * GEOAC_COOP_SLOT : 0;
+    constexpr int LDS_XCHG_BYTES = EQ::COOP ? EQ::XCHG_BYTES : 0;
     constexpr int LDS_WAVE_BYTES = LDS_XCHG_BYTES + (EQ::LDS_STATE ? 2 * GEOAC_MAXE * 64 * (int)sizeof(double) : 0);
     char* const ldsw = (char*)lds_tab + (threadIdx.x >> 6) * LDS_WAVE_BYTES;
     double* const ly = (double*)(ldsw + LDS_XCHG_BYTES) + (threadIdx.x & 63);
@@ -1728,7 +1730,8 @@ __global__ void __launch_bounds__(64) k_probe_grid(GeoacDevParams P, int n, cons
     GridLoc L; grid_locate(P, x, y, z, -1, L);
     double M[3][10];
     if(coop){
-        if constexpr (GRec<GLB>::PACKED) grid_eval3_coop8<true>(P, L, M, (char*)lds_tab);
+        if constexpr (GRec<GLB>::PACKED && GEOAC_COOP_GLDS) grid_eval3_glds<true>(P, L, M, (char*)lds_tab);
+        else if constexpr (GRec<GLB>::PACKED) grid_eval3_coop8<true>(P, L, M, (char*)lds_tab);
         else grid_eval3_coop<true, GLB>(P, L, M, (char*)lds_tab);
     }
     else {
@@ -1811,7 +1814,7 @@ static hipError_t launch_rk4_t(const GeoacDevParams* P, int block, hipStream_t s
     dim3 b(block), g((unsigned)((lanes + block - 1) / block));
     if(n_wg) *n_wg = g.x;
     size_t lds = P->table_in_lds ? (size_t)P->nseg * GEOAC_SEGW * sizeof(double) : 0;
-    if(EQ::LDS_STATE) lds = (size_t)(block / 64) * ((EQ::COOP ? 64 * GEOAC_COOP_SLOT : 0) + 2 * GEOAC_MAXE * 64 * sizeof(double));   // per wave: exchange buffer, y and yn rows (k_rk4)
+    if(EQ::LDS_STATE) lds = (size_t)(block / 64) * ((EQ::COOP ? EQ::XCHG_BYTES : 0) + 2 * GEOAC_MAXE * 64 * sizeof(double));   // per wave: exchange buffer, y and yn rows (k_rk4)
     if(EQ::CACHE){
         if(block != 64) return hipErrorInvalidValue;
         lds += GEOAC_CACHE_BYTES + (size_t)(P->nseg + 1) * sizeof(double);                 // per-lane records, z nodes
@@ -1877,7 +1880,7 @@ extern "C" hipError_t geoac_launch_probe_absorption(const GeoacDevParams* P, int
 extern "C" int geoac_kernels_cart_rec(void){ return GRec<false>::N; }     // doubles per record of the table the Cartesian grid kernels read
 extern "C" hipError_t geoac_launch_probe_grid(const GeoacDevParams* P, int n, const double* a0, const double* a1, const double* a2, int coop,
                                               double* out30, double* api7, hipStream_t s){
-    const size_t lds = coop ? (size_t)64 * GEOAC_COOP_SLOT : 0;
+    const size_t lds = coop ? (size_t)(GEOAC_GLDS_BYTES > 64 * GEOAC_COOP_SLOT ? GEOAC_GLDS_BYTES : 64 * GEOAC_COOP_SLOT) : 0;
     if(P->eqset == GEOAC_EQ_GLOBAL_RNGDEP) hipLaunchKernelGGL(k_probe_grid<true>, dim3((n + 63) / 64), dim3(64), lds, s, *P, n, a0, a1, a2, coop, out30, api7);
     else                                   hipLaunchKernelGGL(k_probe_grid<false>, dim3((n + 63) / 64), dim3(64), lds, s, *P, n, a0, a1, a2, coop, out30, api7);
     return hipGetLastError();

@@ -21,6 +21,8 @@
 // scale the y rows by the y cell size, and AllOrder2's mixed second derivatives stay in SCALED cell coordinates.
 #ifndef GEOAC_RNGDEP_H_
 #define GEOAC_RNGDEP_H_
+#include <utility>
+#include <type_traits>
 
 #define GEOAC_GREC 40        // doubles per (field, kz, node) record of T, u, v: ten cubics
 #define GEOAC_GREC_RHO 16    // rho: F, DxF, DyF, DxyF only (scalar evaluator)
@@ -220,6 +222,9 @@ DEVINL void grid_eval_all(const GeoacDevParams& P, int field, const GridLoc& L, 
 // cost the wave what the gathers cost the texture path.  Tried and dropped: fetching only the (at most two) DISTINCT records of a quad -
 // neighbouring rays fall out of step after their first ground reflection, 20 % of the lanes then need a third record.
 #define GEOAC_COOP_SLOT 176
+#ifndef GEOAC_COOP_GLDS
+#define GEOAC_COOP_GLDS 1             // Cartesian cooperative kernels: gather by LDS-DMA (grid_eval3_glds); 0: register-staged (grid_eval3_coop8)
+#endif
 #ifndef GEOAC_COOP_WAVES
 #define GEOAC_COOP_WAVES 1            // waves per SIMD the cooperative kernels are compiled for
 #endif
@@ -417,6 +422,131 @@ DEVINL void grid_eval3_coop8(const GeoacDevParams& P, const GridLoc& L, double (
     }
 }
 
+// ---- the same gather by LDS-DMA (global_load_lds_dwordx4: table -> LDS, no staging registers, no ds_write) ---------------------------
+// With one wave per SIMD nothing hides a gather's trip to L2 but the wave's own prefetch, and the register-staged forms above can keep
+// only one round (32 VGPRs) in flight.  Here a ROUND is a quarter record - two cubics, 64 bytes - of each of the four lanes of every quad:
+// four loads (load j serves owner j; the four lanes of a quad fetch the owner's 64 bytes, one line piece), each landing lane-linear in a
+// 1-KiB slot of a ring of 5 rounds x 4 slots (20 KiB per wave).  Four rounds (16 loads) are in flight while one is read and evaluated.
+// Lane r of a quad fetches chunk (r + j) & 3 of owner j, so that the owners' reads (ds_read_b128 of chunk c at 1024 o + 64 quad +
+// 16 ((c - o) & 3)) are bank-conflict free.  The loads are asm (hipcc would drain every LDS-DMA before the next ds_read); their completion is
+// counted here: s_waitcnt vmcnt(12) before round rho is read leaves the three younger rounds in flight.  A slot is refilled one whole
+// iteration after it was read, behind a register dependence on what those reads returned.  Arithmetic: the statements of grid_eval_all, one dot4 per accumulator and corner
+// in the same order - the same bits.
+#define GEOAC_GLDS_RING 5
+#define GEOAC_GLDS_BYTES (GEOAC_GLDS_RING * 4096)
+typedef __attribute__((address_space(3))) char geoac_lds_char;
+
+DEVINL void glds_round(const char* base, unsigned o0, unsigned o1, unsigned o2, unsigned o3, unsigned lds_dst, double d0, double d1, double d2, double d3){
+    // d0..d3: one word of each ds_read of the round that was read out of this slot - naming them as inputs makes hipcc wait for those reads
+    // (a counted lgkmcnt: they are a whole iteration old) before the DMA may overwrite what they read
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %6\n\t"
+        "s_nop 4\n\t"
+        "global_load_lds_dwordx4 %2, %1\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, %1\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %4, %1\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %5, %1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep) : "s"(base), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(lds_dst), "v"(d0), "v"(d1), "v"(d2), "v"(d3) : "memory", "scc");
+}
+template <class F, int... I> DEVINL void geoac_static_for(F&& f, std::integer_sequence<int, I...>){ (f(std::integral_constant<int, I>{}), ...); }
+template <int N> DEVINL void glds_wait(){ asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+template <bool ORDER2>
+DEVINL void grid_eval3_glds(const GeoacDevParams& P, const GridLoc& L, double (*M)[10], char* ldsw){
+    const unsigned lane = threadIdx.x & 63u, r = lane & 3u, quad = lane >> 2;
+    const unsigned nn = (unsigned)(P.gnx * P.gny);
+    const Herm hx = hermite(L.xs), hy = hermite(L.ys);
+    const double dxs = L.dxs, dys = L.dys, dxy = dxs * dys;
+    const double t = L.t, th = 0.5 * t, t6 = t * (1.0 / 6.0);
+    const size_t fstride = (size_t)P.nseg * nn * 256u;                                // bytes per field block of the table
+    const char* __restrict__ tabb = (const char*)P.gtab;
+    const unsigned ring = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(geoac_lds_char*)ldsw);   // LDS byte address of the wave's ring, in an SGPR
+    // this lane's chunk c of its own quarter record: slot r of the round, position (c - r) & 3 of its quad's 64 bytes
+    const char* const rq = ldsw + 1024u * r + 64u * quad;
+    const char* const ra0 = rq + 16u * ((0u - r) & 3u), * const ra1 = rq + 16u * ((1u - r) & 3u), * const ra2 = rq + 16u * ((2u - r) & 3u), * const ra3 = rq + 16u * ((3u - r) & 3u);
+    #pragma unroll
+    for(int f = 0; f < 3; f++){
+        #pragma unroll
+        for(int i = 0; i < 10; i++) M[f][i] = 0.0;
+    }
+    unsigned gb[4];                                                                   // byte offsets: owner j's record + the chunk this lane fetches for it
+    #define GEOAC_GLDS_BASES(cnx) { \
+        const unsigned off = ((unsigned)L.kz * nn + (unsigned)corner_node(L, (cnx) >> 1, (cnx) & 1)) * 256u; \
+        gb[0] = quad_bcast_u32<0>(off) + 16u * (r & 3u); gb[1] = quad_bcast_u32<1>(off) + 16u * ((r + 1u) & 3u); \
+        gb[2] = quad_bcast_u32<2>(off) + 16u * ((r + 2u) & 3u); gb[3] = quad_bcast_u32<3>(off) + 16u * ((r + 3u) & 3u); }
+    // round rho = 4 n + qd: record n = 3 corner + field, quarter qd
+    geoac_d2 p0 = { 0.0, 0.0 }, p1 = p0, p2 = p0, p3 = p0;                            // what the previous round's reads returned
+    #define GEOAC_GLDS_ISSUE(rho) { \
+        constexpr int n_ = (rho) >> 2, qd_ = (rho) & 3, cn_ = n_ / 3, f_ = n_ % 3; \
+        if(qd_ == 0 && f_ == 0) GEOAC_GLDS_BASES(cn_) \
+        glds_round(tabb + (size_t)f_ * fstride + 64 * qd_, gb[0], gb[1], gb[2], gb[3], ring + 4096u * ((rho) % GEOAC_GLDS_RING), p0.x, p1.x, p2.x, p3.x); }
+    GEOAC_GLDS_ISSUE(0) GEOAC_GLDS_ISSUE(1) GEOAC_GLDS_ISSUE(2) GEOAC_GLDS_ISSUE(3) GEOAC_GLDS_ISSUE(4)
+    double cF = 0, cFz = 0, cFzz = 0, cDxF = 0, cVxz = 0, cDxFzz = 0, cDyF = 0, cDxyF = 0;   // carried between the quarters of a record
+    auto step = [&](auto RHO) __attribute__((always_inline)) {
+        constexpr int rho = decltype(RHO)::value;
+        constexpr int n = rho >> 2, qd = rho & 3, cn = n / 3, f = n % 3, a = cn >> 1, b = cn & 1;
+        // wait until round rho has landed (rounds up to rho + 3 have been issued: iteration i >= 1 issues round i + 4), read it, and refill
+        // the slot that was read ONE ITERATION AGO with round rho + 4
+        constexpr int issued = rho == 0 ? 4 : (rho + 3 < 47 ? rho + 3 : 47);
+        glds_wait<4 * (issued - rho)>();
+        constexpr int so = 4096 * (rho % GEOAC_GLDS_RING);
+        const geoac_d2 q0 = *(const geoac_d2*)(ra0 + so), q1 = *(const geoac_d2*)(ra1 + so), q2 = *(const geoac_d2*)(ra2 + so), q3 = *(const geoac_d2*)(ra3 + so);
+        if constexpr (rho >= 1 && rho + 4 < 48) GEOAC_GLDS_ISSUE(rho + 4)
+        p0 = q0; p1 = q1; p2 = q2; p3 = q3;
+        const Cub c0 = Cub{ q0.x, q0.y, q1.x, q1.y }, c1 = Cub{ q2.x, q2.y, q3.x, q3.y };
+        CornerW w = corner_weights<ORDER2, ORDER2>(hx, hy, a, b);
+        const double Wq = w.W[2] * dxs;                                               // Q11 row of the f_zz patch (y row scaled by dx)
+        w.W[1] *= dxs; w.W[2] *= dys; w.W[3] *= dxy;
+        if(ORDER2){ w.D[1] *= dxs; w.D[2] *= dys; w.D[3] *= dxy; w.E[1] *= dxs; w.E[2] *= dys; w.E[3] *= dxy; }
+        double* o = M[f];
+        if constexpr (qd == 0){                                                       // F, DxF
+            cF = cub_val(c0, t, t6); cDxF = cub_val(c1, t, t6);
+            cFz = cub_d1(c0, t, th); cVxz = cub_d1(c1, t, th);
+            if(ORDER2){ cFzz = cub_d2(c0, t); cDxFzz = cub_d2(c1, t); }
+        } else if constexpr (qd == 1){                                                // DyF, DxyF
+            const double DyF = cub_val(c0, t, t6), DxyF = cub_val(c1, t, t6);
+            const double Vyz = cub_d1(c0, t, th), DxyFz = cub_d1(c1, t, th);
+            o[0] = dot4(w.W, cF, cDxF, DyF, DxyF, o[0]);
+            o[3] = dot4(w.W, cFz, cVxz, Vyz, DxyFz, o[3]);
+            if(ORDER2){
+                o[8] = dot4(w.D, cFz, cVxz, Vyz, DxyFz, o[8]);
+                o[9] = dot4(w.E, cFz, cVxz, Vyz, DxyFz, o[9]);
+                const double DyFzz = cub_d2(c0, t), DxyFzz = cub_d2(c1, t);
+                o[6] = __builtin_fma(w.W[0], cFzz, __builtin_fma(w.W[1], cDxFzz, __builtin_fma(Wq, DyFzz, __builtin_fma(w.W[3], DxyFzz, o[6]))));
+            }
+            cDyF = DyF; cDxyF = DxyF;
+        } else if constexpr (qd == 2){                                                // DxVx, DxyVx
+            const double DxVx = cub_val(c0, t, t6), DxyVx = cub_val(c1, t, t6);
+            o[1] = dot4(w.W, cDxF, DxVx, cDxyF, DxyVx, o[1]);
+            if(ORDER2){
+                o[4] = dot4(w.D, cDxF, DxVx, cDxyF, DxyVx, o[4]);
+                o[7] = dot4(w.E, cDxF, DxVx, cDxyF, DxyVx, o[7]);
+            }
+        } else {                                                                      // DyVy, DxyVy
+            const double DyVy = cub_val(c0, t, t6), DxyVy = cub_val(c1, t, t6);
+            o[2] = dot4(w.W, cDyF, cDxyF, DyVy, DxyVy, o[2]);
+            if(ORDER2) o[5] = dot4(w.E, cDyF, cDxyF, DyVy, DxyVy, o[5]);
+        }
+    };
+    geoac_static_for(step, std::make_integer_sequence<int, 48>{});
+    #undef GEOAC_GLDS_ISSUE
+    #undef GEOAC_GLDS_BASES
+    if(ORDER2){
+        const double idxs = L.idxs, idys = L.idys;
+        #pragma unroll
+        for(int f = 0; f < 3; f++){ M[f][4] *= idxs; M[f][8] *= idxs; M[f][7] *= idys; M[f][5] *= idys; M[f][9] *= idys; }
+    }
+}
+
 // ---- per-lane record cache (four lanes per ray, small fans: eigenray rounds, -interactive) ---------------------------------------
 // A small fan leaves most of the chip idle and lasts as long as its longest ray: what counts is the latency of one RK4 stage, and that
 // was two dependent trips to memory (z nodes, then the table records) in front of the arithmetic.  A ray stays in one cell and one
@@ -533,7 +663,8 @@ DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double
     double M[3][10];                                               // T, u, v and their derivatives
     // three copies of the evaluator: M[][] stays in registers (rolled, the dynamic index f put it in scratch: 240 B written and read back per stage)
     if(COOP){
-        if constexpr (GRec<false>::PACKED) grid_eval3_coop8<AMP>(P, L, M, ldsw);
+        if constexpr (GRec<false>::PACKED && GEOAC_COOP_GLDS) grid_eval3_glds<AMP>(P, L, M, ldsw);
+        else if constexpr (GRec<false>::PACKED) grid_eval3_coop8<AMP>(P, L, M, ldsw);
         else grid_eval3_coop<AMP, false>(P, L, M, ldsw);
     } else if(CACHE){
         const double* rec = grid_cache_fill<false>(P, L, cq, ldsw, ckey);
