@@ -65,6 +65,8 @@ struct geoac_ctx {
     bool compact = true;             // GEOAC_COMPACT=0: every epoch runs over all slots (no live-ray compaction between epochs)
     DevBuf colmap[3], ncols;         // per chunk: column -> slot list of the rays alive at the start of that epoch; their counts (3 ints)
     bool quad_cache = true;          // GEOAC_QUAD_CACHE=0: four-lane grid kernels without the per-lane record cache (A/B)
+    int  sub_epochs = 4;             // GEOAC_SUB_EPOCHS: sub-epochs of the cooperative grid kernels when a fan has more waves than the chip has wave slots (k_rk4); 1 = off
+    DevBuf sub_flags;
     bool grid_coop = true;           // GEOAC_GRID_COOP=0: per-lane table gathers instead of the wave-cooperative gather (A/B runs, schedule-independence test)
     hipStream_t stream = nullptr; bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -237,6 +239,8 @@ int geoac_create(geoac_ctx** out, int eqset, int device){
     if(qc) ctx->quad_cache = (atoi(qc) != 0);
     const char* gc = getenv("GEOAC_GRID_COOP");
     if(gc) ctx->grid_coop = (atoi(gc) != 0);
+    const char* se = getenv("GEOAC_SUB_EPOCHS");
+    if(se){ ctx->sub_epochs = atoi(se); if(ctx->sub_epochs < 1) ctx->sub_epochs = 1; if(ctx->sub_epochs > 16) ctx->sub_epochs = 16; }
     const char* sc = getenv("GEOAC_SMP_CAP");
     if(sc && atoll(sc) > 0) ctx->smp_cap = atoll(sc);
     *out = ctx;
@@ -253,7 +257,7 @@ int geoac_destroy(geoac_ctx* ctx){
                        &ctx->nlegend[0], &ctx->nlegend[1], &ctx->nlegend[2],
                        &ctx->ev_row[0], &ctx->ev_row[1], &ctx->ev_row[2], &ctx->ev_m[0], &ctx->ev_m[1], &ctx->ev_m[2],
                        &ctx->ev_amp[0], &ctx->ev_amp[1], &ctx->ev_amp[2], &ctx->nev[0], &ctx->nev[1], &ctx->nev[2], &ctx->smp_out,
-                       &ctx->d_gx, &ctx->d_gy, &ctx->d_gz, &ctx->d_gtab, &ctx->d_gtab8, &ctx->d_consts, &ctx->colmap[0], &ctx->colmap[1], &ctx->colmap[2], &ctx->ncols };
+                       &ctx->d_gx, &ctx->d_gy, &ctx->d_gz, &ctx->d_gtab, &ctx->d_gtab8, &ctx->d_consts, &ctx->sub_flags, &ctx->colmap[0], &ctx->colmap[1], &ctx->colmap[2], &ctx->ncols };
     for(DevBuf* b : bufs) b->release();
     if(ctx->h_counters) hipHostFree(ctx->h_counters);
     if(ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -605,6 +609,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
         HIPCHK(ctx->ncols.ensure(4 * sizeof(int)));
     }
     P.n_cols_bound = P.n_pad;
+    P.sub = 1; P.sub_w = 0; P.sub_flags = nullptr;
     const int n_chunks = ctx->two_chunks ? 2 : 3;     // three path chunks in rotation: the post-pass may lag the RK4 by more than one epoch (measured: GeoAc3D 360 x 90 fan 212 -> 160 ms; GEOAC_TWO_CHUNKS=1 for A/B)
     for(int b = 0; b < n_chunks; b++){
         if(sampling){                                             // per-chunk event lists of the WriteRays / WriteCaustics rows
@@ -697,7 +702,16 @@ int geoac_fan_launch(geoac_ctx* ctx){
             HIPCHK(hipStreamWaitEvent(s, ctx->evj[2 * e], 0));
             Pe.slot_hi = P.n_pad;
         } else {
+            // cooperative grid kernels with more waves than the chip has wave slots (1024: one per SIMD): sub-epochs (k_rk4) keep the
+            // last round of the launch from running on a part-empty chip
+            const int waves = (Pe.slot_hi - Pe.slot_lo + 63) / 64;
+            if(P.coop && block == 64 && ctx->sub_epochs > 1 && waves > 1024 && Pe.s_rows >= 16 * ctx->sub_epochs){
+                Pe.sub = ctx->sub_epochs; Pe.sub_w = (waves + 7) / 8 * 8;
+                HIPCHK(ctx->sub_flags.ensure(sizeof(int) * ((size_t)P.n_pad / 64 + 16)));
+                Pe.sub_flags = (int*)ctx->sub_flags.p;
+            }
             HIPCHK(geoac_launch_rk4(&Pe, block, s, &n_wg));
+            Pe.sub = 1;                                // (Pe goes on to the post-pass / sum launches)
         }
         HIPCHK(hipEventRecord(ctx->evs[eb + 1], s));
         HIPCHK(hipMemcpyAsync(ctx->h_counters + 16 * (e & 1), ctx->counters.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -745,6 +759,12 @@ int geoac_fan_launch(geoac_ctx* ctx){
     ctx->path_bytes_r = 2 * ctx->path_bytes_w;
     ctx->ran = true;
     ctx->lastP = P;
+    if(ctx->err_flags & 4ull){
+        // a sub-epoch workgroup gave up waiting for its predecessor: the dispatch order k_rk4 relies on did not hold.  Run the fan again
+        // without sub-epochs (this context keeps them off from now on).
+        if(ctx->sub_epochs > 1){ ctx->sub_epochs = 1; fprintf(stderr, "libgeoac_hip: sub-epoch hand-off timed out, repeating the fan without sub-epochs\n"); return geoac_fan_launch(ctx); }
+        return fail(ctx, GEOAC_E_HIP, "sub-epoch hand-off timed out");
+    }
     if(ctx->err_flags & 2ull) return fail(ctx, GEOAC_E_CAPACITY, "per-epoch sample/caustic event list overflowed");
     if(sampling && ctx->n_samples > (unsigned long long)P.smp_cap)
         return fail(ctx, GEOAC_E_CAPACITY, "sample list overflowed: raise GEOAC_SMP_CAP (needed " + std::to_string(ctx->n_samples) + ")");

@@ -87,6 +87,9 @@ struct GeoacDevParams {
     const int*    colmap;           // live-ray compaction: column of this epoch's chunk -> ray slot (NULL: identity, column = slot)
     const int*    n_cols;           // device: number of valid columns of colmap
     int           n_cols_bound;     // host-side upper bound of the columns in use this epoch (launch sizes of the post-pass / sum kernels); n_pad without compaction
+    int           sub;              // cooperative grid kernels: the epoch is cut into `sub` sub-epochs, each a workgroup of its own (k_rk4); 1 = off
+    int           sub_w;            // workgroups per sub-epoch (multiple of 8: a wave's sub-epochs are dispatched on one XCD, in order)
+    int*          sub_flags;        // [sub_w] sub-epochs completed per wave (zeroed before the launch)
     const int*    perm;             // slot -> ray index of the caller's order (records and samples are written in the caller's order); NULL = identity
     const double* theta_deg;        // [n_rays]
     const double* phi_deg;

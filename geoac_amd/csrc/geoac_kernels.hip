@@ -1301,7 +1301,28 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
     __builtin_amdgcn_s_setprio(3);      // latency-critical serial recurrence: win VALU arbitration against co-resident post-pass waves
     extern __shared__ double lds_tab[];
     if(threadIdx.x == 0) atomicAdd(&P.counters[5], 1ull);       // this workgroup holds its CU now: k_gate releases the previous epoch's post-pass
-    const int tid0 = blockIdx.x * blockDim.x + threadIdx.x;
+    // ---- sub-epochs (cooperative grid kernels, one wave per workgroup): a fan of W waves on S wave slots runs ceil(W / S) rounds per
+    // epoch, the last one part empty (config-4 share: 1493 waves on 1024 slots, 27 % of the slot time idle).  With P.sub > 1 the grid is
+    // sub x sub_w workgroups: workgroup (h, w) integrates rows [h, h + 1) s_rows / sub of wave w's epoch and starts from the state
+    // workgroup (h - 1, w) left behind, which it waits for on a flag.  Workgroups are dispatched in index order, round robin over the
+    // XCDs; sub_w is a multiple of 8, so (h - 1, w) went to the same XCD earlier and is resident or finished: the wait cannot deadlock (and
+    // is bounded all the same: ~2 s, then the error flag).  The rounds of the launch are now 1 / sub as long: the idle part shrinks with it.
+    const int sub_h = (EQ::COOP && P.sub > 1) ? (int)(blockIdx.x / (unsigned)P.sub_w) : 0;
+    const unsigned bidx = (EQ::COOP && P.sub > 1) ? blockIdx.x % (unsigned)P.sub_w : blockIdx.x;
+    const bool sub_on = EQ::COOP && P.sub > 1;
+    if(EQ::COOP && sub_h > 0){
+        const long long t0 = wall_clock64();
+        bool ok = true;
+        while(__hip_atomic_load(P.sub_flags + bidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sub_h){
+            __builtin_amdgcn_s_sleep(32);
+            if(wall_clock64() - t0 > 200000000ll){ ok = false; break; }          // (100 MHz counter)
+        }
+        if(!ok){ if(threadIdx.x == 0) atomicOr(&P.counters[2], 4ull); return; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                      // (invalidates this CU's L1: the state rows another CU stored)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const int row_end = sub_on ? (int)(((long long)P.s_rows * (sub_h + 1)) / P.sub) : P.s_rows;
+    const int tid0 = bidx * blockDim.x + threadIdx.x;
     const int tid = (P.spread > 1) ? tid0 / P.spread : tid0;
     // `col` = this ray's column in the epoch's chunk buffers (path, contrib, row counts, leg-end and sample events); `slot` = its row in the
     // fan-long state block.  Without compaction they are the same number.  With it (P.colmap) the epoch runs over the dense list of the
@@ -1314,10 +1335,13 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
     const size_t np = (size_t)P.n_pad;
     double* st = P.state + (mine ? slot : 0);
     bool done = mine ? (st[ST_DONE * np] != 0.0) : true;
-    if(mine && done){ P.nrows[col] = 0; P.nlegend[col] = 0; if(SMP) P.nev[col] = 0; }
+    if(mine && done && sub_h == 0){ P.nrows[col] = 0; P.nlegend[col] = 0; if(SMP) P.nev[col] = 0; }
     // a workgroup whose rays have all finished leaves before the table is staged (late epochs, and the launch the host
     // enqueues ahead of knowing that the previous epoch finished the fan)
-    if(!__syncthreads_or(!done)) return;
+    if(!__syncthreads_or(!done)){
+        if(EQ::COOP && sub_on && threadIdx.x == 0) __hip_atomic_store(P.sub_flags + bidx, sub_h + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (nothing stored: nothing to release)
+        return;
+    }
     // ---- stage the segment table in LDS (coalesced 8 B/lane loads; 153 KiB for ToyAtmo) ----
     const double* gtab = P.seg;
     if(LDS){
@@ -1348,6 +1372,7 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
     double* const lyn = ly + GEOAC_MAXE * 64;
 
     int nr = 0, nle = 0;
+    if(EQ::COOP && sub_h > 0 && !idle0){ nr = P.nrows[col]; nle = P.nlegend[col]; }   // continue the chunk where the previous sub-epoch stopped
     static_assert(E <= ST_K - ST_Y0, "state block: y[] overruns ST_K");
     static_assert(!EQ::KM2 || ST_YM2 + E <= ST_DPREV, "state block: ym2[] overruns ST_DPREV");
     constexpr bool YM2_REG = EQ::KM2 && !EQ::KM2_MEM;                // row k-2 in registers (else: in the state block, read at reflections)
@@ -1368,16 +1393,16 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
     for(int q = 0; q < 6; q++) C.a[q] = st[(ST_AUX0 + q) * np];
     int seg = P.gtab ? (int)st[ST_SEG * np] : (int)st[ST_SEG * np] * GEOAC_SEGW;   // 1-D sets: element offset of the current spline segment; grid sets: vertical segment index
     unsigned long long steps_here = 0;
-    int nev = 0;                                                // WriteRays / WriteCaustics events of this chunk
+    int nev = (EQ::COOP && SMP && sub_h > 0 && !idle0) ? P.nev[col] : 0;   // WriteRays / WriteCaustics events of this chunk
     double dprev = SMP ? st[ST_DPREV * np] : 0.0;               // Jacobian of the previous row (caustic detection)
     const bool want_rays = SMP && (P.mode & GEOAC_MODE_WRITE_RAYS), want_caus = SMP && EQ::AMP && (P.mode & GEOAC_MODE_WRITE_CAUSTICS);
 
-    if(!EQ::COOP || !idle0) write_row<EQ>(P, nr++, col, q, y);     // carry row: chunk row 0 = current state
+    if(!EQ::COOP || (!idle0 && sub_h == 0)) write_row<EQ>(P, nr++, col, q, y);     // carry row: chunk row 0 = current state
 
     // COOP: wave-uniform loop (every lane stays while any lane of the wave has work; `act` predicates this lane's own work).
     // Other policies: the plain per-lane loop (kept in this form: the latency-bound stratified kernels are sensitive to how the loop is laid out)
-    while(EQ::COOP ? (bool)__any((nr + 2 <= P.s_rows) && !done) : ((nr + 2 <= P.s_rows) && !done)){
-        const bool act = EQ::COOP ? ((nr + 2 <= P.s_rows) && !done) : true;
+    while(EQ::COOP ? (bool)__any((nr + 2 <= row_end) && !done) : ((nr + 2 <= P.s_rows) && !done)){
+        const bool act = EQ::COOP ? ((nr + 2 <= row_end) && !done) : true;
         double ds = P.ds_min;
         if(!EQ::COOP || act){
         // running turning height: max over rows m < k of the height component   (GeoAcGlobal_main.cpp:294)
@@ -1550,10 +1575,19 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
         if((act >> l) & 1ull) s += v;
     }
     const unsigned long long live = __popcll(__ballot(!done && q == 0));
+    const bool last_sub = !sub_on || sub_h == P.sub - 1;          // the live counts of the epoch are those after its last sub-epoch
     if((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1){
         atomicAdd(&P.counters[0], s);
-        atomicAdd(&P.counters[P.live_slot], live);
-        if(live) atomicAdd(&P.counters[P.live_slot == 1 ? 4 : 7], 1ull);     // waves that still carry a live ray
+        if(last_sub){
+            atomicAdd(&P.counters[P.live_slot], live);
+            if(live) atomicAdd(&P.counters[P.live_slot == 1 ? 4 : 7], 1ull);     // waves that still carry a live ray
+        }
+    }
+    if(EQ::COOP && sub_on){
+        // publish the state this workgroup stored (one wave per workgroup: its stores are ordered before the release by the fence)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // (hipcc may drop the wait behind the write-back: MI355X_MICROARCH.md, inter-workgroup visibility)
+        if(threadIdx.x == 0) __hip_atomic_store(P.sub_flags + bidx, sub_h + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1812,6 +1846,13 @@ static hipError_t launch_rk4_t(const GeoacDevParams* P, int block, hipStream_t s
     if(P->slot_lo < 0 || P->slot_hi > P->n_pad || P->slot_lo >= P->slot_hi) return hipErrorInvalidValue;
     const long long lanes = (long long)(P->slot_hi - P->slot_lo) * EQ::LANES * (P->spread > 1 ? P->spread : 1);
     dim3 b(block), g((unsigned)((lanes + block - 1) / block));
+    if(P->sub > 1){
+        // sub-epochs: sub x sub_w workgroups (k_rk4); the flags are zeroed on the launch stream
+        if(!EQ::COOP || block != 64 || !P->sub_flags || P->sub_w < (int)g.x || (P->sub_w & 7)) return hipErrorInvalidValue;
+        hipError_t e = hipMemsetAsync(P->sub_flags, 0, sizeof(int) * (size_t)P->sub_w, s);
+        if(e != hipSuccess) return e;
+        g.x = (unsigned)P->sub_w * (unsigned)P->sub;
+    }
     if(n_wg) *n_wg = g.x;
     size_t lds = P->table_in_lds ? (size_t)P->nseg * GEOAC_SEGW * sizeof(double) : 0;
     if(EQ::LDS_STATE) lds = (size_t)(block / 64) * ((EQ::COOP ? EQ::XCHG_BYTES : 0) + 2 * GEOAC_MAXE * 64 * sizeof(double));   // per wave: exchange buffer, y and yn rows (k_rk4)

@@ -79,11 +79,14 @@ DEVINL void grid_locate(const GeoacDevParams& P, double x, double y, double z, i
 // Hermite basis on [0,1] and its derivative: value weights h[0], h[1] and slope weights g[0], g[1] of the two cell edges
 struct Herm { double h[2], g[2], dh[2], dg[2]; };
 DEVINL Herm hermite(double s){
-    Herm H; double s2 = s * s, s3 = s2 * s;
-    H.h[1] = 3.0 * s2 - 2.0 * s3; H.h[0] = 1.0 - H.h[1];
-    H.g[0] = s - 2.0 * s2 + s3;   H.g[1] = s3 - s2;
-    H.dh[1] = 6.0 * (s - s2);     H.dh[0] = -H.dh[1];
-    H.dg[0] = 1.0 - 4.0 * s + 3.0 * s2; H.dg[1] = 3.0 * s2 - 2.0 * s;
+    // explicit FMAs, contraction off: the evaluators below are inlined into differently shaped code (per-lane, cooperative, LDS-DMA) and
+    // must give a ray the same bits whichever of them serves it - hipcc's own choice of what to fuse varies with the surroundings
+    #pragma clang fp contract(off)
+    Herm H; const double s2 = s * s, s3 = s2 * s;
+    H.h[1] = __builtin_fma(-2.0, s3, 3.0 * s2); H.h[0] = 1.0 - H.h[1];
+    H.g[0] = __builtin_fma(-2.0, s2, s) + s3;   H.g[1] = s3 - s2;
+    H.dh[1] = 6.0 * (s - s2);                   H.dh[0] = -H.dh[1];
+    H.dg[0] = __builtin_fma(3.0, s2, __builtin_fma(-4.0, s, 1.0)); H.dg[1] = __builtin_fma(3.0, s2, -2.0 * s);
     return H;
 }
 

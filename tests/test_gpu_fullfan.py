@@ -68,3 +68,34 @@ def test_config4_share_on_5x5x1400_grid_vs_reference(G, tmp_path):
     gold = {k: g[k] for k in ("steps", "flags", "vals", "val_fields")}
     err = compare_compact(rec, gold, idx=sel)
     print("cfg4 share:", steps, "ray-steps;", len(sel), "rays vs reference, max rel err", {k: f"{v:.2e}" for k, v in err.items()})
+
+
+def test_config4_share_is_schedule_independent(G, tmp_path):
+    """the config-4 share under the launch plans of the grid kernels - default (LDS-DMA cooperative gather, four sub-epochs per epoch),
+    without sub-epochs, 4096-row epochs in eight sub-epochs, no compaction, per-lane gathers - gives bit-identical records"""
+    import os
+    import rngdep_data as RD
+    grid = RD.write_grid(str(tmp_path), short_paths=False, thin=1)
+    th, ph = G.fan_enumerate(theta_min=0.05, theta_max=50.0, theta_step=0.05, phi_min=-180.0, phi_max=-180.0 + 124 * 0.36, phi_step=0.36)
+
+    def run(env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            ctx = G.FanContext(G.EQ_3D_RNGDEP, device=0)      # the knobs are read when the context is created
+            ctx.load_grid(*grid)
+            ctx.set_params(bounces=1, calc_amp=1, mode=0, src=(0.0, 0.0, 0.0))
+            rec, steps = ctx.run(th, ph)
+            ctx.close()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        return rec, steps
+    ref, steps = run({})
+    for env in ({"GEOAC_SUB_EPOCHS": "1"}, {"GEOAC_SUB_EPOCHS": "8", "GEOAC_S_ROWS": "4096"}, {"GEOAC_COMPACT": "0"}, {"GEOAC_GRID_COOP": "0"}):
+        rec, st = run(env)
+        assert st == steps, env
+        assert np.array_equal(rec, ref), env

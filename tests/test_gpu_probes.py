@@ -106,3 +106,28 @@ def test_spherical_grid_interpolant_vs_reference(coop, tmp_path):
     print("globalrd coop" if coop else "globalrd", "AllOrder2 max rel err", f"{e.max():.1e}", "scalar API", [f"{v:.1e}" for v in ea])
     print("   per column", [f"{v:.0e}" for v in e])
     assert e.max() <= RTOL and ea.max() <= RTOL
+
+
+@pytest.mark.parametrize("eqname", ["EQ_3D_RNGDEP", "EQ_GLOBAL_RNGDEP"])
+def test_cooperative_and_per_lane_gathers_give_the_same_bits(eqname, tmp_path):
+    """4096 random points of the grid through the per-lane evaluator (grid_eval_all) and through the wave-cooperative one (LDS-DMA ring for the
+    Cartesian set, register-staged exchange for the spherical one): bit-identical - a ray's numbers must not depend on which gather served it"""
+    import geoac_amd as G
+    import rngdep_data as RD
+    rng = np.random.default_rng(5)
+    n = 4096
+    ctx = G.FanContext(getattr(G, eqname), device=0)
+    if eqname == "EQ_3D_RNGDEP":
+        ctx.load_grid(*RD.write_grid(str(tmp_path), short_paths=False))
+        ctx.set_params(bounces=0, calc_amp=1, mode=0, src=(0.0, 0.0, 0.0))
+        ctx.run(np.array([20.0]), np.array([-90.0]))
+        a = (rng.uniform(-400, 400, n), rng.uniform(-400, 400, n), rng.uniform(0.0, 130.0, n))
+    else:
+        ctx.load_grid(*RD.write_grid_global(str(tmp_path), short_paths=False))
+        ctx.set_params(bounces=0, calc_amp=1, mode=0, src=(0.0, 31.0, 0.0))
+        ctx.run(np.array([20.0]), np.array([-90.0]))
+        a = (np.radians(rng.uniform(27.0, 35.0, n)), np.radians(rng.uniform(-4.0, 4.0, n)), 6370.0 + rng.uniform(0.0, 130.0, n))
+    o0, a0 = ctx.probe_grid(*a, coop=False)
+    o1, a1 = ctx.probe_grid(*a, coop=True)
+    assert np.isfinite(o0).all()
+    assert np.array_equal(o0, o1) and np.array_equal(a0, a1)
