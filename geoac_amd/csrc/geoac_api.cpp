@@ -540,7 +540,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
         P.smp_out = (double*)ctx->smp_out.p;
     }
     HIPCHK(ctx->rec.ensure(sizeof(double) * (size_t)ctx->n_rays * ctx->legs * GEOAC_REC_STRIDE));
-    HIPCHK(ctx->counters.ensure(16 * sizeof(unsigned long long)));
+    HIPCHK(ctx->counters.ensure(32 * sizeof(unsigned long long)));
     P.seg = (const double*)ctx->seg.p; P.rho = (const double*)ctx->rhot.p;
     P.theta_deg = (const double*)ctx->theta.p; P.phi_deg = (const double*)ctx->phi.p;
     P.perm = ctx->have_perm ? (const int*)ctx->perm.p : nullptr;
@@ -629,7 +629,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
     //      buffers alternate, so k_rk4(e+1) runs beside k_postpass(e)/k_accum(e).  The host only waits for the
     //      live-ray count of each RK4 launch (it must know when to stop). ----
     hipStream_t s = ctx->stream, sp = ctx->no_overlap ? ctx->stream : ctx->pp_stream, sa = ctx->no_overlap ? ctx->stream : ctx->acc_stream;
-    HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 16 * sizeof(unsigned long long), s));
+    HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 32 * sizeof(unsigned long long), s));
     HIPCHK(hipEventRecord(ctx->ev0, s));
     HIPCHK(geoac_launch_init(&P, s));
     ctx->n_epochs = 0; ctx->path_bytes_w = 0; ctx->path_bytes_r = 0;
@@ -742,6 +742,18 @@ int geoac_fan_launch(geoac_ctx* ctx){
     HIPCHK(hipMemcpyAsync(ctx->h_counters + 8, ctx->counters.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     ctx->n_samples = ctx->h_counters[8 + 3];
+#ifdef GEOAC_KSTAT
+    {   // diagnostic build (geoac_rngdep.h): distinct (segment, cell) keys per live wave-stage
+        unsigned long long h[16];
+        HIPCHK(hipMemcpy(h, (const unsigned long long*)ctx->counters.p + 16, sizeof(h), hipMemcpyDeviceToHost));
+        unsigned long long tot = 0; for(int i = 0; i < 8; i++) tot += h[i];
+        if(tot){
+            fprintf(stderr, "[kstat] wave-stages %llu; K = 1: %.3f, 2: %.3f, 3-4: %.3f, 5-6: %.3f, 7-8: %.3f, 9-12: %.3f, 13-16: %.3f, > 16: %.3f; mean K %.2f, mean kz span %.2f\n", tot,
+                    (double)h[0] / tot, (double)h[1] / tot, (double)h[2] / tot, (double)h[3] / tot, (double)h[4] / tot, (double)h[5] / tot, (double)h[6] / tot, (double)h[7] / tot,
+                    (double)h[8] / tot, (double)h[9] / tot);
+        }
+    }
+#endif
 
     float ms = 0; hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->ms_total = ms;

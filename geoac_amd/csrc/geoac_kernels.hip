@@ -1403,6 +1403,9 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
     // Other policies: the plain per-lane loop (kept in this form: the latency-bound stratified kernels are sensitive to how the loop is laid out)
     while(EQ::COOP ? (bool)__any((nr + 2 <= row_end) && !done) : ((nr + 2 <= P.s_rows) && !done)){
         const bool act = EQ::COOP ? ((nr + 2 <= row_end) && !done) : true;
+#ifdef GEOAC_KSTAT
+        C.ckey = act ? 1 : 0;
+#endif
         double ds = P.ds_min;
         if(!EQ::COOP || act){
         // running turning height: max over rows m < k of the height component   (GeoAcGlobal_main.cpp:294)

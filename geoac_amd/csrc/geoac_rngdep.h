@@ -665,6 +665,20 @@ DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double
     kz = L.kz;
     double M[3][10];                                               // T, u, v and their derivatives
     // three copies of the evaluator: M[][] stays in registers (rolled, the dynamic index f put it in scratch: 240 B written and read back per stage)
+#ifdef GEOAC_KSTAT
+    if(COOP){   // diagnostic build: histogram of the number of DISTINCT (segment, cell) keys among the live lanes of a wave-stage
+        const bool live = (*ckey != 0);
+        const unsigned key = (unsigned)L.kz * 4096u + (unsigned)L.n00;
+        unsigned long long rem = __ballot(live); int K = 0;
+        while(rem){ const int l = __ffsll((long long)rem) - 1; const unsigned k0 = (unsigned)__shfl((int)key, l); rem &= ~__ballot(live && key == k0); K++; }
+        int kzmin = live ? L.kz : 1 << 30, kzmax = live ? L.kz : -1;
+        for(int o = 32; o > 0; o >>= 1){ kzmin = min(kzmin, __shfl_xor(kzmin, o)); kzmax = max(kzmax, __shfl_xor(kzmax, o)); }
+        if((threadIdx.x & 63) == 0 && K > 0){
+            const int bin = K == 1 ? 0 : K == 2 ? 1 : K <= 4 ? 2 : K <= 6 ? 3 : K <= 8 ? 4 : K <= 12 ? 5 : K <= 16 ? 6 : 7;
+            atomicAdd(&P.counters[16 + bin], 1ull); atomicAdd(&P.counters[24], (unsigned long long)K); atomicAdd(&P.counters[25], (unsigned long long)(kzmax - kzmin + 1));
+        }
+    }
+#endif
     if(COOP){
         if constexpr (GRec<false>::PACKED && GEOAC_COOP_GLDS) grid_eval3_glds<AMP>(P, L, M, ldsw);
         else if constexpr (GRec<false>::PACKED) grid_eval3_coop8<AMP>(P, L, M, ldsw);
