@@ -549,7 +549,7 @@ DEVINL void cart2_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCt
 // ================================================================================================
 template <bool AMP_> struct EqGlobal {
     static constexpr bool AMP = AMP_;
-    static constexpr bool COOP = false; static constexpr bool CACHE = false; static constexpr bool LDS_STATE = false; static constexpr int XCHG_BYTES = 0;
+    static constexpr bool COOP = false; static constexpr bool CACHE = false; static constexpr bool LDS_STATE = false; static constexpr int XCHG_BYTES = 0; static constexpr bool PP_TILE = false; static constexpr bool PP_DEDUP = false;
     static constexpr int PP_WAVES = 3;                              // post-pass waves per SIMD (168 registers; at 128 it spills 148 B and runs 1.5 x slower)
     static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 0, LANES = 1;
     static constexpr bool SPLIT = false;                            // true: the lanes of a ray carry DIFFERENT parts of its state (EqGlobalPair)
@@ -721,6 +721,14 @@ struct EqGlobalPair : EqGlobal<true> {
 };
 
 #include "geoac_rngdep.h"
+#ifndef GEOAC_PP_TILE
+#define GEOAC_PP_TILE 1               // grid sets: post-pass over 16-row x 16-ray tiles (0: one row x 256 rays per workgroup, A/B builds)
+#endif
+#ifndef GEOAC_PP_DEDUP
+#define GEOAC_PP_DEDUP 1              // Cartesian grid set: the post-pass reads the table once per distinct key of a wave (k_postpass)
+#endif
+#define GEOAC_PP_SLOTS 6              // keys per round
+#define GEOAC_PP_SLOTB 2064           // 16 half-records x 128 B + 16 B pad (broadcast reads of different slots fall into different banks)
 
 // Range-dependent Cartesian set (GeoAc3D.RngDep): EquationSets.3DRngDep.cpp + G2S_MultiDimSpline3D.cpp
 template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struct Eq3DRngDep {
@@ -728,6 +736,8 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
     static constexpr bool AMP = AMP_;
     static constexpr bool COOP = COOP_;                             // wave-cooperative record gather through LDS (grid_eval3_glds / _coop8): NL_ = 1, every lane of the wave stays in the loop
     static constexpr int XCHG_BYTES = (GRec<false>::PACKED && GEOAC_COOP_GLDS) ? GEOAC_GLDS_BYTES : 64 * GEOAC_COOP_SLOT;   // per wave: LDS-DMA ring / exchange slots
+    static constexpr bool PP_TILE = GEOAC_PP_TILE;                  // post-pass over 16-row x 16-ray tiles (k_postpass)
+    static constexpr bool PP_DEDUP = GEOAC_PP_TILE && GEOAC_PP_DEDUP;  // and one table read per distinct (cell, segment) key of a wave
     static constexpr bool LDS_STATE = true;                         // the step's rows y and yn live in LDS while the four stages run (the grid kernels use no LDS otherwise)
     static constexpr int NB = 6, NS = 6;
     static constexpr int PP_WAVES = 3;
@@ -843,18 +853,26 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
         }
     }
     // 3DRngDep.cpp:478-542, 598-634
-    static DEVINL void segment(const GeoacDevParams& P, const double* st, size_t np, const double* a, const double* b, double& tt, double& at){
+    // one path segment in two halves (k_postpass fetches the medium of the midpoint itself, one table read per distinct key of a wave)
+    struct SegGeom { double x, y, z, ds, n0, n1, n2, inm; };
+    static DEVINL void seg_mid(const GeoacDevParams& P, size_t np, const double* a, const double* b, SegGeom& G){
         double ax = a[0], ay = a[np], az = a[2 * np], an0 = a[3 * np], an1 = a[4 * np], an2 = a[5 * np];
         double dx = b[0] - ax, dy = b[np] - ay, dz = b[2 * np] - az;
-        double ds = fsqrt(dx * dx + dy * dy + dz * dz);
-        double x = ax + dx / 2.0, y = ay + dy / 2.0, z = az + dz / 2.0;
-        double n0 = an0 + (b[3 * np] - an0) / 2.0, n1 = an1 + (b[4 * np] - an1) / 2.0, n2 = an2 + (b[5 * np] - an2) / 2.0;
-        double inm = frsq(n0 * n0 + n1 * n1 + n2 * n2);
-        Medium3 m = medium3_at<true, false>(P, x, y, z);
-        double cn = m.c * inm;
-        double cp0 = cn * n0 + m.u, cp1 = cn * n1 + m.v, cp2 = cn * n2;
-        tt = ds * frsq(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
-        at = suthbass_alpha(P, z, m.c, m.rho, P.freq, P.dev_consts[0], P.dev_consts[1], P.dev_consts[2]) * ds;
+        G.ds = fsqrt(dx * dx + dy * dy + dz * dz);
+        G.x = ax + dx / 2.0; G.y = ay + dy / 2.0; G.z = az + dz / 2.0;
+        G.n0 = an0 + (b[3 * np] - an0) / 2.0; G.n1 = an1 + (b[4 * np] - an1) / 2.0; G.n2 = an2 + (b[5 * np] - an2) / 2.0;
+        G.inm = frsq(G.n0 * G.n0 + G.n1 * G.n1 + G.n2 * G.n2);
+    }
+    static DEVINL void seg_sums(const GeoacDevParams& P, const SegGeom& G, const Medium3& m, double& tt, double& at){
+        double cn = m.c * G.inm;
+        double cp0 = cn * G.n0 + m.u, cp1 = cn * G.n1 + m.v, cp2 = cn * G.n2;
+        tt = G.ds * frsq(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
+        at = suthbass_alpha(P, G.z, m.c, m.rho, P.freq, P.dev_consts[0], P.dev_consts[1], P.dev_consts[2]) * G.ds;
+    }
+    static DEVINL void segment(const GeoacDevParams& P, const double* st, size_t np, const double* a, const double* b, double& tt, double& at){
+        SegGeom G; seg_mid(P, np, a, b, G);
+        Medium3 m = medium3_at<true, false>(P, G.x, G.y, G.z);
+        seg_sums(P, G, m, tt, at);
     }
 };
 
@@ -865,6 +883,8 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
     static constexpr bool AMP = AMP_;
     static constexpr bool COOP = COOP_;
     static constexpr int XCHG_BYTES = 64 * GEOAC_COOP_SLOT;
+    static constexpr bool PP_TILE = GEOAC_PP_TILE;
+    static constexpr bool PP_DEDUP = false;                         // (two medium evaluations per segment: not done for this set)
     static constexpr bool LDS_STATE = true;
     static constexpr int NB = 6, NS = 6;
     static constexpr int PP_WAVES = 3;
@@ -998,7 +1018,7 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
 
 template <bool AMP_> struct Eq3D {
     static constexpr bool AMP = AMP_;
-    static constexpr bool COOP = false; static constexpr bool CACHE = false; static constexpr bool LDS_STATE = false; static constexpr int XCHG_BYTES = 0;
+    static constexpr bool COOP = false; static constexpr bool CACHE = false; static constexpr bool LDS_STATE = false; static constexpr int XCHG_BYTES = 0; static constexpr bool PP_TILE = false; static constexpr bool PP_DEDUP = false;
     static constexpr int PP_WAVES = 4;                              // post-pass at four waves per SIMD (127 registers, 52 B of spill): GeoAc3D 360 x 90 fan 185 -> 168 ms
     static constexpr int E = AMP_ ? 12 : 4, PW = 4, HIDX = 2, LANES = 1;
     static constexpr bool SPLIT = false;
@@ -1152,7 +1172,7 @@ struct Eq3DPair : Eq3D<true> {
 
 template <bool AMP_> struct Eq2D {
     static constexpr bool AMP = AMP_;
-    static constexpr bool COOP = false; static constexpr bool CACHE = false; static constexpr bool LDS_STATE = false; static constexpr int XCHG_BYTES = 0;
+    static constexpr bool COOP = false; static constexpr bool CACHE = false; static constexpr bool LDS_STATE = false; static constexpr int XCHG_BYTES = 0; static constexpr bool PP_TILE = false; static constexpr bool PP_DEDUP = false;
     static constexpr int NB = 3, NS = 3;
     static constexpr int PP_WAVES = 4;
     static constexpr int E = AMP_ ? 6 : 3, PW = 2, HIDX = 1, LANES = 1;
@@ -1600,12 +1620,83 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
 template <class EQ>
 __global__ void __launch_bounds__(256, EQ::PP_WAVES) k_postpass(GeoacDevParams P, int rows){
     // grid-stride sweep over (segment row i, ray slot); by default the grid covers the sweep in one pass
+    // Grid sets (PP_TILE): a workgroup takes a tile of 16 rows x 16 rays, a wave 16 consecutive rows of 4 rays.  The segment midpoints of
+    // one ray's consecutive rows lie in the same cell and vertical segment nearly always, so the 64 lanes of a table gather touch a handful
+    // of cache lines instead of 64 (the texture path is busy 48 cycles per load with lane-private lines, 17-23 with shared ones); the path
+    // rows are read in 32-byte pieces (16 lines per load) that the four waves of the workgroup share.
     const size_t np = (size_t)P.n_pad;
-    const int bx = (P.n_cols_bound + 255) / 256;                // column-blocks per row
-    const long long total = (long long)bx * (rows - 1);
+    const int bx = EQ::PP_TILE ? (P.n_cols_bound + 15) / 16 : (P.n_cols_bound + 255) / 256;      // column-blocks per row (tile row)
+    const long long total = (long long)bx * (EQ::PP_TILE ? (rows - 1 + 15) / 16 : rows - 1);
     for(long long w = blockIdx.x; w < total; w += gridDim.x){
-        const int i = (int)(w / bx);
-        const int col = (int)(w % bx) * 256 + threadIdx.x;
+        const int i = EQ::PP_TILE ? (int)(w / bx) * 16 + (int)((threadIdx.x & 63u) >> 2) : (int)(w / bx);
+        const int col = EQ::PP_TILE ? (int)(w % bx) * 16 + (int)((threadIdx.x >> 6) << 2) + (int)(threadIdx.x & 3u) : (int)(w % bx) * 256 + threadIdx.x;
+        if constexpr (EQ::PP_DEDUP){
+            // Cartesian grid set: the 64 segments of a wave (16 rows of 4 rays) lie in a handful of (cell, vertical segment) KEYS.  The wave
+            // fetches each distinct key's 16 half-records (T, u, v, rho x 4 corners x 128 B) ONCE - two fully coalesced loads - into an LDS
+            // slot, and every lane evaluates its medium from the slot of its key (broadcast reads): 2 K loads per wave instead of 128
+            // lane-private ones (the kernel was bound by the texture path: 95 % busy).  Up to PP_SLOTS keys per round; more keys, more rounds.
+            extern __shared__ double pp_lds[];
+            char* const wl = (char*)pp_lds + (threadIdx.x >> 6) * (GEOAC_PP_SLOTS * GEOAC_PP_SLOTB);
+            const unsigned lane = threadIdx.x & 63u;
+            const bool valid = (i < rows - 1) && col < (P.colmap ? *P.n_cols : P.n_pad) && (i + 1 < P.nrows[col < (int)np ? col : 0]);
+            const double* a = P.path + ((size_t)(valid ? i : 0) * EQ::PW) * np + (valid ? col : 0);
+            const double* b = a + (size_t)EQ::PW * np;
+            typename EQ::SegGeom G;
+            GridLoc L;
+            unsigned key = 0xffffffffu;
+            const unsigned nn = (unsigned)(P.gnx * P.gny);
+            if(valid){
+                EQ::seg_mid(P, np, a, b, G);
+                const double xe = clampd(G.x, P.gx[0], P.gx[P.gnx - 1]), ye = clampd(G.y, P.gy[0], P.gy[P.gny - 1]), ze = clampd(G.z, P.x_min, P.x_max);
+                grid_locate(P, xe, ye, ze, -1, L);
+                key = (unsigned)L.kz * nn + (unsigned)L.n00;
+            }
+            unsigned long long todo = __ballot(valid);
+            while(todo){                                                              // (wave-uniform)
+                unsigned long long rem = todo, served = 0;
+                int myslot = -1;
+                #pragma unroll 1
+                for(int sl = 0; sl < GEOAC_PP_SLOTS && rem; sl++){
+                    const int l0 = __ffsll((long long)rem) - 1;
+                    const unsigned k0 = (unsigned)__builtin_amdgcn_readlane((int)key, l0);
+                    const unsigned long long m = __ballot(key == k0) & rem;
+                    if((m >> lane) & 1ull) myslot = sl;
+                    const unsigned kz0 = k0 / nn, n00 = k0 - kz0 * nn;
+                    char* dst = wl + sl * GEOAC_PP_SLOTB;
+                    #pragma unroll
+                    for(int j = 0; j < 2; j++){
+                        const unsigned id = 64u * j + lane, rec = id >> 3, c = id & 7u, field = rec >> 2, cn = rec & 3u;
+                        const unsigned node = n00 + (cn >> 1) * (unsigned)P.gny + (cn & 1u);
+                        const double* src = (field < 3u) ? P.gtab + (((size_t)field * P.nseg + kz0) * nn + node) * GRec<false>::N + 2 * c
+                                                         : P.gtab + (size_t)3 * P.nseg * nn * GRec<false>::N + ((size_t)kz0 * nn + node) * GEOAC_GREC_RHO + 2 * c;
+                        *(geoac_d2*)(dst + 16 * id) = *(const geoac_d2*)src;
+                    }
+                    served |= m; rem &= ~m;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+                if(myslot >= 0){
+                    const char* sb = wl + myslot * GEOAC_PP_SLOTB;
+                    Medium3 m;
+                    m.c = sqrt(kGamR * grid_eval_f_slot<false>(L, sb));
+                    m.u = grid_eval_f_slot<false>(L, sb + 512);
+                    m.v = grid_eval_f_slot<false>(L, sb + 1024);
+                    m.rho = grid_eval_f_slot<false>(L, sb + 1536);
+                    m.dcz = m.duz = m.dvz = 0.0;
+                    double tt, at;
+                    EQ::seg_sums(P, G, m, tt, at);
+                    double* o = P.contrib + ((size_t)i * 2) * np + col;
+                    o[0]  = tt;
+                    o[np] = at;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");        // the next round's stores stay behind these reads
+                __builtin_amdgcn_wave_barrier();
+                todo &= ~served;
+            }
+            continue;
+        }
+        if(EQ::PP_TILE && i >= rows - 1) continue;
         if(col >= (P.colmap ? *P.n_cols : P.n_pad)) continue;
         if(i + 1 >= P.nrows[col]) continue;
         const int slot = P.colmap ? P.colmap[col] : col;
@@ -1903,13 +1994,14 @@ extern "C" hipError_t geoac_launch_gate(const GeoacDevParams* P, unsigned long l
 
 extern "C" hipError_t geoac_launch_postpass(const GeoacDevParams* P, int rows, hipStream_t s){
     if(rows < 2) return hipSuccess;
-    long long total = (long long)((P->n_cols_bound + 255) / 256) * (rows - 1);
+    long long total = (P->gtab && GEOAC_PP_TILE) ? (long long)((P->n_cols_bound + 15) / 16) * ((rows - 1 + 15) / 16)       // grid sets: 16 x 16 tiles (k_postpass)
+                              : (long long)((P->n_cols_bound + 255) / 256) * (rows - 1);
     long long nbl = P->pp_blocks > 0 ? P->pp_blocks : total;
     if(total < nbl) nbl = total;
     if(nbl > 0x7fffffffLL) nbl = 0x7fffffffLL;
     int nb = (int)nbl;
     dim3 b(256), g(nb);
-    GEOAC_DISPATCH_EQ(P, hipLaunchKernelGGL(k_postpass<EQ>, g, b, 0, s, *P, rows));
+    GEOAC_DISPATCH_EQ(P, hipLaunchKernelGGL(k_postpass<EQ>, g, b, EQ::PP_DEDUP ? 4 * GEOAC_PP_SLOTS * GEOAC_PP_SLOTB : 0, s, *P, rows));
     return hipGetLastError();
 }
 

@@ -614,6 +614,27 @@ DEVINL double grid_eval_f(const GeoacDevParams& P, int field, const GridLoc& L){
     }
     return v;
 }
+// the same value from 4 x 128 B of half-records (corners n00, n01, n10, n11) staged in LDS (k_postpass)
+template <bool GLB>
+DEVINL double grid_eval_f_slot(const GridLoc& L, const char* rec4){
+    const Herm hx = hermite(L.xs), hy = hermite(L.ys);
+    const double t = L.t, t6 = t * (1.0 / 6.0);
+    double v = 0.0;
+    #pragma unroll 2
+    for(int cn = 0; cn < 4; cn++){
+        {
+            const int a = cn >> 1, b = cn & 1;
+            const double* __restrict__ r = (const double*)(rec4 + 128 * cn);
+            Cub c[4];
+            #pragma unroll
+            for(int i = 0; i < 4; i++) c[i] = load_cubic(r + 4 * i);
+            CornerW w = corner_weights<false, false>(hx, hy, a, b);
+            w.W[1] *= L.dxs; w.W[2] *= (GLB ? L.dys : L.dxs); w.W[3] *= L.dxs * L.dys;
+            v = dot4(w.W, cub_val(c[GC_F], t, t6), cub_val(c[GC_DXF], t, t6), cub_val(c[GC_DYF], t, t6), cub_val(c[GC_DXYF], t, t6), v);
+        }
+    }
+    return v;
+}
 // Eval_Spline_df(.., index = 2, ..) (:920-939): df/dz patch, y rows scaled by dx_scalar (Q11); T, u, v only
 // (spherical twin: Eval_Spline_df(.., index = 0, ..), :823-842, y rows scaled by dp_scalar)
 template <bool GLB>
