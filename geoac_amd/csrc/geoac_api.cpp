@@ -524,6 +524,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
     P.table_in_lds = (!is_grid && lds_need <= 160 * 1024) ? 1 : 0;
     if(is_grid){
         P.gnx = ctx->gnx; P.gny = ctx->gny;
+        P.g_lo[0] = ctx->gx.front(); P.g_hi[0] = ctx->gx.back(); P.g_lo[1] = ctx->gy.front(); P.g_hi[1] = ctx->gy.back();
         P.gx = (const double*)ctx->d_gx.p; P.gy = (const double*)ctx->d_gy.p; P.gz = (const double*)ctx->d_gz.p;
         P.gtab = (const double*)(ctx->d_gtab8.p ? ctx->d_gtab8.p : ctx->d_gtab.p); P.dev_consts = (double*)ctx->d_consts.p;
         for(int q = 0; q < 4; q++) P.xy_lim[q] = p.xy_limits[q];

@@ -78,6 +78,7 @@ struct GeoacDevParams {
     const double* rho;              // [nseg][4]
     // range-dependent sets: grid of profiles
     int           gnx, gny;         // horizontal node counts
+    double        g_lo[2], g_hi[2]; // first / last node of gx and gy (clamp range of the horizontal coordinates; kernel arguments: no loads)
     const double* gx;               // [gnx] node x
     const double* gy;               // [gny] node y
     const double* gz;               // [nseg+1] node z (x_min / x_max hold the z range)

@@ -465,6 +465,7 @@ struct RayCtx {
                       // 3D: nu_x, nu_y, mu_x_th, mu_y_th, mu_x_ph, mu_y_ph ; 2D: cos(phi), sin(phi), cos(theta), sin(theta)
     double t[4];      // Global: proposed sin/cos for the row under test
     mutable int ckey; // record-cache kernels: (segment, node) key of the records this lane holds in LDS (-1: none)
+    mutable int kxy;  // grid sets: horizontal cell of the previous evaluation, kx << 16 | ky (-1: none), grid_locate's hint
 };
 
 template <bool AMP, int NQ = 2, typename TabPtr = const double*>
@@ -782,7 +783,7 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
     static DEVINL double above_ground(const GeoacDevParams& P, const double* y){ return y[2] - P.ground; }
     template <typename TabPtr>
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
-        rngdep_rhs<AMP, NL_, COOP_, CACHE_>(P, seg, yt, dy, (int)(threadIdx.x & (NL_ - 1)), (char*)tab, &C.ckey);
+        rngdep_rhs<AMP, NL_, COOP_, CACHE_>(P, seg, yt, dy, (int)(threadIdx.x & (NL_ - 1)), (char*)tab, &C.ckey, &C.kxy);
     }
     // 3DRngDep.cpp:451-472
     static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, long long k, bool& brk, bool& gnd){
@@ -927,7 +928,7 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
         double s2, c2;
         rot_small(C.a[0], C.a[1], yt[1] - y0[1], s2, c2);          // sin/cos(lat) carried along the ray, as in EqGlobal
-        globalrd_rhs<AMP, NL_, COOP_, CACHE_>(P, seg, yt, s2, c2, dy, (int)(threadIdx.x & (NL_ - 1)), (char*)tab, &C.ckey);
+        globalrd_rhs<AMP, NL_, COOP_, CACHE_>(P, seg, yt, s2, c2, dy, (int)(threadIdx.x & (NL_ - 1)), (char*)tab, &C.ckey, &C.kxy);
     }
     // GeoAc_BreakCheck / GeoAc_GroundCheck: GlobalRngDep.cpp:523-545
     static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, long long k, bool& brk, bool& gnd){
@@ -1277,7 +1278,7 @@ __global__ void __launch_bounds__(256) k_init(GeoacDevParams P){
     const double ph = kPi / 2.0 - P.phi_deg[i] * kPi / 180.0;     // :245
     double y[GEOAC_MAXE];
     for(int e = 0; e < GEOAC_MAXE; e++) y[e] = 0.0;
-    RayCtx C;
+    RayCtx C; C.ckey = -1; C.kxy = -1;
     EQ::init(P, th, ph, y, C);
     for(int e = 0; e < GEOAC_MAXE; e++) st[(ST_Y0 + e) * np] = y[e];
     st[ST_C0 * np] = C.c0; st[ST_NU0 * np] = C.nu0;
@@ -1407,7 +1408,7 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
     int leg = (int)st[ST_LEG * np];
     double hmax = st[ST_HMAX * np];
     RayCtx C;
-    C.ckey = -1;
+    C.ckey = -1; C.kxy = -1;
     C.c0 = st[ST_C0 * np]; C.nu0 = st[ST_NU0 * np];
     #pragma unroll
     for(int q = 0; q < 6; q++) C.a[q] = st[(ST_AUX0 + q) * np];

@@ -52,12 +52,29 @@ struct GridLoc {
 };
 
 // locate (x, y, z) (already clamped to the grid): cell, corners, vertical segment.  kz_hint < 0: search from scratch.
-DEVINL void grid_locate(const GeoacDevParams& P, double x, double y, double z, int kz_hint, GridLoc& L, const double* __restrict__ gzp = nullptr){
+// kxy (the RK4 kernels): the cell of this ray's previous evaluation, kx << 16 | ky, or -1.  A ray stays in one cell for thousands of stages:
+// with the hint the node coordinates of the cell are four loads issued together (one trip to memory, beside the z nodes') and a range test;
+// the scan over the nodes - one DEPENDENT trip per node, hipcc cannot take them through the scalar cache - runs only when the ray has
+// left the cell.  (Measured on the four-lane kernel of the eigenray rounds: the scans were nine round trips of a stage's ~8000 cycles.)
+DEVINL void grid_locate(const GeoacDevParams& P, double x, double y, double z, int kz_hint, GridLoc& L, const double* __restrict__ gzp = nullptr, int* kxy = nullptr){
     const double* __restrict__ gz = gzp ? gzp : P.gz;              // the z nodes: global table, or the kernel's LDS copy (record-cache kernels)
     const int nx = P.gnx, ny = P.gny;
     int kx = 0, ky = 0;
-    for(int i = 1; i < nx - 1; i++) kx += (x >= P.gx[i]) ? 1 : 0;       // last i with x >= X[i], capped at nx-2 (branch-free scan)
-    for(int j = 1; j < ny - 1; j++) ky += (y >= P.gy[j]) ? 1 : 0;
+    double X1 = 0.0, X2 = 0.0, Y1 = 0.0, Y2 = 0.0;
+    bool found = false;
+    if(kxy && *kxy >= 0){
+        kx = *kxy >> 16; ky = *kxy & 0xffff;
+        X1 = P.gx[kx]; X2 = P.gx[kx + 1]; Y1 = P.gy[ky]; Y2 = P.gy[ky + 1];
+        // the scan's answer is kx iff x lies in [X1, X2) - the first cell also takes what is below it, the last one what is above
+        found = (x >= X1 || kx == 0) && (x < X2 || kx == nx - 2) && (y >= Y1 || ky == 0) && (y < Y2 || ky == ny - 2);
+    }
+    if(!found){
+        kx = 0; ky = 0;
+        for(int i = 1; i < nx - 1; i++) kx += (x >= P.gx[i]) ? 1 : 0;   // last i with x >= X[i], capped at nx-2 (branch-free scan)
+        for(int j = 1; j < ny - 1; j++) ky += (y >= P.gy[j]) ? 1 : 0;
+        X1 = P.gx[kx]; X2 = P.gx[kx + 1]; Y1 = P.gy[ky]; Y2 = P.gy[ky + 1];
+        if(kxy) *kxy = (nx < 32768 && ny < 32768) ? ((kx << 16) | ky) : -1;
+    }
     int kz;
     if(kz_hint < 0){
         double span = P.x_max - P.x_min;                                  // x_min/x_max hold the z range for this set
@@ -70,7 +87,6 @@ DEVINL void grid_locate(const GeoacDevParams& P, double x, double y, double z, i
     L.t = z - gz[kz];
     L.n00 = kx * ny + ky;       L.n01 = kx * ny + ky + 1;
     L.n10 = (kx + 1) * ny + ky; L.n11 = (kx + 1) * ny + ky + 1;
-    const double X1 = P.gx[kx], X2 = P.gx[kx + 1], Y1 = P.gy[ky], Y2 = P.gy[ky + 1];
     L.dxs = X2 - X1; L.dys = Y2 - Y1;
     L.idxs = frcp(L.dxs); L.idys = frcp(L.dys);
     L.xs = (x - X1) * L.idxs; L.ys = (y - Y1) * L.idys;
@@ -680,9 +696,9 @@ DEVINL Medium3 medium3_at(const GeoacDevParams& P, double x, double y, double z)
 // fused GeoAc_UpdateSources + GeoAc_EvalSrcEq of the range-dependent Cartesian set (EquationSets.3DRngDep.cpp:218-393)
 // y: x, y, z, nu_x, nu_y, nu_z | X_th(3), mu_th(3) | X_ph(3), mu_ph(3)
 template <bool AMP, int NL = 1, bool COOP = false, bool CACHE = false>
-DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double* dy, int cq = 0, char* ldsw = nullptr, int* ckey = nullptr){
-    const double xe = clampd(y[0], P.gx[0], P.gx[P.gnx - 1]), ye = clampd(y[1], P.gy[0], P.gy[P.gny - 1]), ze = clampd(y[2], P.x_min, P.x_max);
-    GridLoc L; grid_locate(P, xe, ye, ze, kz, L, CACHE ? (const double*)(ldsw + GEOAC_CACHE_BYTES) : nullptr);
+DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double* dy, int cq = 0, char* ldsw = nullptr, int* ckey = nullptr, int* kxy = nullptr){
+    const double xe = clampd(y[0], P.g_lo[0], P.g_hi[0]), ye = clampd(y[1], P.g_lo[1], P.g_hi[1]), ze = clampd(y[2], P.x_min, P.x_max);
+    GridLoc L; grid_locate(P, xe, ye, ze, kz, L, CACHE ? (const double*)(ldsw + GEOAC_CACHE_BYTES) : nullptr, kxy);
     kz = L.kz;
     double M[3][10];                                               // T, u, v and their derivatives
     // three copies of the evaluator: M[][] stays in registers (rolled, the dynamic index f put it in scratch: 240 B written and read back per stage)
@@ -772,10 +788,10 @@ DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double
 // the algebra of global_rhs (geoac_kernels.hip) with the full gradient and second-derivative matrices of c, u, v (w = 0).
 // y: r, lat, lon, nu_r, nu_t, nu_p | R_lt(3), mu_lt(3) | R_lp(3), mu_lp(3);  sth/cth = sin/cos(lat) from the caller.
 template <bool AMP, int NL = 1, bool COOP = false, bool CACHE = false>
-DEVINL void globalrd_rhs(const GeoacDevParams& P, int& kz, const double* y, double sth, double cth, double* dy, int cq = 0, char* ldsw = nullptr, int* ckey = nullptr){
+DEVINL void globalrd_rhs(const GeoacDevParams& P, int& kz, const double* y, double sth, double cth, double* dy, int cq = 0, char* ldsw = nullptr, int* ckey = nullptr, int* kxy = nullptr){
     const double r = y[0];
-    const double te = clampd(y[1], P.gx[0], P.gx[P.gnx - 1]), pe = clampd(y[2], P.gy[0], P.gy[P.gny - 1]), re = clampd(r, P.x_min, P.x_max);
-    GridLoc L; grid_locate(P, te, pe, re, kz, L, CACHE ? (const double*)(ldsw + GEOAC_CACHE_BYTES) : nullptr);
+    const double te = clampd(y[1], P.g_lo[0], P.g_hi[0]), pe = clampd(y[2], P.g_lo[1], P.g_hi[1]), re = clampd(r, P.x_min, P.x_max);
+    GridLoc L; grid_locate(P, te, pe, re, kz, L, CACHE ? (const double*)(ldsw + GEOAC_CACHE_BYTES) : nullptr, kxy);
     kz = L.kz;
     double M[3][10];                                               // table order: f, f_t, f_p, f_r, f_tt, f_pp, f_rr, f_tp, f_tr, f_pr
     if(COOP) grid_eval3_coop<AMP, true>(P, L, M, ldsw);
