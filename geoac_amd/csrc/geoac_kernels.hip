@@ -466,6 +466,7 @@ struct RayCtx {
     double t[4];      // Global: proposed sin/cos for the row under test
     mutable int ckey; // record-cache kernels: (segment, node) key of the records this lane holds in LDS (-1: none)
     mutable int kxy;  // grid sets: horizontal cell of the previous evaluation, kx << 16 | ky (-1: none), grid_locate's hint
+    mutable double cell[4];   // and its node coordinates X1, X2, Y1, Y2
 };
 
 template <bool AMP, int NQ = 2, typename TabPtr = const double*>
@@ -722,6 +723,9 @@ struct EqGlobalPair : EqGlobal<true> {
 };
 
 #include "geoac_rngdep.h"
+#ifndef GEOAC_CELL_REGS
+#define GEOAC_CELL_REGS(C) ((CACHE_ || !COOP_) ? (C).cell : nullptr)   // node coordinates of the hinted cell in registers (not in the cooperative kernels: no registers to spare)
+#endif
 #ifndef GEOAC_PP_TILE
 #define GEOAC_PP_TILE 1               // grid sets: post-pass over 16-row x 16-ray tiles (0: one row x 256 rays per workgroup, A/B builds)
 #endif
@@ -783,7 +787,7 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
     static DEVINL double above_ground(const GeoacDevParams& P, const double* y){ return y[2] - P.ground; }
     template <typename TabPtr>
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
-        rngdep_rhs<AMP, NL_, COOP_, CACHE_>(P, seg, yt, dy, (int)(threadIdx.x & (NL_ - 1)), (char*)tab, &C.ckey, &C.kxy);
+        rngdep_rhs<AMP, NL_, COOP_, CACHE_>(P, seg, yt, dy, (int)(threadIdx.x & (NL_ - 1)), (char*)tab, &C.ckey, &C.kxy, GEOAC_CELL_REGS(C));
     }
     // 3DRngDep.cpp:451-472
     static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, long long k, bool& brk, bool& gnd){
@@ -928,7 +932,7 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
         double s2, c2;
         rot_small(C.a[0], C.a[1], yt[1] - y0[1], s2, c2);          // sin/cos(lat) carried along the ray, as in EqGlobal
-        globalrd_rhs<AMP, NL_, COOP_, CACHE_>(P, seg, yt, s2, c2, dy, (int)(threadIdx.x & (NL_ - 1)), (char*)tab, &C.ckey, &C.kxy);
+        globalrd_rhs<AMP, NL_, COOP_, CACHE_>(P, seg, yt, s2, c2, dy, (int)(threadIdx.x & (NL_ - 1)), (char*)tab, &C.ckey, &C.kxy, GEOAC_CELL_REGS(C));
     }
     // GeoAc_BreakCheck / GeoAc_GroundCheck: GlobalRngDep.cpp:523-545
     static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, long long k, bool& brk, bool& gnd){

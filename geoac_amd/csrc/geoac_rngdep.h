@@ -43,6 +43,7 @@ template <bool GLB> struct GRec {
 
 struct GridLoc {
     int kz;                 // vertical segment
+    int ny;                 // nodes per x row
     int n00, n01, n10, n11; // node index (ix*ny + iy) of the cell corners n<a><b>, a <-> x edge, b <-> y edge (scalars, not an array: a rolled
                             // corner loop would index an array dynamically and put it in scratch)
     double t;               // z - z0[kz]
@@ -56,7 +57,7 @@ struct GridLoc {
 // with the hint the node coordinates of the cell are four loads issued together (one trip to memory, beside the z nodes') and a range test;
 // the scan over the nodes - one DEPENDENT trip per node, hipcc cannot take them through the scalar cache - runs only when the ray has
 // left the cell.  (Measured on the four-lane kernel of the eigenray rounds: the scans were nine round trips of a stage's ~8000 cycles.)
-DEVINL void grid_locate(const GeoacDevParams& P, double x, double y, double z, int kz_hint, GridLoc& L, const double* __restrict__ gzp = nullptr, int* kxy = nullptr){
+DEVINL void grid_locate(const GeoacDevParams& P, double x, double y, double z, int kz_hint, GridLoc& L, const double* __restrict__ gzp = nullptr, int* kxy = nullptr, double* cell = nullptr){
     const double* __restrict__ gz = gzp ? gzp : P.gz;              // the z nodes: global table, or the kernel's LDS copy (record-cache kernels)
     const int nx = P.gnx, ny = P.gny;
     int kx = 0, ky = 0;
@@ -64,7 +65,8 @@ DEVINL void grid_locate(const GeoacDevParams& P, double x, double y, double z, i
     bool found = false;
     if(kxy && *kxy >= 0){
         kx = *kxy >> 16; ky = *kxy & 0xffff;
-        X1 = P.gx[kx]; X2 = P.gx[kx + 1]; Y1 = P.gy[ky]; Y2 = P.gy[ky + 1];
+        if(cell){ X1 = cell[0]; X2 = cell[1]; Y1 = cell[2]; Y2 = cell[3]; }       // (the hinted cell's node coordinates, kept by the caller)
+        else { X1 = P.gx[kx]; X2 = P.gx[kx + 1]; Y1 = P.gy[ky]; Y2 = P.gy[ky + 1]; }
         // the scan's answer is kx iff x lies in [X1, X2) - the first cell also takes what is below it, the last one what is above
         found = (x >= X1 || kx == 0) && (x < X2 || kx == nx - 2) && (y >= Y1 || ky == 0) && (y < Y2 || ky == ny - 2);
     }
@@ -74,6 +76,7 @@ DEVINL void grid_locate(const GeoacDevParams& P, double x, double y, double z, i
         for(int j = 1; j < ny - 1; j++) ky += (y >= P.gy[j]) ? 1 : 0;
         X1 = P.gx[kx]; X2 = P.gx[kx + 1]; Y1 = P.gy[ky]; Y2 = P.gy[ky + 1];
         if(kxy) *kxy = (nx < 32768 && ny < 32768) ? ((kx << 16) | ky) : -1;
+        if(cell){ cell[0] = X1; cell[1] = X2; cell[2] = Y1; cell[3] = Y2; }
     }
     int kz;
     if(kz_hint < 0){
@@ -85,6 +88,7 @@ DEVINL void grid_locate(const GeoacDevParams& P, double x, double y, double z, i
     while(kz < P.nseg - 1 && z > gz[kz + 1]) kz++;
     L.kz = kz;
     L.t = z - gz[kz];
+    L.ny = ny;
     L.n00 = kx * ny + ky;       L.n01 = kx * ny + ky + 1;
     L.n10 = (kx + 1) * ny + ky; L.n11 = (kx + 1) * ny + ky + 1;
     L.dxs = X2 - X1; L.dys = Y2 - Y1;
@@ -140,7 +144,12 @@ DEVINL CornerW corner_weights(const Herm& hx, const Herm& hy, int a, int b){
     if(WANT_E){ w.E[0] = xh * ydh; w.E[1] = xg * ydh; w.E[2] = xh * ydg; w.E[3] = xg * ydg; }
     return w;
 }
-DEVINL int corner_node(const GridLoc& L, int a, int b){ return a ? (b ? L.n11 : L.n10) : (b ? L.n01 : L.n00); }
+// (arithmetic, not a select over n00..n11: with a lane-dependent corner hipcc turns the select into a 16-byte table in scratch, a trip to
+// memory on the critical path of every stage of the four-lane kernels)
+DEVINL int corner_node(const GridLoc& L, int a, int b){ return L.n00 + a * L.ny + b; }
+// the select form, for the LANE-dependent corner of the two- and four-lane kernels (there the arithmetic form costs the record-cache kernel
+// 190 spilled registers and 5 % of its speed; the table it becomes is read once per stage)
+DEVINL int corner_node_sel(const GridLoc& L, int a, int b){ return a ? (b ? L.n11 : L.n10) : (b ? L.n01 : L.n00); }
 DEVINL double dot4(const double* w, double F, double FX, double FY, double FXY, double acc){
     return __builtin_fma(w[0], F, __builtin_fma(w[1], FX, __builtin_fma(w[2], FY, __builtin_fma(w[3], FXY, acc))));
 }
@@ -185,7 +194,7 @@ DEVINL void grid_eval_all(const GeoacDevParams& P, int field, const GridLoc& L, 
     for(int cn = cq * (4 / NL); cn < (cq + 1) * (4 / NL); cn++){
         {
             const int a = cn >> 1, b = cn & 1;
-            const double* r = rec_lds ? rec_lds : base + (size_t)corner_node(L, a, b) * R::N;
+            const double* r = rec_lds ? rec_lds : base + (size_t)(NL > 1 ? corner_node_sel(L, a, b) : corner_node(L, a, b)) * R::N;
             Cub c[R::NCUB];                                        // all loads of the corner in flight before the first use
             #pragma unroll
             for(int i = 0; i < R::NCUB; i++) c[i] = load_cubic(r + 4 * i);
@@ -579,7 +588,7 @@ DEVINL const double* grid_cache_fill(const GeoacDevParams& P, const GridLoc& L, 
     constexpr int RB = GRec<GLB>::N * (int)sizeof(double), NCH = RB / 16;             // bytes and 16-byte chunks per record
     const unsigned lane = threadIdx.x & 63u;
     const unsigned nn = (unsigned)(P.gnx * P.gny);
-    const int key = L.kz * (int)nn + corner_node(L, cq >> 1, cq & 1);
+    const int key = L.kz * (int)nn + corner_node_sel(L, cq >> 1, cq & 1);
     char* mine = cache + lane * GEOAC_CACHE_SLOT;
     if(key != *ckey){                                              // (the four lanes of a ray change cell / segment together)
         const size_t fstride = (size_t)P.nseg * nn * RB;
@@ -696,9 +705,9 @@ DEVINL Medium3 medium3_at(const GeoacDevParams& P, double x, double y, double z)
 // fused GeoAc_UpdateSources + GeoAc_EvalSrcEq of the range-dependent Cartesian set (EquationSets.3DRngDep.cpp:218-393)
 // y: x, y, z, nu_x, nu_y, nu_z | X_th(3), mu_th(3) | X_ph(3), mu_ph(3)
 template <bool AMP, int NL = 1, bool COOP = false, bool CACHE = false>
-DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double* dy, int cq = 0, char* ldsw = nullptr, int* ckey = nullptr, int* kxy = nullptr){
+DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double* dy, int cq = 0, char* ldsw = nullptr, int* ckey = nullptr, int* kxy = nullptr, double* cell = nullptr){
     const double xe = clampd(y[0], P.g_lo[0], P.g_hi[0]), ye = clampd(y[1], P.g_lo[1], P.g_hi[1]), ze = clampd(y[2], P.x_min, P.x_max);
-    GridLoc L; grid_locate(P, xe, ye, ze, kz, L, CACHE ? (const double*)(ldsw + GEOAC_CACHE_BYTES) : nullptr, kxy);
+    GridLoc L; grid_locate(P, xe, ye, ze, kz, L, CACHE ? (const double*)(ldsw + GEOAC_CACHE_BYTES) : nullptr, kxy, cell);
     kz = L.kz;
     double M[3][10];                                               // T, u, v and their derivatives
     // three copies of the evaluator: M[][] stays in registers (rolled, the dynamic index f put it in scratch: 240 B written and read back per stage)
@@ -788,10 +797,10 @@ DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double
 // the algebra of global_rhs (geoac_kernels.hip) with the full gradient and second-derivative matrices of c, u, v (w = 0).
 // y: r, lat, lon, nu_r, nu_t, nu_p | R_lt(3), mu_lt(3) | R_lp(3), mu_lp(3);  sth/cth = sin/cos(lat) from the caller.
 template <bool AMP, int NL = 1, bool COOP = false, bool CACHE = false>
-DEVINL void globalrd_rhs(const GeoacDevParams& P, int& kz, const double* y, double sth, double cth, double* dy, int cq = 0, char* ldsw = nullptr, int* ckey = nullptr, int* kxy = nullptr){
+DEVINL void globalrd_rhs(const GeoacDevParams& P, int& kz, const double* y, double sth, double cth, double* dy, int cq = 0, char* ldsw = nullptr, int* ckey = nullptr, int* kxy = nullptr, double* cell = nullptr){
     const double r = y[0];
     const double te = clampd(y[1], P.g_lo[0], P.g_hi[0]), pe = clampd(y[2], P.g_lo[1], P.g_hi[1]), re = clampd(r, P.x_min, P.x_max);
-    GridLoc L; grid_locate(P, te, pe, re, kz, L, CACHE ? (const double*)(ldsw + GEOAC_CACHE_BYTES) : nullptr, kxy);
+    GridLoc L; grid_locate(P, te, pe, re, kz, L, CACHE ? (const double*)(ldsw + GEOAC_CACHE_BYTES) : nullptr, kxy, cell);
     kz = L.kz;
     double M[3][10];                                               // table order: f, f_t, f_p, f_r, f_tt, f_pp, f_rr, f_tp, f_tr, f_pr
     if(COOP) grid_eval3_coop<AMP, true>(P, L, M, ldsw);
