@@ -65,6 +65,7 @@ struct geoac_ctx {
     bool compact = true;             // GEOAC_COMPACT=0: every epoch runs over all slots (no live-ray compaction between epochs)
     DevBuf colmap[3], ncols;         // per chunk: column -> slot list of the rays alive at the start of that epoch; their counts (3 ints)
     bool quad_cache = true;          // GEOAC_QUAD_CACHE=0: four-lane grid kernels without the per-lane record cache (A/B)
+    int  sub_min_waves = 1024;       // GEOAC_SUB_MIN_WAVES: smallest launch (waves) that is cut into sub-epochs (tests lower it to cover the hand-off with small fans)
     int  sub_epochs = 4;             // GEOAC_SUB_EPOCHS: sub-epochs of the cooperative grid kernels when a fan has more waves than the chip has wave slots (k_rk4); 1 = off
     DevBuf sub_flags;
     bool grid_coop = true;           // GEOAC_GRID_COOP=0: per-lane table gathers instead of the wave-cooperative gather (A/B runs, schedule-independence test)
@@ -241,6 +242,8 @@ int geoac_create(geoac_ctx** out, int eqset, int device){
     if(gc) ctx->grid_coop = (atoi(gc) != 0);
     const char* se = getenv("GEOAC_SUB_EPOCHS");
     if(se){ ctx->sub_epochs = atoi(se); if(ctx->sub_epochs < 1) ctx->sub_epochs = 1; if(ctx->sub_epochs > 16) ctx->sub_epochs = 16; }
+    const char* smw = getenv("GEOAC_SUB_MIN_WAVES");
+    if(smw && atoi(smw) >= 0) ctx->sub_min_waves = atoi(smw);
     const char* sc = getenv("GEOAC_SMP_CAP");
     if(sc && atoll(sc) > 0) ctx->smp_cap = atoll(sc);
     *out = ctx;
@@ -706,7 +709,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
             // cooperative grid kernels with more waves than the chip has wave slots (1024: one per SIMD): sub-epochs (k_rk4) keep the
             // last round of the launch from running on a part-empty chip
             const int waves = (Pe.slot_hi - Pe.slot_lo + 63) / 64;
-            if(P.coop && block == 64 && ctx->sub_epochs > 1 && waves > 1024 && Pe.s_rows >= 16 * ctx->sub_epochs){
+            if(P.coop && block == 64 && ctx->sub_epochs > 1 && waves > ctx->sub_min_waves && Pe.s_rows >= 16 * ctx->sub_epochs){
                 Pe.sub = ctx->sub_epochs; Pe.sub_w = (waves + 7) / 8 * 8;
                 HIPCHK(ctx->sub_flags.ensure(sizeof(int) * ((size_t)P.n_pad / 64 + 16)));
                 Pe.sub_flags = (int*)ctx->sub_flags.p;

@@ -40,14 +40,19 @@ def _compare_files(got, want):
     return nsame, ntok
 
 
-@pytest.mark.parametrize("case", ["global", "3d", "2d", "global_norays", "3drd", "globalrd", "global+groups", "3drd+groups"])
+@pytest.mark.parametrize("case", ["global", "3d", "2d", "global_norays", "3drd", "globalrd", "global+groups", "3drd+groups", "3drd+sub"])
 def test_cli_files_match_reference_binaries(case, tmp_path):
     """"+groups": the same fan integrated one azimuth group at a time (the path large WriteRays fans take: bounded sample list, text of
-    group g written while group g+1 is on the GPU) must give the same files"""
+    group g written while group g+1 is on the GPU) must give the same files.  "+sub": the launch plan of saturated grid fans forced on the
+    small one - one lane per ray, cooperative LDS-DMA gather, 512-row epochs in four sub-epochs handed from workgroup to workgroup - with the
+    raypath samples and caustics on"""
     env = dict(os.environ)
     if case.endswith("+groups"):
         case = case[:-len("+groups")]
         env["GEOAC_CLI_RAYS_PER_BATCH"] = "2"
+    if case.endswith("+sub"):
+        case = case[:-len("+sub")]
+        env.update({"GEOAC_GRID_LANES": "1", "GEOAC_SPREAD": "1", "GEOAC_SUB_MIN_WAVES": "0", "GEOAC_SUB_EPOCHS": "4", "GEOAC_S_ROWS": "512"})
     gold = os.path.join(CLI_GOLD, case)
     args = open(os.path.join(gold, "ARGS")).read().split()
     binary, params = args[0], args[1:]
