@@ -60,6 +60,7 @@ struct geoac_ctx {
                                      // instead of every wave waiting for its one long ray: the post-pass then lands on idle SIMDs (metric fan +13 %)
     DevBuf perm; bool have_perm = false;
     bool no_quad = false;            // GEOAC_NO_QUAD=1: never use the multi-lane grid kernels
+    bool oct = true;                 // GEOAC_OCT=0: small spherical grid fans with amplitudes on the four-lane kernel instead of the eight-lane one
     int  grid_lanes = 0;             // GEOAC_GRID_LANES=1|2|4: force the lanes-per-ray variant of the grid kernels (tests); 0 = by fan size
     int  spread_override = 0;        // GEOAC_SPREAD=n: force n-way lane thinning of the grid-set RK4 waves (1 = dense); 0 = automatic
     bool compact = true;             // GEOAC_COMPACT=0: every epoch runs over all slots (no live-ray compaction between epochs)
@@ -231,7 +232,9 @@ int geoac_create(geoac_ctx** out, int eqset, int device){
     const char* nq = getenv("GEOAC_NO_QUAD");
     if(nq && atoi(nq) != 0) ctx->no_quad = true;
     const char* gl = getenv("GEOAC_GRID_LANES");
-    if(gl && (atoi(gl) == 1 || atoi(gl) == 2 || atoi(gl) == 4)) ctx->grid_lanes = atoi(gl);
+    if(gl && (atoi(gl) == 1 || atoi(gl) == 2 || atoi(gl) == 4 || atoi(gl) == 8)) ctx->grid_lanes = atoi(gl);
+    const char* oc = getenv("GEOAC_OCT");
+    if(oc) ctx->oct = (atoi(oc) != 0);
     const char* nsp = getenv("GEOAC_SPREAD");
     if(nsp && atoi(nsp) > 0) ctx->spread_override = atoi(nsp);
     const char* cp = getenv("GEOAC_COMPACT");
@@ -568,6 +571,11 @@ int geoac_fan_launch(geoac_ctx* ctx){
         else if((long long)P.n_pad * 2 / 64 <= 1024) P.lanes_per_ray = 2;
     }
     if(is_grid && ctx->grid_lanes) P.lanes_per_ray = ctx->grid_lanes;
+    // spherical grid set with amplitudes, fans of a few rays (the eigenray rounds): eight lanes per ray - four cell corners x the two launch-angle
+    // systems (EqGlobalRngDepOct) - while that is at most one wave per CU
+    const bool oct_ok = ctx->eqset == GEOAC_EQ_GLOBAL_RNGDEP && p.calc_amp && !sampling && ctx->quad_cache && (long long)P.n_pad * 8 / 64 <= 256;
+    if(P.lanes_per_ray == 8 && !oct_ok) P.lanes_per_ray = 4;
+    if(is_grid && !ctx->grid_lanes && !ctx->no_quad && ctx->oct && oct_ok && P.lanes_per_ray == 4) P.lanes_per_ray = 8;
     // RK4 workgroup shape: with the table in LDS one workgroup owns a CU, so spread the waves over the 256 CUs
     int waves = P.n_pad * P.lanes_per_ray / 64;
     int wpb = (waves + 255) / 256;
@@ -585,8 +593,10 @@ int geoac_fan_launch(geoac_ctx* ctx){
         if(ctx->spread_override > 0){ P.spread = 1; while(P.spread * 2 <= ctx->spread_override && P.spread < 64) P.spread *= 2; }
     }
     // small four-lane fans (at most one wave per CU): records and z nodes cached in LDS, the stage latency is what such a fan costs
-    P.quad_cache = (is_grid && P.lanes_per_ray == 4 && ctx->quad_cache && (long long)P.n_pad * 4 / 64 <= 256 &&
+    P.quad_cache = (is_grid && (P.lanes_per_ray == 4 || P.lanes_per_ray == 8) && ctx->quad_cache && (long long)P.n_pad * P.lanes_per_ray / 64 <= 256 &&
                     2 * GEOAC_MAXE * 64 * sizeof(double) + 64 * 976 + (size_t)(P.nseg + 1) * sizeof(double) <= 160 * 1024) ? 1 : 0;
+    if(P.lanes_per_ray == 8 && !P.quad_cache){ P.lanes_per_ray = 4; P.quad_cache = (is_grid && (P.lanes_per_ray == 4 || P.lanes_per_ray == 8) && ctx->quad_cache && (long long)P.n_pad * P.lanes_per_ray / 64 <= 256 &&
+                    2 * GEOAC_MAXE * 64 * sizeof(double) + 64 * 976 + (size_t)(P.nseg + 1) * sizeof(double) <= 160 * 1024) ? 1 : 0; }      // (the eight-lane kernel exists with the record cache only)
     // dense one-lane-per-ray grid fans (more waves than SIMDs): the quads of a wave fetch the table records together (grid_eval3_coop)
     P.coop = (is_grid && P.lanes_per_ray == 1 && P.spread == 1 && ctx->grid_coop && ctx->gtab_bytes < (4ull << 30)) ? 1 : 0;   // (32-bit record offsets)
 

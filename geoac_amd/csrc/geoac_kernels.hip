@@ -551,7 +551,7 @@ DEVINL void cart2_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCt
 // ================================================================================================
 template <bool AMP_> struct EqGlobal {
     static constexpr bool AMP = AMP_;
-    static constexpr bool COOP = false; static constexpr bool CACHE = false; static constexpr bool LDS_STATE = false; static constexpr int XCHG_BYTES = 0; static constexpr bool PP_TILE = false; static constexpr bool PP_DEDUP = false;
+    static constexpr bool COOP = false; static constexpr bool CACHE = false; static constexpr bool LDS_STATE = false; static constexpr int XCHG_BYTES = 0; static constexpr bool PP_TILE = false; static constexpr bool PP_DEDUP = false; static constexpr int SYS_SHIFT = 0; static constexpr bool ROW_SPLIT = false;
     static constexpr int PP_WAVES = 3;                              // post-pass waves per SIMD (168 registers; at 128 it spills 148 B and runs 1.5 x slower)
     static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 0, LANES = 1;
     static constexpr bool SPLIT = false;                            // true: the lanes of a ray carry DIFFERENT parts of its state (EqGlobalPair)
@@ -697,7 +697,7 @@ template <bool AMP_> struct EqGlobal {
 struct EqGlobalPair : EqGlobal<true> {
     using Full = EqGlobal<true>;
     static constexpr int E = 12, LANES = 2;
-    static constexpr bool SPLIT = true;
+    static constexpr bool SPLIT = true; static constexpr bool ROW_SPLIT = true;      // (the two lanes also store half a path row each)
     template <typename TabPtr>
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
         global_rhs<true, 1>(tab, P, seg, yt, C.a[0], C.a[1], yt[1] - y0[1], dy);
@@ -743,6 +743,7 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
     static constexpr int XCHG_BYTES = (GRec<false>::PACKED && GEOAC_COOP_GLDS) ? GEOAC_GLDS_BYTES : 64 * GEOAC_COOP_SLOT;   // per wave: LDS-DMA ring / exchange slots
     static constexpr bool PP_TILE = GEOAC_PP_TILE;                  // post-pass over 16-row x 16-ray tiles (k_postpass)
     static constexpr bool PP_DEDUP = GEOAC_PP_TILE && GEOAC_PP_DEDUP;  // and one table read per distinct (cell, segment) key of a wave
+    static constexpr int SYS_SHIFT = 0; static constexpr bool ROW_SPLIT = false;
     static constexpr bool LDS_STATE = true;                         // the step's rows y and yn live in LDS while the four stages run (the grid kernels use no LDS otherwise)
     static constexpr int NB = 6, NS = 6;
     static constexpr int PP_WAVES = 3;
@@ -890,6 +891,7 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
     static constexpr int XCHG_BYTES = 64 * GEOAC_COOP_SLOT;
     static constexpr bool PP_TILE = GEOAC_PP_TILE;
     static constexpr bool PP_DEDUP = false;                         // (two medium evaluations per segment: not done for this set)
+    static constexpr int SYS_SHIFT = 0; static constexpr bool ROW_SPLIT = false;
     static constexpr bool LDS_STATE = true;
     static constexpr int NB = 6, NS = 6;
     static constexpr int PP_WAVES = 3;
@@ -1021,9 +1023,45 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
 };
 
 
+// Eight lanes per ray for the spherical grid set with amplitudes, small fans (the eigenray rounds): lane q of a ray evaluates cell corner
+// q & 3 (as in the four-lane kernels: partial sums added across the quad) and carries the base ray plus ONE of the two launch-angle
+// systems, q >> 2 (as EqGlobalPair does for the stratified set).  The stage of the four-lane kernel is 1 245 instructions, issue-bound,
+// 270 of them the second system's right-hand side and state update; a fan of a few rays has lanes to spare.
+struct EqGlobalRngDepOct : EqGlobalRngDep<true, 4, false, true> {
+    using Full = EqGlobalRngDep<true, 4, false, true>;
+    static constexpr int E = 12, LANES = 8;
+    static constexpr bool SPLIT = true; static constexpr bool ROW_SPLIT = false;
+    static constexpr int SYS_SHIFT = 2;
+    template <typename TabPtr>
+    static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
+        double s2, c2;
+        rot_small(C.a[0], C.a[1], yt[1] - y0[1], s2, c2);
+        globalrd_rhs<true, 4, false, true, 1>(P, seg, yt, s2, c2, dy, (int)(threadIdx.x & 3), (char*)tab, &C.ckey, &C.kxy, C.cell);
+    }
+    // ApproximateIntercept + SetReflectionConditions of the base ray and of this lane's system: GlobalRngDep.cpp:141-210
+    static DEVINL void reflect(const GeoacDevParams& P, const RayCtx& C, const double* yn, double* y, const double* ym2){
+        double dr_k = yn[0] - y[0];
+        double dr_g = y[0] - P.ground;
+        double prev[E];
+        #pragma unroll
+        for(int e = 0; e < E; e++) prev[e] = y[e] + (y[e] - yn[e]) / dr_k * dr_g;
+        Medium3 mr = medium3_at<false, true, true>(P, prev[1], prev[2], prev[0]);
+        double c_ref = mr.c;
+        double dnu_r_ds = -1.0 / c_ref * (C.c0 / c_ref * mr.dcz + prev[4] * mr.dvz + prev[5] * mr.duz
+                                          + c_ref / prev[0] * (prev[4] * prev[4] + prev[5] * prev[5]));
+        #pragma unroll
+        for(int e = 0; e < E; e++) y[e] = prev[e];
+        y[0] = P.ground;
+        y[3] = -prev[3];
+        y[6] = -prev[6];
+        double den = c_ref / C.c0 * prev[3];
+        y[9] = -prev[9] + 2.0 * dnu_r_ds * prev[6] / den;
+    }
+};
+
 template <bool AMP_> struct Eq3D {
     static constexpr bool AMP = AMP_;
-    static constexpr bool COOP = false; static constexpr bool CACHE = false; static constexpr bool LDS_STATE = false; static constexpr int XCHG_BYTES = 0; static constexpr bool PP_TILE = false; static constexpr bool PP_DEDUP = false;
+    static constexpr bool COOP = false; static constexpr bool CACHE = false; static constexpr bool LDS_STATE = false; static constexpr int XCHG_BYTES = 0; static constexpr bool PP_TILE = false; static constexpr bool PP_DEDUP = false; static constexpr int SYS_SHIFT = 0; static constexpr bool ROW_SPLIT = false;
     static constexpr int PP_WAVES = 4;                              // post-pass at four waves per SIMD (127 registers, 52 B of spill): GeoAc3D 360 x 90 fan 185 -> 168 ms
     static constexpr int E = AMP_ ? 12 : 4, PW = 4, HIDX = 2, LANES = 1;
     static constexpr bool SPLIT = false;
@@ -1152,7 +1190,7 @@ template <bool AMP_> struct Eq3D {
 struct Eq3DPair : Eq3D<true> {
     using Full = Eq3D<true>;
     static constexpr int E = 8, LANES = 2;
-    static constexpr bool SPLIT = true;
+    static constexpr bool SPLIT = true; static constexpr bool ROW_SPLIT = true;
     template <typename TabPtr>
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
         cart3_rhs<true, 1>(tab, P, seg, C, yt, dy, (int)(threadIdx.x & 1));
@@ -1177,7 +1215,7 @@ struct Eq3DPair : Eq3D<true> {
 
 template <bool AMP_> struct Eq2D {
     static constexpr bool AMP = AMP_;
-    static constexpr bool COOP = false; static constexpr bool CACHE = false; static constexpr bool LDS_STATE = false; static constexpr int XCHG_BYTES = 0; static constexpr bool PP_TILE = false; static constexpr bool PP_DEDUP = false;
+    static constexpr bool COOP = false; static constexpr bool CACHE = false; static constexpr bool LDS_STATE = false; static constexpr int XCHG_BYTES = 0; static constexpr bool PP_TILE = false; static constexpr bool PP_DEDUP = false; static constexpr int SYS_SHIFT = 0; static constexpr bool ROW_SPLIT = false;
     static constexpr int NB = 3, NS = 3;
     static constexpr int PP_WAVES = 4;
     static constexpr int E = AMP_ ? 6 : 3, PW = 2, HIDX = 1, LANES = 1;
@@ -1303,8 +1341,8 @@ template <class EQ> DEVINL void arrival_of(const GeoacDevParams& P, const RayCtx
 template <class EQ>
 DEVINL void write_row(const GeoacDevParams& P, int row, int col, int q, const double* y){
     double* p = P.path + ((size_t)row * EQ::PW) * P.n_pad + col;
-    if(!EQ::SPLIT && EQ::LANES > 1 && q != 0) return;   // multi-lane grid kernels: the lanes hold the same row, lane 0 stores it
-    if(EQ::SPLIT){                    // pair kernels: each lane stores half of the row (Global: r, lat, lon | nu_r, nu_t, nu_p; 3D: x, y | z, nu_z)
+    if(!EQ::ROW_SPLIT && EQ::LANES > 1 && q != 0) return;   // multi-lane grid kernels: the lanes hold the same row, lane 0 stores it
+    if(EQ::ROW_SPLIT){                    // pair kernels: each lane stores half of the row (Global: r, lat, lon | nu_r, nu_t, nu_p; 3D: x, y | z, nu_z)
         constexpr int H = EQ::PW / 2;
         p += (size_t)(H * q) * P.n_pad;
         #pragma unroll
@@ -1354,6 +1392,7 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
     // rays that were still alive after the previous epoch (k_compact): column p integrates slot colmap[p], finished rays hold no lane.
     const int col = P.slot_lo + tid / EQ::LANES;
     const int q = tid % EQ::LANES;                              // pair kernel: which derivative system this lane carries; quad kernels: which cell corner
+    const int qs = EQ::SPLIT ? (q >> EQ::SYS_SHIFT) : 0;        // split-state policies: the launch-angle system of this lane (eight-lane kernel: q >> 2)
     const int col_hi = P.colmap ? min(P.slot_hi, *P.n_cols) : P.slot_hi;
     const bool mine = !(P.spread > 1 && (tid0 & (P.spread - 1))) && col < col_hi;   // spread > 1: sparse lanes (grid sets, small fans)
     const int slot = (P.colmap && mine) ? P.colmap[col] : col;  // ray slot
@@ -1403,10 +1442,10 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
     constexpr bool YM2_REG = EQ::KM2 && !EQ::KM2_MEM;                // row k-2 in registers (else: in the state block, read at reflections)
     double y[E], ym2[YM2_REG ? E : 1];
     #pragma unroll
-    for(int e = 0; e < E; e++) y[e] = st[(ST_Y0 + ((EQ::SPLIT && e >= EQ::NB) ? e + EQ::NS * q : e)) * np];
+    for(int e = 0; e < E; e++) y[e] = st[(ST_Y0 + ((EQ::SPLIT && e >= EQ::NB) ? e + EQ::NS * qs : e)) * np];
     if(YM2_REG){
         #pragma unroll
-        for(int e = 0; e < E; e++) ym2[e] = st[(ST_YM2 + ((EQ::SPLIT && e >= EQ::NB) ? e + EQ::NS * q : e)) * np];
+        for(int e = 0; e < E; e++) ym2[e] = st[(ST_YM2 + ((EQ::SPLIT && e >= EQ::NB) ? e + EQ::NS * qs : e)) * np];
     }
     long long k = (long long)st[ST_K * np];
     int leg = (int)st[ST_LEG * np];
@@ -1527,9 +1566,9 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
                 for(int e = 0; e < EQ::NB; e++) yf[e] = yn[e];
                 #pragma unroll
                 for(int e = 0; e < EQ::NS; e++){
-                    double mine = yn[EQ::NB + e], other = __shfl_xor(mine, 1);
-                    yf[EQ::NB + e]  = q ? other : mine;
-                    yf[EQ::NB + EQ::NS + e] = q ? mine : other;
+                    double mine = yn[EQ::NB + e], other = __shfl_xor(mine, 1 << EQ::SYS_SHIFT);
+                    yf[EQ::NB + e]  = qs ? other : mine;
+                    yf[EQ::NB + EQ::NS + e] = qs ? mine : other;
                 }
             } else {
                 #pragma unroll
@@ -1576,10 +1615,10 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
     // ---- save state (pair kernel: both lanes store the identical base ray; each stores its own derivative system) ----
     if(!(EQ::COOP && idle0)){
     #pragma unroll
-    for(int e = 0; e < E; e++) st[(ST_Y0 + ((EQ::SPLIT && e >= EQ::NB) ? e + EQ::NS * q : e)) * np] = y[e];
+    for(int e = 0; e < E; e++) st[(ST_Y0 + ((EQ::SPLIT && e >= EQ::NB) ? e + EQ::NS * qs : e)) * np] = y[e];
     if(YM2_REG){
         #pragma unroll
-        for(int e = 0; e < E; e++) st[(ST_YM2 + ((EQ::SPLIT && e >= EQ::NB) ? e + EQ::NS * q : e)) * np] = ym2[e];
+        for(int e = 0; e < E; e++) st[(ST_YM2 + ((EQ::SPLIT && e >= EQ::NB) ? e + EQ::NS * qs : e)) * np] = ym2[e];
     }
     st[ST_K * np] = (double)k; st[ST_LEG * np] = (double)leg; st[ST_DONE * np] = done ? 1.0 : 0.0;
     st[ST_HMAX * np] = hmax; st[ST_SEG * np] = P.gtab ? (double)seg : (double)(seg / GEOAC_SEGW);
@@ -1903,7 +1942,10 @@ __global__ void __launch_bounds__(64) k_probe_grid(GeoacDevParams P, int n, cons
 
 // RK4 only: the grid sets have four-lanes-per-ray variants (small fans)
 #define GEOAC_DISPATCH_EQ_RK4(P, CALL) \
-    if((P)->lanes_per_ray == 4 && (P)->quad_cache){ \
+    if((P)->lanes_per_ray == 8){ \
+        if((P)->eqset == GEOAC_EQ_GLOBAL_RNGDEP && (P)->calc_amp && (P)->quad_cache){ using EQ = EqGlobalRngDepOct; CALL; } \
+        else return hipErrorNotSupported; \
+    } else if((P)->lanes_per_ray == 4 && (P)->quad_cache){ \
         switch((P)->eqset * 2 + ((P)->calc_amp ? 1 : 0)){ \
             case GEOAC_EQ_3D_RNGDEP * 2 + 1: { using EQ = Eq3DRngDep<true, 4, false, true>;  CALL; } break; \
             case GEOAC_EQ_3D_RNGDEP * 2 + 0: { using EQ = Eq3DRngDep<false, 4, false, true>; CALL; } break; \
@@ -1960,6 +2002,7 @@ static hipError_t launch_rk4_t(const GeoacDevParams* P, int block, hipStream_t s
         lds += GEOAC_CACHE_BYTES + (size_t)(P->nseg + 1) * sizeof(double);                 // per-lane records, z nodes
     }
     const bool smp = (P->mode & (GEOAC_MODE_WRITE_RAYS | GEOAC_MODE_WRITE_CAUSTICS)) != 0;
+    if(smp && EQ::SPLIT && !EQ::ROW_SPLIT) return hipErrorNotSupported;                  // (the eight-lane kernel has no sample capture)
     #define GEOAC_RK4_LAUNCH(LDSF, SMPF) do { \
         if(lds > 65536){ \
             hipError_t err = hipFuncSetAttribute((const void*)k_rk4<EQ, LDSF, SMPF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

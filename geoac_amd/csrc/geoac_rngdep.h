@@ -112,9 +112,16 @@ DEVINL Herm hermite(double s){
 
 // one vertical cubic (c0, c1, 2 c2, 6 c3), 32-byte aligned: two 16-byte loads
 struct Cub { double c0, c1, d2, e3; };
+typedef __attribute__((address_space(3))) char geoac_lds_char;
 typedef double geoac_d2 __attribute__((ext_vector_type(2)));       // one 16-byte chunk (native vector: stays in registers)
 DEVINL Cub load_cubic(const double* c){
     const geoac_d2* q = (const geoac_d2*)__builtin_assume_aligned(c, 16);
+    const geoac_d2 lo = q[0], hi = q[1];
+    return Cub{ lo.x, lo.y, hi.x, hi.y };
+}
+typedef __attribute__((address_space(3))) const geoac_d2 geoac_lds_d2;
+DEVINL Cub load_cubic_lds(unsigned lds_off){                           // the same from an LDS byte offset (explicit ds_read_b128)
+    const geoac_lds_d2* q = (const geoac_lds_d2*)(size_t)lds_off;
     const geoac_d2 lo = q[0], hi = q[1];
     return Cub{ lo.x, lo.y, hi.x, hi.y };
 }
@@ -180,8 +187,9 @@ DEVINL double pair_sum(double v){
 // NL = 2 or 4 lanes per ray (small fans).  Lane cq of the group evaluates 4/NL of the cell corners and the partial sums are added
 // across the group: 3 (NL = 4) or 6 (NL = 2) dependent gather batches per RHS instead of 12 (the kernel is bound by their latency).
 // rec_lds (four-lane kernels with a record cache): this lane's record of `field` for its corner, already in LDS
-template <bool ORDER2, bool GLB, int NL = 1>
-DEVINL void grid_eval_all(const GeoacDevParams& P, int field, const GridLoc& L, double* out, int cq = 0, const double* rec_lds = nullptr){
+// LDSOFF (eight-lane kernel): the record is read from LDS byte offset lds_off
+template <bool ORDER2, bool GLB, int NL = 1, bool LDSOFF = false>
+DEVINL void grid_eval_all(const GeoacDevParams& P, int field, const GridLoc& L, double* out, int cq = 0, const double* rec_lds = nullptr, unsigned lds_off = 0){
     const Herm hx = hermite(L.xs), hy = hermite(L.ys);
     const double dxs = L.dxs, dys = L.dys, dxy = dxs * dys;
     const double t = L.t, th = 0.5 * t, t6 = t * (1.0 / 6.0);
@@ -197,7 +205,7 @@ DEVINL void grid_eval_all(const GeoacDevParams& P, int field, const GridLoc& L, 
             const double* r = rec_lds ? rec_lds : base + (size_t)(NL > 1 ? corner_node_sel(L, a, b) : corner_node(L, a, b)) * R::N;
             Cub c[R::NCUB];                                        // all loads of the corner in flight before the first use
             #pragma unroll
-            for(int i = 0; i < R::NCUB; i++) c[i] = load_cubic(r + 4 * i);
+            for(int i = 0; i < R::NCUB; i++) c[i] = LDSOFF ? load_cubic_lds(lds_off + 32u * i) : load_cubic(r + 4 * i);
             CornerW w = corner_weights<ORDER2, ORDER2>(hx, hy, a, b);
             // fold the cell-size factors of the FX / FY / FXY rows into the weights
             const double Wq = w.W[2] * (GLB ? dys : dxs);          // Cartesian: Q11 row of the f_zz patch (y row scaled by dx)
@@ -462,7 +470,6 @@ DEVINL void grid_eval3_coop8(const GeoacDevParams& P, const GridLoc& L, double (
 // in the same order - the same bits.
 #define GEOAC_GLDS_RING 5
 #define GEOAC_GLDS_BYTES (GEOAC_GLDS_RING * 4096)
-typedef __attribute__((address_space(3))) char geoac_lds_char;
 
 DEVINL void glds_round(const char* base, unsigned o0, unsigned o1, unsigned o2, unsigned o3, unsigned lds_dst, double d0, double d1, double d2, double d3){
     // d0..d3: one word of each ds_read of the round that was read out of this slot - naming them as inputs makes hipcc wait for those reads
@@ -796,7 +803,8 @@ DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double
 // fused GeoAc_UpdateSources + GeoAc_EvalSrcEq of the range-dependent spherical set (EquationSets.GlobalRngDep.cpp:226-458):
 // the algebra of global_rhs (geoac_kernels.hip) with the full gradient and second-derivative matrices of c, u, v (w = 0).
 // y: r, lat, lon, nu_r, nu_t, nu_p | R_lt(3), mu_lt(3) | R_lp(3), mu_lp(3);  sth/cth = sin/cos(lat) from the caller.
-template <bool AMP, int NL = 1, bool COOP = false, bool CACHE = false>
+// NSYS = 1 (the eight-lane kernel, EqGlobalRngDepOct): y = base ray | ONE launch-angle system, the lane's own
+template <bool AMP, int NL = 1, bool COOP = false, bool CACHE = false, int NSYS = 2>
 DEVINL void globalrd_rhs(const GeoacDevParams& P, int& kz, const double* y, double sth, double cth, double* dy, int cq = 0, char* ldsw = nullptr, int* ckey = nullptr, int* kxy = nullptr, double* cell = nullptr){
     const double r = y[0];
     const double te = clampd(y[1], P.g_lo[0], P.g_hi[0]), pe = clampd(y[2], P.g_lo[1], P.g_hi[1]), re = clampd(r, P.x_min, P.x_max);
@@ -806,8 +814,15 @@ DEVINL void globalrd_rhs(const GeoacDevParams& P, int& kz, const double* y, doub
     if(COOP) grid_eval3_coop<AMP, true>(P, L, M, ldsw);
     else if(CACHE){
         const double* rec = grid_cache_fill<true>(P, L, cq, ldsw, ckey);
-        #pragma unroll
-        for(int f = 0; f < 3; f++) grid_eval_all<AMP, true, NL>(P, f, L, M[f], cq, rec + f * GRec<true>::N);
+        if(NSYS == 1){                                             // eight-lane kernel: keep the record reads in the stage loop (hipcc otherwise parks the
+            unsigned off = (unsigned)(size_t)(geoac_lds_char*)rec;  // three records in AGPRs across the stages: 230 v_accvgpr moves per stage instead of 60
+            asm volatile("" : "+v"(off));                          // ds_read_b128): the LDS offset is laundered and the reads are explicit LDS reads
+            #pragma unroll
+            for(int f = 0; f < 3; f++) grid_eval_all<AMP, true, NL, true>(P, f, L, M[f], cq, rec, off + f * (unsigned)(GRec<true>::N * sizeof(double)));
+        } else {
+            #pragma unroll
+            for(int f = 0; f < 3; f++) grid_eval_all<AMP, true, NL>(P, f, L, M[f], cq, rec + f * GRec<true>::N);
+        }
     } else {
         #pragma unroll
         for(int f = 0; f < 3; f++) grid_eval_all<AMP, true, NL>(P, f, L, M[f], cq);
@@ -860,7 +875,7 @@ DEVINL void globalrd_rhs(const GeoacDevParams& P, int& kz, const double* y, doub
         const double ir2 = ir * ir, ico2 = ico * ico;
         const double cnn1 = cn * n1, cnn2 = cn * n2;
         #pragma unroll
-        for(int q = 0; q < 2; q++){
+        for(int q = 0; q < NSYS; q++){
             const double R[3] = { y[6 + 6 * q], y[7 + 6 * q], y[8 + 6 * q] };
             const double m0 = y[9 + 6 * q], m1 = y[10 + 6 * q], m2 = y[11 + 6 * q];
             double dca = 0.0, dua = 0.0, dva = 0.0;
