@@ -589,6 +589,9 @@ DEVINL void grid_eval3_glds(const GeoacDevParams& P, const GridLoc& L, double (*
 // 16 B pad: the ds_read_b128 / ds_write_b128 of a wave are bank-conflict free), filled from the table only when (segment, node)
 // changes - and the kernel keeps a copy of the z nodes behind it.  One wave per CU (92 KB of LDS): for fans of at most 256 waves.
 #define GEOAC_CACHE_SLOT 976
+#ifndef GEOAC_CACHE_LDSOFF
+#define GEOAC_CACHE_LDSOFF 1          // record-cache kernels read their records by explicit LDS offset (laundered per stage)
+#endif
 #define GEOAC_CACHE_BYTES (64 * GEOAC_CACHE_SLOT)
 template <bool GLB>
 DEVINL const double* grid_cache_fill(const GeoacDevParams& P, const GridLoc& L, int cq, char* cache, int* ckey){
@@ -738,8 +741,15 @@ DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double
         else grid_eval3_coop<AMP, false>(P, L, M, ldsw);
     } else if(CACHE){
         const double* rec = grid_cache_fill<false>(P, L, cq, ldsw, ckey);
-        #pragma unroll
-        for(int f = 0; f < 3; f++) grid_eval_all<AMP, false, NL>(P, f, L, M[f], cq, rec + f * GRec<false>::N);
+        if(GEOAC_CACHE_LDSOFF){
+            unsigned off = (unsigned)(size_t)(geoac_lds_char*)rec;
+            asm volatile("" : "+v"(off));
+            #pragma unroll
+            for(int f = 0; f < 3; f++) grid_eval_all<AMP, false, NL, true>(P, f, L, M[f], cq, rec, off + f * (unsigned)(GRec<false>::N * sizeof(double)));
+        } else {
+            #pragma unroll
+            for(int f = 0; f < 3; f++) grid_eval_all<AMP, false, NL>(P, f, L, M[f], cq, rec + f * GRec<false>::N);
+        }
     } else {
         #pragma unroll
         for(int f = 0; f < 3; f++) grid_eval_all<AMP, false, NL>(P, f, L, M[f], cq);
@@ -814,7 +824,7 @@ DEVINL void globalrd_rhs(const GeoacDevParams& P, int& kz, const double* y, doub
     if(COOP) grid_eval3_coop<AMP, true>(P, L, M, ldsw);
     else if(CACHE){
         const double* rec = grid_cache_fill<true>(P, L, cq, ldsw, ckey);
-        if(NSYS == 1){                                             // eight-lane kernel: keep the record reads in the stage loop (hipcc otherwise parks the
+        if(NSYS == 1 || GEOAC_CACHE_LDSOFF){                       // eight-lane kernel: keep the record reads in the stage loop (hipcc otherwise parks the
             unsigned off = (unsigned)(size_t)(geoac_lds_char*)rec;  // three records in AGPRs across the stages: 230 v_accvgpr moves per stage instead of 60
             asm volatile("" : "+v"(off));                          // ds_read_b128): the LDS offset is laundered and the reads are explicit LDS reads
             #pragma unroll
