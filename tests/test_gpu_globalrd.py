@@ -83,3 +83,15 @@ def test_every_lanes_per_ray_variant_vs_golden(gold, grid, lanes, monkeypatch):
     assert steps == int(gold["steps_amp1_mode3"])
     compare_records(rec, gold["rec_amp1_mode3"], E=18, hidx=0)
     assert len(ctx.fetch_samples()) == int(gold["nsmp_amp1_mode3"])
+
+
+def test_eight_lane_kernel_gives_the_four_lane_kernels_bits(gold, grid, monkeypatch):
+    """small arrivals-only fans with amplitudes run eight lanes per ray (four cell corners x the two launch-angle systems, EqGlobalRngDepOct);
+    GEOAC_OCT=0 keeps them on the four-lane kernel: same records bit for bit, and both within tolerance of the golden ones"""
+    out = {}
+    for oct_on in ("1", "0"):
+        monkeypatch.setenv("GEOAC_OCT", oct_on)
+        ctx = _ctx(grid, bounces=2, calc_amp=1, mode=0, src=(0.0, 31.0, 0.0))
+        out[oct_on] = ctx.run(gold["theta"], gold["phi"])
+    assert out["1"][1] == out["0"][1]
+    assert np.array_equal(out["1"][0], out["0"][0])
