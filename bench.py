@@ -158,8 +158,18 @@ class FanRun:
         if self.world == 1:
             self.rec, steps = ctx.run(self.theta, self.phi, out=self.rec_host.numpy())    # set_angles + launch + fetch (geoac_fan_run)
             return steps
-        ctx.set_angles(self.theta, self.phi)
-        ctx.launch()
+        # a rank that cannot run its share (out of memory on a shared device, ...) must not leave the others waiting in the gather: every rank
+        # learns about it before any data collective and all of them raise
+        err = None
+        try:
+            ctx.set_angles(self.theta, self.phi)
+            ctx.launch()
+        except Exception as e:                                           # noqa: BLE001
+            err = e
+        ok = self.torch.tensor([0 if err else 1], dtype=self.torch.int64, device=self.coll_dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            raise RuntimeError(f"rank {self.rank}: {err!r}" if err else "another rank failed to launch its share of the fan")
         ctx.copy_records_to(self.rec_local.data_ptr())                  # D2D on the context's (= torch's current) stream
         # the whole fan's table on every GPU: RCCL all_gather over xGMI (gloo: host rehearsal)
         full = gather_records(self.rec_local if self.coll_dev == self.dev else self.rec_local.cpu(), self.n_az, self.n_theta)

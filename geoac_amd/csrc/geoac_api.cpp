@@ -632,11 +632,24 @@ int geoac_fan_launch(geoac_ctx* ctx){
             HIPCHK(ctx->ev_amp[b].ensure(sizeof(double) * (size_t)P.ev_cap * P.n_pad));
             HIPCHK(ctx->nev[b].ensure(sizeof(int) * (size_t)P.n_pad));
         }
-        HIPCHK(ctx->path[b].ensure(row_bytes * (size_t)P.s_rows));
-        HIPCHK(ctx->contrib[b].ensure(sizeof(double) * 2 * (size_t)P.n_pad * P.s_rows));
         HIPCHK(ctx->nrows[b].ensure(sizeof(int) * (size_t)P.n_pad));
         HIPCHK(ctx->nlegend[b].ensure(sizeof(int) * (size_t)P.n_pad));
         HIPCHK(ctx->legend[b].ensure(sizeof(int) * (size_t)P.n_pad * GEOAC_MAXLEGS));
+    }
+
+    // the path chunks themselves.  The free-memory figure above can be stale by the time they are allocated (another process on the same
+    // device sized its own chunks from the same figure): on an out-of-memory answer give the chunks back, halve the epoch and try again.
+    for(;;){
+        hipError_t e = hipSuccess;
+        for(int b = 0; b < n_chunks && e == hipSuccess; b++){
+            e = ctx->path[b].ensure(row_bytes * (size_t)P.s_rows);
+            if(e == hipSuccess) e = ctx->contrib[b].ensure(sizeof(double) * 2 * (size_t)P.n_pad * P.s_rows);
+        }
+        if(e == hipSuccess) break;
+        (void)hipGetLastError();
+        for(int b = 0; b < 3; b++){ ctx->path[b].release(); ctx->contrib[b].release(); }
+        if(e != hipErrorOutOfMemory || P.s_rows < 32 || ctx->s_rows_override >= 8) return hipfail(ctx, e, "path chunks");
+        P.s_rows /= 2;
     }
 
     // ---- epoch pipeline: RK4 of epoch e on the context's stream, post-pass of epoch e on a second stream, chunk
