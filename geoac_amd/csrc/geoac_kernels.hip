@@ -889,7 +889,7 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
     static constexpr bool AMP = AMP_;
     static constexpr bool COOP = COOP_;
     static constexpr int XCHG_BYTES = 64 * GEOAC_COOP_SLOT;
-    static constexpr bool PP_TILE = GEOAC_PP_TILE;
+    static constexpr bool PP_TILE = false;                          // (the tiles only pay with the per-key table reads: Cartesian set)
     static constexpr bool PP_DEDUP = false;                         // (two medium evaluations per segment: not done for this set)
     static constexpr int SYS_SHIFT = 0; static constexpr bool ROW_SPLIT = false;
     static constexpr bool LDS_STATE = true;
@@ -2042,7 +2042,7 @@ extern "C" hipError_t geoac_launch_gate(const GeoacDevParams* P, unsigned long l
 
 extern "C" hipError_t geoac_launch_postpass(const GeoacDevParams* P, int rows, hipStream_t s){
     if(rows < 2) return hipSuccess;
-    long long total = (P->gtab && GEOAC_PP_TILE) ? (long long)((P->n_cols_bound + 15) / 16) * ((rows - 1 + 15) / 16)       // grid sets: 16 x 16 tiles (k_postpass)
+    long long total = (P->gtab && GEOAC_PP_TILE && P->eqset == GEOAC_EQ_3D_RNGDEP) ? (long long)((P->n_cols_bound + 15) / 16) * ((rows - 1 + 15) / 16)       // grid sets: 16 x 16 tiles (k_postpass)
                               : (long long)((P->n_cols_bound + 255) / 256) * (rows - 1);
     long long nbl = P->pp_blocks > 0 ? P->pp_blocks : total;
     if(total < nbl) nbl = total;
