@@ -743,6 +743,7 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
     static constexpr int XCHG_BYTES = (GRec<false>::PACKED && GEOAC_COOP_GLDS) ? GEOAC_GLDS_BYTES : 64 * GEOAC_COOP_SLOT;   // per wave: LDS-DMA ring / exchange slots
     static constexpr bool PP_TILE = GEOAC_PP_TILE;                  // post-pass over 16-row x 16-ray tiles (k_postpass)
     static constexpr bool PP_DEDUP = GEOAC_PP_TILE && GEOAC_PP_DEDUP;  // and one table read per distinct (cell, segment) key of a wave
+    static constexpr bool PP_TWO = false, GLOBAL = false;
     static constexpr int SYS_SHIFT = 0; static constexpr bool ROW_SPLIT = false;
     static constexpr bool LDS_STATE = true;                         // the step's rows y and yn live in LDS while the four stages run (the grid kernels use no LDS otherwise)
     static constexpr int NB = 6, NS = 6;
@@ -869,7 +870,7 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
         G.n0 = an0 + (b[3 * np] - an0) / 2.0; G.n1 = an1 + (b[4 * np] - an1) / 2.0; G.n2 = an2 + (b[5 * np] - an2) / 2.0;
         G.inm = frsq(G.n0 * G.n0 + G.n1 * G.n1 + G.n2 * G.n2);
     }
-    static DEVINL void seg_sums(const GeoacDevParams& P, const SegGeom& G, const Medium3& m, double& tt, double& at){
+    static DEVINL void seg_sums(const GeoacDevParams& P, const SegGeom& G, const Medium3& m, const Medium3& /*g: spherical set only*/, double& tt, double& at){
         double cn = m.c * G.inm;
         double cp0 = cn * G.n0 + m.u, cp1 = cn * G.n1 + m.v, cp2 = cn * G.n2;
         tt = G.ds * frsq(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
@@ -878,7 +879,7 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
     static DEVINL void segment(const GeoacDevParams& P, const double* st, size_t np, const double* a, const double* b, double& tt, double& at){
         SegGeom G; seg_mid(P, np, a, b, G);
         Medium3 m = medium3_at<true, false>(P, G.x, G.y, G.z);
-        seg_sums(P, G, m, tt, at);
+        seg_sums(P, G, m, m, tt, at);
     }
 };
 
@@ -888,9 +889,10 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
     static constexpr bool CACHE = CACHE_;
     static constexpr bool AMP = AMP_;
     static constexpr bool COOP = COOP_;
-    static constexpr int XCHG_BYTES = 64 * GEOAC_COOP_SLOT;
-    static constexpr bool PP_TILE = false;                          // (the tiles only pay with the per-key table reads: Cartesian set)
-    static constexpr bool PP_DEDUP = false;                         // (two medium evaluations per segment: not done for this set)
+    static constexpr int XCHG_BYTES = GEOAC_COOP_GLDS ? GEOAC_GLDS_BYTES : 64 * GEOAC_COOP_SLOT;
+    static constexpr bool PP_TILE = GEOAC_PP_TILE;
+    static constexpr bool PP_DEDUP = GEOAC_PP_TILE && GEOAC_PP_DEDUP;
+    static constexpr bool PP_TWO = true, GLOBAL = true;             // (a second point per segment: the absorption's reference state at ground level)
     static constexpr int SYS_SHIFT = 0; static constexpr bool ROW_SPLIT = false;
     static constexpr bool LDS_STATE = true;
     static constexpr int NB = 6, NS = 6;
@@ -999,26 +1001,36 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
     }
     // one path segment: GlobalRngDep.cpp:549-612 (travel time), 657-693 (attenuation, sin(lat) in ds: Q3).  SuthBass reference
     // state at radius z_grnd (clamps to the lowest node) and the LOCAL lat/lon (Atmo_State.Absorption.Global.cpp:31-32)
-    static DEVINL void segment(const GeoacDevParams& P, const double* st, size_t np, const double* a, const double* b, double& tt, double& at){
+    // in two halves (k_postpass fetches the medium at the midpoint and at ground level itself, one table read per distinct key of a wave);
+    // SegGeom in table order: x = latitude, y = longitude, z = radius of the midpoint
+    struct SegGeom { double x, y, z, ds_tt, ds_at, n0, n1, n2, inm; };
+    static DEVINL void seg_mid(const GeoacDevParams& P, size_t np, const double* a, const double* b, SegGeom& G){
         double ar = a[0], at_ = a[np], ap = a[2 * np], an0 = a[3 * np], an1 = a[4 * np], an2 = a[5 * np];
         double dr = b[0] - ar, dt = b[np] - at_, dp = b[2 * np] - ap;
         double r = ar + dr / 2.0, t = at_ + dt / 2.0, p = ap + dp / 2.0;
         double sn, cs; fsincos(t, sn, cs);
         double rdt = r * dt;
         double e1 = r * cs * dp, e2 = r * sn * dp;
-        double ds_tt = fsqrt(dr * dr + rdt * rdt + e1 * e1);
-        double ds_at = fsqrt(dr * dr + rdt * rdt + e2 * e2);
-        double n0 = an0 + (b[3 * np] - an0) / 2.0, n1 = an1 + (b[4 * np] - an1) / 2.0, n2 = an2 + (b[5 * np] - an2) / 2.0;
-        double inm = frsq(n0 * n0 + n1 * n1 + n2 * n2);
-        Medium3 m = medium3_at<true, false, true>(P, t, p, r);
-        Medium3 g = medium3_at<true, false, true, false>(P, t, p, P.z_grnd);      // reference state: c and rho only
-        double cn = m.c * inm;
-        double cp0 = cn * n0, cp1 = cn * n1 + m.v, cp2 = cn * n2 + m.u;
-        tt = ds_tt * frsq(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
+        G.ds_tt = fsqrt(dr * dr + rdt * rdt + e1 * e1);
+        G.ds_at = fsqrt(dr * dr + rdt * rdt + e2 * e2);
+        G.n0 = an0 + (b[3 * np] - an0) / 2.0; G.n1 = an1 + (b[4 * np] - an1) / 2.0; G.n2 = an2 + (b[5 * np] - an2) / 2.0;
+        G.inm = frsq(G.n0 * G.n0 + G.n1 * G.n1 + G.n2 * G.n2);
+        G.x = t; G.y = p; G.z = r;
+    }
+    static DEVINL void seg_sums(const GeoacDevParams& P, const SegGeom& G, const Medium3& m, const Medium3& g, double& tt, double& at){
+        double cn = m.c * G.inm;
+        double cp0 = cn * G.n0, cp1 = cn * G.n1 + m.v, cp2 = cn * G.n2 + m.u;
+        tt = G.ds_tt * frsq(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
         double cm = g.c * 1000.0;
         double T_o = cm * cm / (kRgas * kGam);
         double P_o = g.rho * (cm * cm) / kGam * 1000.0;
-        at = suthbass_alpha(P, r - P.r_earth, m.c, m.rho, P.freq, T_o, P_o, cbrt(T_o)) * ds_at;
+        at = suthbass_alpha(P, G.z - P.r_earth, m.c, m.rho, P.freq, T_o, P_o, cbrt(T_o)) * G.ds_at;
+    }
+    static DEVINL void segment(const GeoacDevParams& P, const double* st, size_t np, const double* a, const double* b, double& tt, double& at){
+        SegGeom G; seg_mid(P, np, a, b, G);
+        Medium3 m = medium3_at<true, false, true>(P, G.x, G.y, G.z);
+        Medium3 g = medium3_at<true, false, true, false>(P, G.x, G.y, P.z_grnd);      // reference state: c and rho only
+        seg_sums(P, G, m, g, tt, at);
     }
 };
 
@@ -1661,6 +1673,50 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
 // ------------------------------------------------------------------------------------------------
 // k_postpass: one thread per path segment (row i -> row i+1 of one ray)
 // ------------------------------------------------------------------------------------------------
+// c, u, v, rho (WANT_UV = false: c and rho) at this lane's point, table read once per distinct key of the wave (k_postpass).  Every lane of
+// the wave takes part; lanes without a segment carry key 0xffffffff.  Up to GEOAC_PP_SLOTS keys per round; more keys, more rounds.
+template <bool GLB, bool WANT_UV>
+DEVINL void pp_medium_by_key(const GeoacDevParams& P, char* wl, bool valid, unsigned key, const GridLoc& L, Medium3& out){
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned nn = (unsigned)(P.gnx * P.gny);
+    unsigned long long todo = __ballot(valid);
+    out.c = out.u = out.v = out.rho = out.dcz = out.duz = out.dvz = 0.0;
+    while(todo){                                                              // (wave-uniform)
+        unsigned long long rem = todo, served = 0;
+        int myslot = -1;
+        #pragma unroll 1
+        for(int sl = 0; sl < GEOAC_PP_SLOTS && rem; sl++){
+            const int l0 = __ffsll((long long)rem) - 1;
+            const unsigned k0 = (unsigned)__builtin_amdgcn_readlane((int)key, l0);
+            const unsigned long long m = __ballot(key == k0) & rem;
+            if((m >> lane) & 1ull) myslot = sl;
+            const unsigned kz0 = k0 / nn, n00 = k0 - kz0 * nn;
+            char* dst = wl + sl * GEOAC_PP_SLOTB;
+            #pragma unroll
+            for(int j = 0; j < 2; j++){
+                const unsigned id = 64u * j + lane, rec = id >> 3, c = id & 7u, field = rec >> 2, cn = rec & 3u;
+                const unsigned node = n00 + (cn >> 1) * (unsigned)P.gny + (cn & 1u);
+                const double* src = (field < 3u) ? P.gtab + (((size_t)field * P.nseg + kz0) * nn + node) * GRec<GLB>::N + 2 * c
+                                                 : P.gtab + (size_t)3 * P.nseg * nn * GRec<GLB>::N + ((size_t)kz0 * nn + node) * GEOAC_GREC_RHO + 2 * c;
+                *(geoac_d2*)(dst + 16 * id) = *(const geoac_d2*)src;
+            }
+            served |= m; rem &= ~m;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        if(myslot >= 0){
+            const char* sb = wl + myslot * GEOAC_PP_SLOTB;
+            out.c = sqrt(kGamR * grid_eval_f_slot<GLB>(L, sb));
+            if(WANT_UV){ out.u = grid_eval_f_slot<GLB>(L, sb + 512); out.v = grid_eval_f_slot<GLB>(L, sb + 1024); }
+            out.rho = grid_eval_f_slot<GLB>(L, sb + 1536);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");        // the next round's stores stay behind these reads
+        __builtin_amdgcn_wave_barrier();
+        todo &= ~served;
+    }
+}
+
 template <class EQ>
 __global__ void __launch_bounds__(256, EQ::PP_WAVES) k_postpass(GeoacDevParams P, int rows){
     // grid-stride sweep over (segment row i, ray slot); by default the grid covers the sweep in one pass
@@ -1675,68 +1731,39 @@ __global__ void __launch_bounds__(256, EQ::PP_WAVES) k_postpass(GeoacDevParams P
         const int i = EQ::PP_TILE ? (int)(w / bx) * 16 + (int)((threadIdx.x & 63u) >> 2) : (int)(w / bx);
         const int col = EQ::PP_TILE ? (int)(w % bx) * 16 + (int)((threadIdx.x >> 6) << 2) + (int)(threadIdx.x & 3u) : (int)(w % bx) * 256 + threadIdx.x;
         if constexpr (EQ::PP_DEDUP){
-            // Cartesian grid set: the 64 segments of a wave (16 rows of 4 rays) lie in a handful of (cell, vertical segment) KEYS.  The wave
-            // fetches each distinct key's 16 half-records (T, u, v, rho x 4 corners x 128 B) ONCE - two fully coalesced loads - into an LDS
-            // slot, and every lane evaluates its medium from the slot of its key (broadcast reads): 2 K loads per wave instead of 128
-            // lane-private ones (the kernel was bound by the texture path: 95 % busy).  Up to PP_SLOTS keys per round; more keys, more rounds.
+            // Grid sets: the 64 segments of a wave (16 rows of 4 rays) lie in a handful of (cell, vertical segment) KEYS.  The wave fetches each
+            // distinct key's 16 half-records (T, u, v, rho x 4 corners x 128 B) ONCE - two fully coalesced loads - into an LDS slot, and every
+            // lane evaluates its medium from the slot of its key (pp_medium_by_key): 2 K loads per wave instead of 128 lane-private ones (the
+            // kernel was bound by the texture path: 95 % busy).  The spherical set evaluates a second point per segment, the reference state
+            // of the absorption at ground level under the midpoint: same cell, lowest segment - one or two keys per wave.
             extern __shared__ double pp_lds[];
             char* const wl = (char*)pp_lds + (threadIdx.x >> 6) * (GEOAC_PP_SLOTS * GEOAC_PP_SLOTB);
-            const unsigned lane = threadIdx.x & 63u;
             const bool valid = (i < rows - 1) && col < (P.colmap ? *P.n_cols : P.n_pad) && (i + 1 < P.nrows[col < (int)np ? col : 0]);
             const double* a = P.path + ((size_t)(valid ? i : 0) * EQ::PW) * np + (valid ? col : 0);
             const double* b = a + (size_t)EQ::PW * np;
             typename EQ::SegGeom G;
-            GridLoc L;
-            unsigned key = 0xffffffffu;
+            GridLoc L, L2;
+            unsigned key = 0xffffffffu, key2 = 0xffffffffu;
             const unsigned nn = (unsigned)(P.gnx * P.gny);
             if(valid){
                 EQ::seg_mid(P, np, a, b, G);
-                const double xe = clampd(G.x, P.gx[0], P.gx[P.gnx - 1]), ye = clampd(G.y, P.gy[0], P.gy[P.gny - 1]), ze = clampd(G.z, P.x_min, P.x_max);
+                const double xe = clampd(G.x, P.g_lo[0], P.g_hi[0]), ye = clampd(G.y, P.g_lo[1], P.g_hi[1]), ze = clampd(G.z, P.x_min, P.x_max);
                 grid_locate(P, xe, ye, ze, -1, L);
                 key = (unsigned)L.kz * nn + (unsigned)L.n00;
+                if(EQ::PP_TWO){
+                    grid_locate(P, xe, ye, clampd(P.z_grnd, P.x_min, P.x_max), -1, L2);
+                    key2 = (unsigned)L2.kz * nn + (unsigned)L2.n00;
+                }
             }
-            unsigned long long todo = __ballot(valid);
-            while(todo){                                                              // (wave-uniform)
-                unsigned long long rem = todo, served = 0;
-                int myslot = -1;
-                #pragma unroll 1
-                for(int sl = 0; sl < GEOAC_PP_SLOTS && rem; sl++){
-                    const int l0 = __ffsll((long long)rem) - 1;
-                    const unsigned k0 = (unsigned)__builtin_amdgcn_readlane((int)key, l0);
-                    const unsigned long long m = __ballot(key == k0) & rem;
-                    if((m >> lane) & 1ull) myslot = sl;
-                    const unsigned kz0 = k0 / nn, n00 = k0 - kz0 * nn;
-                    char* dst = wl + sl * GEOAC_PP_SLOTB;
-                    #pragma unroll
-                    for(int j = 0; j < 2; j++){
-                        const unsigned id = 64u * j + lane, rec = id >> 3, c = id & 7u, field = rec >> 2, cn = rec & 3u;
-                        const unsigned node = n00 + (cn >> 1) * (unsigned)P.gny + (cn & 1u);
-                        const double* src = (field < 3u) ? P.gtab + (((size_t)field * P.nseg + kz0) * nn + node) * GRec<false>::N + 2 * c
-                                                         : P.gtab + (size_t)3 * P.nseg * nn * GRec<false>::N + ((size_t)kz0 * nn + node) * GEOAC_GREC_RHO + 2 * c;
-                        *(geoac_d2*)(dst + 16 * id) = *(const geoac_d2*)src;
-                    }
-                    served |= m; rem &= ~m;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-                if(myslot >= 0){
-                    const char* sb = wl + myslot * GEOAC_PP_SLOTB;
-                    Medium3 m;
-                    m.c = sqrt(kGamR * grid_eval_f_slot<false>(L, sb));
-                    m.u = grid_eval_f_slot<false>(L, sb + 512);
-                    m.v = grid_eval_f_slot<false>(L, sb + 1024);
-                    m.rho = grid_eval_f_slot<false>(L, sb + 1536);
-                    m.dcz = m.duz = m.dvz = 0.0;
-                    double tt, at;
-                    EQ::seg_sums(P, G, m, tt, at);
-                    double* o = P.contrib + ((size_t)i * 2) * np + col;
-                    o[0]  = tt;
-                    o[np] = at;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");        // the next round's stores stay behind these reads
-                __builtin_amdgcn_wave_barrier();
-                todo &= ~served;
+            Medium3 m, g;
+            pp_medium_by_key<EQ::GLOBAL, true>(P, wl, valid, key, L, m);
+            if(EQ::PP_TWO) pp_medium_by_key<EQ::GLOBAL, false>(P, wl, valid, key2, L2, g);
+            if(valid){
+                double tt, at;
+                EQ::seg_sums(P, G, m, g, tt, at);
+                double* o = P.contrib + ((size_t)i * 2) * np + col;
+                o[0]  = tt;
+                o[np] = at;
             }
             continue;
         }
@@ -1902,7 +1929,7 @@ __global__ void __launch_bounds__(64) k_probe_grid(GeoacDevParams P, int n, cons
     GridLoc L; grid_locate(P, x, y, z, -1, L);
     double M[3][10];
     if(coop){
-        if constexpr (GRec<GLB>::PACKED && GEOAC_COOP_GLDS) grid_eval3_glds<true>(P, L, M, (char*)lds_tab);
+        if constexpr ((GRec<GLB>::PACKED || GLB) && GEOAC_COOP_GLDS) grid_eval3_glds<true, GLB>(P, L, M, (char*)lds_tab);
         else if constexpr (GRec<GLB>::PACKED) grid_eval3_coop8<true>(P, L, M, (char*)lds_tab);
         else grid_eval3_coop<true, GLB>(P, L, M, (char*)lds_tab);
     }
@@ -2042,7 +2069,7 @@ extern "C" hipError_t geoac_launch_gate(const GeoacDevParams* P, unsigned long l
 
 extern "C" hipError_t geoac_launch_postpass(const GeoacDevParams* P, int rows, hipStream_t s){
     if(rows < 2) return hipSuccess;
-    long long total = (P->gtab && GEOAC_PP_TILE && P->eqset == GEOAC_EQ_3D_RNGDEP) ? (long long)((P->n_cols_bound + 15) / 16) * ((rows - 1 + 15) / 16)       // grid sets: 16 x 16 tiles (k_postpass)
+    long long total = (P->gtab && GEOAC_PP_TILE) ? (long long)((P->n_cols_bound + 15) / 16) * ((rows - 1 + 15) / 16)       // grid sets: 16 x 16 tiles (k_postpass)
                               : (long long)((P->n_cols_bound + 255) / 256) * (rows - 1);
     long long nbl = P->pp_blocks > 0 ? P->pp_blocks : total;
     if(total < nbl) nbl = total;

@@ -495,14 +495,18 @@ DEVINL void glds_round(const char* base, unsigned o0, unsigned o1, unsigned o2, 
 template <class F, int... I> DEVINL void geoac_static_for(F&& f, std::integer_sequence<int, I...>){ (f(std::integral_constant<int, I>{}), ...); }
 template <int N> DEVINL void glds_wait(){ asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
-template <bool ORDER2>
+template <bool ORDER2, bool GLB = false>
 DEVINL void grid_eval3_glds(const GeoacDevParams& P, const GridLoc& L, double (*M)[10], char* ldsw){
+    // Cartesian set: packed records, 4 rounds of two cubics each (F, DxF | DyF, DxyF | DxVx, DxyVx | DyVy, DxyVy).  Spherical set: the full
+    // 320-byte records (64-byte aligned: a quad's piece never straddles a line), 5 rounds (F, DxF | DyF, DxyF | Vx, DxVx | DxyVx, Vy | DyVy, DxyVy)
+    constexpr int NR = GLB ? 5 : 4, NROUND = 12 * NR;
+    constexpr unsigned RB = GLB ? 320u : 256u;
     const unsigned lane = threadIdx.x & 63u, r = lane & 3u, quad = lane >> 2;
     const unsigned nn = (unsigned)(P.gnx * P.gny);
     const Herm hx = hermite(L.xs), hy = hermite(L.ys);
     const double dxs = L.dxs, dys = L.dys, dxy = dxs * dys;
     const double t = L.t, th = 0.5 * t, t6 = t * (1.0 / 6.0);
-    const size_t fstride = (size_t)P.nseg * nn * 256u;                                // bytes per field block of the table
+    const size_t fstride = (size_t)P.nseg * nn * RB;                                  // bytes per field block of the table
     const char* __restrict__ tabb = (const char*)P.gtab;
     const unsigned ring = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(geoac_lds_char*)ldsw);   // LDS byte address of the wave's ring, in an SGPR
     // this lane's chunk c of its own quarter record: slot r of the round, position (c - r) & 3 of its quad's 64 bytes
@@ -515,56 +519,75 @@ DEVINL void grid_eval3_glds(const GeoacDevParams& P, const GridLoc& L, double (*
     }
     unsigned gb[4];                                                                   // byte offsets: owner j's record + the chunk this lane fetches for it
     #define GEOAC_GLDS_BASES(cnx) { \
-        const unsigned off = ((unsigned)L.kz * nn + (unsigned)corner_node(L, (cnx) >> 1, (cnx) & 1)) * 256u; \
+        const unsigned off = ((unsigned)L.kz * nn + (unsigned)corner_node(L, (cnx) >> 1, (cnx) & 1)) * RB; \
         gb[0] = quad_bcast_u32<0>(off) + 16u * (r & 3u); gb[1] = quad_bcast_u32<1>(off) + 16u * ((r + 1u) & 3u); \
         gb[2] = quad_bcast_u32<2>(off) + 16u * ((r + 2u) & 3u); gb[3] = quad_bcast_u32<3>(off) + 16u * ((r + 3u) & 3u); }
-    // round rho = 4 n + qd: record n = 3 corner + field, quarter qd
     geoac_d2 p0 = { 0.0, 0.0 }, p1 = p0, p2 = p0, p3 = p0;                            // what the previous round's reads returned
+    // round rho = NR n + qd: record n = 3 corner + field, piece qd
     #define GEOAC_GLDS_ISSUE(rho) { \
-        constexpr int n_ = (rho) >> 2, qd_ = (rho) & 3, cn_ = n_ / 3, f_ = n_ % 3; \
+        constexpr int n_ = (rho) / NR, qd_ = (rho) % NR, cn_ = n_ / 3, f_ = n_ % 3; \
         if(qd_ == 0 && f_ == 0) GEOAC_GLDS_BASES(cn_) \
         glds_round(tabb + (size_t)f_ * fstride + 64 * qd_, gb[0], gb[1], gb[2], gb[3], ring + 4096u * ((rho) % GEOAC_GLDS_RING), p0.x, p1.x, p2.x, p3.x); }
     GEOAC_GLDS_ISSUE(0) GEOAC_GLDS_ISSUE(1) GEOAC_GLDS_ISSUE(2) GEOAC_GLDS_ISSUE(3) GEOAC_GLDS_ISSUE(4)
-    double cF = 0, cFz = 0, cFzz = 0, cDxF = 0, cVxz = 0, cDxFzz = 0, cDyF = 0, cDxyF = 0;   // carried between the quarters of a record
+    // carried between the pieces of a record
+    double cF = 0, cFz = 0, cFzz = 0, cDxF = 0, cVxz = 0, cDxFzz = 0, cDyF = 0, cDxyF = 0, cDxyFz = 0, cDxVx = 0;
     auto step = [&](auto RHO) __attribute__((always_inline)) {
         constexpr int rho = decltype(RHO)::value;
-        constexpr int n = rho >> 2, qd = rho & 3, cn = n / 3, f = n % 3, a = cn >> 1, b = cn & 1;
+        constexpr int n = rho / NR, qd = rho % NR, cn = n / 3, f = n % 3, a = cn >> 1, b = cn & 1;
         // wait until round rho has landed (rounds up to rho + 3 have been issued: iteration i >= 1 issues round i + 4), read it, and refill
         // the slot that was read ONE ITERATION AGO with round rho + 4
-        constexpr int issued = rho == 0 ? 4 : (rho + 3 < 47 ? rho + 3 : 47);
+        constexpr int issued = rho == 0 ? 4 : (rho + 3 < NROUND - 1 ? rho + 3 : NROUND - 1);
         glds_wait<4 * (issued - rho)>();
         constexpr int so = 4096 * (rho % GEOAC_GLDS_RING);
         const geoac_d2 q0 = *(const geoac_d2*)(ra0 + so), q1 = *(const geoac_d2*)(ra1 + so), q2 = *(const geoac_d2*)(ra2 + so), q3 = *(const geoac_d2*)(ra3 + so);
-        if constexpr (rho >= 1 && rho + 4 < 48) GEOAC_GLDS_ISSUE(rho + 4)
+        if constexpr (rho >= 1 && rho + 4 < NROUND) GEOAC_GLDS_ISSUE(rho + 4)
         p0 = q0; p1 = q1; p2 = q2; p3 = q3;
         const Cub c0 = Cub{ q0.x, q0.y, q1.x, q1.y }, c1 = Cub{ q2.x, q2.y, q3.x, q3.y };
         CornerW w = corner_weights<ORDER2, ORDER2>(hx, hy, a, b);
-        const double Wq = w.W[2] * dxs;                                               // Q11 row of the f_zz patch (y row scaled by dx)
+        const double Wq = w.W[2] * (GLB ? dys : dxs);                                 // Cartesian: Q11 row of the f_zz patch (y row scaled by dx)
         w.W[1] *= dxs; w.W[2] *= dys; w.W[3] *= dxy;
         if(ORDER2){ w.D[1] *= dxs; w.D[2] *= dys; w.D[3] *= dxy; w.E[1] *= dxs; w.E[2] *= dys; w.E[3] *= dxy; }
         double* o = M[f];
         if constexpr (qd == 0){                                                       // F, DxF
             cF = cub_val(c0, t, t6); cDxF = cub_val(c1, t, t6);
-            cFz = cub_d1(c0, t, th); cVxz = cub_d1(c1, t, th);
+            cFz = cub_d1(c0, t, th);
+            if(!GLB) cVxz = cub_d1(c1, t, th);                                        // (packed table: V_x = D_x F)
             if(ORDER2){ cFzz = cub_d2(c0, t); cDxFzz = cub_d2(c1, t); }
         } else if constexpr (qd == 1){                                                // DyF, DxyF
             const double DyF = cub_val(c0, t, t6), DxyF = cub_val(c1, t, t6);
-            const double Vyz = cub_d1(c0, t, th), DxyFz = cub_d1(c1, t, th);
+            const double DxyFz = cub_d1(c1, t, th);
             o[0] = dot4(w.W, cF, cDxF, DyF, DxyF, o[0]);
-            o[3] = dot4(w.W, cFz, cVxz, Vyz, DxyFz, o[3]);
             if(ORDER2){
-                o[8] = dot4(w.D, cFz, cVxz, Vyz, DxyFz, o[8]);
-                o[9] = dot4(w.E, cFz, cVxz, Vyz, DxyFz, o[9]);
                 const double DyFzz = cub_d2(c0, t), DxyFzz = cub_d2(c1, t);
                 o[6] = __builtin_fma(w.W[0], cFzz, __builtin_fma(w.W[1], cDxFzz, __builtin_fma(Wq, DyFzz, __builtin_fma(w.W[3], DxyFzz, o[6]))));
             }
-            cDyF = DyF; cDxyF = DxyF;
-        } else if constexpr (qd == 2){                                                // DxVx, DxyVx
+            if(!GLB){
+                const double Vyz = cub_d1(c0, t, th);                                 // (V_y = D_y F)
+                o[3] = dot4(w.W, cFz, cVxz, Vyz, DxyFz, o[3]);
+                if(ORDER2){
+                    o[8] = dot4(w.D, cFz, cVxz, Vyz, DxyFz, o[8]);
+                    o[9] = dot4(w.E, cFz, cVxz, Vyz, DxyFz, o[9]);
+                }
+            }
+            cDyF = DyF; cDxyF = DxyF; cDxyFz = DxyFz;
+        } else if constexpr (!GLB && qd == 2){                                        // DxVx, DxyVx
             const double DxVx = cub_val(c0, t, t6), DxyVx = cub_val(c1, t, t6);
             o[1] = dot4(w.W, cDxF, DxVx, cDxyF, DxyVx, o[1]);
             if(ORDER2){
                 o[4] = dot4(w.D, cDxF, DxVx, cDxyF, DxyVx, o[4]);
                 o[7] = dot4(w.E, cDxF, DxVx, cDxyF, DxyVx, o[7]);
+            }
+        } else if constexpr (GLB && qd == 2){                                         // Vx, DxVx
+            cVxz = cub_d1(c0, t, th); cDxVx = cub_val(c1, t, t6);
+        } else if constexpr (GLB && qd == 3){                                         // DxyVx, Vy
+            const double DxyVx = cub_val(c0, t, t6), Vyz = cub_d1(c1, t, th);
+            o[1] = dot4(w.W, cDxF, cDxVx, cDxyF, DxyVx, o[1]);
+            o[3] = dot4(w.W, cFz, cVxz, Vyz, cDxyFz, o[3]);
+            if(ORDER2){
+                o[4] = dot4(w.D, cDxF, cDxVx, cDxyF, DxyVx, o[4]);
+                o[7] = dot4(w.E, cDxF, cDxVx, cDxyF, DxyVx, o[7]);
+                o[8] = dot4(w.D, cFz, cVxz, Vyz, cDxyFz, o[8]);
+                o[9] = dot4(w.E, cFz, cVxz, Vyz, cDxyFz, o[9]);
             }
         } else {                                                                      // DyVy, DxyVy
             const double DyVy = cub_val(c0, t, t6), DxyVy = cub_val(c1, t, t6);
@@ -572,10 +595,10 @@ DEVINL void grid_eval3_glds(const GeoacDevParams& P, const GridLoc& L, double (*
             if(ORDER2) o[5] = dot4(w.E, cDyF, cDxyF, DyVy, DxyVy, o[5]);
         }
     };
-    geoac_static_for(step, std::make_integer_sequence<int, 48>{});
+    geoac_static_for(step, std::make_integer_sequence<int, NROUND>{});
     #undef GEOAC_GLDS_ISSUE
     #undef GEOAC_GLDS_BASES
-    if(ORDER2){
+    if(ORDER2 && !GLB){                                                               // spherical set: left in scaled coordinates (Q12c)
         const double idxs = L.idxs, idys = L.idys;
         #pragma unroll
         for(int f = 0; f < 3; f++){ M[f][4] *= idxs; M[f][8] *= idxs; M[f][7] *= idys; M[f][5] *= idys; M[f][9] *= idys; }
@@ -821,7 +844,10 @@ DEVINL void globalrd_rhs(const GeoacDevParams& P, int& kz, const double* y, doub
     GridLoc L; grid_locate(P, te, pe, re, kz, L, CACHE ? (const double*)(ldsw + GEOAC_CACHE_BYTES) : nullptr, kxy, cell);
     kz = L.kz;
     double M[3][10];                                               // table order: f, f_t, f_p, f_r, f_tt, f_pp, f_rr, f_tp, f_tr, f_pr
-    if(COOP) grid_eval3_coop<AMP, true>(P, L, M, ldsw);
+    if(COOP){
+        if constexpr (GEOAC_COOP_GLDS != 0) grid_eval3_glds<AMP, true>(P, L, M, ldsw);
+        else grid_eval3_coop<AMP, true>(P, L, M, ldsw);
+    }
     else if(CACHE){
         const double* rec = grid_cache_fill<true>(P, L, cq, ldsw, ckey);
         if(NSYS == 1 || GEOAC_CACHE_LDSOFF){                       // eight-lane kernel: keep the record reads in the stage loop (hipcc otherwise parks the
