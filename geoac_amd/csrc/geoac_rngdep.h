@@ -621,7 +621,7 @@ DEVINL const double* grid_cache_fill(const GeoacDevParams& P, const GridLoc& L, 
     constexpr int RB = GRec<GLB>::N * (int)sizeof(double), NCH = RB / 16;             // bytes and 16-byte chunks per record
     const unsigned lane = threadIdx.x & 63u;
     const unsigned nn = (unsigned)(P.gnx * P.gny);
-    const int key = L.kz * (int)nn + corner_node_sel(L, cq >> 1, cq & 1);
+    const int key = L.kz * (int)nn + corner_node(L, cq >> 1, cq & 1);
     char* mine = cache + lane * GEOAC_CACHE_SLOT;
     if(key != *ckey){                                              // (the four lanes of a ray change cell / segment together)
         const size_t fstride = (size_t)P.nseg * nn * RB;
