@@ -318,9 +318,10 @@ def main():
             n_th4 = int(np.sum(ph4 == ph4[0]))
             r4 = FanRun(G, G.EQ_3D_RNGDEP, lambda c: c.load_grid(*grid), dict(bounces=1, calc_amp=1, mode=0, src=(0.0, 0.0, 0.0)),
                         th4, ph4, n_th4, rank, world, dev, coll_dev, stream, 2)
+            r4.one_pass()                                                # first pass: allocations and first touch of the path chunks (~150 GB), not timed
             s4, t4, _ = r4.timed(1)
             extras["config4_fan_strong"] = {"value": s4 / t4, "unit": "RK4 ray-steps/s", "seconds_per_pass": t4, "rays": int(len(th4)), "rays_per_gpu": int(len(r4.theta)),
-                                            "scaling": "strong", "workload": "GeoAc3D.RngDep 5x5x1400 grid, 1000 az x 1000 incl, bounces=1, CalcAmp=True, azimuth-sharded; one pass, first-touch allocations included",
+                                            "scaling": "strong", "workload": "GeoAc3D.RngDep 5x5x1400 grid, 1000 az x 1000 incl, bounces=1, CalcAmp=True, azimuth-sharded; one timed pass after an untimed one (allocations warm)",
                                             "parity": "tests/test_gpu_fullfan.py::test_config4_share_on_5x5x1400_grid_vs_reference"}
             del r4
         except Exception as e:                                          # the extras never take the line down

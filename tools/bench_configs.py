@@ -85,6 +85,18 @@ def cfg4(thin=1):
                 E=18, kernel="k_rk4<Eq3DRngDep<true,1,true>,false,false>", grid=True)
 
 
+def cfg4_full():
+    """the whole 1000 az x 1000 incl fan of config 4 on ONE GPU (999 000 rays; the path chunks take most of the device memory)"""
+    import rngdep_data as RD
+    grid = RD.write_grid(os.path.join(tempfile.gettempdir(), "gdb1"), short_paths=False, thin=1)
+    ctx = G.FanContext(G.EQ_3D_RNGDEP, device=0); ctx.load_grid(*grid)
+    ctx.set_params(bounces=1, calc_amp=1, mode=0, src=(0.0, 0.0, 0.0))
+    th, ph = G.fan_enumerate(theta_min=0.05, theta_max=50.0, theta_step=0.05, phi_min=-180.0, phi_max=-180.0 + 999 * 0.36, phi_step=0.36)
+    steps, dt = run_fan(ctx, th, ph, reps=1)
+    return dict(config="cfg4 GeoAc3D.RngDep 5x5x1400 grid, the whole 1000 az x 1000 incl fan on one GPU, bounces=1, CalcAmp=True", rays=len(th), ray_steps=steps, seconds=dt,
+                E=18, kernel="k_rk4<Eq3DRngDep<true,1,true>,false,false>", grid=True)
+
+
 def cfg4_350():
     """the same fan on the thinned 5x5x350 grid of the small parity fixtures (table 9.6 MB instead of 38 MB)"""
     return cfg4(thin=4)
@@ -105,7 +117,7 @@ def cfg5():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"]
+    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"]          # (also: cfg4_350, cfg4_full)
     for w in which:
         LAST.clear()
         r = globals()[w]()
