@@ -68,8 +68,15 @@ def test_globalrd_write_rays_caustics_vs_golden(gold, grid):
             assert (d / scale).max() <= 1e-6, (col, (d / scale).max())
 
 
-@pytest.mark.parametrize("lanes", [1, 2, 4, "coop", "dense"])
+@pytest.mark.parametrize("lanes", [1, 2, 4, "coop", "dense", "coop+sub"])
 def test_every_lanes_per_ray_variant_vs_golden(gold, grid, lanes, monkeypatch):
+    if lanes == "coop+sub":
+        # the launch plan of saturated fans forced on the small one: cooperative LDS-DMA gather, 512-row epochs in four sub-epochs handed from
+        # workgroup to workgroup (sample and caustic events carried across the hand-off)
+        monkeypatch.setenv("GEOAC_SUB_MIN_WAVES", "0")
+        monkeypatch.setenv("GEOAC_SUB_EPOCHS", "4")
+        monkeypatch.setenv("GEOAC_S_ROWS", "512")
+        lanes = "coop"
     if lanes in ("coop", "dense"):
         # one lane per ray without lane thinning, as a large fan runs: "coop" = wave-cooperative table gather through LDS (58 of the
         # wave's 64 lanes are helpers without a ray here), "dense" = the same launch with per-lane gathers
