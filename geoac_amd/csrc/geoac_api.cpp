@@ -571,9 +571,9 @@ int geoac_fan_launch(geoac_ctx* ctx){
         else if((long long)P.n_pad * 2 / 64 <= 1024) P.lanes_per_ray = 2;
     }
     if(is_grid && ctx->grid_lanes) P.lanes_per_ray = ctx->grid_lanes;
-    // spherical grid set with amplitudes, fans of a few rays (the eigenray rounds): eight lanes per ray - four cell corners x the two launch-angle
-    // systems (EqGlobalRngDepOct) - while that is at most one wave per CU
-    const bool oct_ok = ctx->eqset == GEOAC_EQ_GLOBAL_RNGDEP && p.calc_amp && !sampling && ctx->quad_cache && (long long)P.n_pad * 8 / 64 <= 256;
+    // grid sets with amplitudes, fans of a few rays (the eigenray rounds): eight lanes per ray - four cell corners x the two launch-angle
+    // systems (EqGlobalRngDepOct, Eq3DRngDepOct) - while that is at most one wave per CU
+    const bool oct_ok = is_grid && p.calc_amp && !sampling && ctx->quad_cache && (long long)P.n_pad * 8 / 64 <= 256;
     if(P.lanes_per_ray == 8 && !oct_ok) P.lanes_per_ray = 4;
     if(is_grid && !ctx->grid_lanes && !ctx->no_quad && ctx->oct && oct_ok && P.lanes_per_ray == 4) P.lanes_per_ray = 8;
     // RK4 workgroup shape: with the table in LDS one workgroup owns a CU, so spread the waves over the 256 CUs

@@ -883,6 +883,37 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
     }
 };
 
+// Eight lanes per ray for the Cartesian grid set with amplitudes, small fans (eigenray rounds): cell corner q & 3, launch-angle system q >> 2
+// (see EqGlobalRngDepOct).  Row k - 2 of the quadratic intercept stays in the state block (KM2_MEM), each system's part stored by its first lane.
+struct Eq3DRngDepOct : Eq3DRngDep<true, 4, false, true> {
+    using Full = Eq3DRngDep<true, 4, false, true>;
+    static constexpr int E = 12, LANES = 8;
+    static constexpr bool SPLIT = true; static constexpr bool ROW_SPLIT = false;
+    static constexpr int SYS_SHIFT = 2;
+    template <typename TabPtr>
+    static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
+        rngdep_rhs<true, 4, false, true, 1>(P, seg, yt, dy, (int)(threadIdx.x & 3), (char*)tab, &C.ckey, &C.kxy, C.cell);
+    }
+    // quadratic intercept + reflection of the base ray and of this lane's system: 3DRngDep.cpp:146-216
+    static DEVINL void reflect(const GeoacDevParams& P, const RayCtx& C, const double* yn, double* y, const double* ym2){
+        double dz_k = yn[2] - y[2];
+        double dz_g = y[2] - P.ground;
+        double prev[E];
+        #pragma unroll
+        for(int e = 0; e < E; e++)
+            prev[e] = y[e] + (y[e] - yn[e]) / dz_k * dz_g + 1.0 / 2.0 * (yn[e] + ym2[e] - 2.0 * y[e]) / (dz_k * dz_k) * (dz_g * dz_g);
+        Medium3 mg = medium3_at<false, true>(P, prev[0], prev[1], P.z_grnd);
+        double dnuz_ds = -1.0 / mg.c * (C.c0 / mg.c * mg.dcz + prev[3] * mg.duz + prev[4] * mg.dvz);
+        #pragma unroll
+        for(int e = 0; e < E; e++) y[e] = prev[e];
+        y[2] = P.ground;
+        y[5] = -prev[5];
+        y[8] = -prev[8];
+        double den = mg.c / C.c0 * prev[5];
+        y[11] = -prev[11] + 2.0 * dnuz_ds * prev[8] / den;
+    }
+};
+
 // Range-dependent spherical set (GeoAcGlobal.RngDep): EquationSets.GlobalRngDep.cpp + G2S_GlobalMultiDimSpline3D.cpp.
 // Grid axes in table order: x = latitude, y = longitude [rad], z = geocentric radius; xy_lim = lat/lon box of the break check.
 template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struct EqGlobalRngDep {
@@ -1601,7 +1632,7 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
                     if(EQ::KM2 && EQ::KM2_MEM){
                         double r2[E];
                         #pragma unroll
-                        for(int e = 0; e < E; e++) r2[e] = st[(ST_YM2 + e) * np];
+                        for(int e = 0; e < E; e++) r2[e] = st[(ST_YM2 + ((EQ::SPLIT && e >= EQ::NB) ? e + EQ::NS * qs : e)) * np];
                         EQ::reflect(P, C, yn, y, r2);
                     } else EQ::reflect(P, C, yn, y, ym2);
                     leg++; k = 0;
@@ -1613,9 +1644,10 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
             if(YM2_REG){
                 #pragma unroll
                 for(int e = 0; e < E; e++) ym2[e] = y[e];
-            } else if(EQ::KM2 && (EQ::LANES == 1 || q == 0)){       // KM2_MEM (not a split-state policy): one coalesced row per step
+            } else if(EQ::KM2 && (EQ::LANES == 1 || (EQ::SPLIT ? (q & ((1 << EQ::SYS_SHIFT) - 1)) == 0 : q == 0))){
+                // KM2_MEM: one coalesced row per step, stored by the ray's first lane (split state: by the first lane of each launch-angle system, its part)
                 #pragma unroll
-                for(int e = 0; e < E; e++) st[(ST_YM2 + e) * np] = y[e];
+                for(int e = 0; e < E; e++) st[(ST_YM2 + ((EQ::SPLIT && e >= EQ::NB) ? e + EQ::NS * qs : e)) * np] = y[e];
             }
             #pragma unroll
             for(int e = 0; e < E; e++) y[e] = yn[e];
@@ -1971,6 +2003,7 @@ __global__ void __launch_bounds__(64) k_probe_grid(GeoacDevParams P, int n, cons
 #define GEOAC_DISPATCH_EQ_RK4(P, CALL) \
     if((P)->lanes_per_ray == 8){ \
         if((P)->eqset == GEOAC_EQ_GLOBAL_RNGDEP && (P)->calc_amp && (P)->quad_cache){ using EQ = EqGlobalRngDepOct; CALL; } \
+        else if((P)->eqset == GEOAC_EQ_3D_RNGDEP && (P)->calc_amp && (P)->quad_cache){ using EQ = Eq3DRngDepOct; CALL; } \
         else return hipErrorNotSupported; \
     } else if((P)->lanes_per_ray == 4 && (P)->quad_cache){ \
         switch((P)->eqset * 2 + ((P)->calc_amp ? 1 : 0)){ \

@@ -737,7 +737,8 @@ DEVINL Medium3 medium3_at(const GeoacDevParams& P, double x, double y, double z)
 
 // fused GeoAc_UpdateSources + GeoAc_EvalSrcEq of the range-dependent Cartesian set (EquationSets.3DRngDep.cpp:218-393)
 // y: x, y, z, nu_x, nu_y, nu_z | X_th(3), mu_th(3) | X_ph(3), mu_ph(3)
-template <bool AMP, int NL = 1, bool COOP = false, bool CACHE = false>
+// NSYS = 1 (the eight-lane kernel, Eq3DRngDepOct): y = base ray | ONE launch-angle system, the lane's own
+template <bool AMP, int NL = 1, bool COOP = false, bool CACHE = false, int NSYS = 2>
 DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double* dy, int cq = 0, char* ldsw = nullptr, int* ckey = nullptr, int* kxy = nullptr, double* cell = nullptr){
     const double xe = clampd(y[0], P.g_lo[0], P.g_hi[0]), ye = clampd(y[1], P.g_lo[1], P.g_hi[1]), ze = clampd(y[2], P.x_min, P.x_max);
     GridLoc L; grid_locate(P, xe, ye, ze, kz, L, CACHE ? (const double*)(ldsw + GEOAC_CACHE_BYTES) : nullptr, kxy, cell);
@@ -802,7 +803,7 @@ DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double
         const int ij[3][3] = { {4, 7, 8}, {7, 5, 9}, {8, 9, 6} };
         const double hc3 = (0.25 * kGamR * kGamR) * (ic * ic * ic);                // gamR^2 / (4 c^3)
         #pragma unroll
-        for(int a = 0; a < 2; a++){
+        for(int a = 0; a < NSYS; a++){
             const double X[3] = { y[6 + 6 * a], y[7 + 6 * a], y[8 + 6 * a] };
             const double m[3] = { y[9 + 6 * a], y[10 + 6 * a], y[11 + 6 * a] };
             double dc3 = 0.0, du3 = 0.0, dv3 = 0.0;

@@ -88,3 +88,15 @@ def test_every_lanes_per_ray_variant_vs_golden(gold, grid, lanes, monkeypatch):
     rec, steps = ctx.run(gold["theta"], gold["phi"])
     assert steps == int(gold["steps_amp0_mode0"])
     compare_records(rec, gold["rec_amp0_mode0"], E=6, hidx=2)
+
+
+def test_eight_lane_kernel_gives_the_four_lane_kernels_bits(gold, grid, monkeypatch):
+    """small arrivals-only fans with amplitudes run eight lanes per ray (four cell corners x the two launch-angle systems, Eq3DRngDepOct; row k - 2
+    of the quadratic intercept split between the systems' first lanes); GEOAC_OCT=0 keeps them on the four-lane kernel: same records bit for bit"""
+    out = {}
+    for oct_on in ("1", "0"):
+        monkeypatch.setenv("GEOAC_OCT", oct_on)
+        ctx = _ctx(grid, bounces=2, calc_amp=1, mode=0, src=(0.0, 0.0, 0.0))
+        out[oct_on] = ctx.run(gold["theta"], gold["phi"])
+    assert out["1"][1] == out["0"][1]
+    assert np.array_equal(out["1"][0], out["0"][0])
