@@ -286,9 +286,10 @@ class FanContext:
             self._chk(L.geoac_eig_fetch(res, _p(eig)))
         if ns:
             self._chk(L.geoac_eig_fetch_samples(res, _p(smp)))
-        st = (ctypes.c_uint64 * 4)()
-        L.geoac_eig_stats(res, st)
-        return dict(eig=eig[:ne], smp=smp[:ns], stats=dict(launches=int(st[0]), rays=int(st[1]), steps=int(st[2]), rounds=int(st[3])))
+        st = (ctypes.c_uint64 * 8)()
+        L.geoac_eig_stats_ex(res, st)
+        return dict(eig=eig[:ne], smp=smp[:ns], stats=dict(launches=int(st[0]), rays=int(st[1]), steps=int(st[2]), rounds=int(st[3]),
+                                                              critical_steps=int(st[4]), amp_launches=int(st[5])))
 
     def eig_search(self, receivers, theta_min=0.5, theta_max=45.0, bnc_min=0, bnc_max=0, iterations=25, azimuth_err_lim=2.0, verbose=False):
         """GeoAc's -eig_search for every receiver [lat, lon] (degrees) around the context's source, decision rounds of all receivers

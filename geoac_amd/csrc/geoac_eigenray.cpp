@@ -618,7 +618,7 @@ struct geoac_eig_result {
     std::vector<double> eig;               // count x GEOAC_EIG_STRIDE
     std::vector<double> smp;
     std::vector<std::string> logs;
-    uint64_t stats[4] = {0, 0, 0, 0};
+    uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 // integrate all pending requests: one fan launch per (bounces, calc_amp, mode) group
@@ -639,6 +639,16 @@ static int serve(geoac_ctx* ctx, const geoac_params& base, std::vector<Request*>
         rc = geoac_fan_run(ctx, n, th.data(), ph.data(), rec.data(), &steps);
         if(rc) return rc;
         res->stats[0] += 1; res->stats[1] += (uint64_t)n; res->stats[2] += steps;
+        {   // the launch's longest ray (all legs)
+            double longest = 0.0;
+            for(int i = 0; i < n; i++){
+                double sum = 0.0;
+                for(int l = 0; l < legs; l++) sum += rec[((size_t)i * legs + l) * GEOAC_REC_STRIDE + GEOAC_REC_STEPS];
+                longest = std::max(longest, sum);
+            }
+            res->stats[4] += (uint64_t)longest;
+            if(p.calc_amp) res->stats[5] += 1;
+        }
         std::vector<double> smp;
         if(p.mode){
             int64_t ns = 0;
@@ -799,6 +809,11 @@ int geoac_eig_stats(const geoac_eig_result* r, uint64_t stats[4]){
     if(!r || !stats) return GEOAC_E_INVALID;
     for(int i = 0; i < 4; i++) stats[i] = r->stats[i];
     return 0;
+}
+int geoac_eig_stats_ex(const geoac_eig_result* r, uint64_t stats[8]){
+    if(!r || !stats) return GEOAC_E_INVALID;
+    for(int i = 0; i < 8; i++) stats[i] = r->stats[i];
+    return GEOAC_OK;
 }
 void geoac_eig_free(geoac_eig_result* r){ delete r; }
 

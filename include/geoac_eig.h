@@ -70,6 +70,9 @@ int         geoac_eig_fetch_samples(const geoac_eig_result* r, double* smp);
 const char* geoac_eig_log(const geoac_eig_result* r, int rcvr);
 /* [0] fan launches, [1] rays integrated, [2] RK4 ray-steps, [3] rounds (decision points served) */
 int         geoac_eig_stats(const geoac_eig_result* r, uint64_t stats[4]);
+/* the same plus [4] critical ray-steps: the sum over the fan launches of the longest ray's step count (a launch lasts as long as its longest
+ * ray: what the search costs on a latency-bound device), [5] fan launches that carried the auxiliary (amplitude) equations, [6], [7] reserved */
+int         geoac_eig_stats_ex(const geoac_eig_result* r, uint64_t stats[8]);
 void        geoac_eig_free(geoac_eig_result* r);
 
 #ifdef __cplusplus

@@ -51,7 +51,8 @@ def cfg1():
     ctx.set_params(bounces=2, calc_amp=1, mode=1)
     th, ph = G.fan_enumerate(theta_min=1.0, theta_max=10.0, theta_step=1.0, phi_min=-90.0, phi_max=-90.0)
     steps, dt = run_fan(ctx, th, ph)
-    return dict(config="cfg1 GeoAc2D -prop ToyAtmo.met theta 1..10 (10 rays, WriteRays)", rays=len(th), ray_steps=steps, seconds=dt)
+    return dict(config="cfg1 GeoAc2D -prop ToyAtmo.met theta 1..10 (10 rays, WriteRays)", rays=len(th), ray_steps=steps, seconds=dt, E=6,
+                kernel="k_rk4<Eq2D<true>,true,true> (one wave: the run lasts as long as its longest ray)")
 
 
 def cfg2():
@@ -112,8 +113,17 @@ def cfg5():
     rcv = np.stack([31.0 + 2.5 * np.cos(az), 2.5 * np.sin(az) / np.cos(np.radians(31.0))], axis=1)
     t0 = time.perf_counter(); out = ctx.eig_search(rcv, bnc_min=0, bnc_max=2); dt = time.perf_counter() - t0
     st = out["stats"]
+    # roofline of a latency-bound search: a fan launch lasts as long as its longest ray, and a ray advances one RK4 stage per pass of ONE wave
+    # through the stage loop - 1 113 instructions of the eight-lane kernel at 4 cycles each (wave64 on a 16-lane SIMD) = 4 452 cycles, i.e.
+    # at most 2.4e9 / (4 x 4 452) = 1.35e5 steps/s along a ray.  achieved = the critical path's steps (sum over the launches of the longest
+    # ray) / wall seconds of the whole search, host decisions and copies included.
+    peak = 2.4e9 / (4 * 1113 * 4)
+    ach = st["critical_steps"] / dt
     return dict(config="cfg5 GeoAcGlobal.RngDep -eig_search, 8 of 64 receivers (every 8th) on a 2.5 deg ring, bounces 0..2", rays=st["rays"], ray_steps=st["steps"],
-                seconds=dt, eigenrays=int(len(out["eig"])), fan_launches=st["launches"])
+                seconds=dt, eigenrays=int(len(out["eig"])), fan_launches=st["launches"],
+                roofline={"kernel": "k_rk4<EqGlobalRngDepOct,false,false> (221 of the 295 launches; k_rk4<EqGlobalRngDep<false,4,false,true>,...> for the amplitude-less scans)",
+                          "bound": "wave_issue_serial", "critical_ray_steps": st["critical_steps"], "achieved": ach, "peak": peak, "unit": "ray-steps/s along the critical path",
+                          "frac": ach / peak, "stage_instructions": 1113, "traffic": None})
 
 
 if __name__ == "__main__":
@@ -122,7 +132,7 @@ if __name__ == "__main__":
         LAST.clear()
         r = globals()[w]()
         r["ray_steps_per_s"] = r["ray_steps"] / r["seconds"]
-        rf = roofline(r, grid_gather=bool(r.pop("grid", False))) if w not in ("cfg1", "cfg5") else None
+        rf = roofline(r, grid_gather=bool(r.pop("grid", False))) if w != "cfg5" else r.get("roofline")
         r.pop("E", None); r.pop("kernel", None)
         if rf:
             r["roofline"] = rf

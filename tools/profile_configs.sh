@@ -3,7 +3,7 @@
 # passes of tools/pmc_cfg.sh for cfg4; everything lands in gpurun_out/<tag>/, the summaries to keep are copied to profiles/ afterwards.
 set -e
 R=$GRAFT_REPO_ROOT; TAG=${1:-r02_cfg}; O=$R/gpurun_out/$TAG; mkdir -p $O
-cd $R && python3 tools/bench_configs.py cfg2 cfg3 cfg4_350 cfg4 cfg5 > $O/configs.jsonl 2> $O/configs.err
+cd $R && python3 tools/bench_configs.py cfg1 cfg2 cfg3 cfg4_350 cfg4 cfg4_full cfg5 > $O/configs.jsonl 2> $O/configs.err
 cd /tmp && export TMPDIR=/tmp
 for c in cfg4 cfg5; do
   timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/stats_$c -o $c --output-format csv -- python3 $R/tools/bench_configs.py $c > $O/${c}_under_rocprof.json 2> $O/stats_$c.err || echo "stats $c failed"
