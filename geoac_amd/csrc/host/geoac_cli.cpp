@@ -957,8 +957,9 @@ static int run_eig(char* inputs[], int count, bool direct){
         }
     }
     if(!direct) results.close();
-    uint64_t st[4]; geoac_eig_stats(res, st);
-    cerr << kName << ": " << st[1] << " rays in " << st[0] << " fan launches (" << st[3] << " rounds), " << st[2] << " RK4 ray-steps on the GPU" << '\n';
+    uint64_t st[8]; geoac_eig_stats_ex(res, st);
+    cerr << kName << ": " << st[1] << " rays in " << st[0] << " fan launches (" << st[3] << " rounds), " << st[2] << " RK4 ray-steps on the GPU, " << st[4]
+         << " of them along the critical path (the longest ray of every launch)" << '\n';
     write_stats(direct ? "-eig_direct" : "-eig_search", (long)st[1], st[2], std::chrono::duration<double>(std::chrono::steady_clock::now() - t_eig0).count(),
                 vector<int>(1, 0), vector<uint64_t>(1, st[1]), vector<uint64_t>(1, st[2]), vector<uint64_t>(1, st[0]));
     geoac_eig_free(res);
