@@ -216,7 +216,8 @@ class FanContext:
             rec = np.empty((self.n_rays, legs, REC_STRIDE))
         else:
             rec = out
-            assert rec.dtype == np.float64 and rec.flags.c_contiguous and rec.shape == (self.n_rays, legs, REC_STRIDE)
+            if not (isinstance(rec, np.ndarray) and rec.dtype == np.float64 and rec.flags.c_contiguous and rec.shape == (self.n_rays, legs, REC_STRIDE)):
+                raise GeoAcError(f"fetch(out=): need a C-contiguous float64 array of shape {(self.n_rays, legs, REC_STRIDE)}")
         steps = ctypes.c_uint64(0)
         self._chk(self.lib.geoac_fan_fetch(self._h, _p(rec), ctypes.byref(steps)))
         return rec, int(steps.value)
@@ -251,6 +252,25 @@ class FanContext:
         out = np.zeros(n)
         self._chk(self.lib.geoac_probe_absorption(self._h, n, _p(x), _p(f), _p(out)))
         return out
+
+    def probe_absorption_table(self, x):
+        """alpha from the absorption table the post-pass of the stratified sets reads (-1 where the table does not serve the point)"""
+        x = _arr(x); n = len(x)
+        out = np.zeros(n)
+        self._chk(self.lib.geoac_probe_absorption_table(self._h, n, _p(x), _p(out)))
+        return out
+
+    def abs_table_info(self):
+        """of the last launch: table entries (0 = exact evaluation everywhere), entries flagged at build time, path segments evaluated exactly"""
+        e, f, n, w = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_uint64(0), ctypes.c_double(0)
+        self._chk(self.lib.geoac_abs_table_info(self._h, ctypes.byref(e), ctypes.byref(f), ctypes.byref(n), ctypes.byref(w)))
+        return dict(entries=e.value, flagged=f.value, fixup_segments=int(n.value), worst_rel_err=w.value)
+
+    def fan_status(self):
+        """condition flags of the last launch (GEOAC_FAN_STEP_LIMIT = 1)"""
+        fl = ctypes.c_uint64(0)
+        self._chk(self.lib.geoac_fan_status(self._h, ctypes.byref(fl)))
+        return int(fl.value)
 
     def probe_grid(self, a0, a1, a2, coop=False):
         a0, a1, a2 = _arr(a0), _arr(a1), _arr(a2); n = len(a0)
@@ -332,6 +352,7 @@ class FanPool:
             raise GeoAcError(f"geoac_pool_create: {self.lib.geoac_strerror(rc).decode()}")
         self.lib.geoac_pool_last_error.restype = ctypes.c_char_p
         self.params = default_params(eqset)
+        self._chk(self.lib.geoac_pool_set_params(self._h, ctypes.byref(self.params)))
 
     def _chk(self, rc):
         if rc:

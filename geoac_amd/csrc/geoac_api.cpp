@@ -18,6 +18,7 @@
 extern "C" void geoac_natural_spline_slopes(int n, const double* x, const double* f, double* slopes);
 extern "C" hipError_t geoac_launch_init(const GeoacDevParams* P, hipStream_t s);
 extern "C" hipError_t geoac_launch_rk4(const GeoacDevParams* P, int block, hipStream_t s, unsigned* n_wg);
+extern "C" size_t geoac_duo_lds(int nseg);
 extern "C" size_t geoac_gridbuild_work_doubles(int nx, int ny, int nz);
 extern "C" size_t geoac_gridpack_doubles(int nx, int ny, int nz);
 extern "C" hipError_t geoac_gridpack_launch(int nx, int ny, int nz, const double* d_tab, double* d_tab8, hipStream_t s);
@@ -28,10 +29,13 @@ extern "C" hipError_t geoac_launch_accum(const GeoacDevParams* P, hipStream_t s)
 extern "C" hipError_t geoac_launch_compact(const GeoacDevParams* P, const int* cur, const int* n_cur, int n_first, int* next, int* n_next, hipStream_t s);
 extern "C" hipError_t geoac_launch_probe_atmo1d(const GeoacDevParams* P, int n, const double* x, double* out9, double* rho, hipStream_t s);
 extern "C" hipError_t geoac_launch_probe_absorption(const GeoacDevParams* P, int n, const double* x, const double* f, double* out, hipStream_t s);
+extern "C" hipError_t geoac_launch_probe_atab(const GeoacDevParams* P, int n, const double* x, double* out, hipStream_t s);
 extern "C" hipError_t geoac_launch_probe_grid(const GeoacDevParams* P, int n, const double* a0, const double* a1, const double* a2, int coop,
                                               double* out30, double* api7, hipStream_t s);
 extern "C" hipError_t geoac_launch_gate(const GeoacDevParams* P, unsigned long long expected, hipStream_t s);
 extern "C" hipError_t geoac_launch_postpass(const GeoacDevParams* P, int rows, hipStream_t s);
+extern "C" hipError_t geoac_launch_postpass_tab(const GeoacDevParams* P, int rows, hipStream_t s);
+extern "C" hipError_t geoac_launch_atab_build(const GeoacDevParams* P, double* tab, double tol, hipStream_t s);
 
 namespace {
 
@@ -111,6 +115,15 @@ struct geoac_ctx {
     bool trace_epochs = false;                    // GEOAC_TRACE_EPOCHS=1: per-epoch live counts on stderr
     bool no_gate = false;                         // GEOAC_NO_GATE=1: post-pass not held back behind the next RK4 launch (A/B measurements)
     bool no_pair = false;                         // GEOAC_NO_PAIR=1: force one lane per ray (A/B measurements)
+    int duo = 8;                                  // GEOAC_DUO=0: never the wave-specialised kernel (A/B runs, schedule-independence tests); 1, 2, 4: hand-off variants (A/B), 8: shipped
+    // absorption table of the stratified sets (k_atab_build): rebuilt when the atmosphere or one of the parameters it depends on changes
+    bool abs_table = true;                        // GEOAC_ABS_TABLE=0: exact Sutherland-Bass evaluation at every segment midpoint (A/B runs, equivalence test)
+    DevBuf atab;
+    unsigned long long atmo_version = 0, atab_version = ~0ull;
+    double atab_key[7] = {0, 0, 0, 0, 0, 0, 0};   // freq, tweak_abs, T_o, P_o, r_earth, strip width, tolerance
+    int atab_entries = 0, atab_flagged = 0;       // of the current table
+    double atab_worst = 0;                        // largest relative error the build saw at its check points, unflagged entries
+    unsigned long long pp_fixup_segments = 0;     // last launch: path segments the table did not serve (evaluated exactly)
     std::string err;
 };
 
@@ -215,6 +228,10 @@ int geoac_create(geoac_ctx** out, int eqset, int device){
     if(nov && atoi(nov) != 0) ctx->no_overlap = true;
     const char* ppb = getenv("GEOAC_PP_BLOCKS");
     if(ppb && atoi(ppb) > 0) ctx->pp_blocks = atoi(ppb);
+    const char* abt = getenv("GEOAC_ABS_TABLE");
+    if(abt) ctx->abs_table = (atoi(abt) != 0);
+    const char* du = getenv("GEOAC_DUO");
+    if(du) ctx->duo = atoi(du);
     const char* npr = getenv("GEOAC_NO_PAIR");
     if(npr && atoi(npr) != 0) ctx->no_pair = true;
     const char* pf = getenv("GEOAC_PAIR_FRAC");
@@ -263,7 +280,7 @@ int geoac_destroy(geoac_ctx* ctx){
                        &ctx->nlegend[0], &ctx->nlegend[1], &ctx->nlegend[2],
                        &ctx->ev_row[0], &ctx->ev_row[1], &ctx->ev_row[2], &ctx->ev_m[0], &ctx->ev_m[1], &ctx->ev_m[2],
                        &ctx->ev_amp[0], &ctx->ev_amp[1], &ctx->ev_amp[2], &ctx->nev[0], &ctx->nev[1], &ctx->nev[2], &ctx->smp_out,
-                       &ctx->d_gx, &ctx->d_gy, &ctx->d_gz, &ctx->d_gtab, &ctx->d_gtab8, &ctx->d_consts, &ctx->sub_flags, &ctx->colmap[0], &ctx->colmap[1], &ctx->colmap[2], &ctx->ncols };
+                       &ctx->d_gx, &ctx->d_gy, &ctx->d_gz, &ctx->d_gtab, &ctx->d_gtab8, &ctx->d_consts, &ctx->sub_flags, &ctx->colmap[0], &ctx->colmap[1], &ctx->colmap[2], &ctx->ncols, &ctx->atab };
     for(DevBuf* b : bufs) b->release();
     if(ctx->h_counters) hipHostFree(ctx->h_counters);
     if(ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -315,6 +332,8 @@ int geoac_upload_atmo_1d(geoac_ctx* ctx, int n, const double* x, const double* T
     // GeoAc_SetPropRegion (G2S_Spline1D.cpp:22-28 / G2S_GlobalSpline1D.cpp:22-30): vert_limit = top node
     if(!(ctx->prm.vert_limit == ctx->prm.vert_limit)) ctx->prm.vert_limit = x[n - 1];
     ctx->have_atmo = true;
+    ctx->atmo_version++;
+    ctx->ran = false;                             // (the probes launch with the tables of the last fan: not after a new upload)
     return GEOAC_OK;
 }
 
@@ -372,6 +391,8 @@ int geoac_upload_atmo_3d(geoac_ctx* ctx, int nx, int ny, int nz, const double* x
     const double ext[4] = { x[0], x[nx - 1], y[0], y[ny - 1] };
     for(int q = 0; q < 4; q++) if(!(ctx->prm.xy_limits[q] == ctx->prm.xy_limits[q])) ctx->prm.xy_limits[q] = ext[q];
     ctx->have_grid = true; ctx->have_atmo = true;
+    ctx->atmo_version++;
+    ctx->ran = false;                             // (the probes launch with the tables of the last fan: not after a new upload)
     return GEOAC_OK;
 }
 
@@ -553,6 +574,31 @@ int geoac_fan_launch(geoac_ctx* ctx){
     P.perm = ctx->have_perm ? (const int*)ctx->perm.p : nullptr;
     P.state = (double*)ctx->state.p;
     P.rec = (double*)ctx->rec.p; P.counters = (unsigned long long*)ctx->counters.p;
+    // absorption table (stratified sets; k_atab_build): alpha is a function of the height coordinate alone there
+    P.atab = nullptr; P.atab_on = 0; P.atab_D = 0.0;
+    P.seg_per_x = (double)P.nseg / (P.x_max - P.x_min);
+    if(!is_grid && ctx->abs_table){
+        const double D = std::max(std::min(0.05, p.ds_max), p.ds_min), tol = 1e-10;
+        const double key[7] = { P.freq, P.tweak_abs, P.T_o, P.P_o, P.r_earth, D, tol };
+        P.atab_D = D;
+        if(ctx->atab_version != ctx->atmo_version || memcmp(key, ctx->atab_key, sizeof(key)) != 0){
+            const size_t n_ent = (size_t)P.nseg + 2;
+            HIPCHK(ctx->atab.ensure(sizeof(double) * GEOAC_ATABW * n_ent));
+            HIPCHK(geoac_launch_atab_build(&P, (double*)ctx->atab.p, tol, ctx->stream));
+            std::vector<double> h(GEOAC_ATABW * n_ent);
+            HIPCHK(hipMemcpyAsync(h.data(), ctx->atab.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            ctx->atab_entries = (int)n_ent; ctx->atab_flagged = 0; ctx->atab_worst = 0.0;
+            for(size_t e = 0; e < n_ent; e++){
+                if(h[e * GEOAC_ATABW + 1] != 0.0) ctx->atab_flagged++;
+                else ctx->atab_worst = std::max(ctx->atab_worst, h[e * GEOAC_ATABW + GEOAC_ATABW - 1]);
+            }
+            memcpy(ctx->atab_key, key, sizeof(key));
+            ctx->atab_version = ctx->atmo_version;
+        }
+        // a profile most of whose segments the interpolant cannot serve (very long segments) keeps the exact post-pass
+        if(4 * ctx->atab_flagged <= ctx->atab_entries){ P.atab = (const double*)ctx->atab.p; P.atab_on = 1; }
+    }
 
     // two lanes per ray (EqGlobalPair) for the Global set with amplitudes when no sample capture is requested
     {   // largest displacement of one RK4 step: ds = max(min(0.05 - ..., ds_max), ds_min)  (GeoAc_Set_ds)
@@ -565,6 +611,12 @@ int geoac_fan_launch(geoac_ctx* ctx){
     P.slot_lo = 0; P.slot_hi = P.n_pad; P.live_slot = 1;
     // two lanes per ray shorten the serial chain (x1.25) at twice the lanes: only worth it while the fan leaves SIMDs idle
     P.lanes_per_ray = ((is_global || ctx->eqset == GEOAC_EQ_3D) && p.calc_amp && !sampling && !ctx->no_pair && (long long)P.n_pad * 2 / 64 <= 1024) ? 2 : 1;
+    // Global set with amplitudes, arrivals only, a fan of at most one workgroup per CU (128 rays each) and a profile whose packed table
+    // leaves room for the message slots: the wave-specialised kernel (geoac_duo.h) - the ray on one wave, its two launch-angle derivative
+    // systems on a second one
+    P.duo = (is_global && p.calc_amp && !sampling && ctx->duo && !ctx->no_pair && P.table_in_lds && geoac_duo_lds(P.nseg) <= 160 * 1024 &&
+             (long long)P.n_pad <= 256ll * 128) ? ctx->duo : 0;
+    if(P.duo) P.lanes_per_ray = 1;
     // grid sets, small fans: four lanes per ray (one cell corner each) while that still leaves one wave per SIMD
     if(is_grid && !ctx->no_quad){
         if((long long)P.n_pad * 4 / 64 <= 1024) P.lanes_per_ray = 4;
@@ -671,7 +723,8 @@ int geoac_fan_launch(geoac_ctx* ctx){
         HIPCHK(hipStreamWaitEvent(sp, ctx->evs[4 * e + 1], 0));
         if(gate_expected > 0 && sp != s && !ctx->no_gate) HIPCHK(geoac_launch_gate(&Pq, gate_expected, sp));
         HIPCHK(hipEventRecord(ctx->evs[4 * e + 2], sp));
-        HIPCHK(geoac_launch_postpass(&Pq, Pq.s_rows, sp));
+        if(Pq.atab_on) HIPCHK(geoac_launch_postpass_tab(&Pq, Pq.s_rows, sp));
+        else HIPCHK(geoac_launch_postpass(&Pq, Pq.s_rows, sp));
         // the per-ray running sums (one thread per ray, latency-bound, 106 VGPRs: fits beside an RK4 wave) on their own stream, in
         // epoch order, so that the next epoch's post-pass does not queue behind them
         if(sa != sp){
@@ -753,6 +806,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
             const unsigned long long* hc = ctx->h_counters + 16 * ((e - 1) & 1);
             live = hc[1] + hc[6];
             live_bound = live;
+            if(hc[2] & 8ull){ hipDeviceSynchronize(); return fail(ctx, GEOAC_E_HIP, "k_rk4_duo: a wave waited more than a second for the other wave of its pair"); }
             if(live == 0){ ctx->n_epochs = e; break; }
             // hybrid fan: once the rays still alive would fit on half of the SIMDs as two-lane waves (hc[4] two-lane waves alive, hc[7]
             // one-lane waves that would become two each), or the two-lane share has finished, everything continues on the two-lane
@@ -769,6 +823,9 @@ int geoac_fan_launch(geoac_ctx* ctx){
     HIPCHK(hipMemcpyAsync(ctx->h_counters + 8, ctx->counters.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     ctx->n_samples = ctx->h_counters[8 + 3];
+    {   unsigned long long fx = 0;
+        HIPCHK(hipMemcpy(&fx, (const unsigned long long*)ctx->counters.p + GEOAC_CNT_PPFLAG + 1, sizeof(fx), hipMemcpyDeviceToHost));
+        ctx->pp_fixup_segments = fx; }
 #ifdef GEOAC_KSTAT
     {   // diagnostic build (geoac_rngdep.h): distinct (segment, cell) keys per live wave-stage
         unsigned long long h[16];
@@ -804,12 +861,22 @@ int geoac_fan_launch(geoac_ctx* ctx){
         if(ctx->sub_epochs > 1){ ctx->sub_epochs = 1; fprintf(stderr, "libgeoac_hip: sub-epoch hand-off timed out, repeating the fan without sub-epochs\n"); return geoac_fan_launch(ctx); }
         return fail(ctx, GEOAC_E_HIP, "sub-epoch hand-off timed out");
     }
+    if(ctx->err_flags & 8ull) return fail(ctx, GEOAC_E_HIP, "k_rk4_duo: a wave waited more than a second for the other wave of its pair");
     if(ctx->err_flags & 2ull) return fail(ctx, GEOAC_E_CAPACITY, "per-epoch sample/caustic event list overflowed");
     if(sampling && ctx->n_samples > (unsigned long long)P.smp_cap)
         return fail(ctx, GEOAC_E_CAPACITY, "sample list overflowed: raise GEOAC_SMP_CAP (needed " + std::to_string(ctx->n_samples) + ")");
     // a ray that exhausts step_limit is an ordinary leg end for the reference (GeoAc_Propagate_RK4 returns step_limit with check = false
     // and the mains write the row): the fan is complete and valid, the condition is reported through geoac_fan_status
     if(ctx->err_flags & 1ull) ctx->err = "warning: a ray reached step_limit (GeoAc.Solver.cpp:14) without leaving the region or reaching the ground";
+    return GEOAC_OK;
+}
+
+int geoac_abs_table_info(geoac_ctx* ctx, int* entries, int* flagged, uint64_t* fixup_segments, double* worst_rel_err){
+    if(!ctx || !ctx->ran) return GEOAC_E_INVALID;
+    if(worst_rel_err) *worst_rel_err = ctx->lastP.atab_on ? ctx->atab_worst : 0.0;
+    if(entries) *entries = ctx->lastP.atab_on ? ctx->atab_entries : 0;
+    if(flagged) *flagged = ctx->lastP.atab_on ? ctx->atab_flagged : 0;
+    if(fixup_segments) *fixup_segments = (uint64_t)ctx->pp_fixup_segments;
     return GEOAC_OK;
 }
 
@@ -927,6 +994,18 @@ int geoac_probe_absorption(geoac_ctx* ctx, int n, const double* x, const double*
     ProbeBufs B; double* dx = B.in(x, (size_t)n); double* df = B.in(freq, (size_t)n); double* da = B.out((size_t)n);
     if(!dx || !df || !da) return fail(ctx, GEOAC_E_NOMEM, "probe: device allocation failed");
     HIPCHK(geoac_launch_probe_absorption(&ctx->lastP, n, dx, df, da, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(alpha, da, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+    return GEOAC_OK;
+}
+
+int geoac_probe_absorption_table(geoac_ctx* ctx, int n, const double* x, double* alpha){
+    if(!ctx || n <= 0 || !x || !alpha) return fail(ctx, GEOAC_E_INVALID, "probe_absorption_table: bad arguments");
+    if(!ctx->ran || ctx->have_grid || !ctx->lastP.atab_on) return fail(ctx, GEOAC_E_INVALID, "probe_absorption_table: needs a completed launch of a 1-D set with the absorption table on");
+    HIPCHK(hipSetDevice(ctx->device));
+    ProbeBufs B; double* dx = B.in(x, (size_t)n); double* da = B.out((size_t)n);
+    if(!dx || !da) return fail(ctx, GEOAC_E_NOMEM, "probe: device allocation failed");
+    HIPCHK(geoac_launch_probe_atab(&ctx->lastP, n, dx, da, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipMemcpy(alpha, da, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
     return GEOAC_OK;

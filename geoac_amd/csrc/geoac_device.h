@@ -20,6 +20,9 @@
 #define GEOAC_SEGW      14      // doubles per segment in the T/u/v table
 #define GEOAC_MAXE      18
 #define GEOAC_MAXLEGS   64      // legs per ray supported by the per-epoch leg-end event list
+#define GEOAC_ATABW     28      // doubles per entry of the absorption table: 2 / h, flag, 3 x 8 coefficients, pad, worst check-point error
+#define GEOAC_PP_ROWS   8       // path segments per thread of k_postpass_tab (consecutive rows of one ray: each row is read once)
+#define GEOAC_CNT_PPFLAG 28     // counters[]: path segments of the current post-pass the table could not serve (fix-up pass of k_postpass); [+1]: the same, summed over the fan
 
 // per-ray state slots (SoA rows of the state buffer)
 enum {
@@ -53,6 +56,8 @@ struct GeoacDevParams {
     int     live_slot;              // index into counters[] of the live-ray count this launch adds to (1, or 6 for the second launch of a hybrid fan)
     int     slot_lo, slot_hi;       // k_rk4 integrates the ray slots [slot_lo, slot_hi) (a fan may be split over two concurrent launches)
     int     lanes_per_ray;          // 2: Global + CalcAmp without sample capture runs the two-lanes-per-ray kernel
+    int     duo;                    // 1: the wave-specialised kernel k_rk4_duo (geoac_duo.h): one wave integrates 64 rays, a second one their
+                                    // launch-angle derivative systems from per-stage messages in LDS (lanes_per_ray = 1: the one-lane state layout)
     int     spread;                 // grid sets: only every spread-th lane of a wave carries a ray (power of two, 1..64): a small fan is
                                     // spread over more waves so that each divergent table gather touches fewer cache lines per instruction
     int     quad_cache;             // grid sets, four lanes per ray, at most 256 waves: per-lane record cache and z nodes in LDS (grid_cache_fill)
@@ -76,6 +81,13 @@ struct GeoacDevParams {
     // buffers
     const double* seg;              // [nseg][SEGW]
     const double* rho;              // [nseg][4]
+    // stratified sets: absorption table (k_atab_build): Sutherland-Bass alpha is a function of the height coordinate alone there, so it is
+    // tabulated per spline segment instead of being evaluated at every path-segment midpoint (k_postpass_tab)
+    const double* atab;             // [nseg + 2][GEOAC_ATABW]: 2/h, flag, 3 x eight coefficients in s = 2 t / h - 1 (atab_eval); entries nseg / nseg + 1: the
+                                    // strips of width atab_D below the first / above the last node (medium clamped there, height not)
+    int           atab_on;          // 1: k_postpass_tab + fix-up of the flagged segments; 0: exact evaluation at every midpoint (k_postpass)
+    double        atab_D;           // width of the two strips
+    double        seg_per_x;        // nseg / (x_max - x_min): first guess of the segment index without a division
     // range-dependent sets: grid of profiles
     int           gnx, gny;         // horizontal node counts
     double        g_lo[2], g_hi[2]; // first / last node of gx and gy (clamp range of the horizontal coordinates; kernel arguments: no loads)

@@ -16,6 +16,7 @@
 // No MFMA: there is no dense contraction anywhere on this path.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <type_traits>
 #include "geoac_device.h"
 #include "../../include/geoac_hip.h"
 
@@ -166,24 +167,39 @@ DEVINL void seg_eval(TabPtr tab, int k, double x, Atm9& a){ seg_eval_at(tab + k 
 // stage of some tens (<= 50 m per stage against ~100 m between nodes, far less for shallow rays), so the usual stage costs ONE
 // LDS round trip instead of two dependent ones (bounds, then coefficients).  seg_fetch issues the loads; the caller puts the
 // table-independent part of its right-hand side between seg_fetch and seg_resolve, which hides that round trip as well.
-template <typename TabPtr>
+// W = doubles per record of the table `tab`: GEOAC_SEGW (x0, x1, 12 coefficients: the table in global memory and its plain LDS copy) or
+// 13 (x0, 12 coefficients; x1 is the next record's x0: the packed LDS copy of k_rk4_duo, which needs the room for its message slots).
+// Either way 14 consecutive doubles, returned in the order x0, x1, coefficients.
+template <int W = GEOAC_SEGW, typename TabPtr>
 DEVINL void seg_fetch(TabPtr tab, int off, double* r){
     const auto* p = tab + off;
-    #pragma unroll
-    for(int c = 0; c < GEOAC_SEGW; c++) r[c] = p[c];
+    if(W == GEOAC_SEGW){
+        #pragma unroll
+        for(int c = 0; c < GEOAC_SEGW; c++) r[c] = p[c];
+    } else {
+        r[0] = p[0]; r[1] = p[13];
+        #pragma unroll
+        for(int c = 0; c < 12; c++) r[2 + c] = p[1 + c];
+    }
 }
-template <typename TabPtr>
+template <int W = GEOAC_SEGW, typename TabPtr>
 DEVINL void seg_resolve(TabPtr tab, const GeoacDevParams& P, double x, int& off, double* r, Atm9& a){
-    const int last = (P.nseg - 1) * GEOAC_SEGW;
+    const int last = (P.nseg - 1) * W;
     const bool up = (x > r[1]) & (off < last), down = (x < r[0]) & (off > 0);
     if(up | down){                                               // rare, divergent: step to the neighbour and fetch again
-        off += (up ? GEOAC_SEGW : 0) - (down ? GEOAC_SEGW : 0);
+        off += (up ? W : 0) - (down ? W : 0);
         if(!P.seg_safe){                                         // wave-uniform: only for profiles with nodes closer than one step
             const auto* p = tab + off;
-            const double x0 = p[0], x1 = p[1];
-            if(((x < x0) & (off > 0)) | ((x > x1) & (off < last))) off = seg_find(tab, P.nseg, x, off / GEOAC_SEGW) * GEOAC_SEGW;
+            const double x0 = p[0], x1 = p[W == GEOAC_SEGW ? 1 : 13];
+            if(((x < x0) & (off > 0)) | ((x > x1) & (off < last))){
+                int k = off / W;
+                k = k < 0 ? 0 : (k > P.nseg - 1 ? P.nseg - 1 : k);
+                while(k > 0 && x < tab[k * W]) k--;
+                while(k < P.nseg - 1 && x > tab[k * W + (W == GEOAC_SEGW ? 1 : 13)]) k++;
+                off = k * W;
+            }
         }
-        seg_fetch(tab, off, r);
+        seg_fetch<W>(tab, off, r);
     }
     seg_eval_at(r, x, a);
 }
@@ -218,18 +234,28 @@ DEVINL double rho_eval(const GeoacDevParams& P, int k, double x){
 // y: r, lat, lon, nu_r, nu_t, nu_p | R_lt(3), mu_lt(3) | R_lp(3), mu_lp(3)
 // sth0/cth0: sin/cos of the latitude at the start of the step, dlat: latitude increment of this stage (small-angle rotation).
 // ------------------------------------------------------------------------------------------------
-// NQ = number of launch-angle derivative systems carried in y after the 6 base components: 2 = the reference layout
-// (theta then phi), 1 = the two-lanes-per-ray kernel where each lane of a pair carries the base ray and ONE of the two systems.
-template <bool AMP, int NQ, typename TabPtr>
-DEVINL void global_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const double* y, double sth0, double cth0, double dlat, double* dy){
+// What the launch-angle derivative systems need from the base ray's right-hand side at one RK4 stage: everything else they use follows
+// from these by a few multiplications (GlobalDerived).  17 doubles: the per-stage message of the wave-specialised kernel (k_rk4_duo),
+// where one wave integrates the base rays and another the derivative systems.
+struct GlobalStage { double n0, n1, n2, inm, cn, icg, dc, du, dv, v, cg2, ir, ico, sth, cth, H0, K2; };
+#define GEOAC_GSTAGE_W 17
+
+// Base ray: sources + right-hand side of r, lat, lon, nu_r, nu_t, nu_p (Global.cpp:222-272, 369-390).  S: the stage values the derivative
+// systems read (K2 only with AMP).
+struct NoHook { DEVINL void operator()() const {} };
+// HOOK: called once the segment record has arrived (k_rk4_duo reads the consumed-message counter there, so that the answer is back
+// when the stage's message is published); ROT0: stage 0 of a step - the stage latitude IS the step's, no rotation (bit-identical to a rotation by 0)
+template <bool AMP, int W, typename TabPtr, class HOOK = NoHook, bool ROT0 = false>
+DEVINL void global_base(TabPtr tab, const GeoacDevParams& P, int& seg, const double* y, double sth0, double cth0, double dlat, double* dy, GlobalStage& S, const HOOK& hook = HOOK()){
     const double r = y[0];
     const double n0 = y[3], n1 = y[4], n2 = y[5];
     const double xe = clampd(r, P.x_min, P.x_max);
-    double rec[GEOAC_SEGW];
-    seg_fetch(tab, seg, rec);                                    // LDS loads in flight while the table-independent terms are formed
+    double rec[14];
+    seg_fetch<W>(tab, seg, rec);                                 // LDS loads in flight while the table-independent terms are formed
     __builtin_amdgcn_sched_barrier(0);                           // (the scheduler would otherwise issue them after that arithmetic)
     double sth, cth;
-    rot_small(sth0, cth0, dlat, sth, cth);                       // sin / cos of the stage latitude from the step's (stage 0: zero angle, exact identity)
+    if(ROT0){ sth = sth0; cth = cth0; }
+    else rot_small(sth0, cth0, dlat, sth, cth);                  // sin / cos of the stage latitude from the step's (stage 0: zero angle, exact identity)
     // |nu|   (Global.cpp:249)
     const double nn  = __builtin_fma(n0, n0, __builtin_fma(n1, n1, n2 * n2));
     const double inm0 = frsq(nn);
@@ -240,7 +266,8 @@ DEVINL void global_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const doub
     // taken) re-fetch branch and the wave then sits out the LDS round trip with nothing to issue
     asm volatile("" : "+v"(ir), "+v"(ico), "+v"(inm_), "+v"(sth), "+v"(cth));
     Atm9 a;
-    seg_resolve(tab, P, xe, seg, rec, a);
+    seg_resolve<W>(tab, P, xe, seg, rec, a);
+    hook();
     const double inm = inm_, numag = nn * inm;
     const double u = a.u, v = a.v, du = a.du, dv = a.dv;
 
@@ -266,7 +293,7 @@ DEVINL void global_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const doub
     const double ncs  = __builtin_fma(n0, cth, n1 * sth);
     const double n2cg2 = n2 * cg2;
     const double T0 = ir * nc12;
-    const double T1 = __builtin_fma(n2cg2, tn, -(cn * n0) * n1);
+    const double T1 = __builtin_fma(n2cg2, tn, -cg0 * n1);
     const double T2 = -n2 * __builtin_fma(cn, ncs, v * sth);
     const double H0 = __builtin_fma(numag, dc, __builtin_fma(n1, dv, n2 * du));
     const double g1i = G1 * icg, g2i = G2 * icg;
@@ -280,42 +307,77 @@ DEVINL void global_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const doub
 
     if(AMP){
         const double ddc = __builtin_fma(hc, a.ddT, -(dc * dc) * ic);     // c'' = gamR/(2c) T'' - c'^2/c
-        const double K2  = __builtin_fma(numag, ddc, __builtin_fma(n1, a.ddv, n2 * a.ddu));
-        const double ir2 = ir * ir, ico2 = ico * ico;
-        const double cnn1 = cn * n1, cnn2 = cn * n2;
-        #pragma unroll
-        for(int q = 0; q < NQ; q++){
-            const double R0 = y[6 + 6 * q], R1 = y[7 + 6 * q];
-            const double m0 = y[9 + 6 * q], m1 = y[10 + 6 * q], m2 = y[11 + 6 * q];
-            const double dnu = __builtin_fma(n0, m0, __builtin_fma(n1, m1, n2 * m2)) * inm;       // d|nu|
-            const double dca = R0 * dc, dva = R0 * dv, dua = R0 * du;
-            const double al  = inm * __builtin_fma(-cn, dnu, dca);                               // d(c/|nu|)
-            const double a1  = __builtin_fma(n1, al, cn * m1);
-            const double a2  = __builtin_fma(n2, al, cn * m2);
-            const double dcg0 = __builtin_fma(n0, al, cn * m0);
-            const double dcg1 = a1 + dva;
-            const double dcg2 = a2 + dua;
-            const double e   = icg * __builtin_fma(u0, dcg0, __builtin_fma(u1, dcg1, u2 * dcg2)); // d|c_g| / |c_g|
-            const double w0 = __builtin_fma(icg, dcg0, -u0 * e);
-            const double w1 = __builtin_fma(icg, dcg1, -u1 * e);
-            const double w2 = __builtin_fma(icg, dcg2, -u2 * e);
-            const double dG1 = -R0 * ir2;
-            const double dG2 = G2 * __builtin_fma(tn, R1, -R0 * ir);
-            const double s22 = __builtin_fma(m2, cg2, n2 * dcg2);
-            const double dT0 = __builtin_fma(dG1, nc12, ir * __builtin_fma(m1, cg1, __builtin_fma(n1, dcg1, s22)));
-            const double dT1 = __builtin_fma(-cnn1, m0, __builtin_fma(-n0, a1, __builtin_fma(tn, s22, (n2cg2 * R1) * ico2)));
-            const double dncs = __builtin_fma(m0, cth, __builtin_fma(m1, sth, R1 * __builtin_fma(n1, cth, -n0 * sth)));
-            const double dT2 = -__builtin_fma(__builtin_fma(m2, v, n2 * dva), sth,
-                                 __builtin_fma((n2 * v) * R1, cth, __builtin_fma(a2, ncs, cnn2 * dncs)));
+        S.K2 = __builtin_fma(numag, ddc, __builtin_fma(n1, a.ddv, n2 * a.ddu));
+        S.n0 = n0; S.n1 = n1; S.n2 = n2; S.inm = inm; S.cn = cn; S.icg = icg; S.dc = dc; S.du = du; S.dv = dv; S.v = v; S.cg2 = cg2;
+        S.ir = ir; S.ico = ico; S.sth = sth; S.cth = cth; S.H0 = H0;
+    }
+}
 
-            dy[6 + 6 * q] = w0;
-            dy[7 + 6 * q] = __builtin_fma(dG1, u1, G1 * w1);
-            dy[8 + 6 * q] = __builtin_fma(dG2, u2, G2 * w2);
-            dy[9 + 6 * q]  = icg * (__builtin_fma(e, H0, -dT0)
-                                    - __builtin_fma(dnu, dc, __builtin_fma(m1, dv, __builtin_fma(m2, du, R0 * K2))));
-            dy[10 + 6 * q] = -icg * __builtin_fma(dG1, T1, G1 * dT1);
-            dy[11 + 6 * q] = -icg * __builtin_fma(dG2, T2, G2 * dT2);
-        }
+// the products of the stage values that both derivative systems share (recomputed from the message in k_rk4_duo; in the one-wave kernels the
+// compiler finds them among the base ray's own terms: the same operations on the same operands either way)
+struct GlobalDerived { double cg0, cg1, u0, u1, u2, tn, G2, nc12, ncs, n2cg2, T1, T2, ir2, ico2, cnn1, cnn2; };
+DEVINL void global_derive(const GlobalStage& S, GlobalDerived& D){
+    D.cg0 = S.cn * S.n0;
+    D.cg1 = __builtin_fma(S.cn, S.n1, S.v);
+    D.u0 = D.cg0 * S.icg; D.u1 = D.cg1 * S.icg; D.u2 = S.cg2 * S.icg;
+    D.tn = S.sth * S.ico;
+    D.G2 = S.ir * S.ico;
+    D.nc12 = __builtin_fma(S.n1, D.cg1, S.n2 * S.cg2);
+    D.ncs  = __builtin_fma(S.n0, S.cth, S.n1 * S.sth);
+    D.n2cg2 = S.n2 * S.cg2;
+    D.T1 = __builtin_fma(D.n2cg2, D.tn, -D.cg0 * S.n1);
+    D.T2 = -S.n2 * __builtin_fma(S.cn, D.ncs, S.v * S.sth);
+    D.ir2 = S.ir * S.ir; D.ico2 = S.ico * S.ico;
+    D.cnn1 = S.cn * S.n1; D.cnn2 = S.cn * S.n2;
+}
+
+// One launch-angle derivative system (Global.cpp:273-367 is this code written twice, once per angle).  ya: R_r, R_t, R_p, mu_r, mu_t, mu_p.
+DEVINL void global_aux(const GlobalStage& S, const GlobalDerived& D, const double* ya, double* dya){
+    const double n0 = S.n0, n1 = S.n1, n2 = S.n2, inm = S.inm, cn = S.cn, icg = S.icg, dc = S.dc, du = S.du, dv = S.dv, v = S.v, cg2 = S.cg2;
+    const double ir = S.ir, sth = S.sth, cth = S.cth, H0 = S.H0, K2 = S.K2, G1 = S.ir;
+    const double R0 = ya[0], R1 = ya[1];
+    const double m0 = ya[3], m1 = ya[4], m2 = ya[5];
+    const double dnu = __builtin_fma(n0, m0, __builtin_fma(n1, m1, n2 * m2)) * inm;       // d|nu|
+    const double dca = R0 * dc, dva = R0 * dv, dua = R0 * du;
+    const double al  = inm * __builtin_fma(-cn, dnu, dca);                               // d(c/|nu|)
+    const double a1  = __builtin_fma(n1, al, cn * m1);
+    const double a2  = __builtin_fma(n2, al, cn * m2);
+    const double dcg0 = __builtin_fma(n0, al, cn * m0);
+    const double dcg1 = a1 + dva;
+    const double dcg2 = a2 + dua;
+    const double e   = icg * __builtin_fma(D.u0, dcg0, __builtin_fma(D.u1, dcg1, D.u2 * dcg2)); // d|c_g| / |c_g|
+    const double w0 = __builtin_fma(icg, dcg0, -D.u0 * e);
+    const double w1 = __builtin_fma(icg, dcg1, -D.u1 * e);
+    const double w2 = __builtin_fma(icg, dcg2, -D.u2 * e);
+    const double dG1 = -R0 * D.ir2;
+    const double dG2 = D.G2 * __builtin_fma(D.tn, R1, -R0 * ir);
+    const double s22 = __builtin_fma(m2, cg2, n2 * dcg2);
+    const double dT0 = __builtin_fma(dG1, D.nc12, ir * __builtin_fma(m1, D.cg1, __builtin_fma(n1, dcg1, s22)));
+    const double dT1 = __builtin_fma(-D.cnn1, m0, __builtin_fma(-n0, a1, __builtin_fma(D.tn, s22, (D.n2cg2 * R1) * D.ico2)));
+    const double dncs = __builtin_fma(m0, cth, __builtin_fma(m1, sth, R1 * __builtin_fma(n1, cth, -n0 * sth)));
+    const double dT2 = -__builtin_fma(__builtin_fma(m2, v, n2 * dva), sth,
+                         __builtin_fma((n2 * v) * R1, cth, __builtin_fma(a2, D.ncs, D.cnn2 * dncs)));
+
+    dya[0] = w0;
+    dya[1] = __builtin_fma(dG1, D.u1, G1 * w1);
+    dya[2] = __builtin_fma(dG2, D.u2, D.G2 * w2);
+    dya[3] = icg * (__builtin_fma(e, H0, -dT0)
+                    - __builtin_fma(dnu, dc, __builtin_fma(m1, dv, __builtin_fma(m2, du, R0 * K2))));
+    dya[4] = -icg * __builtin_fma(dG1, D.T1, G1 * dT1);
+    dya[5] = -icg * __builtin_fma(dG2, D.T2, D.G2 * dT2);
+}
+
+// NQ = number of launch-angle derivative systems carried in y after the 6 base components: 2 = the reference layout
+// (theta then phi), 1 = the two-lanes-per-ray kernel where each lane of a pair carries the base ray and ONE of the two systems.
+template <bool AMP, int NQ, typename TabPtr>
+DEVINL void global_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const double* y, double sth0, double cth0, double dlat, double* dy){
+    GlobalStage S;
+    global_base<AMP, GEOAC_SEGW>(tab, P, seg, y, sth0, cth0, dlat, dy, S);
+    if(AMP){
+        GlobalDerived D;
+        global_derive(S, D);
+        #pragma unroll
+        for(int q = 0; q < NQ; q++) global_aux(S, D, y + 6 + 6 * q, dy + 6 + 6 * q);
     }
 }
 
@@ -371,7 +433,9 @@ DEVINL double fsqrt(double x){ double r = x * frsq(x); return (x > 0.0) ? r : 0.
 // half the FP64 vector peak, and an IEEE division costs three times an frcp.  Kept correctly rounded: sqrt(1 + nu^2), whose
 // difference to 1 the classical term takes (catastrophic cancellation in the reference itself - the last bit of that root is
 // worth 1e-6 of a_cl at 80 km).
-DEVINL double suthbass_alpha(const GeoacDevParams& P, double zr, double c_snd, double rho, double freq, double T_o, double P_o, double cbrt_To){
+// PARTS (k_atab_build): also returns the three smooth functions the absorption table holds - see atab_eval.
+template <bool PARTS = false>
+DEVINL double suthbass_alpha(const GeoacDevParams& P, double zr, double c_snd, double rho, double freq, double T_o, double P_o, double cbrt_To, double* parts = nullptr){
     const double mu_o = 18.192E-6, S = 117.0;
     double cm = c_snd * 1000.0;
     double T_z = cm * cm * (1.0 / (kRgas * kGam));
@@ -449,7 +513,68 @@ DEVINL double suthbass_alpha(const GeoacDevParams& P, double zr, double c_snd, d
         // (A_max / c) (2 f^2 / f_vib) / (1 + (f/f_vib)^2),  A_max = X (pi/2) C_R / (Cp (Cv + C_R))
         a_vib += (Xm[m] * (kPi / 2) * C_R) * (ic * f2x2 * ifv) * frcp((Cp_R[m] * (Cv_R[m] + C_R)) * __builtin_fma(fr, fr, 1.0));
     }
+    if(PARTS){
+        // alpha = S + sqrt((sqrt(1 + N) - 1) Q):  S = the rotational and vibrational terms, N = nu^2, Q = what multiplies (sq - 1) under the root
+        // of the classical (+ diffusion, 0.003 of it) term, constants folded in
+        const double kk = P.tweak_abs * 8.685889;
+        parts[0] = (a_rot + a_vib) * kk;
+        parts[1] = nu2;
+        parts[2] = (w0 * w0) * 0.5 * (1.0 + cc2) * frcp((1.0 + nu2) * (1.0 + sc2)) * ((1.003 * kk) * (1.003 * kk));
+    }
     return (a_cl + a_rot + a_diff + a_vib) * P.tweak_abs * 8.685889;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Absorption table of the stratified sets.  There c and rho are functions of the height coordinate alone, so SuthBass_Alpha - which the
+// reference evaluates at the midpoint of every path segment (Global.cpp:634-670 and twins; ~1 500 FP64 instructions per 64 midpoints
+// here) - is a function of one variable.  It is not a SMOOTH function of it as the reference (and suthbass_alpha above) computes it: the
+// classical term takes sqrt(1 + nu^2) - 1 with nu^2 between 1e-20 and 1e-7, so below ~70 km it is a staircase in the last bits of
+// that root (exactly 0 below ~35 km), worth up to 2e-5 of alpha - and parity means reproducing the staircase.  So the table holds,
+// per spline segment, the degree-7 interpolants (Chebyshev nodes, kept as polynomials in s = 2 t / h - 1) of the three smooth pieces
+//     S = (a_rot + a_vib) k,   N = nu^2,   Q = (w0^2 / 2) (1 + cchi^2) / ((1 + nu^2)(1 + (sigma cchi)^2)) (1.003 k)^2,   k = tweak x 8.685889
+// and the post-pass forms alpha = S + sqrt((sqrt(1 + N) - 1) Q) with the same correctly rounded root: N is reproduced to ~1e-13 relative,
+// far inside the spacing of the doubles next to 1, so 1 + N rounds as in the exact routine.  k_atab_build samples the pieces from the
+// exact routine itself (inside a spline segment the medium is a cubic and the pieces analytic) and checks the reassembled alpha against
+// it at eight other points of the segment: an entry that misses 1e-10 relative anywhere (a branch point of the reference's piecewise
+// fits inside the segment, a very long segment) is flagged, and the post-pass evaluates the segments that fall into it exactly (fix-up
+// pass of k_postpass).  Two more entries cover the strips just below the first and above the last node, where the reference clamps
+// the medium but not the height (the row below the ground, the row above the top).
+// ------------------------------------------------------------------------------------------------
+DEVINL double atab_poly(const double* __restrict__ c, double s){
+    double p = c[7];
+    p = __builtin_fma(p, s, c[6]); p = __builtin_fma(p, s, c[5]); p = __builtin_fma(p, s, c[4]); p = __builtin_fma(p, s, c[3]);
+    p = __builtin_fma(p, s, c[2]); p = __builtin_fma(p, s, c[1]); p = __builtin_fma(p, s, c[0]);
+    return p;
+}
+DEVINL double atab_eval(const double* __restrict__ e, double t){
+    const double s = __builtin_fma(t, e[0], -1.0);
+    const double S = atab_poly(e + 2, s), N = atab_poly(e + 10, s), Q = atab_poly(e + 18, s);
+    const double sq = sqrt(1.0 + N);                              // IEEE, as in suthbass_alpha
+    return S + fsqrt((sq - 1.0) * Q);
+}
+// alpha [dB/km, tweak included] at abscissa x; xe = x clamped to the profile, k / x0 = spline segment of xe and its left node.
+// -1: the table does not serve this point.
+DEVINL double atab_alpha(const GeoacDevParams& P, double x, double xe, int k, double x0){
+    const bool below = x < P.x_min, above = x > P.x_max;
+    const int e = below ? P.nseg : (above ? P.nseg + 1 : k);
+    const double t = below ? x - (P.x_min - P.atab_D) : (above ? x - P.x_max : xe - x0);
+    const double* r = P.atab + (size_t)e * GEOAC_ATABW;
+    const bool bad = (r[1] != 0.0) | (t < 0.0) | (above & (t > P.atab_D));
+    const double a = atab_eval(r, t);
+    return bad ? -1.0 : a;
+}
+// segment index of xe: first guess by multiplication, then the walk over the node abscissae (seg_find)
+template <typename TabPtr>
+DEVINL int seg_guess_mul(TabPtr tab, const GeoacDevParams& P, double xe){
+    return seg_find(tab, P.nseg, xe, (int)((xe - P.x_min) * P.seg_per_x));
+}
+// T, u, v of the segment record p at abscissa x (values only)
+DEVINL void seg_eval_f(const double* __restrict__ p, double x, double& T, double& u, double& v){
+    const double t = x - p[0], t6 = t * (1.0 / 6.0);
+    const double fT = __builtin_fma(t, p[5], p[4]), fu = __builtin_fma(t, p[9], p[8]), fv = __builtin_fma(t, p[13], p[12]);
+    T = __builtin_fma(t, __builtin_fma(t6, p[4] + (p[4] + fT), p[3]), p[2]);
+    u = __builtin_fma(t, __builtin_fma(t6, p[8] + (p[8] + fu), p[7]), p[6]);
+    v = __builtin_fma(t, __builtin_fma(t6, p[12] + (p[12] + fv), p[11]), p[10]);
 }
 
 
@@ -663,19 +788,34 @@ template <bool AMP_> struct EqGlobal {
             y[15] = -prev[15] + 2.0 * dnu_r_ds * prev[12] / den;
         }
     }
-    // one path segment: travel time (Global.cpp:527-589) and attenuation (Global.cpp:634-670, sin(lat) in ds: Q3)
-    static DEVINL void segment(const GeoacDevParams& P, const double* st, size_t np, const double* a, const double* b, double& tt, double& at){
-        double ar = a[0], at_ = a[np], ap = a[2 * np], an0 = a[3 * np], an1 = a[4 * np], an2 = a[5 * np];
-        double dr = b[0] - ar, dt = b[np] - at_, dp = b[2 * np] - ap;
+    // one path segment: travel time (Global.cpp:527-589) and attenuation (Global.cpp:634-670, sin(lat) in ds: Q3); A, B = its two path rows.
+    // TAB: medium values only and alpha from the absorption table (k_postpass_tab; at = -1: left to the fix-up pass)
+    static DEVINL void pp_aux(const GeoacDevParams& P, const double* st, size_t np, double* aux){}
+    template <bool TAB>
+    static DEVINL void segment_rows(const GeoacDevParams& P, const double* aux, const double* A, const double* B, double& tt, double& at){
+        double ar = A[0], at_ = A[1], ap = A[2], an0 = A[3], an1 = A[4], an2 = A[5];
+        double dr = B[0] - ar, dt = B[1] - at_, dp = B[2] - ap;
         double r = ar + dr / 2.0, t = at_ + dt / 2.0;
         double sn, cs; fsincos(t, sn, cs);
         double rdt = r * dt;
         double e1 = r * cs * dp, e2 = r * sn * dp;
         double ds_tt = fsqrt(dr * dr + rdt * rdt + e1 * e1);
         double ds_at = fsqrt(dr * dr + rdt * rdt + e2 * e2);
-        double n0 = an0 + (b[3 * np] - an0) / 2.0, n1 = an1 + (b[4 * np] - an1) / 2.0, n2 = an2 + (b[5 * np] - an2) / 2.0;
+        double n0 = an0 + (B[3] - an0) / 2.0, n1 = an1 + (B[4] - an1) / 2.0, n2 = an2 + (B[5] - an2) / 2.0;
         double inm = frsq(n0 * n0 + n1 * n1 + n2 * n2);               // 1 / |nu|
         double xe = clampd(r, P.x_min, P.x_max);
+        if(TAB){
+            const int k = seg_guess_mul(P.seg, P, xe);
+            const double* p = P.seg + (size_t)k * GEOAC_SEGW;
+            double T, u, v; seg_eval_f(p, xe, T, u, v);
+            double qT = kGamR * T;
+            double cn = (qT * frsq(qT)) * inm;
+            double cp0 = cn * n0, cp1 = cn * n1 + v, cp2 = cn * n2 + u;
+            tt = ds_tt * frsq(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
+            const double al = atab_alpha(P, r, xe, k, p[0]);
+            at = (al < 0.0) ? -1.0 : al * ds_at;
+            return;
+        }
         int k = seg_guess(P.seg, P, xe);
         Atm9 m; seg_eval<false>(P.seg, k, xe, m);
         double qT = kGamR * m.T;
@@ -685,6 +825,12 @@ template <bool AMP_> struct EqGlobal {
         double cp0 = cn * n0, cp1 = cn * n1 + m.v, cp2 = cn * n2 + m.u;
         tt = ds_tt * frsq(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
         at = suthbass_alpha(P, r - P.r_earth, c, rho, P.freq, P.T_o, P.P_o, P.cbrt_To) * ds_at;
+    }
+    static DEVINL void segment(const GeoacDevParams& P, const double* st, size_t np, const double* a, const double* b, double& tt, double& at){
+        double A[6], B[6];
+        #pragma unroll
+        for(int c = 0; c < 6; c++){ A[c] = a[c * np]; B[c] = b[c * np]; }
+        segment_rows<false>(P, nullptr, A, B, tt, at);
     }
 };
 
@@ -1207,15 +1353,30 @@ template <bool AMP_> struct Eq3D {
             y[11] = -prev[11] + 2.0 * dnuz_ds * prev[10] / den;
         }
     }
-    // 3DStratified.cpp:348-405 (c(0,0,0) instead of c0, w ignored: Q5) and :456-490
-    static DEVINL void segment(const GeoacDevParams& P, const double* st, size_t np, const double* a, const double* b, double& tt, double& at){
-        double nx = st[(ST_AUX0 + 0) * np], ny = st[(ST_AUX0 + 1) * np];
-        double ax = a[0], ay = a[np], az = a[2 * np], anz = a[3 * np];
-        double dx = b[0] - ax, dy = b[np] - ay, dz = b[2 * np] - az;
+    // 3DStratified.cpp:348-405 (c(0,0,0) instead of c0, w ignored: Q5) and :456-490; A, B = the segment's two path rows, aux = nu_x, nu_y of the ray
+    static DEVINL void pp_aux(const GeoacDevParams& P, const double* st, size_t np, double* aux){ aux[0] = st[(ST_AUX0 + 0) * np]; aux[1] = st[(ST_AUX0 + 1) * np]; }
+    template <bool TAB>
+    static DEVINL void segment_rows(const GeoacDevParams& P, const double* aux, const double* A, const double* B, double& tt, double& at){
+        double nx = aux[0], ny = aux[1];
+        double ax = A[0], ay = A[1], az = A[2], anz = A[3];
+        double dx = B[0] - ax, dy = B[1] - ay, dz = B[2] - az;
         double ds = fsqrt(dx * dx + dy * dy + dz * dz);
         double z = az + dz / 2.0;
-        double nz = anz + (b[3 * np] - anz) / 2.0;
+        double nz = anz + (B[3] - anz) / 2.0;
         double xe = clampd(z, P.x_min, P.x_max);
+        if(TAB){
+            const int k = seg_guess_mul(P.seg, P, xe);
+            const double* p = P.seg + (size_t)k * GEOAC_SEGW;
+            double T, u, v; seg_eval_f(p, xe, T, u, v);
+            double qT = kGamR * T;
+            double c = qT * frsq(qT);
+            double cn = (c * c) * frcp(P.c000 - nx * u - ny * v);
+            double cp0 = cn * nx + u, cp1 = cn * ny + v, cp2 = cn * nz;
+            tt = ds * frsq(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
+            const double al = atab_alpha(P, z, xe, k, p[0]);
+            at = (al < 0.0) ? -1.0 : al * ds;
+            return;
+        }
         int k = seg_guess(P.seg, P, xe);
         Atm9 m; seg_eval<false>(P.seg, k, xe, m);
         double qT = kGamR * m.T;
@@ -1225,6 +1386,13 @@ template <bool AMP_> struct Eq3D {
         double cp0 = cn * nx + m.u, cp1 = cn * ny + m.v, cp2 = cn * nz;
         tt = ds * frsq(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
         at = suthbass_alpha(P, z, c, rho, P.freq, P.T_o, P.P_o, P.cbrt_To) * ds;
+    }
+    static DEVINL void segment(const GeoacDevParams& P, const double* st, size_t np, const double* a, const double* b, double& tt, double& at){
+        double A[4], B[4], aux[2];
+        pp_aux(P, st, np, aux);
+        #pragma unroll
+        for(int c = 0; c < 4; c++){ A[c] = a[c * np]; B[c] = b[c * np]; }
+        segment_rows<false>(P, aux, A, B, tt, at);
     }
 };
 
@@ -1328,14 +1496,27 @@ template <bool AMP_> struct Eq2D {
             y[5] = -prev[5] + 2.0 * dnuz_ds * prev[4] / (mg.c / C.c0 * prev[2]);
         }
     }
-    // 2DStratified.cpp:217-286
-    static DEVINL void segment(const GeoacDevParams& P, const double* st, size_t np, const double* a, const double* b, double& tt, double& at){
-        double cph = st[(ST_AUX0 + 0) * np], sph = st[(ST_AUX0 + 1) * np];
-        double ar = a[0], az = a[np];
-        double dr = b[0] - ar, dz = b[np] - az;
+    // 2DStratified.cpp:217-286; A, B = the segment's two path rows, aux = cos / sin of the ray's azimuth
+    static DEVINL void pp_aux(const GeoacDevParams& P, const double* st, size_t np, double* aux){ aux[0] = st[(ST_AUX0 + 0) * np]; aux[1] = st[(ST_AUX0 + 1) * np]; }
+    template <bool TAB>
+    static DEVINL void segment_rows(const GeoacDevParams& P, const double* aux, const double* A, const double* B, double& tt, double& at){
+        double cph = aux[0], sph = aux[1];
+        double ar = A[0], az = A[1];
+        double dr = B[0] - ar, dz = B[1] - az;
         double z = az + dz / 2.0;
         double ds = fsqrt(dr * dr + dz * dz);
         double xe = clampd(z, P.x_min, P.x_max);
+        if(TAB){
+            const int k = seg_guess_mul(P.seg, P, xe);
+            const double* p = P.seg + (size_t)k * GEOAC_SEGW;
+            double T, u, v; seg_eval_f(p, xe, T, u, v);
+            double qT = kGamR * T;
+            double c = qT * frsq(qT);
+            tt = ds * frcp(c + u * cph + v * sph);
+            const double al = atab_alpha(P, z, xe, k, p[0]);
+            at = (al < 0.0) ? -1.0 : al * ds;
+            return;
+        }
         int k = seg_guess(P.seg, P, xe);
         Atm9 m; seg_eval<false>(P.seg, k, xe, m);
         double qT = kGamR * m.T;
@@ -1344,7 +1525,15 @@ template <bool AMP_> struct Eq2D {
         tt = ds * frcp(c + m.u * cph + m.v * sph);
         at = suthbass_alpha(P, z, c, rho, P.freq, P.T_o, P.P_o, P.cbrt_To) * ds;
     }
+    static DEVINL void segment(const GeoacDevParams& P, const double* st, size_t np, const double* a, const double* b, double& tt, double& at){
+        double A[2], B[2], aux[2];
+        pp_aux(P, st, np, aux);
+        A[0] = a[0]; A[1] = a[np]; B[0] = b[0]; B[1] = b[np];
+        segment_rows<false>(P, aux, A, B, tt, at);
+    }
 };
+
+#include "geoac_duo.h"
 
 // ------------------------------------------------------------------------------------------------
 // k_init: launch angles -> initial conditions + per-ray state
@@ -1750,7 +1939,10 @@ DEVINL void pp_medium_by_key(const GeoacDevParams& P, char* wl, bool valid, unsi
 }
 
 template <class EQ>
-__global__ void __launch_bounds__(256, EQ::PP_WAVES) k_postpass(GeoacDevParams P, int rows){
+__global__ void __launch_bounds__(256, EQ::PP_WAVES) k_postpass(GeoacDevParams P, int rows, int fixup){
+    // fixup: second pass behind k_postpass_tab - only the segments that kernel marked (attenuation increment -1), and none at all when it
+    // marked none (the usual case: the table serves every midpoint of a profile like ToyAtmo)
+    if(fixup && __hip_atomic_load(P.counters + GEOAC_CNT_PPFLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) return;
     // grid-stride sweep over (segment row i, ray slot); by default the grid covers the sweep in one pass
     // Grid sets (PP_TILE): a workgroup takes a tile of 16 rows x 16 rays, a wave 16 consecutive rows of 4 rays.  The segment midpoints of
     // one ray's consecutive rows lie in the same cell and vertical segment nearly always, so the 64 lanes of a table gather touch a handful
@@ -1805,12 +1997,120 @@ __global__ void __launch_bounds__(256, EQ::PP_WAVES) k_postpass(GeoacDevParams P
         const int slot = P.colmap ? P.colmap[col] : col;
         const double* a = P.path + ((size_t)i * EQ::PW) * np + col;
         const double* b = a + (size_t)EQ::PW * np;
+        double* o = P.contrib + ((size_t)i * 2) * np + col;
+        if(fixup && !(o[np] < 0.0)) continue;
         double tt, at;
         EQ::segment(P, P.state + slot, np, a, b, tt, at);
-        double* o = P.contrib + ((size_t)i * 2) * np + col;
         o[0]  = tt;
         o[np] = at;
     }
+}
+
+// k_postpass_tab: the post-pass of the stratified sets with the absorption table.  One thread walks GEOAC_PP_ROWS consecutive segments
+// of one ray (every path row is read once, by the thread that also needs it as the next segment's first row); a segment costs the
+// geometry, one spline evaluation and a degree-7 polynomial (~150 instructions per 64 segments instead of ~1 500).
+template <class EQ>
+__global__ void __launch_bounds__(256) k_postpass_tab(GeoacDevParams P, int rows){
+    constexpr int PW = EQ::PW, R = GEOAC_PP_ROWS;
+    const size_t np = (size_t)P.n_pad;
+    const int bx = (P.n_cols_bound + 255) / 256;
+    const long long total = (long long)bx * ((rows - 1 + R - 1) / R);
+    const int ncol = P.colmap ? *P.n_cols : P.n_pad;
+    unsigned flagged = 0;
+    for(long long w = blockIdx.x; w < total; w += gridDim.x){
+        const int col = (int)(w % bx) * 256 + (int)threadIdx.x;
+        const int i0 = (int)(w / bx) * R;
+        if(col >= ncol) continue;
+        const int nr = P.nrows[col];
+        if(i0 + 1 >= nr) continue;
+        const int slot = P.colmap ? P.colmap[col] : col;
+        double aux[2] = { 0.0, 0.0 };
+        EQ::pp_aux(P, P.state + slot, np, aux);
+        const double* a = P.path + ((size_t)i0 * PW) * np + col;
+        double A[PW], B[PW];
+        #pragma unroll
+        for(int c = 0; c < PW; c++) A[c] = a[(size_t)c * np];
+        #pragma unroll 2
+        for(int j = 0; j < R; j++){
+            const int i = i0 + j;
+            if(i + 1 >= nr) break;
+            const double* b = P.path + ((size_t)(i + 1) * PW) * np + col;
+            #pragma unroll
+            for(int c = 0; c < PW; c++) B[c] = b[(size_t)c * np];
+            double tt, at;
+            EQ::template segment_rows<true>(P, aux, A, B, tt, at);
+            double* o = P.contrib + ((size_t)i * 2) * np + col;
+            o[0]  = tt;
+            o[np] = at;
+            flagged += (at < 0.0) ? 1u : 0u;
+            #pragma unroll
+            for(int c = 0; c < PW; c++) A[c] = B[c];
+        }
+    }
+    if(flagged){ atomicAdd(&P.counters[GEOAC_CNT_PPFLAG], (unsigned long long)flagged); atomicAdd(&P.counters[GEOAC_CNT_PPFLAG + 1], (unsigned long long)flagged); }
+}
+
+// k_atab_build: one thread per table entry (see atab_eval).  Entry e < nseg: spline segment e; nseg: the strip [x_min - D, x_min];
+// nseg + 1: [x_max, x_max + D].  The exact value at abscissa x is what the exact post-pass computes there: medium at the clamped abscissa,
+// height x - r_earth unclamped.
+__global__ void __launch_bounds__(64) k_atab_build(GeoacDevParams P, double* __restrict__ tab, double tol){
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if(e >= P.nseg + 2) return;
+    double x0, h;
+    if(e < P.nseg){ x0 = P.seg[(size_t)e * GEOAC_SEGW]; h = P.seg[(size_t)e * GEOAC_SEGW + 1] - x0; }
+    else if(e == P.nseg){ x0 = P.x_min - P.atab_D; h = P.atab_D; }
+    else { x0 = P.x_max; h = P.atab_D; }
+    const int k = (e < P.nseg) ? e : (e == P.nseg ? 0 : P.nseg - 1);
+    const double* p = P.seg + (size_t)k * GEOAC_SEGW;
+    auto exact = [&](double s, double* parts) -> double {
+        const double x = x0 + 0.5 * (s + 1.0) * h;
+        const double xe = clampd(x, P.x_min, P.x_max);
+        double T, u, v; seg_eval_f(p, xe, T, u, v);
+        const double qT = kGamR * T;
+        const double c = qT * frsq(qT);
+        const double rho = rho_eval(P, k, xe);
+        return parts ? suthbass_alpha<true>(P, x - P.r_earth, c, rho, P.freq, P.T_o, P.P_o, P.cbrt_To, parts)
+                     : suthbass_alpha<false>(P, x - P.r_earth, c, rho, P.freq, P.T_o, P.P_o, P.cbrt_To);
+    };
+    double f[3][8];
+    for(int j = 0; j < 8; j++){
+        double pr[3];
+        exact(cospi((j + 0.5) / 8.0), pr);
+        f[0][j] = pr[0]; f[1][j] = pr[1]; f[2][j] = pr[2];
+    }
+    double* o = tab + (size_t)e * GEOAC_ATABW;
+    o[0] = 2.0 / h;
+    for(int q = 0; q < 3; q++){
+        double cc[8];
+        for(int m = 0; m < 8; m++){
+            double acc = 0.0;
+            for(int j = 0; j < 8; j++) acc += f[q][j] * cospi(m * (j + 0.5) / 8.0);
+            cc[m] = 0.25 * acc;
+        }
+        double* w = o + 2 + 8 * q;                                // Chebyshev series -> powers of s
+        w[0] = 0.5 * cc[0] - cc[2] + cc[4] - cc[6];
+        w[1] = cc[1] - 3.0 * cc[3] + 5.0 * cc[5] - 7.0 * cc[7];
+        w[2] = 2.0 * cc[2] - 8.0 * cc[4] + 18.0 * cc[6];
+        w[3] = 4.0 * cc[3] - 20.0 * cc[5] + 56.0 * cc[7];
+        w[4] = 8.0 * cc[4] - 48.0 * cc[6];
+        w[5] = 16.0 * cc[5] - 112.0 * cc[7];
+        w[6] = 32.0 * cc[6];
+        w[7] = 64.0 * cc[7];
+    }
+    // the reassembled alpha against the exact routine at points that are not the nodes
+    const double chk[8] = { -0.9999, -0.83, -0.5, -0.17, 0.2, 0.55, 0.87, 0.9999 };
+    double worst = 0.0;
+    bool ok = true;
+    for(int q = 0; q < 8; q++){
+        const double fx = exact(chk[q], nullptr);
+        const double px = atab_eval(o, 0.5 * (chk[q] + 1.0) * h);
+        if(!(fx > 0.0) || !(px == px)) ok = false;
+        const double err = fabs(px - fx) / fabs(fx);
+        if(!(err <= tol)) ok = false;
+        worst = (err > worst) ? err : worst;
+    }
+    o[1] = ok ? 0.0 : (worst > 0.0 ? worst : 1.0);           // flag (non-zero: not served); carries the worst relative error seen
+    o[GEOAC_ATABW - 1] = worst;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1948,6 +2248,15 @@ __global__ void __launch_bounds__(256) k_probe_absorption(GeoacDevParams P, int 
     out[i] = suthbass_alpha(P, x[i] - P.r_earth, m.c, m.rho, f[i], P.T_o, P.P_o, P.cbrt_To);
 }
 
+// the absorption table at abscissa x[i] (atab_alpha as k_postpass_tab calls it; -1 where the table does not serve the point)
+__global__ void __launch_bounds__(256) k_probe_atab(GeoacDevParams P, int n, const double* __restrict__ x, double* __restrict__ out){
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if(i >= n) return;
+    const double xe = clampd(x[i], P.x_min, P.x_max);
+    const int k = seg_guess_mul(P.seg, P, xe);
+    out[i] = atab_alpha(P, x[i], xe, k, P.seg[(size_t)k * GEOAC_SEGW]);
+}
+
 // grid interpolant at (a0, a1, a2) in table order ((x, y, z) Cartesian, (lat, lon, r) spherical): out30 = the ten outputs of
 // grid_eval_all / grid_eval3_coop for T, u, v (table order of geoac_rngdep.h); api7 = c, rho, u, v, dc/dz, du/dz, dv/dz of medium3_at.
 // coop != 0: whole waves through the cooperative gather (blocks of 64, LDS exchange buffer; n is padded by repeating the last point)
@@ -2075,7 +2384,31 @@ static hipError_t launch_rk4_t(const GeoacDevParams* P, int block, hipStream_t s
     return hipGetLastError();
 }
 
+// the wave-specialised kernel of the stratified Global set with amplitudes (geoac_duo.h): 128 rays per workgroup
+extern "C" size_t geoac_duo_lds(int nseg){ return geoac_duo_lds_bytes(nseg); }
+static hipError_t launch_rk4_duo(const GeoacDevParams* P, hipStream_t s, unsigned* n_wg){
+    if(P->eqset != GEOAC_EQ_GLOBAL || !P->calc_amp || P->gtab || (P->mode & (GEOAC_MODE_WRITE_RAYS | GEOAC_MODE_WRITE_CAUSTICS))) return hipErrorNotSupported;
+    if(P->slot_lo < 0 || P->slot_hi > P->n_pad || P->slot_lo >= P->slot_hi) return hipErrorInvalidValue;
+    const size_t lds = geoac_duo_lds_bytes(P->nseg);
+    if(lds > 160 * 1024) return hipErrorInvalidValue;
+    dim3 b(256), g((unsigned)((P->slot_hi - P->slot_lo + 127) / 128));
+    if(n_wg) *n_wg = g.x;
+    #define GEOAC_DUO_LAUNCH(VV) do { \
+        hipError_t err = hipFuncSetAttribute((const void*)k_rk4_duo<VV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if(err != hipSuccess) return err; \
+        hipLaunchKernelGGL(k_rk4_duo<VV>, g, b, lds, s, *P); } while(0)
+    switch(P->duo){                              // A/B variants of the hand-off (geoac_duo.h); 8 = the shipped one
+        case 1: GEOAC_DUO_LAUNCH(0); break;
+        case 2: GEOAC_DUO_LAUNCH(1); break;
+        case 4: GEOAC_DUO_LAUNCH(3); break;
+        default: GEOAC_DUO_LAUNCH(7); break;
+    }
+    #undef GEOAC_DUO_LAUNCH
+    return hipGetLastError();
+}
+
 extern "C" hipError_t geoac_launch_rk4(const GeoacDevParams* P, int block, hipStream_t s, unsigned* n_wg){
+    if(P->duo) return launch_rk4_duo(P, s, n_wg);
     if(P->lanes_per_ray == 2 && !P->gtab && P->eqset == GEOAC_EQ_GLOBAL) return launch_rk4_t<EqGlobalPair>(P, block, s, n_wg);
     if(P->lanes_per_ray == 2 && !P->gtab && P->eqset == GEOAC_EQ_3D) return launch_rk4_t<Eq3DPair>(P, block, s, n_wg);
     GEOAC_DISPATCH_EQ_RK4(P, return launch_rk4_t<EQ>(P, block, s, n_wg));
@@ -2109,7 +2442,36 @@ extern "C" hipError_t geoac_launch_postpass(const GeoacDevParams* P, int rows, h
     if(nbl > 0x7fffffffLL) nbl = 0x7fffffffLL;
     int nb = (int)nbl;
     dim3 b(256), g(nb);
-    GEOAC_DISPATCH_EQ(P, hipLaunchKernelGGL(k_postpass<EQ>, g, b, EQ::PP_DEDUP ? 4 * GEOAC_PP_SLOTS * GEOAC_PP_SLOTB : 0, s, *P, rows));
+    GEOAC_DISPATCH_EQ(P, hipLaunchKernelGGL(k_postpass<EQ>, g, b, EQ::PP_DEDUP ? 4 * GEOAC_PP_SLOTS * GEOAC_PP_SLOTB : 0, s, *P, rows, 0));
+    return hipGetLastError();
+}
+
+// post-pass of a stratified set through the absorption table: reset of the marked-segment count, k_postpass_tab, then the exact kernel
+// as a fix-up pass over whatever the table did not serve (a persistent grid that leaves at once when nothing was marked)
+extern "C" hipError_t geoac_launch_postpass_tab(const GeoacDevParams* P, int rows, hipStream_t s){
+    if(rows < 2) return hipSuccess;
+    if(!P->atab || P->gtab) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(P->counters + GEOAC_CNT_PPFLAG, 0, sizeof(unsigned long long), s);
+    if(e != hipSuccess) return e;
+    long long total = (long long)((P->n_cols_bound + 255) / 256) * ((rows - 1 + GEOAC_PP_ROWS - 1) / GEOAC_PP_ROWS);
+    if(total > 0x7fffffffLL) total = 0x7fffffffLL;
+    dim3 b(256), g((unsigned)total), gf(2048);
+    #define GEOAC_PPT(EQT) do { hipLaunchKernelGGL(k_postpass_tab<EQT>, g, b, 0, s, *P, rows); hipLaunchKernelGGL(k_postpass<EQT>, gf, b, 0, s, *P, rows, 1); } while(0)
+    switch(P->eqset * 2 + (P->calc_amp ? 1 : 0)){
+        case GEOAC_EQ_GLOBAL * 2 + 1: GEOAC_PPT(EqGlobal<true>); break;
+        case GEOAC_EQ_GLOBAL * 2 + 0: GEOAC_PPT(EqGlobal<false>); break;
+        case GEOAC_EQ_3D * 2 + 1:     GEOAC_PPT(Eq3D<true>); break;
+        case GEOAC_EQ_3D * 2 + 0:     GEOAC_PPT(Eq3D<false>); break;
+        case GEOAC_EQ_2D * 2 + 1:     GEOAC_PPT(Eq2D<true>); break;
+        case GEOAC_EQ_2D * 2 + 0:     GEOAC_PPT(Eq2D<false>); break;
+        default: return hipErrorNotSupported;
+    }
+    #undef GEOAC_PPT
+    return hipGetLastError();
+}
+
+extern "C" hipError_t geoac_launch_atab_build(const GeoacDevParams* P, double* tab, double tol, hipStream_t s){
+    hipLaunchKernelGGL(k_atab_build, dim3((P->nseg + 2 + 63) / 64), dim3(64), 0, s, *P, tab, tol);
     return hipGetLastError();
 }
 
@@ -2119,6 +2481,11 @@ extern "C" hipError_t geoac_launch_probe_atmo1d(const GeoacDevParams* P, int n, 
 }
 extern "C" hipError_t geoac_launch_probe_absorption(const GeoacDevParams* P, int n, const double* x, const double* f, double* out, hipStream_t s){
     hipLaunchKernelGGL(k_probe_absorption, dim3((n + 255) / 256), dim3(256), 0, s, *P, n, x, f, out);
+    return hipGetLastError();
+}
+extern "C" hipError_t geoac_launch_probe_atab(const GeoacDevParams* P, int n, const double* x, double* out, hipStream_t s){
+    if(!P->atab) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_probe_atab, dim3((n + 255) / 256), dim3(256), 0, s, *P, n, x, out);
     return hipGetLastError();
 }
 extern "C" int geoac_kernels_cart_rec(void){ return GRec<false>::N; }     // doubles per record of the table the Cartesian grid kernels read

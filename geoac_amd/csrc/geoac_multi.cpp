@@ -14,7 +14,7 @@ struct geoac_pool {
     std::vector<geoac_ctx*> ctx;
     std::vector<uint64_t> rays, steps, groups;
     std::string err;
-    int legs = 1;
+    uint64_t status = 0;                       // geoac_fan_status flags of the last run, OR-ed over every group
 };
 
 static int pool_fail(geoac_pool* p, int rc, const std::string& m){ if(p) p->err = m; return rc; }
@@ -68,13 +68,24 @@ int geoac_pool_set_params(geoac_pool* p, const geoac_params* prm){
     if(!p || !prm) return GEOAC_E_INVALID;
     if(prm->mode & (GEOAC_MODE_WRITE_RAYS | GEOAC_MODE_WRITE_CAUSTICS)) return pool_fail(p, GEOAC_E_UNSUPPORTED, "pool: sample capture (WriteRays / WriteCaustics) runs on a single context");
     for(geoac_ctx* c : p->ctx){ int rc = geoac_set_params(c, prm); if(rc) return pool_fail(p, rc, geoac_last_error(c)); }
-    p->legs = prm->bounces + 1;
     return GEOAC_OK;
 }
 
 int geoac_pool_fan_run(geoac_pool* p, int n_rays, const double* theta, const double* phi, int rays_per_group, double* rec_host, uint64_t* total_steps){
     if(!p || n_rays <= 0 || !theta || !phi || !rec_host) return pool_fail(p, GEOAC_E_INVALID, "pool_fan_run: bad arguments");
     const size_t D = p->ctx.size();
+    // the record stride comes from the contexts themselves (their defaults or whatever was set through the pool or through
+    // geoac_pool_ctx): every context must write the same number of legs per ray in the same mode, or the groups would overlap
+    geoac_params p0{};
+    if(geoac_get_params(p->ctx[0], &p0)) return pool_fail(p, GEOAC_E_INVALID, "pool_fan_run: context without parameters");
+    for(size_t d = 1; d < D; d++){
+        geoac_params pd{};
+        geoac_get_params(p->ctx[d], &pd);
+        if(pd.bounces != p0.bounces || pd.calc_amp != p0.calc_amp || pd.mode != p0.mode)
+            return pool_fail(p, GEOAC_E_INVALID, "pool_fan_run: the pool's contexts hold different parameters (bounces / calc_amp / mode)");
+    }
+    if(p0.mode & (GEOAC_MODE_WRITE_RAYS | GEOAC_MODE_WRITE_CAUSTICS)) return pool_fail(p, GEOAC_E_UNSUPPORTED, "pool: sample capture (WriteRays / WriteCaustics) runs on a single context");
+    const int legs = p0.bounces + 1;
     // azimuth boundaries: the reference's outer loop variable (rays are phi-major)
     std::vector<int> az;
     for(int i = 0; i < n_rays; i++) if(i == 0 || phi[i] != phi[i - 1]) az.push_back(i);
@@ -96,7 +107,8 @@ int geoac_pool_fan_run(geoac_pool* p, int n_rays, const double* theta, const dou
     std::atomic<int> first_rc{0};
     std::mutex m;
     std::fill(p->rays.begin(), p->rays.end(), 0); std::fill(p->steps.begin(), p->steps.end(), 0); std::fill(p->groups.begin(), p->groups.end(), 0);
-    const size_t row = (size_t)p->legs * GEOAC_REC_STRIDE;
+    const size_t row = (size_t)legs * GEOAC_REC_STRIDE;
+    std::atomic<uint64_t> status{0};
     std::vector<std::thread> th;
     for(size_t d = 0; d < D; d++){
         th.emplace_back([&, d]{
@@ -113,11 +125,14 @@ int geoac_pool_fan_run(geoac_pool* p, int n_rays, const double* theta, const dou
                     if(first_rc.compare_exchange_strong(expected, rc)){ std::lock_guard<std::mutex> lk(m); p->err = geoac_last_error(c); }
                     break;
                 }
+                uint64_t fl = 0;
+                if(geoac_fan_status(c, &fl) == GEOAC_OK) status.fetch_or(fl);
                 p->rays[d] += (uint64_t)(i1 - i0); p->steps[d] += st; p->groups[d] += 1;
             }
         });
     }
     for(auto& t : th) t.join();
+    p->status = status.load();
     if(first_rc.load()) return first_rc.load();
     if(total_steps){ uint64_t s = 0; for(uint64_t v : p->steps) s += v; *total_steps = s; }
     return GEOAC_OK;
@@ -126,6 +141,12 @@ int geoac_pool_fan_run(geoac_pool* p, int n_rays, const double* theta, const dou
 int geoac_pool_last_shares(const geoac_pool* p, uint64_t* rays, uint64_t* steps, uint64_t* groups){
     if(!p) return GEOAC_E_INVALID;
     for(size_t i = 0; i < p->ctx.size(); i++){ if(rays) rays[i] = p->rays[i]; if(steps) steps[i] = p->steps[i]; if(groups) groups[i] = p->groups[i]; }
+    return GEOAC_OK;
+}
+
+int geoac_pool_fan_status(const geoac_pool* p, uint64_t* flags){
+    if(!p || !flags) return GEOAC_E_INVALID;
+    *flags = p->status;
     return GEOAC_OK;
 }
 

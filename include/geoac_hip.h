@@ -154,6 +154,13 @@ int  geoac_fan_sync(geoac_ctx* ctx);
  * reads one row it never wrote - here the sums end at the last integrated row). */
 #define GEOAC_FAN_STEP_LIMIT 1
 int  geoac_fan_status(geoac_ctx* ctx, uint64_t* flags);
+/* Stratified sets: in a stratified medium SuthBass_Alpha (Atmo_State.Absorption{,.Global}.cpp:12-141) depends on the height coordinate
+ * alone, so the post-pass does not evaluate it at every path-segment midpoint: per spline segment a table holds degree-7 interpolants of
+ * its smooth pieces, built on the device from the exact routine and checked against it (the classical term's sqrt(1 + nu^2) - 1 is formed
+ * at the midpoint as the reference forms it), and only the path segments the table does not serve are evaluated exactly.  Of the last
+ * completed launch: entries of the table (0: table not in use), entries flagged at build time (reassembled alpha off by more than 1e-10
+ * relative at a check point), path segments evaluated exactly, largest check-point error of the unflagged entries. */
+int  geoac_abs_table_info(geoac_ctx* ctx, int* entries, int* flagged, uint64_t* fixup_segments, double* worst_rel_err);
 
 /* device pointer to the record table [n_rays][bounces+1][GEOAC_REC_STRIDE] f64 (valid after launch,
  * ordered on the context's stream) - what a multi-GPU caller hands to its gather collective */

@@ -42,6 +42,8 @@ int  geoac_pool_fan_run(geoac_pool* pool, int n_rays, const double* theta_deg, c
                         double* rec_host, uint64_t* total_steps);
 /* [i] = rays / ray-steps / groups integrated by context i in the last geoac_pool_fan_run (load balance) */
 int  geoac_pool_last_shares(const geoac_pool* pool, uint64_t* rays, uint64_t* steps, uint64_t* groups);
+/* geoac_fan_status flags of the last geoac_pool_fan_run, OR-ed over every group of every device (GEOAC_FAN_STEP_LIMIT) */
+int  geoac_pool_fan_status(const geoac_pool* pool, uint64_t* flags);
 const char* geoac_pool_last_error(const geoac_pool* pool);
 
 #ifdef __cplusplus

@@ -27,6 +27,12 @@ int geoac_probe_atmo_1d(geoac_ctx* ctx, int n, const double* x, double* out9, do
 /* 1-D sets: SuthBass_Alpha(x[i], freq[i]) * tweak_abs * 8.685889 as the post-pass evaluates it (z_grnd and abs_coeff of geoac_set_params) */
 int geoac_probe_absorption(geoac_ctx* ctx, int n, const double* x, const double* freq, double* alpha);
 
+/* 1-D sets: the same coefficient from the absorption table the post-pass reads (k_atab_build: per spline segment the degree-7 interpolant of
+ * the routine above at the frequency of geoac_set_params; Atmo_State.Absorption{,.Global}.cpp:12-141 tabulated, as alpha depends on the
+ * height coordinate alone in a stratified medium).  alpha[i] = -1 where the table does not serve x[i] (flagged segment, beyond the strips
+ * at the two ends of the profile): the post-pass evaluates such midpoints with the exact routine. */
+int geoac_probe_absorption_table(geoac_ctx* ctx, int n, const double* x, double* alpha);
+
 /* grid sets: point (a0, a1, a2) in table order - (x, y, z) for GEOAC_EQ_3D_RNGDEP, (lat, lon, r) [rad, rad, km] for
  * GEOAC_EQ_GLOBAL_RNGDEP.  out30[30 i + 10 f + q]: field f = T, u, v; q = f, d/da0, d/da1, d/da2, d2/da0^2, d2/da1^2, d2/da2^2,
  * d2/da0 da1, d2/da0 da2, d2/da1 da2 (Eval_Spline_AllOrder2 with the reference's quirks Q11 / Q12).  api7[7 i ..] = c, rho, u, v and

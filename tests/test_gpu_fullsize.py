@@ -71,7 +71,7 @@ def test_metric_fan_global_360x90(G):
     assert len(th) == 32400
     c_g = H.Oracle(H.EQ_GLOBAL).atmo_probe(np.array([6370.0]))[0][0, 0]
     narr = _properties(rec, steps, 18, slice(3, 6), c_ratio=1.0)      # source on the ground: c0 = c(ground)
-    assert steps == 874273730                                         # pinned by sampled-oracle agreement below
+    assert steps == 874273730                                         # (the reference's own total: tests/golden/full_metric.npz, test_gpu_fullfan.py)
     assert narr > 90000
     _sample_vs_oracle(G, H.EQ_GLOBAL, params, th, ph, rec, E=18)
 
@@ -130,9 +130,14 @@ def test_full_fan_is_schedule_independent(G, eqname, total):
         return rec, steps
     ref, steps = run({})
     assert steps == total
-    # GEOAC_NO_PAIR: one launch per epoch, which runs over the compacted list of live rays (k_compact); with GEOAC_COMPACT=0 over all slots
-    for env in ({"GEOAC_PAIR_FRAC": "0.03"}, {"GEOAC_NO_PAIR": "1"}, {"GEOAC_NO_PAIR": "1", "GEOAC_COMPACT": "0"},
-                {"GEOAC_TWO_CHUNKS": "1", "GEOAC_S_ROWS": "4096"}, {"GEOAC_PAIR_FRAC": "1.0"}, {"GEOAC_PAIR_FRAC": "0"}):
+    # GEOAC_NO_PAIR: one launch per epoch, which runs over the compacted list of live rays (k_compact); with GEOAC_COMPACT=0 over all slots.
+    # The spherical set's default plan is the wave-specialised kernel (k_rk4_duo: the ray on one wave, its derivative systems on another);
+    # GEOAC_DUO=0 gives the one-wave kernels and their hybrid plan - same bits.
+    plans = [{"GEOAC_PAIR_FRAC": "0.03"}, {"GEOAC_NO_PAIR": "1"}, {"GEOAC_NO_PAIR": "1", "GEOAC_COMPACT": "0"},
+             {"GEOAC_TWO_CHUNKS": "1", "GEOAC_S_ROWS": "4096"}, {"GEOAC_PAIR_FRAC": "1.0"}, {"GEOAC_PAIR_FRAC": "0"}]
+    if eqname == "EQ_GLOBAL":
+        plans = [dict(e, GEOAC_DUO="0") for e in plans] + [{"GEOAC_DUO": "0"}, {"GEOAC_COMPACT": "0"}, {"GEOAC_TWO_CHUNKS": "1", "GEOAC_S_ROWS": "3000"}]
+    for env in plans:
         rec, st = run(env)
         assert st == steps, env
         assert np.array_equal(rec, ref), env

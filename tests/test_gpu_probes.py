@@ -131,3 +131,81 @@ def test_cooperative_and_per_lane_gathers_give_the_same_bits(eqname, tmp_path):
     o1, a1 = ctx.probe_grid(*a, coop=True)
     assert np.isfinite(o0).all()
     assert np.array_equal(o0, o1) and np.array_equal(a0, a1)
+
+
+@pytest.mark.parametrize("eq", [H.EQ_GLOBAL, H.EQ_3D, H.EQ_2D])
+def test_absorption_table_vs_exact_routine_and_reference(eq):
+    """The table the post-pass of the stratified sets reads (k_atab_build: degree-7 interpolant of SuthBass_Alpha per spline segment,
+    Atmo_State.Absorption{,.Global}.cpp:12-141) against (a) the exact device routine at 40 000 abscissae - nodes, points next to nodes and
+    the strips beyond both ends of the profile included - to 1e-9 relative, and (b) the reference's own values at the golden (altitude,
+    frequency) pairs to 1e-6 (a table per frequency).  Points the table does not serve come back as -1: none inside ToyAtmo."""
+    g = np.load(f"{H.GOLDEN_DIR}/{H.EQ_NAMES[eq]}_small.npz")
+    ctx = _ctx_1d(eq)
+    info = ctx.abs_table_info()
+    import geoac_amd as G
+    a = G.met_load(H.TOYATMO, eq)
+    x0, x1, nodes = a["x"][0], a["x"][-1], a["x"]
+    assert info["entries"] == len(nodes) + 1, info                   # nseg + 2
+    rng = np.random.default_rng(7)
+    xs = np.concatenate([rng.uniform(x0 - 0.04, x1 + 0.04, 36000), nodes, nodes[1:] - 1e-9, nodes[:-1] + 1e-9,
+                         np.array([x0 - 0.049, x0 - 1e-12, x1 + 1e-12, x1 + 0.049, x0 - 0.2, x1 + 0.2])])
+    tab = ctx.probe_absorption_table(xs)
+    ex = ctx.probe_absorption(xs, np.full(len(xs), 0.1))
+    served = tab >= 0.0
+    beyond = (xs < x0 - 0.05) | (xs > x1 + 0.05)
+    assert not served[beyond].any()                                   # beyond the strips: left to the exact pass
+    inside = ~beyond
+    print(H.EQ_NAMES[eq], "table entries", info["entries"], "flagged", info["flagged"], "served", served[inside].mean())
+    assert info["flagged"] == 0 and served[inside].all()
+    # An abscissa that IS a node belongs to two segments; where the node is also a branch point of the reference's piecewise fits
+    # (30, 76, 80, 90, 95 km) the segment above it holds the upper fit and the exact routine takes the lower one AT the point (zr > 30. is
+    # false there): the two values differ by the jump of the fit itself (0.5 % at 30 km).  A path-segment midpoint hits a node with
+    # probability zero; the points a nanometre to either side must agree.
+    at_node = np.isin(xs, nodes)
+    rel = np.abs(tab - ex) / ex
+    print(H.EQ_NAMES[eq], "table vs exact routine: max rel err off the nodes", rel[served & ~at_node].max(), "at the nodes", rel[served & at_node].max())
+    assert rel[served & ~at_node].max() <= 1e-9                      # (the exact routine itself carries ~2e-11 of rounding noise from sqrt(1 + nu^2) - 1)
+    assert rel[served & at_node].max() <= 1e-2 and np.median(rel[served & at_node]) <= 1e-12
+    # the reference's values: one table per frequency
+    idx = np.argsort(g["abs_f"])[np.linspace(0, len(g["abs_f"]) - 1, 12).astype(int)]
+    worst = 0.0
+    for i in idx:
+        f = float(g["abs_f"][i])
+        ctx.set_params(freq=f)
+        ctx.run(np.array([20.0]), np.array([-90.0]))
+        same_f = np.isclose(g["abs_f"], f, rtol=0, atol=0)
+        t = ctx.probe_absorption_table(g["abs_x"][same_f])
+        want = g["abs_alpha"][same_f]
+        assert (t >= 0).all()
+        worst = max(worst, float((np.abs(t - want) / want).max()))
+    print(H.EQ_NAMES[eq], "table vs reference SuthBass_Alpha at", len(idx), "frequencies: max rel err", worst)
+    assert worst <= RTOL
+
+
+@pytest.mark.parametrize("eq", [H.EQ_GLOBAL, H.EQ_3D, H.EQ_2D])
+def test_table_and_exact_post_pass_agree(eq, monkeypatch):
+    """A fan through the table post-pass (k_postpass_tab + fix-up) and through the exact one (GEOAC_ABS_TABLE=0): travel times identical,
+    attenuations to 1e-10 relative; with a raised ground and a lowered ceiling some midpoints fall below the first / above the last node
+    (strips) and rays leave through the top."""
+    import geoac_amd as G
+    th, ph = G.fan_enumerate(theta_min=1.0, theta_max=45.0, theta_step=1.0, phi_min=-90.0, phi_max=0.0, phi_step=30.0)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GEOAC_ABS_TABLE", mode)
+        ctx = G.FanContext(eq, device=0)
+        ctx.load_met(H.TOYATMO)
+        ctx.set_params(bounces=2, calc_amp=1, mode=0)
+        rec, steps = ctx.run(th, ph)
+        out[mode] = (rec.copy(), steps, ctx.abs_table_info())
+        ctx.close()
+    (r1, s1, i1), (r0, s0, i0) = out["1"], out["0"]
+    assert s1 == s0 and i1["entries"] > 0 and i0["entries"] == 0
+    valid = r0[:, :, G.REC["VALID"]] == 1.0
+    tt1, tt0 = r1[:, :, G.REC["TTIME"]][valid], r0[:, :, G.REC["TTIME"]][valid]
+    at1, at0 = r1[:, :, G.REC["ATTEN"]][valid], r0[:, :, G.REC["ATTEN"]][valid]
+    print(H.EQ_NAMES[eq], "arrivals", valid.sum(), "fix-up segments", i1["fixup_segments"], "TTIME max rel", np.abs(tt1 / tt0 - 1).max(), "ATTEN max rel", np.abs(at1 / at0 - 1).max())
+    assert np.abs(tt1 / tt0 - 1).max() <= 1e-14
+    assert np.abs(at1 / at0 - 1).max() <= 1e-10
+    other = [k for k in G.REC if k not in ("TTIME", "ATTEN")]
+    for k in other:
+        np.testing.assert_array_equal(r1[:, :, G.REC[k]], r0[:, :, G.REC[k]])
