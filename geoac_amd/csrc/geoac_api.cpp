@@ -590,7 +590,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
             HIPCHK(hipStreamSynchronize(ctx->stream));
             ctx->atab_entries = (int)n_ent; ctx->atab_flagged = 0; ctx->atab_worst = 0.0;
             for(size_t e = 0; e < n_ent; e++){
-                if(h[e * GEOAC_ATABW + 1] != 0.0) ctx->atab_flagged++;
+                if(h[e * GEOAC_ATABW] < 0.0) ctx->atab_flagged++;
                 else ctx->atab_worst = std::max(ctx->atab_worst, h[e * GEOAC_ATABW + GEOAC_ATABW - 1]);
             }
             memcpy(ctx->atab_key, key, sizeof(key));
@@ -823,6 +823,12 @@ int geoac_fan_launch(geoac_ctx* ctx){
     HIPCHK(hipMemcpyAsync(ctx->h_counters + 8, ctx->counters.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     ctx->n_samples = ctx->h_counters[8 + 3];
+    if(P.duo >= 16){                                          // diagnostic variants of k_rk4_duo: where the waves spent their time
+        unsigned long long h[8];
+        HIPCHK(hipMemcpy(h, (const unsigned long long*)ctx->counters.p + 16, sizeof(h), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[duo] base waves: %.4g ticks in the kernel, %.1f %% waiting for the slot, %llu waits spun; aux waves: %.4g ticks, %.1f %% waiting for a message, %llu waits spun; %llu messages\n",
+                (double)h[0], 100.0 * (double)h[1] / (double)(h[0] ? h[0] : 1), h[2], (double)h[3], 100.0 * (double)h[4] / (double)(h[3] ? h[3] : 1), h[5], h[6]);
+    }
     {   unsigned long long fx = 0;
         HIPCHK(hipMemcpy(&fx, (const unsigned long long*)ctx->counters.p + GEOAC_CNT_PPFLAG + 1, sizeof(fx), hipMemcpyDeviceToHost));
         ctx->pp_fixup_segments = fx; }

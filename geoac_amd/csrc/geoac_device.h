@@ -20,9 +20,9 @@
 #define GEOAC_SEGW      14      // doubles per segment in the T/u/v table
 #define GEOAC_MAXE      18
 #define GEOAC_MAXLEGS   64      // legs per ray supported by the per-epoch leg-end event list
-#define GEOAC_ATABW     28      // doubles per entry of the absorption table: 2 / h, flag, 3 x 8 coefficients, pad, worst check-point error
-#define GEOAC_PP_ROWS   8       // path segments per thread of k_postpass_tab (consecutive rows of one ray: each row is read once)
-#define GEOAC_CNT_PPFLAG 28     // counters[]: path segments of the current post-pass the table could not serve (fix-up pass of k_postpass); [+1]: the same, summed over the fan
+#define GEOAC_ATABW     20      // doubles per entry of the absorption table: 2 / h (negative: flagged), 3 x 6 coefficients, worst check-point error
+#define GEOAC_PP_ROWS   16      // path segments per thread of k_postpass_tab (consecutive rows of one ray: each row is read once)
+#define GEOAC_CNT_PPFLAG 28     // counters[+1]: path segments of the fan the absorption table did not serve (evaluated exactly by k_postpass_tab)
 
 // per-ray state slots (SoA rows of the state buffer)
 enum {
@@ -83,7 +83,7 @@ struct GeoacDevParams {
     const double* rho;              // [nseg][4]
     // stratified sets: absorption table (k_atab_build): Sutherland-Bass alpha is a function of the height coordinate alone there, so it is
     // tabulated per spline segment instead of being evaluated at every path-segment midpoint (k_postpass_tab)
-    const double* atab;             // [nseg + 2][GEOAC_ATABW]: 2/h, flag, 3 x eight coefficients in s = 2 t / h - 1 (atab_eval); entries nseg / nseg + 1: the
+    const double* atab;             // [nseg + 2][GEOAC_ATABW]: 2/h (negative: flagged), 3 x six coefficients in s = 2 t / h - 1 (atab_eval); entries nseg / nseg + 1: the
                                     // strips of width atab_D below the first / above the last node (medium clamped there, height not)
     int           atab_on;          // 1: k_postpass_tab + fix-up of the flagged segments; 0: exact evaluation at every midpoint (k_postpass)
     double        atab_D;           // width of the two strips

@@ -43,6 +43,8 @@ struct DuoPort {                    // LDS byte addresses (explicit address-spac
     int n;                          // this wave's count: published (base) / consumed (aux)
     int lane;
     bool dead;                      // a wait ran out (~1 s: the other wave of the pair is gone): every later wait returns at once, the wave leaves
+    bool prof;                      // diagnostic variants (V & 8): shader-clock ticks spent in the wait loops, number of waits that had to spin
+    long long t_wait; int n_spin;
 };
 #define GEOAC_DUO_SPIN_MAX (1 << 22)
 DEVINL int duo_ctl_load(unsigned a){ return *(geoac_lds_vint*)(size_t)a; }
@@ -53,10 +55,13 @@ struct DuoMsg { double v[GEOAC_GSTAGE_W]; };
 
 // ---- producer side (base wave) ----
 DEVINL void duo_wait_free(DuoPort& pt){                          // the slot is free once everything published has been consumed
+    long long t0 = 0;
+    if(pt.prof){ if(__builtin_amdgcn_readfirstlane(duo_ctl_load(pt.ack)) == pt.n) return; t0 = clock64(); pt.n_spin++; }
     for(int it = 0; !pt.dead && __builtin_amdgcn_readfirstlane(duo_ctl_load(pt.ack)) != pt.n; it++){
         if(it > GEOAC_DUO_SPIN_MAX) pt.dead = true;
         __builtin_amdgcn_s_sleep(1);
     }
+    if(pt.prof) pt.t_wait += clock64() - t0;
     asm volatile("" ::: "memory");
 }
 // the consumed count, read early (issued where the caller stands, back by the time duo_wait_free_peeked looks at it): it only grows
@@ -84,10 +89,13 @@ DEVINL void duo_put_stage(DuoPort& pt, const GlobalStage& S){
 
 // ---- consumer side (aux wave) ----
 DEVINL void duo_wait_msg(DuoPort& pt){
+    long long t0 = 0;
+    if(pt.prof){ if(__builtin_amdgcn_readfirstlane(duo_ctl_load(pt.seq)) != pt.n) return; t0 = clock64(); pt.n_spin++; }
     for(int it = 0; !pt.dead && __builtin_amdgcn_readfirstlane(duo_ctl_load(pt.seq)) == pt.n; it++){
         if(it > GEOAC_DUO_SPIN_MAX) pt.dead = true;
         __builtin_amdgcn_s_sleep(1);
     }
+    if(pt.prof) pt.t_wait += clock64() - t0;
     asm volatile("" ::: "memory");
 }
 DEVINL void duo_consumed(DuoPort& pt){                           // behind the data loads (in order again)
@@ -119,6 +127,19 @@ DEVINL void duo_take(DuoPort& pt, int seen, DuoMsg& m){
     }
     duo_consumed(pt);
 }
+// a prefetch issued a while ago: if the message was there, hand the slot back NOW (the base wave can publish the one after it while this
+// wave still works on the current one) and remember that the message is in hand; if not, the next duo_take waits for it
+DEVINL void duo_commit(DuoPort& pt, int& seen, bool& in_hand){
+    in_hand = (__builtin_amdgcn_readfirstlane(seen) != pt.n);
+    if(in_hand) duo_consumed(pt);
+}
+DEVINL void duo_take_committed(DuoPort& pt, bool in_hand, DuoMsg& m){
+    if(!in_hand){
+        duo_wait_msg(pt);
+        duo_read(pt, m);
+        duo_consumed(pt);
+    }
+}
 DEVINL void duo_stage_of(const DuoMsg& m, GlobalStage& S){
     S.n0 = m.v[0]; S.n1 = m.v[1]; S.n2 = m.v[2]; S.inm = m.v[3]; S.cn = m.v[4]; S.icg = m.v[5]; S.dc = m.v[6]; S.du = m.v[7];
     S.dv = m.v[8]; S.v = m.v[9]; S.cg2 = m.v[10]; S.ir = m.v[11]; S.ico = m.v[12]; S.sth = m.v[13]; S.cth = m.v[14]; S.H0 = m.v[15]; S.K2 = m.v[16];
@@ -148,6 +169,7 @@ DEVINL void duo_base(const GeoacDevParams& P, const double* tab13, DuoPort& pt, 
     C.c0 = st[ST_C0 * np]; C.nu0 = st[ST_NU0 * np];
     #pragma unroll
     for(int q = 0; q < 6; q++) C.a[q] = st[(ST_AUX0 + q) * np];
+    EQ::resume(P, C, y);
     int seg = (int)st[ST_SEG * np] * 13;
     int nr = 0, nle = 0;
     unsigned long long steps_here = 0;
@@ -177,10 +199,12 @@ DEVINL void duo_base(const GeoacDevParams& P, const double* tab13, DuoPort& pt, 
             ds = (ds < P.ds_min) ? P.ds_min : ds;
         }
         // header of the step: what the previous step ended with, whether this lane takes the step, its ds
+        if(!(V & 32)){
         if(V & 2) duo_wait_free_peeked(pt, peek); else duo_wait_free(pt);
         duo_put2(pt, 0, ds, (double)(ev | (act ? DUO_ACT : 0)));
         duo_publish(pt);
-        if(__any(ev != DUO_EV_NONE)){
+        }
+        if(!(V & 32) && __any(ev != DUO_EV_NONE)){
             duo_wait_free(pt);
             duo_put2(pt, 0, L.yn[0], L.yn[1]); duo_put2(pt, 1, L.yn[2], L.yn[3]); duo_put2(pt, 2, L.yn[4], L.yn[5]);
             duo_put2(pt, 3, L.dr_k, L.dr_g); duo_put2(pt, 4, L.dnu_r_ds, L.den);
@@ -196,10 +220,12 @@ DEVINL void duo_base(const GeoacDevParams& P, const double* tab13, DuoPort& pt, 
         auto peek_hook = [&](){ if(V & 2) peek = duo_peek_ack(pt); };
         auto stage_body = [&](int stage, auto rot0){
             GlobalStage S;
-            global_base<true, 13, const double*, decltype(peek_hook), decltype(rot0)::value>(tab13, P, seg, yt, C.a[0], C.a[1], yt[1] - y[1], dy, S, peek_hook);
-            if(V & 2) duo_wait_free_peeked(pt, peek); else duo_wait_free(pt);
-            duo_put_stage(pt, S);
-            duo_publish(pt);
+            global_base<true, 13, const double*, decltype(peek_hook), decltype(rot0)::value>(tab13, P, seg, yt, C.cur[0], C.cur[1], yt[1] - y[1], dy, S, peek_hook);
+            if(!(V & 32)){
+                if(V & 2) duo_wait_free_peeked(pt, peek); else duo_wait_free(pt);
+                duo_put_stage(pt, S);
+                duo_publish(pt);
+            }
             const double wa = ((stage == 2) ? 1.0 : 0.5) * ds;
             const double wb = ((stage == 0 || stage == 3) ? (1.0 / 6.0) : (1.0 / 3.0)) * ds;
             #pragma unroll
@@ -275,7 +301,7 @@ DEVINL void duo_base(const GeoacDevParams& P, const double* tab13, DuoPort& pt, 
         st[ST_K * np] = (double)k; st[ST_LEG * np] = (double)leg; st[ST_DONE * np] = done ? 1.0 : 0.0;
         st[ST_HMAX * np] = hmax; st[ST_SEG * np] = (double)(seg / 13);
         #pragma unroll
-        for(int q = 0; q < 4; q++) st[(ST_AUX0 + q) * np] = C.a[q];
+        for(int q = 0; q < 6; q++) st[(ST_AUX0 + q) * np] = C.a[q];
         P.nrows[col] = nr; P.nlegend[col] = nle;
     }
     steps_out = steps_here;
@@ -288,6 +314,19 @@ DEVINL void duo_base(const GeoacDevParams& P, const double* tab13, DuoPort& pt, 
 template <int V>
 DEVINL void duo_aux(const GeoacDevParams& P, DuoPort& pt, int col, int slot, bool mine, bool done0){
     using EQ = EqGlobal<true>;
+    if(V & 32) return;                                           // (timing diagnostic: the base wave alone, no messages)
+    if(V & 64){                                                  // (timing diagnostic: messages consumed, nothing computed)
+        DuoMsg mm;
+        for(;;){
+            duo_wait_msg(pt); duo_read(pt, mm); duo_consumed(pt);
+            const int code = (int)mm.v[1];
+            if(__any((code & 15) != DUO_EV_NONE)){ duo_wait_msg(pt); duo_read(pt, mm); duo_consumed(pt); }
+            if(!__any((code & DUO_ACT) != 0) || pt.dead) break;
+            for(int sgi = 0; sgi < 4; sgi++){ duo_wait_msg(pt); duo_read(pt, mm); duo_consumed(pt); }
+        }
+        if(mm.v[0] == 1.2345e300) P.counters[31] = 1ull;        // (keeps the reads alive)
+        return;
+    }
     constexpr bool PF = (V & 1) != 0;
     const size_t np = (size_t)P.n_pad;
     double* st = P.state + (mine ? slot : 0);
@@ -300,11 +339,11 @@ DEVINL void duo_aux(const GeoacDevParams& P, DuoPort& pt, int col, int slot, boo
     bool prev_act = false;
     DuoMsg m;
     int seen = 0;
-    auto recv = [&](){                                           // the next message into m (prefetched already when PF and `seen` is set)
-        if(PF) duo_take(pt, seen, m);
+    bool in_hand = false;
+    auto recv = [&](){                                           // the next message into m (already there when a prefetch was committed)
+        if(PF){ duo_take_committed(pt, in_hand, m); in_hand = false; }
         else { duo_wait_msg(pt); duo_read(pt, m); duo_consumed(pt); }
     };
-    if(PF) duo_prefetch(pt, seen, m);
 
     for(;;){
         recv();                                                  // header of the step
@@ -314,7 +353,6 @@ DEVINL void duo_aux(const GeoacDevParams& P, DuoPort& pt, int col, int slot, boo
         const bool act = (code & DUO_ACT) != 0;
         DuoLegEnd L;
         if(__any(ev != DUO_EV_NONE)){
-            if(PF) duo_prefetch(pt, seen, m);
             recv();
             #pragma unroll
             for(int e = 0; e < 6; e++) L.yn[e] = m.v[e];
@@ -359,7 +397,6 @@ DEVINL void duo_aux(const GeoacDevParams& P, DuoPort& pt, int col, int slot, boo
         double yt[12];
         #pragma unroll
         for(int e = 0; e < 12; e++){ yt[e] = y[e]; yn[e] = y[e]; }
-        if(PF) duo_prefetch(pt, seen, m);                        // (the first stage's message: usually not there yet - the base wave is computing it)
         auto stage_body = [&](int stage){
             recv();
             GlobalStage S;
@@ -368,8 +405,9 @@ DEVINL void duo_aux(const GeoacDevParams& P, DuoPort& pt, int col, int slot, boo
             global_derive(S, D);
             double dy[12];
             global_aux(S, D, yt, dy);
-            if(PF) duo_prefetch(pt, seen, m);                    // the next stage's message (after the last stage: the next step's header)
+            if(PF) duo_prefetch(pt, seen, m);                    // the next stage's message (after the last stage: the next step's header) ...
             global_aux(S, D, yt + 6, dy + 6);
+            if(PF) duo_commit(pt, seen, in_hand);                // ... taken and acknowledged one system later if it was there
             const double wa = ((stage == 2) ? 1.0 : 0.5) * ds;
             const double wb = ((stage == 0 || stage == 3) ? (1.0 / 6.0) : (1.0 / 3.0)) * ds;
             #pragma unroll
@@ -422,6 +460,8 @@ __global__ void __launch_bounds__(256, 1) k_rk4_duo(GeoacDevParams P){
     __syncthreads();
     DuoPort pt;
     pt.slot = slots + pr * GEOAC_DUO_SLOT_BYTES; pt.seq = ctl + 8 * pr; pt.ack = ctl + 8 * pr + 4; pt.n = 0; pt.lane = lane; pt.dead = false;
+    pt.prof = (V & 8) != 0; pt.t_wait = 0; pt.n_spin = 0;
+    const long long t_start = (V & 8) ? clock64() : 0;
     if(is_base){
         unsigned long long steps_here = 0; bool done = true;
         duo_base<V>(P, lds_tab, pt, col, slot, mine, done0, steps_here, done);
@@ -438,6 +478,13 @@ __global__ void __launch_bounds__(256, 1) k_rk4_duo(GeoacDevParams P){
         duo_aux<V>(P, pt, col, slot, mine, done0);
     }
     if(pt.dead && lane == 0) atomicOr(&P.counters[2], 8ull);    // a hand-off timed out: the host reports the fan as failed
+    if((V & 8) && lane == 0){                                     // [16..18] base: ticks in the kernel, ticks waiting, messages that had to wait; [19..21] aux; [22] messages
+        const int o = is_base ? 16 : 19;
+        atomicAdd(&P.counters[o], (unsigned long long)(clock64() - t_start));
+        atomicAdd(&P.counters[o + 1], (unsigned long long)pt.t_wait);
+        atomicAdd(&P.counters[o + 2], (unsigned long long)pt.n_spin);
+        if(is_base) atomicAdd(&P.counters[22], (unsigned long long)pt.n);
+    }
 }
 
 #endif  // GEOAC_DUO_H_

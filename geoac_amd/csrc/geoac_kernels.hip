@@ -21,6 +21,13 @@
 #include "../../include/geoac_hip.h"
 
 #define DEVINL __device__ __forceinline__
+#define GEOAC_ROT_MAX 1.0e-3             // largest angle rot_small is asked to rotate by (EqGlobal::checks)
+
+// Floating-point contraction: OFF for the stratified sets' code (from here to the include of geoac_rngdep.h, and again from geoac_duo.h
+// on) - the only fused multiply-adds are the ones written out as __builtin_fma.  hipcc's default (fast) lets the optimiser fuse a
+// product into a following sum wherever it sees one, and what it sees depends on the kernel a function is inlined into: the same source
+// then gives different bits in k_rk4<EqGlobal>, k_rk4<EqGlobalPair> and k_rk4_duo, and records must not depend on the launch plan.
+#pragma clang fp contract(off)
 
 static constexpr double kPi   = 3.141592653589793238462643;   // GeoAc.Parameters.cpp:27
 static constexpr double kGam  = 1.4;
@@ -292,7 +299,6 @@ DEVINL void global_base(TabPtr tab, const GeoacDevParams& P, int& seg, const dou
     const double nc12 = __builtin_fma(n1, cg1, n2 * cg2);
     const double ncs  = __builtin_fma(n0, cth, n1 * sth);
     const double n2cg2 = n2 * cg2;
-    const double T0 = ir * nc12;
     const double T1 = __builtin_fma(n2cg2, tn, -cg0 * n1);
     const double T2 = -n2 * __builtin_fma(cn, ncs, v * sth);
     const double H0 = __builtin_fma(numag, dc, __builtin_fma(n1, dv, n2 * du));
@@ -301,7 +307,7 @@ DEVINL void global_base(TabPtr tab, const GeoacDevParams& P, int& seg, const dou
     dy[0] = u0;
     dy[1] = G1 * u1;
     dy[2] = G2 * u2;
-    dy[3] = -icg * (H0 + T0);
+    dy[3] = -icg * __builtin_fma(ir, nc12, H0);                  // H0 + T0, T0 = nc12 / r
     dy[4] = -g1i * T1;
     dy[5] = -g2i * T2;
 
@@ -338,13 +344,13 @@ DEVINL void global_aux(const GlobalStage& S, const GlobalDerived& D, const doubl
     const double R0 = ya[0], R1 = ya[1];
     const double m0 = ya[3], m1 = ya[4], m2 = ya[5];
     const double dnu = __builtin_fma(n0, m0, __builtin_fma(n1, m1, n2 * m2)) * inm;       // d|nu|
-    const double dca = R0 * dc, dva = R0 * dv, dua = R0 * du;
+    const double dca = R0 * dc, dva = R0 * dv;
     const double al  = inm * __builtin_fma(-cn, dnu, dca);                               // d(c/|nu|)
     const double a1  = __builtin_fma(n1, al, cn * m1);
     const double a2  = __builtin_fma(n2, al, cn * m2);
     const double dcg0 = __builtin_fma(n0, al, cn * m0);
-    const double dcg1 = a1 + dva;
-    const double dcg2 = a2 + dua;
+    const double dcg1 = __builtin_fma(R0, dv, a1);
+    const double dcg2 = __builtin_fma(R0, du, a2);
     const double e   = icg * __builtin_fma(D.u0, dcg0, __builtin_fma(D.u1, dcg1, D.u2 * dcg2)); // d|c_g| / |c_g|
     const double w0 = __builtin_fma(icg, dcg0, -D.u0 * e);
     const double w1 = __builtin_fma(icg, dcg1, -D.u1 * e);
@@ -530,7 +536,7 @@ DEVINL double suthbass_alpha(const GeoacDevParams& P, double zr, double c_snd, d
 // here) - is a function of one variable.  It is not a SMOOTH function of it as the reference (and suthbass_alpha above) computes it: the
 // classical term takes sqrt(1 + nu^2) - 1 with nu^2 between 1e-20 and 1e-7, so below ~70 km it is a staircase in the last bits of
 // that root (exactly 0 below ~35 km), worth up to 2e-5 of alpha - and parity means reproducing the staircase.  So the table holds,
-// per spline segment, the degree-7 interpolants (Chebyshev nodes, kept as polynomials in s = 2 t / h - 1) of the three smooth pieces
+// per spline segment, the degree-5 interpolants (Chebyshev nodes, kept as polynomials in s = 2 t / h - 1) of the three smooth pieces
 //     S = (a_rot + a_vib) k,   N = nu^2,   Q = (w0^2 / 2) (1 + cchi^2) / ((1 + nu^2)(1 + (sigma cchi)^2)) (1.003 k)^2,   k = tweak x 8.685889
 // and the post-pass forms alpha = S + sqrt((sqrt(1 + N) - 1) Q) with the same correctly rounded root: N is reproduced to ~1e-13 relative,
 // far inside the spacing of the doubles next to 1, so 1 + N rounds as in the exact routine.  k_atab_build samples the pieces from the
@@ -540,34 +546,46 @@ DEVINL double suthbass_alpha(const GeoacDevParams& P, double zr, double c_snd, d
 // pass of k_postpass).  Two more entries cover the strips just below the first and above the last node, where the reference clamps
 // the medium but not the height (the row below the ground, the row above the top).
 // ------------------------------------------------------------------------------------------------
-DEVINL double atab_poly(const double* __restrict__ c, double s){
-    double p = c[7];
-    p = __builtin_fma(p, s, c[6]); p = __builtin_fma(p, s, c[5]); p = __builtin_fma(p, s, c[4]); p = __builtin_fma(p, s, c[3]);
-    p = __builtin_fma(p, s, c[2]); p = __builtin_fma(p, s, c[1]); p = __builtin_fma(p, s, c[0]);
+DEVINL double atab_poly(const double* c, double s){              // degree 5
+    double p = c[5];
+    p = __builtin_fma(p, s, c[4]); p = __builtin_fma(p, s, c[3]); p = __builtin_fma(p, s, c[2]);
+    p = __builtin_fma(p, s, c[1]); p = __builtin_fma(p, s, c[0]);
     return p;
 }
-DEVINL double atab_eval(const double* __restrict__ e, double t){
-    const double s = __builtin_fma(t, e[0], -1.0);
-    const double S = atab_poly(e + 2, s), N = atab_poly(e + 10, s), Q = atab_poly(e + 18, s);
+// e: a table entry (in memory or in registers): [0] 2 / h (NEGATIVE: the entry is flagged), [1..6] S, [7..12] N, [13..18] Q; t: offset from its left end
+DEVINL double atab_eval(const double* e, double t){
+    const double s = __builtin_fma(t, fabs(e[0]), -1.0);
+    const double S = atab_poly(e + 1, s), N = atab_poly(e + 7, s), Q = atab_poly(e + 13, s);
     const double sq = sqrt(1.0 + N);                              // IEEE, as in suthbass_alpha
     return S + fsqrt((sq - 1.0) * Q);
 }
-// alpha [dB/km, tweak included] at abscissa x; xe = x clamped to the profile, k / x0 = spline segment of xe and its left node.
-// -1: the table does not serve this point.
-DEVINL double atab_alpha(const GeoacDevParams& P, double x, double xe, int k, double x0){
+// table entry and offset within it of abscissa x; xe = x clamped to the profile, k / x0 = spline segment of xe and its left node.  t < 0
+// or t > the entry's length: beyond the strips, not served
+DEVINL int atab_locate(const GeoacDevParams& P, double x, double xe, int k, double x0, double& t, bool& out){
     const bool below = x < P.x_min, above = x > P.x_max;
-    const int e = below ? P.nseg : (above ? P.nseg + 1 : k);
-    const double t = below ? x - (P.x_min - P.atab_D) : (above ? x - P.x_max : xe - x0);
+    t = below ? x - (P.x_min - P.atab_D) : (above ? x - P.x_max : xe - x0);
+    out = (t < 0.0) | (above & (t > P.atab_D));
+    return below ? P.nseg : (above ? P.nseg + 1 : k);
+}
+// alpha [dB/km, tweak included] at abscissa x (see atab_locate); -1: the table does not serve this point
+DEVINL double atab_alpha(const GeoacDevParams& P, double x, double xe, int k, double x0){
+    double t; bool out;
+    const int e = atab_locate(P, x, xe, k, x0, t, out);
     const double* r = P.atab + (size_t)e * GEOAC_ATABW;
-    const bool bad = (r[1] != 0.0) | (t < 0.0) | (above & (t > P.atab_D));
     const double a = atab_eval(r, t);
-    return bad ? -1.0 : a;
+    return (out | (r[0] < 0.0)) ? -1.0 : a;
 }
 // segment index of xe: first guess by multiplication, then the walk over the node abscissae (seg_find)
 template <typename TabPtr>
 DEVINL int seg_guess_mul(TabPtr tab, const GeoacDevParams& P, double xe){
     return seg_find(tab, P.nseg, xe, (int)((xe - P.x_min) * P.seg_per_x));
 }
+// a path segment as k_postpass_tab sees it: abscissa of the midpoint, path lengths of the travel-time and the attenuation integral, and up to
+// four set-specific values of the midpoint (Global: nu and 1 / |nu|; 3-D: nu_z)
+struct PPGeom { double x, ds_tt, ds_at, a0, a1, a2, a3; };
+// exact post-pass of one segment of a stratified set: geometry, medium at the midpoint, travel time, SuthBass_Alpha x path length
+template <class EQ>
+DEVINL void pp_exact(const GeoacDevParams& P, const double* aux, const double* A, const double* B, double& tt, double& at);
 // T, u, v of the segment record p at abscissa x (values only)
 DEVINL void seg_eval_f(const double* __restrict__ p, double x, double& T, double& u, double& v){
     const double t = x - p[0], t6 = t * (1.0 / 6.0);
@@ -589,6 +607,8 @@ struct RayCtx {
     double a[6];      // Global: sin/cos(lat), sin/cos(lon - lon_src) carried along the ray
                       // 3D: nu_x, nu_y, mu_x_th, mu_y_th, mu_x_ph, mu_y_ph ; 2D: cos(phi), sin(phi), cos(theta), sin(theta)
     double t[4];      // Global: proposed sin/cos for the row under test
+    double cur[4];    // Global (stratified): sin/cos(lat), sin/cos(lon - lon_src) of the current row - a[] then holds the REFERENCE point they are
+                      // rotated from: lat_ref, sin, cos, (lon - lon_src)_ref, sin, cos (EqGlobal::checks)
     mutable int ckey; // record-cache kernels: (segment, node) key of the records this lane holds in LDS (-1: none)
     mutable int kxy;  // grid sets: horizontal cell of the previous evaluation, kx << 16 | ky (-1: none), grid_locate's hint
     mutable double cell[4];   // and its node coordinates X1, X2, Y1, Y2
@@ -707,33 +727,46 @@ template <bool AMP_> struct EqGlobal {
             }
         }
         C.c0 = c0; C.nu0 = 1.0 / MS;
-        fsincos(lat0, C.a[0], C.a[1]);
-        C.a[2] = 0.0; C.a[3] = 1.0; C.a[4] = 0.0; C.a[5] = 0.0;
+        C.a[0] = lat0; fsincos(lat0, C.a[1], C.a[2]);
+        C.a[3] = 0.0; C.a[4] = 0.0; C.a[5] = 1.0;
+        resume(P, C, y);
     }
     static DEVINL void fan_init(const GeoacDevParams& P){}
     static DEVINL double height(const GeoacDevParams& P, const double* y){ return y[0] - P.r_earth; }
     static DEVINL double above_ground(const GeoacDevParams& P, const double* y){ return y[0] - P.ground; }
 
+    // sin / cos of the latitude and of (lon - lon_src) are carried along the ray: rotated from a REFERENCE point (a[]: angle, sin, cos - exact
+    // values, in the ray's state) by the angle to the row in question, which stays below GEOAC_ROT_MAX (1e-3 rad, ~6 km of travel: the series of
+    // rot_small are then exact to 1e-17); a row further away becomes the new reference (fsincos, rare and per ray).  No error accumulates, and the
+    // values of a row depend on the ray's own rows only - not on where an epoch or a kernel began.
+    static DEVINL void resume(const GeoacDevParams& P, RayCtx& C, const double* y){   // current row from the reference (kernel entry)
+        rot_small(C.a[1], C.a[2], y[1] - C.a[0], C.cur[0], C.cur[1]);
+        rot_small(C.a[4], C.a[5], (y[2] - P.src[2] * kPi / 180.0) - C.a[3], C.cur[2], C.cur[3]);
+    }
     template <typename TabPtr>
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
-        global_rhs<AMP, 2>(tab, P, seg, yt, C.a[0], C.a[1], yt[1] - y0[1], dy);
+        global_rhs<AMP, 2>(tab, P, seg, yt, C.cur[0], C.cur[1], yt[1] - y0[1], dy);
     }
     // GeoAc_BreakCheck / GeoAc_GroundCheck on the new row (Global.cpp:500-522)
     static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, long long k, bool& brk, bool& gnd){
-        const double lat0 = P.src[1] * kPi / 180.0, lon0 = P.src[2] * kPi / 180.0;
-        if((k & 63) == 0){ fsincos(yn[1], C.t[0], C.t[1]); fsincos(yn[2] - lon0, C.t[2], C.t[3]); }   // periodic exact re-sync
-        else { rot_small(C.a[0], C.a[1], yn[1] - y[1], C.t[0], C.t[1]); rot_small(C.a[2], C.a[3], yn[2] - y[2], C.t[2], C.t[3]); }
+        const double lon0 = P.src[2] * kPi / 180.0;
+        const double dl = yn[1] - C.a[0], pl = yn[2] - lon0, dp = pl - C.a[3];
+        if(fabs(dl) > GEOAC_ROT_MAX){ C.a[0] = yn[1]; fsincos(yn[1], C.a[1], C.a[2]); C.t[0] = C.a[1]; C.t[1] = C.a[2]; }   // (rare, per ray)
+        else rot_small(C.a[1], C.a[2], dl, C.t[0], C.t[1]);
+        if(fabs(dp) > GEOAC_ROT_MAX){ C.a[3] = pl; fsincos(pl, C.a[4], C.a[5]); C.t[2] = C.a[4]; C.t[3] = C.a[5]; }
+        else rot_small(C.a[4], C.a[5], dp, C.t[2], C.t[3]);
         // haversine of the great-circle range: hav = sin^2(dlat/2) + cos(lat0) cos(lat) sin^2(dlon/2), with 2 sin^2(x/2) = 1 - cos x;
         // range = 2 R asin(sqrt(hav)) > limit  <=>  hav > sin^2(limit / 2R)
         const double sl0 = P.src_trig[0], cl0 = P.src_trig[1];
-        double hav = 0.5 * (1.0 - __builtin_fma(C.t[1], cl0, C.t[0] * sl0)) + (cl0 * C.t[1]) * (0.5 * (1.0 - C.t[3]));
+        double hav = __builtin_fma(cl0 * C.t[1], 0.5 * (1.0 - C.t[3]), 0.5 * (1.0 - __builtin_fma(C.t[1], cl0, C.t[0] * sl0)));
         brk = (yn[0] > P.vert_limit) || (hav > P.range_thresh);
         gnd = yn[0] < P.ground;
     }
-    static DEVINL void accept(RayCtx& C){ C.a[0] = C.t[0]; C.a[1] = C.t[1]; C.a[2] = C.t[2]; C.a[3] = C.t[3]; }
-    static DEVINL void restart(const GeoacDevParams& P, RayCtx& C, const double* y){
-        fsincos(y[1], C.a[0], C.a[1]);
-        fsincos(y[2] - P.src[2] * kPi / 180.0, C.a[2], C.a[3]);
+    static DEVINL void accept(RayCtx& C){ C.cur[0] = C.t[0]; C.cur[1] = C.t[1]; C.cur[2] = C.t[2]; C.cur[3] = C.t[3]; }
+    static DEVINL void restart(const GeoacDevParams& P, RayCtx& C, const double* y){      // start of a leg: the reflected row is the new reference
+        C.a[0] = y[1]; fsincos(y[1], C.a[1], C.a[2]);
+        C.a[3] = y[2] - P.src[2] * kPi / 180.0; fsincos(C.a[3], C.a[4], C.a[5]);
+        C.cur[0] = C.a[1]; C.cur[1] = C.a[2]; C.cur[2] = C.a[4]; C.cur[3] = C.a[5];
     }
     // arrival row: GeoAcGlobal_main.cpp:296-317
     static DEVINL void arrival(const GeoacDevParams& P, const RayCtx& C, int slot, const double* yn, double* R){
@@ -788,49 +821,34 @@ template <bool AMP_> struct EqGlobal {
             y[15] = -prev[15] + 2.0 * dnu_r_ds * prev[12] / den;
         }
     }
-    // one path segment: travel time (Global.cpp:527-589) and attenuation (Global.cpp:634-670, sin(lat) in ds: Q3); A, B = its two path rows.
-    // TAB: medium values only and alpha from the absorption table (k_postpass_tab; at = -1: left to the fix-up pass)
+    // one path segment: travel time (Global.cpp:527-589) and attenuation (Global.cpp:634-670, sin(lat) in ds: Q3); A, B = its two path rows
     static DEVINL void pp_aux(const GeoacDevParams& P, const double* st, size_t np, double* aux){}
-    template <bool TAB>
-    static DEVINL void segment_rows(const GeoacDevParams& P, const double* aux, const double* A, const double* B, double& tt, double& at){
+    // k_postpass_tab: the segment's geometry (G.x = the abscissa of its midpoint) and, once the medium there is known, its travel time
+    static DEVINL void pp_geom(const GeoacDevParams& P, const double* aux, const double* A, const double* B, PPGeom& G){
         double ar = A[0], at_ = A[1], ap = A[2], an0 = A[3], an1 = A[4], an2 = A[5];
         double dr = B[0] - ar, dt = B[1] - at_, dp = B[2] - ap;
         double r = ar + dr / 2.0, t = at_ + dt / 2.0;
         double sn, cs; fsincos(t, sn, cs);
         double rdt = r * dt;
         double e1 = r * cs * dp, e2 = r * sn * dp;
-        double ds_tt = fsqrt(dr * dr + rdt * rdt + e1 * e1);
-        double ds_at = fsqrt(dr * dr + rdt * rdt + e2 * e2);
-        double n0 = an0 + (B[3] - an0) / 2.0, n1 = an1 + (B[4] - an1) / 2.0, n2 = an2 + (B[5] - an2) / 2.0;
-        double inm = frsq(n0 * n0 + n1 * n1 + n2 * n2);               // 1 / |nu|
-        double xe = clampd(r, P.x_min, P.x_max);
-        if(TAB){
-            const int k = seg_guess_mul(P.seg, P, xe);
-            const double* p = P.seg + (size_t)k * GEOAC_SEGW;
-            double T, u, v; seg_eval_f(p, xe, T, u, v);
-            double qT = kGamR * T;
-            double cn = (qT * frsq(qT)) * inm;
-            double cp0 = cn * n0, cp1 = cn * n1 + v, cp2 = cn * n2 + u;
-            tt = ds_tt * frsq(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
-            const double al = atab_alpha(P, r, xe, k, p[0]);
-            at = (al < 0.0) ? -1.0 : al * ds_at;
-            return;
-        }
-        int k = seg_guess(P.seg, P, xe);
-        Atm9 m; seg_eval<false>(P.seg, k, xe, m);
-        double qT = kGamR * m.T;
-        double c = qT * frsq(qT);
-        double rho = rho_eval(P, k, xe);
-        double cn = c * inm;
-        double cp0 = cn * n0, cp1 = cn * n1 + m.v, cp2 = cn * n2 + m.u;
-        tt = ds_tt * frsq(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
-        at = suthbass_alpha(P, r - P.r_earth, c, rho, P.freq, P.T_o, P.P_o, P.cbrt_To) * ds_at;
+        G.ds_tt = fsqrt(dr * dr + rdt * rdt + e1 * e1);
+        G.ds_at = fsqrt(dr * dr + rdt * rdt + e2 * e2);
+        G.a0 = an0 + (B[3] - an0) / 2.0; G.a1 = an1 + (B[4] - an1) / 2.0; G.a2 = an2 + (B[5] - an2) / 2.0;
+        G.a3 = frsq(G.a0 * G.a0 + G.a1 * G.a1 + G.a2 * G.a2);       // 1 / |nu|
+        G.x = r;
     }
+    static DEVINL double pp_tt(const GeoacDevParams& P, const double* aux, const PPGeom& G, double T, double u, double v){
+        double qT = kGamR * T;
+        double cn = (qT * frsq(qT)) * G.a3;
+        double cp0 = cn * G.a0, cp1 = cn * G.a1 + v, cp2 = cn * G.a2 + u;
+        return G.ds_tt * frsq(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
+    }
+    // the exact post-pass (k_postpass; GEOAC_ABS_TABLE=0): SuthBass_Alpha evaluated at the midpoint
     static DEVINL void segment(const GeoacDevParams& P, const double* st, size_t np, const double* a, const double* b, double& tt, double& at){
         double A[6], B[6];
         #pragma unroll
         for(int c = 0; c < 6; c++){ A[c] = a[c * np]; B[c] = b[c * np]; }
-        segment_rows<false>(P, nullptr, A, B, tt, at);
+        pp_exact<EqGlobal<AMP_>>(P, nullptr, A, B, tt, at);
     }
 };
 
@@ -846,7 +864,7 @@ struct EqGlobalPair : EqGlobal<true> {
     static constexpr bool SPLIT = true; static constexpr bool ROW_SPLIT = true;      // (the two lanes also store half a path row each)
     template <typename TabPtr>
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
-        global_rhs<true, 1>(tab, P, seg, yt, C.a[0], C.a[1], yt[1] - y0[1], dy);
+        global_rhs<true, 1>(tab, P, seg, yt, C.cur[0], C.cur[1], yt[1] - y0[1], dy);
     }
     // reflection of the base ray and of this lane's derivative system (Global.cpp:140-205, Q1 linear intercept)
     static DEVINL void reflect(const GeoacDevParams& P, const RayCtx& C, const double* yn, double* y, const double* ym2){
@@ -868,6 +886,7 @@ struct EqGlobalPair : EqGlobal<true> {
     }
 };
 
+#pragma clang fp contract(fast)          // grid sets: as before (their kernels are compared with each other to rounding, see DESIGN)
 #include "geoac_rngdep.h"
 #ifndef GEOAC_CELL_REGS
 #define GEOAC_CELL_REGS(C) ((CACHE_ || !COOP_) ? (C).cell : nullptr)   // node coordinates of the hinted cell in registers (not in the cooperative kernels: no registers to spare)
@@ -943,6 +962,7 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
         gnd = yn[2] < P.ground;
     }
     static DEVINL void accept(RayCtx& C){}
+    static DEVINL void resume(const GeoacDevParams& P, RayCtx& C, const double* y){}
     static DEVINL void restart(const GeoacDevParams& P, RayCtx& C, const double* y){}
     // GeoAc3D.RngDep_main.cpp:298-301
     static DEVINL void arrival(const GeoacDevParams& P, const RayCtx& C, int slot, const double* yn, double* R){
@@ -1123,6 +1143,7 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
         gnd = yn[0] < P.ground;
     }
     static DEVINL void accept(RayCtx& C){ C.a[0] = C.t[0]; C.a[1] = C.t[1]; }
+    static DEVINL void resume(const GeoacDevParams& P, RayCtx& C, const double* y){}
     static DEVINL void restart(const GeoacDevParams& P, RayCtx& C, const double* y){ fsincos(y[1], C.a[0], C.a[1]); }
     // arrival row: GeoAcGlobal.RngDep_main.cpp:304-329 (inclination without the leading minus: Q10)
     static DEVINL void arrival(const GeoacDevParams& P, const RayCtx& C, int slot, const double* yn, double* R){
@@ -1248,6 +1269,7 @@ struct EqGlobalRngDepOct : EqGlobalRngDep<true, 4, false, true> {
     }
 };
 
+#pragma clang fp contract(off)           // stratified sets again
 template <bool AMP_> struct Eq3D {
     static constexpr bool AMP = AMP_;
     static constexpr bool COOP = false; static constexpr bool CACHE = false; static constexpr bool LDS_STATE = false; static constexpr int XCHG_BYTES = 0; static constexpr bool PP_TILE = false; static constexpr bool PP_DEDUP = false; static constexpr int SYS_SHIFT = 0; static constexpr bool ROW_SPLIT = false;
@@ -1294,6 +1316,7 @@ template <bool AMP_> struct Eq3D {
         gnd = yn[2] < P.ground;
     }
     static DEVINL void accept(RayCtx& C){}
+    static DEVINL void resume(const GeoacDevParams& P, RayCtx& C, const double* y){}
     static DEVINL void restart(const GeoacDevParams& P, RayCtx& C, const double* y){}
     // GeoAc_Jacobian / GeoAc_Amplitude: 3DStratified.cpp:410-451 (nu_mag0 sign slip, c_prop[2] without w: Q4)
     static DEVINL void arrival(const GeoacDevParams& P, const RayCtx& C, int slot, const double* yn, double* R){
@@ -1355,44 +1378,28 @@ template <bool AMP_> struct Eq3D {
     }
     // 3DStratified.cpp:348-405 (c(0,0,0) instead of c0, w ignored: Q5) and :456-490; A, B = the segment's two path rows, aux = nu_x, nu_y of the ray
     static DEVINL void pp_aux(const GeoacDevParams& P, const double* st, size_t np, double* aux){ aux[0] = st[(ST_AUX0 + 0) * np]; aux[1] = st[(ST_AUX0 + 1) * np]; }
-    template <bool TAB>
-    static DEVINL void segment_rows(const GeoacDevParams& P, const double* aux, const double* A, const double* B, double& tt, double& at){
-        double nx = aux[0], ny = aux[1];
+    static DEVINL void pp_geom(const GeoacDevParams& P, const double* aux, const double* A, const double* B, PPGeom& G){
         double ax = A[0], ay = A[1], az = A[2], anz = A[3];
         double dx = B[0] - ax, dy = B[1] - ay, dz = B[2] - az;
-        double ds = fsqrt(dx * dx + dy * dy + dz * dz);
-        double z = az + dz / 2.0;
-        double nz = anz + (B[3] - anz) / 2.0;
-        double xe = clampd(z, P.x_min, P.x_max);
-        if(TAB){
-            const int k = seg_guess_mul(P.seg, P, xe);
-            const double* p = P.seg + (size_t)k * GEOAC_SEGW;
-            double T, u, v; seg_eval_f(p, xe, T, u, v);
-            double qT = kGamR * T;
-            double c = qT * frsq(qT);
-            double cn = (c * c) * frcp(P.c000 - nx * u - ny * v);
-            double cp0 = cn * nx + u, cp1 = cn * ny + v, cp2 = cn * nz;
-            tt = ds * frsq(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
-            const double al = atab_alpha(P, z, xe, k, p[0]);
-            at = (al < 0.0) ? -1.0 : al * ds;
-            return;
-        }
-        int k = seg_guess(P.seg, P, xe);
-        Atm9 m; seg_eval<false>(P.seg, k, xe, m);
-        double qT = kGamR * m.T;
+        G.ds_tt = G.ds_at = fsqrt(dx * dx + dy * dy + dz * dz);
+        G.x = az + dz / 2.0;
+        G.a0 = anz + (B[3] - anz) / 2.0;
+        G.a1 = G.a2 = G.a3 = 0.0;
+    }
+    static DEVINL double pp_tt(const GeoacDevParams& P, const double* aux, const PPGeom& G, double T, double u, double v){
+        double nx = aux[0], ny = aux[1];
+        double qT = kGamR * T;
         double c = qT * frsq(qT);
-        double rho = rho_eval(P, k, xe);
-        double cn = (c * c) * frcp(P.c000 - nx * m.u - ny * m.v);      // c / nu_mag, nu_mag = (c(0,0,0) - nu_x u - nu_y v) / c  (Q5)
-        double cp0 = cn * nx + m.u, cp1 = cn * ny + m.v, cp2 = cn * nz;
-        tt = ds * frsq(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
-        at = suthbass_alpha(P, z, c, rho, P.freq, P.T_o, P.P_o, P.cbrt_To) * ds;
+        double cn = (c * c) * frcp(P.c000 - nx * u - ny * v);
+        double cp0 = cn * nx + u, cp1 = cn * ny + v, cp2 = cn * G.a0;
+        return G.ds_tt * frsq(cp0 * cp0 + cp1 * cp1 + cp2 * cp2);
     }
     static DEVINL void segment(const GeoacDevParams& P, const double* st, size_t np, const double* a, const double* b, double& tt, double& at){
         double A[4], B[4], aux[2];
         pp_aux(P, st, np, aux);
         #pragma unroll
         for(int c = 0; c < 4; c++){ A[c] = a[c * np]; B[c] = b[c * np]; }
-        segment_rows<false>(P, aux, A, B, tt, at);
+        pp_exact<Eq3D<AMP_>>(P, aux, A, B, tt, at);
     }
 };
 
@@ -1456,6 +1463,7 @@ template <bool AMP_> struct Eq2D {
         gnd = yn[1] < P.ground;
     }
     static DEVINL void accept(RayCtx& C){}
+    static DEVINL void resume(const GeoacDevParams& P, RayCtx& C, const double* y){}
     static DEVINL void restart(const GeoacDevParams& P, RayCtx& C, const double* y){}
     // GeoAc2D_main.cpp:216-226; Jacobian / Amplitude: 2DStratified.cpp:291-313
     static DEVINL void arrival(const GeoacDevParams& P, const RayCtx& C, int slot, const double* yn, double* R){
@@ -1498,41 +1506,39 @@ template <bool AMP_> struct Eq2D {
     }
     // 2DStratified.cpp:217-286; A, B = the segment's two path rows, aux = cos / sin of the ray's azimuth
     static DEVINL void pp_aux(const GeoacDevParams& P, const double* st, size_t np, double* aux){ aux[0] = st[(ST_AUX0 + 0) * np]; aux[1] = st[(ST_AUX0 + 1) * np]; }
-    template <bool TAB>
-    static DEVINL void segment_rows(const GeoacDevParams& P, const double* aux, const double* A, const double* B, double& tt, double& at){
-        double cph = aux[0], sph = aux[1];
+    static DEVINL void pp_geom(const GeoacDevParams& P, const double* aux, const double* A, const double* B, PPGeom& G){
         double ar = A[0], az = A[1];
         double dr = B[0] - ar, dz = B[1] - az;
-        double z = az + dz / 2.0;
-        double ds = fsqrt(dr * dr + dz * dz);
-        double xe = clampd(z, P.x_min, P.x_max);
-        if(TAB){
-            const int k = seg_guess_mul(P.seg, P, xe);
-            const double* p = P.seg + (size_t)k * GEOAC_SEGW;
-            double T, u, v; seg_eval_f(p, xe, T, u, v);
-            double qT = kGamR * T;
-            double c = qT * frsq(qT);
-            tt = ds * frcp(c + u * cph + v * sph);
-            const double al = atab_alpha(P, z, xe, k, p[0]);
-            at = (al < 0.0) ? -1.0 : al * ds;
-            return;
-        }
-        int k = seg_guess(P.seg, P, xe);
-        Atm9 m; seg_eval<false>(P.seg, k, xe, m);
-        double qT = kGamR * m.T;
+        G.x = az + dz / 2.0;
+        G.ds_tt = G.ds_at = fsqrt(dr * dr + dz * dz);
+        G.a0 = G.a1 = G.a2 = G.a3 = 0.0;
+    }
+    static DEVINL double pp_tt(const GeoacDevParams& P, const double* aux, const PPGeom& G, double T, double u, double v){
+        double qT = kGamR * T;
         double c = qT * frsq(qT);
-        double rho = rho_eval(P, k, xe);
-        tt = ds * frcp(c + m.u * cph + m.v * sph);
-        at = suthbass_alpha(P, z, c, rho, P.freq, P.T_o, P.P_o, P.cbrt_To) * ds;
+        return G.ds_tt * frcp(c + u * aux[0] + v * aux[1]);
     }
     static DEVINL void segment(const GeoacDevParams& P, const double* st, size_t np, const double* a, const double* b, double& tt, double& at){
         double A[2], B[2], aux[2];
         pp_aux(P, st, np, aux);
         A[0] = a[0]; A[1] = a[np]; B[0] = b[0]; B[1] = b[np];
-        segment_rows<false>(P, aux, A, B, tt, at);
+        pp_exact<Eq2D<AMP_>>(P, aux, A, B, tt, at);
     }
 };
 
+template <class EQ>
+DEVINL void pp_exact(const GeoacDevParams& P, const double* aux, const double* A, const double* B, double& tt, double& at){
+    PPGeom G;
+    EQ::pp_geom(P, aux, A, B, G);
+    const double xe = clampd(G.x, P.x_min, P.x_max);
+    const int k = seg_guess(P.seg, P, xe);
+    double T, u, v; seg_eval_f(P.seg + (size_t)k * GEOAC_SEGW, xe, T, u, v);
+    tt = EQ::pp_tt(P, aux, G, T, u, v);
+    const double qT = kGamR * T;
+    at = suthbass_alpha(P, G.x - P.r_earth, qT * frsq(qT), rho_eval(P, k, xe), P.freq, P.T_o, P.P_o, P.cbrt_To) * G.ds_at;
+}
+
+#pragma clang fp contract(off)
 #include "geoac_duo.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -1687,6 +1693,7 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
     C.c0 = st[ST_C0 * np]; C.nu0 = st[ST_NU0 * np];
     #pragma unroll
     for(int q = 0; q < 6; q++) C.a[q] = st[(ST_AUX0 + q) * np];
+    EQ::resume(P, C, y);
     int seg = P.gtab ? (int)st[ST_SEG * np] : (int)st[ST_SEG * np] * GEOAC_SEGW;   // 1-D sets: element offset of the current spline segment; grid sets: vertical segment index
     unsigned long long steps_here = 0;
     int nev = (EQ::COOP && SMP && sub_h > 0 && !idle0) ? P.nev[col] : 0;   // WriteRays / WriteCaustics events of this chunk
@@ -1856,7 +1863,7 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
     st[ST_K * np] = (double)k; st[ST_LEG * np] = (double)leg; st[ST_DONE * np] = done ? 1.0 : 0.0;
     st[ST_HMAX * np] = hmax; st[ST_SEG * np] = P.gtab ? (double)seg : (double)(seg / GEOAC_SEGW);
     #pragma unroll
-    for(int q = 0; q < 4; q++) st[(ST_AUX0 + q) * np] = C.a[q];
+    for(int q = 0; q < 6; q++) st[(ST_AUX0 + q) * np] = C.a[q];
     P.nrows[col] = nr; P.nlegend[col] = nle;
     if(SMP){
         st[ST_DPREV * np] = dprev;
@@ -1939,10 +1946,7 @@ DEVINL void pp_medium_by_key(const GeoacDevParams& P, char* wl, bool valid, unsi
 }
 
 template <class EQ>
-__global__ void __launch_bounds__(256, EQ::PP_WAVES) k_postpass(GeoacDevParams P, int rows, int fixup){
-    // fixup: second pass behind k_postpass_tab - only the segments that kernel marked (attenuation increment -1), and none at all when it
-    // marked none (the usual case: the table serves every midpoint of a profile like ToyAtmo)
-    if(fixup && __hip_atomic_load(P.counters + GEOAC_CNT_PPFLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) return;
+__global__ void __launch_bounds__(256, EQ::PP_WAVES) k_postpass(GeoacDevParams P, int rows){
     // grid-stride sweep over (segment row i, ray slot); by default the grid covers the sweep in one pass
     // Grid sets (PP_TILE): a workgroup takes a tile of 16 rows x 16 rays, a wave 16 consecutive rows of 4 rays.  The segment midpoints of
     // one ray's consecutive rows lie in the same cell and vertical segment nearly always, so the 64 lanes of a table gather touch a handful
@@ -1998,7 +2002,6 @@ __global__ void __launch_bounds__(256, EQ::PP_WAVES) k_postpass(GeoacDevParams P
         const double* a = P.path + ((size_t)i * EQ::PW) * np + col;
         const double* b = a + (size_t)EQ::PW * np;
         double* o = P.contrib + ((size_t)i * 2) * np + col;
-        if(fixup && !(o[np] < 0.0)) continue;
         double tt, at;
         EQ::segment(P, P.state + slot, np, a, b, tt, at);
         o[0]  = tt;
@@ -2007,8 +2010,10 @@ __global__ void __launch_bounds__(256, EQ::PP_WAVES) k_postpass(GeoacDevParams P
 }
 
 // k_postpass_tab: the post-pass of the stratified sets with the absorption table.  One thread walks GEOAC_PP_ROWS consecutive segments
-// of one ray (every path row is read once, by the thread that also needs it as the next segment's first row); a segment costs the
-// geometry, one spline evaluation and a degree-7 polynomial (~150 instructions per 64 segments instead of ~1 500).
+// of one ray: every path row is read once (the next one is already on its way while a segment is evaluated), and the spline record and the
+// table entry of the midpoint stay in registers from one segment to the next - consecutive steps of a ray are 1 - 50 m apart, the nodes
+// ~100 m - so the usual segment has no dependent memory access at all: geometry, one spline evaluation, three degree-5 polynomials and
+// two square roots (~200 instructions per 64 segments instead of ~1 500).
 template <class EQ>
 __global__ void __launch_bounds__(256) k_postpass_tab(GeoacDevParams P, int rows){
     constexpr int PW = EQ::PW, R = GEOAC_PP_ROWS;
@@ -2026,28 +2031,60 @@ __global__ void __launch_bounds__(256) k_postpass_tab(GeoacDevParams P, int rows
         const int slot = P.colmap ? P.colmap[col] : col;
         double aux[2] = { 0.0, 0.0 };
         EQ::pp_aux(P, P.state + slot, np, aux);
+        const int i1 = min(i0 + R, nr - 1);                       // segments i0 .. i1 - 1
         const double* a = P.path + ((size_t)i0 * PW) * np + col;
-        double A[PW], B[PW];
+        double A[PW], B[PW], Bn[PW];
         #pragma unroll
-        for(int c = 0; c < PW; c++) A[c] = a[(size_t)c * np];
-        #pragma unroll 2
-        for(int j = 0; j < R; j++){
-            const int i = i0 + j;
-            if(i + 1 >= nr) break;
-            const double* b = P.path + ((size_t)(i + 1) * PW) * np + col;
+        for(int c = 0; c < PW; c++){ A[c] = a[(size_t)c * np]; Bn[c] = a[(size_t)(PW + c) * np]; }
+        double rec[GEOAC_SEGW], tb[19];                           // the spline record and the table entry in hand (k, ent: which)
+        int k = -1, ent = -1;
+        rec[0] = 1.0; rec[1] = 0.0;
+        #pragma unroll
+        for(int c = 2; c < GEOAC_SEGW; c++) rec[c] = 0.0;
+        #pragma unroll
+        for(int c = 0; c < 19; c++) tb[c] = 0.0;
+        for(int i = i0; i < i1; i++){
             #pragma unroll
-            for(int c = 0; c < PW; c++) B[c] = b[(size_t)c * np];
-            double tt, at;
-            EQ::template segment_rows<true>(P, aux, A, B, tt, at);
+            for(int c = 0; c < PW; c++) B[c] = Bn[c];
+            if(i + 2 <= i1){                                      // the row after next, while this segment is evaluated
+                const double* b = P.path + ((size_t)(i + 2) * PW) * np + col;
+                #pragma unroll
+                for(int c = 0; c < PW; c++) Bn[c] = b[(size_t)c * np];
+            }
+            PPGeom G;
+            EQ::pp_geom(P, aux, A, B, G);
+            const double xe = clampd(G.x, P.x_min, P.x_max);
+            if(!((xe >= rec[0]) & (xe <= rec[1]))){               // (also the first segment: rec[0] > rec[1])
+                k = seg_find(P.seg, P.nseg, xe, k < 0 ? (int)((xe - P.x_min) * P.seg_per_x) : k);
+                const double* p = P.seg + (size_t)k * GEOAC_SEGW;
+                #pragma unroll
+                for(int c = 0; c < GEOAC_SEGW; c++) rec[c] = p[c];
+            }
+            double t; bool out;
+            const int e = atab_locate(P, G.x, xe, k, rec[0], t, out);
+            if(e != ent){
+                const double* q = P.atab + (size_t)e * GEOAC_ATABW;
+                #pragma unroll
+                for(int c = 0; c < 19; c++) tb[c] = q[c];
+                ent = e;
+            }
+            double T, u, v; seg_eval_f(rec, xe, T, u, v);
+            const double tt = EQ::pp_tt(P, aux, G, T, u, v);
+            const bool bad = out | (tb[0] < 0.0);
+            double at = atab_eval(tb, t) * G.ds_at;
+            if(bad){                                              // not served by the table (rare, divergent): the exact routine, as k_postpass calls it
+                const double qT = kGamR * T;
+                at = suthbass_alpha(P, G.x - P.r_earth, qT * frsq(qT), rho_eval(P, k, xe), P.freq, P.T_o, P.P_o, P.cbrt_To) * G.ds_at;
+            }
             double* o = P.contrib + ((size_t)i * 2) * np + col;
             o[0]  = tt;
             o[np] = at;
-            flagged += (at < 0.0) ? 1u : 0u;
+            flagged += bad ? 1u : 0u;
             #pragma unroll
             for(int c = 0; c < PW; c++) A[c] = B[c];
         }
     }
-    if(flagged){ atomicAdd(&P.counters[GEOAC_CNT_PPFLAG], (unsigned long long)flagged); atomicAdd(&P.counters[GEOAC_CNT_PPFLAG + 1], (unsigned long long)flagged); }
+    if(flagged) atomicAdd(&P.counters[GEOAC_CNT_PPFLAG + 1], (unsigned long long)flagged);     // (statistics: geoac_abs_table_info)
 }
 
 // k_atab_build: one thread per table entry (see atab_eval).  Entry e < nseg: spline segment e; nseg: the strip [x_min - D, x_min];
@@ -2072,31 +2109,33 @@ __global__ void __launch_bounds__(64) k_atab_build(GeoacDevParams P, double* __r
         return parts ? suthbass_alpha<true>(P, x - P.r_earth, c, rho, P.freq, P.T_o, P.P_o, P.cbrt_To, parts)
                      : suthbass_alpha<false>(P, x - P.r_earth, c, rho, P.freq, P.T_o, P.P_o, P.cbrt_To);
     };
-    double f[3][8];
-    for(int j = 0; j < 8; j++){
+    double f[3][6];
+    #pragma unroll
+    for(int j = 0; j < 6; j++){
         double pr[3];
-        exact(cospi((j + 0.5) / 8.0), pr);
+        exact(cospi((j + 0.5) / 6.0), pr);
         f[0][j] = pr[0]; f[1][j] = pr[1]; f[2][j] = pr[2];
     }
     double* o = tab + (size_t)e * GEOAC_ATABW;
-    o[0] = 2.0 / h;
+    #pragma unroll
     for(int q = 0; q < 3; q++){
-        double cc[8];
-        for(int m = 0; m < 8; m++){
+        double cc[6];
+        #pragma unroll
+        for(int m = 0; m < 6; m++){
             double acc = 0.0;
-            for(int j = 0; j < 8; j++) acc += f[q][j] * cospi(m * (j + 0.5) / 8.0);
-            cc[m] = 0.25 * acc;
+            #pragma unroll
+            for(int j = 0; j < 6; j++) acc += f[q][j] * cospi(m * (j + 0.5) / 6.0);
+            cc[m] = acc * (1.0 / 3.0);
         }
-        double* w = o + 2 + 8 * q;                                // Chebyshev series -> powers of s
-        w[0] = 0.5 * cc[0] - cc[2] + cc[4] - cc[6];
-        w[1] = cc[1] - 3.0 * cc[3] + 5.0 * cc[5] - 7.0 * cc[7];
-        w[2] = 2.0 * cc[2] - 8.0 * cc[4] + 18.0 * cc[6];
-        w[3] = 4.0 * cc[3] - 20.0 * cc[5] + 56.0 * cc[7];
-        w[4] = 8.0 * cc[4] - 48.0 * cc[6];
-        w[5] = 16.0 * cc[5] - 112.0 * cc[7];
-        w[6] = 32.0 * cc[6];
-        w[7] = 64.0 * cc[7];
+        double* w = o + 1 + 6 * q;                                // Chebyshev series -> powers of s
+        w[0] = 0.5 * cc[0] - cc[2] + cc[4];
+        w[1] = cc[1] - 3.0 * cc[3] + 5.0 * cc[5];
+        w[2] = 2.0 * cc[2] - 8.0 * cc[4];
+        w[3] = 4.0 * cc[3] - 20.0 * cc[5];
+        w[4] = 8.0 * cc[4];
+        w[5] = 16.0 * cc[5];
     }
+    o[0] = 2.0 / h;
     // the reassembled alpha against the exact routine at points that are not the nodes
     const double chk[8] = { -0.9999, -0.83, -0.5, -0.17, 0.2, 0.55, 0.87, 0.9999 };
     double worst = 0.0;
@@ -2109,7 +2148,7 @@ __global__ void __launch_bounds__(64) k_atab_build(GeoacDevParams P, double* __r
         if(!(err <= tol)) ok = false;
         worst = (err > worst) ? err : worst;
     }
-    o[1] = ok ? 0.0 : (worst > 0.0 ? worst : 1.0);           // flag (non-zero: not served); carries the worst relative error seen
+    if(!ok) o[0] = -o[0];                                       // flagged: not served
     o[GEOAC_ATABW - 1] = worst;
 }
 
@@ -2401,6 +2440,11 @@ static hipError_t launch_rk4_duo(const GeoacDevParams* P, hipStream_t s, unsigne
         case 1: GEOAC_DUO_LAUNCH(0); break;
         case 2: GEOAC_DUO_LAUNCH(1); break;
         case 4: GEOAC_DUO_LAUNCH(3); break;
+        case 16: GEOAC_DUO_LAUNCH(8); break;     // (diagnostic: wait-time counters, variant 0 / variant 7)
+        case 17: GEOAC_DUO_LAUNCH(15); break;
+        case 32: GEOAC_DUO_LAUNCH(32); break;    // (timing diagnostics: base wave alone / messages consumed but not used - records are NOT valid)
+        case 64: GEOAC_DUO_LAUNCH(64); break;
+        case 66: GEOAC_DUO_LAUNCH(66); break;
         default: GEOAC_DUO_LAUNCH(7); break;
     }
     #undef GEOAC_DUO_LAUNCH
@@ -2442,31 +2486,27 @@ extern "C" hipError_t geoac_launch_postpass(const GeoacDevParams* P, int rows, h
     if(nbl > 0x7fffffffLL) nbl = 0x7fffffffLL;
     int nb = (int)nbl;
     dim3 b(256), g(nb);
-    GEOAC_DISPATCH_EQ(P, hipLaunchKernelGGL(k_postpass<EQ>, g, b, EQ::PP_DEDUP ? 4 * GEOAC_PP_SLOTS * GEOAC_PP_SLOTB : 0, s, *P, rows, 0));
+    GEOAC_DISPATCH_EQ(P, hipLaunchKernelGGL(k_postpass<EQ>, g, b, EQ::PP_DEDUP ? 4 * GEOAC_PP_SLOTS * GEOAC_PP_SLOTB : 0, s, *P, rows));
     return hipGetLastError();
 }
 
-// post-pass of a stratified set through the absorption table: reset of the marked-segment count, k_postpass_tab, then the exact kernel
-// as a fix-up pass over whatever the table did not serve (a persistent grid that leaves at once when nothing was marked)
+// post-pass of a stratified set through the absorption table (k_postpass_tab; the few segments the table does not serve are evaluated
+// exactly inside the same kernel)
 extern "C" hipError_t geoac_launch_postpass_tab(const GeoacDevParams* P, int rows, hipStream_t s){
     if(rows < 2) return hipSuccess;
     if(!P->atab || P->gtab) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(P->counters + GEOAC_CNT_PPFLAG, 0, sizeof(unsigned long long), s);
-    if(e != hipSuccess) return e;
     long long total = (long long)((P->n_cols_bound + 255) / 256) * ((rows - 1 + GEOAC_PP_ROWS - 1) / GEOAC_PP_ROWS);
     if(total > 0x7fffffffLL) total = 0x7fffffffLL;
-    dim3 b(256), g((unsigned)total), gf(2048);
-    #define GEOAC_PPT(EQT) do { hipLaunchKernelGGL(k_postpass_tab<EQT>, g, b, 0, s, *P, rows); hipLaunchKernelGGL(k_postpass<EQT>, gf, b, 0, s, *P, rows, 1); } while(0)
+    dim3 b(256), g((unsigned)total);
     switch(P->eqset * 2 + (P->calc_amp ? 1 : 0)){
-        case GEOAC_EQ_GLOBAL * 2 + 1: GEOAC_PPT(EqGlobal<true>); break;
-        case GEOAC_EQ_GLOBAL * 2 + 0: GEOAC_PPT(EqGlobal<false>); break;
-        case GEOAC_EQ_3D * 2 + 1:     GEOAC_PPT(Eq3D<true>); break;
-        case GEOAC_EQ_3D * 2 + 0:     GEOAC_PPT(Eq3D<false>); break;
-        case GEOAC_EQ_2D * 2 + 1:     GEOAC_PPT(Eq2D<true>); break;
-        case GEOAC_EQ_2D * 2 + 0:     GEOAC_PPT(Eq2D<false>); break;
+        case GEOAC_EQ_GLOBAL * 2 + 1: hipLaunchKernelGGL(k_postpass_tab<EqGlobal<true>>, g, b, 0, s, *P, rows); break;
+        case GEOAC_EQ_GLOBAL * 2 + 0: hipLaunchKernelGGL(k_postpass_tab<EqGlobal<false>>, g, b, 0, s, *P, rows); break;
+        case GEOAC_EQ_3D * 2 + 1:     hipLaunchKernelGGL(k_postpass_tab<Eq3D<true>>, g, b, 0, s, *P, rows); break;
+        case GEOAC_EQ_3D * 2 + 0:     hipLaunchKernelGGL(k_postpass_tab<Eq3D<false>>, g, b, 0, s, *P, rows); break;
+        case GEOAC_EQ_2D * 2 + 1:     hipLaunchKernelGGL(k_postpass_tab<Eq2D<true>>, g, b, 0, s, *P, rows); break;
+        case GEOAC_EQ_2D * 2 + 0:     hipLaunchKernelGGL(k_postpass_tab<Eq2D<false>>, g, b, 0, s, *P, rows); break;
         default: return hipErrorNotSupported;
     }
-    #undef GEOAC_PPT
     return hipGetLastError();
 }
 

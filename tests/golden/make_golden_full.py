@@ -116,6 +116,29 @@ def cfg4(pool):
     print(f"cfg4: {len(sel)} of {len(th)} rays, {int(steps.sum())} ray-steps -> {path} ({os.path.getsize(path) // 1024} KiB)", flush=True)
 
 
+def cfg4_shares(pool):
+    """config 4, the shares of ranks 1..7 of the 8-GPU run (geoac_amd.sharding: rank r takes the azimuths r, r + 8, ... of the 1000): of each,
+    five azimuths spread over the circle x every 20th inclination = 250 rays, so that every rank's share has reference rays of its own"""
+    import tempfile
+    import rngdep_data as RD
+    grid = RD.write_grid(os.path.join(tempfile.gettempdir(), "gf"), thin=1)
+    cfgkw = dict(bounces=1, calc_amp=True, mode=0, src=(0.0, 0.0, 0.0))
+    th, ph = H.fan_angles(theta_min=0.05, theta_max=50.0, theta_step=0.05, phi_min=-180.0, phi_max=-180.0 + 999 * 0.36, phi_step=0.36)
+    n_th = int(np.sum(ph == ph[0])); n_ph = len(th) // n_th
+    assert n_th * n_ph == len(th) and n_ph == 999 and n_th == 1000, (n_th, n_ph)       # (repeated addition of 0.36 stops one short of 1000)
+    out = {}
+    for r in range(1, 8):
+        az = r + 8 * np.array([3, 28, 53, 78, 103])                # azimuth indices of rank r's share (r mod 8)
+        sel = (az[:, None] * n_th + np.arange(11, n_th, 20)[None, :]).ravel()
+        jobs = [("cfg4", H.EQ_3D_RNGDEP, tuple(grid), cfgkw, th[c], ph[c]) for c in np.array_split(sel, len(sel) // 10)]
+        res = run_jobs(pool, jobs, f"cfg4 share {r}")
+        out[f"az{r}"] = az.astype(np.int32); out[f"sel{r}"] = sel.astype(np.int64); out[f"theta{r}"] = th[sel]; out[f"phi{r}"] = ph[sel]
+        out[f"steps{r}"] = np.concatenate([q[0][0] for q in res]); out[f"flags{r}"] = np.concatenate([q[0][1] for q in res]); out[f"vals{r}"] = np.concatenate([q[0][2] for q in res])
+    path = os.path.join(OUT, "full_cfg4_shares.npz")
+    np.savez_compressed(path, bounces=1, n_theta=n_th, n_phi=n_ph, val_fields=np.array(VAL_FIELDS), **out)
+    print(f"cfg4 shares 1..7: {sum(len(out[f'sel{r}']) for r in range(1, 8))} rays -> {path} ({os.path.getsize(path) // 1024} KiB)", flush=True)
+
+
 SENS_EPS = 1e-12
 
 
@@ -193,6 +216,15 @@ def cfg5(nproc):
             print(f"  cfg5 receiver {k}: {dt:.0f} s, {files}", flush=True)
 
 
+def cfg5_ranks(nproc):
+    """config 5, one receiver of each of the ranks 1..7 (rank r searches the receivers r, r + 8, ... of the 64-ring: the first of them),
+    kept as cfg5_r8 .. cfg5_r14"""
+    rc = ring_receivers(every=1)
+    with mp.get_context("fork").Pool(nproc) as pool:
+        for k, dt, files in pool.imap_unordered(_run_cfg5, [(7 + r, float(rc[r, 0]), float(rc[r, 1])) for r in range(1, 8)]):
+            print(f"  cfg5 receiver {k} (ring position {k - 7}): {dt:.0f} s, {files}", flush=True)
+
+
 def main():
     args = sys.argv[1:]
     nproc = 6
@@ -203,12 +235,17 @@ def main():
         if w == "cfg5":
             cfg5(nproc)
             continue
+        if w == "cfg5_ranks":
+            cfg5_ranks(nproc)
+            continue
         # a fresh pool per configuration: one equation set / atmosphere per reference process
         with mp.get_context("fork").Pool(nproc) as pool:
             if w.startswith("sens_"):
                 sens(pool, w[5:])
             elif w == "cfg4":
                 cfg4(pool)
+            elif w == "cfg4_shares":
+                cfg4_shares(pool)
             else:
                 stratified(pool, w)
 

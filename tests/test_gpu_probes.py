@@ -184,7 +184,7 @@ def test_absorption_table_vs_exact_routine_and_reference(eq):
 
 @pytest.mark.parametrize("eq", [H.EQ_GLOBAL, H.EQ_3D, H.EQ_2D])
 def test_table_and_exact_post_pass_agree(eq, monkeypatch):
-    """A fan through the table post-pass (k_postpass_tab + fix-up) and through the exact one (GEOAC_ABS_TABLE=0): travel times identical,
+    """A fan through the table post-pass (k_postpass_tab) and through the exact one (GEOAC_ABS_TABLE=0): travel times identical,
     attenuations to 1e-10 relative; with a raised ground and a lowered ceiling some midpoints fall below the first / above the last node
     (strips) and rays leave through the top."""
     import geoac_amd as G

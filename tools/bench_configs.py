@@ -21,6 +21,10 @@ def run_fan(ctx, th, ph, reps=2):
         tm = ctx.timing(); ms_rk4 += tm["ms_rk4"]; epochs += tm["epochs"]
     dt = (time.perf_counter() - t0) / reps
     LAST.update(ms_rk4=ms_rk4 / reps, epochs=epochs / reps)
+    try:
+        LAST.update(abs_table=ctx.abs_table_info())
+    except Exception:
+        pass
     return ctx.total_steps(), dt
 
 
@@ -136,4 +140,6 @@ if __name__ == "__main__":
         r.pop("E", None); r.pop("kernel", None)
         if rf:
             r["roofline"] = rf
+        if LAST.get("abs_table"):
+            r["abs_table"] = LAST["abs_table"]
         print(json.dumps(r), flush=True)
