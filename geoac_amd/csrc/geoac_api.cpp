@@ -115,7 +115,9 @@ struct geoac_ctx {
     bool trace_epochs = false;                    // GEOAC_TRACE_EPOCHS=1: per-epoch live counts on stderr
     bool no_gate = false;                         // GEOAC_NO_GATE=1: post-pass not held back behind the next RK4 launch (A/B measurements)
     bool no_pair = false;                         // GEOAC_NO_PAIR=1: force one lane per ray (A/B measurements)
-    int duo = 8;                                  // GEOAC_DUO=0: never the wave-specialised kernel (A/B runs, schedule-independence tests); 1, 2, 4: hand-off variants (A/B), 8: shipped
+    int ev_slack = 72;                            // GEOAC_EV_SLACK: per-epoch event rows of a ray beyond its raypath samples (caustics); tests lower it to reach the overflow path
+    int duo = 0;                                  // GEOAC_DUO=1: the wave-specialised kernel k_rk4_duo for Global fans with amplitudes (measured SLOWER than the two-lane
+                                                  // kernel on MI355X - 3.0 vs 2.7 us per step, DESIGN 3 - kept for A/B runs and the schedule-independence tests); 32, 66: timing diagnostics
     // absorption table of the stratified sets (k_atab_build): rebuilt when the atmosphere or one of the parameters it depends on changes
     bool abs_table = true;                        // GEOAC_ABS_TABLE=0: exact Sutherland-Bass evaluation at every segment midpoint (A/B runs, equivalence test)
     DevBuf atab;
@@ -232,6 +234,8 @@ int geoac_create(geoac_ctx** out, int eqset, int device){
     if(abt) ctx->abs_table = (atoi(abt) != 0);
     const char* du = getenv("GEOAC_DUO");
     if(du) ctx->duo = atoi(du);
+    const char* evs = getenv("GEOAC_EV_SLACK");
+    if(evs && atoi(evs) >= 0) ctx->ev_slack = atoi(evs);
     const char* npr = getenv("GEOAC_NO_PAIR");
     if(npr && atoi(npr) != 0) ctx->no_pair = true;
     const char* pf = getenv("GEOAC_PAIR_FRAC");
@@ -495,6 +499,8 @@ int geoac_fan_launch(geoac_ctx* ctx){
     P.rays_form = ((p.mode & (GEOAC_MODE_WRITE_RAYS | GEOAC_MODE_WRITE_CAUSTICS)) != 0 || ctx->eqset == GEOAC_EQ_2D) ? 1 : 0;
     P.nseg = ctx->n_nodes - 1;
     P.step_limit = (long long)(p.ray_limit * (int)(1.0 / (p.ds_min * 10)));   // GeoAc.Solver.cpp:14
+    if(P.step_limit > 0x7fffffffLL) P.step_limit = 0x7fffffffLL;             // (the kernels count a leg's steps in 32 bits; the reference's own `int step_limit` overflows beyond this)
+    if(P.step_limit < 2) P.step_limit = 2;
     P.x_min = ctx->x[0]; P.x_max = ctx->x[ctx->n_nodes - 1];
     P.ds_min = p.ds_min; P.ds_max = p.ds_max;
     P.r_earth = is_sph ? p.r_earth : 0.0; P.z_grnd = p.z_grnd;
@@ -561,7 +567,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
     HIPCHK(ctx->state.ensure(sizeof(double) * (size_t)ST_NSTATE * P.n_pad));
     const bool sampling = (p.mode & (GEOAC_MODE_WRITE_RAYS | GEOAC_MODE_WRITE_CAUSTICS)) != 0;
     P.smp_stride = p.sample_stride > 0 ? p.sample_stride : 25;
-    P.ev_cap = sampling ? (P.s_rows / P.smp_stride + 72) : 0;
+    P.ev_cap = sampling ? (P.s_rows / P.smp_stride + ctx->ev_slack) : 0;
     P.smp_cap = sampling ? ctx->smp_cap : 0;
     if(sampling){
         HIPCHK(ctx->smp_out.ensure(sizeof(double) * GEOAC_SMP_STRIDE * (size_t)P.smp_cap));
@@ -618,9 +624,10 @@ int geoac_fan_launch(geoac_ctx* ctx){
              (long long)P.n_pad <= 256ll * 128) ? ctx->duo : 0;
     if(P.duo) P.lanes_per_ray = 1;
     // grid sets, small fans: four lanes per ray (one cell corner each) while that still leaves one wave per SIMD
+    // (16 385 - 32 768 rays used to take two lanes per ray: measured on MI355X, profiles/r03_midfans.txt, the cooperative one-lane kernel is faster
+    // there for the Cartesian set - 4.8e8 against 4.1e8 ray-steps/s at 24 000 rays - and within 5 % for the spherical one, and it uses no scratch)
     if(is_grid && !ctx->no_quad){
         if((long long)P.n_pad * 4 / 64 <= 1024) P.lanes_per_ray = 4;
-        else if((long long)P.n_pad * 2 / 64 <= 1024) P.lanes_per_ray = 2;
     }
     if(is_grid && ctx->grid_lanes) P.lanes_per_ray = ctx->grid_lanes;
     // grid sets with amplitudes, fans of a few rays (the eigenray rounds): eight lanes per ray - four cell corners x the two launch-angle
@@ -823,12 +830,6 @@ int geoac_fan_launch(geoac_ctx* ctx){
     HIPCHK(hipMemcpyAsync(ctx->h_counters + 8, ctx->counters.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     ctx->n_samples = ctx->h_counters[8 + 3];
-    if(P.duo >= 16){                                          // diagnostic variants of k_rk4_duo: where the waves spent their time
-        unsigned long long h[8];
-        HIPCHK(hipMemcpy(h, (const unsigned long long*)ctx->counters.p + 16, sizeof(h), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[duo] base waves: %.4g ticks in the kernel, %.1f %% waiting for the slot, %llu waits spun; aux waves: %.4g ticks, %.1f %% waiting for a message, %llu waits spun; %llu messages\n",
-                (double)h[0], 100.0 * (double)h[1] / (double)(h[0] ? h[0] : 1), h[2], (double)h[3], 100.0 * (double)h[4] / (double)(h[3] ? h[3] : 1), h[5], h[6]);
-    }
     {   unsigned long long fx = 0;
         HIPCHK(hipMemcpy(&fx, (const unsigned long long*)ctx->counters.p + GEOAC_CNT_PPFLAG + 1, sizeof(fx), hipMemcpyDeviceToHost));
         ctx->pp_fixup_segments = fx; }

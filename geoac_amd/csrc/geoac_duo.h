@@ -43,8 +43,6 @@ struct DuoPort {                    // LDS byte addresses (explicit address-spac
     int n;                          // this wave's count: published (base) / consumed (aux)
     int lane;
     bool dead;                      // a wait ran out (~1 s: the other wave of the pair is gone): every later wait returns at once, the wave leaves
-    bool prof;                      // diagnostic variants (V & 8): shader-clock ticks spent in the wait loops, number of waits that had to spin
-    long long t_wait; int n_spin;
 };
 #define GEOAC_DUO_SPIN_MAX (1 << 22)
 DEVINL int duo_ctl_load(unsigned a){ return *(geoac_lds_vint*)(size_t)a; }
@@ -55,13 +53,10 @@ struct DuoMsg { double v[GEOAC_GSTAGE_W]; };
 
 // ---- producer side (base wave) ----
 DEVINL void duo_wait_free(DuoPort& pt){                          // the slot is free once everything published has been consumed
-    long long t0 = 0;
-    if(pt.prof){ if(__builtin_amdgcn_readfirstlane(duo_ctl_load(pt.ack)) == pt.n) return; t0 = clock64(); pt.n_spin++; }
     for(int it = 0; !pt.dead && __builtin_amdgcn_readfirstlane(duo_ctl_load(pt.ack)) != pt.n; it++){
         if(it > GEOAC_DUO_SPIN_MAX) pt.dead = true;
         __builtin_amdgcn_s_sleep(1);
     }
-    if(pt.prof) pt.t_wait += clock64() - t0;
     asm volatile("" ::: "memory");
 }
 // the consumed count, read early (issued where the caller stands, back by the time duo_wait_free_peeked looks at it): it only grows
@@ -89,13 +84,10 @@ DEVINL void duo_put_stage(DuoPort& pt, const GlobalStage& S){
 
 // ---- consumer side (aux wave) ----
 DEVINL void duo_wait_msg(DuoPort& pt){
-    long long t0 = 0;
-    if(pt.prof){ if(__builtin_amdgcn_readfirstlane(duo_ctl_load(pt.seq)) != pt.n) return; t0 = clock64(); pt.n_spin++; }
     for(int it = 0; !pt.dead && __builtin_amdgcn_readfirstlane(duo_ctl_load(pt.seq)) == pt.n; it++){
         if(it > GEOAC_DUO_SPIN_MAX) pt.dead = true;
         __builtin_amdgcn_s_sleep(1);
     }
-    if(pt.prof) pt.t_wait += clock64() - t0;
     asm volatile("" ::: "memory");
 }
 DEVINL void duo_consumed(DuoPort& pt){                           // behind the data loads (in order again)
@@ -111,35 +103,6 @@ DEVINL void duo_read(const DuoPort& pt, DuoMsg& m){
     }
     m.v[16] = ((geoac_lds_dbl*)(size_t)(pt.slot + 8 * 64 * 16))[pt.lane];
 }
-// non-blocking fetch of the NEXT message while the current one is being worked on: the published count first, then the data - LDS
-// executes a wave's instructions in order, so if the count shows the message, the data read behind it is that message
-DEVINL void duo_prefetch(const DuoPort& pt, int& seen, DuoMsg& m){
-    asm volatile("" ::: "memory");
-    seen = duo_ctl_load(pt.seq);
-    duo_read(pt, m);
-    asm volatile("" ::: "memory");
-}
-// the prefetched message becomes the current one (read again, after waiting, if it had not been published yet); the slot goes back
-DEVINL void duo_take(DuoPort& pt, int seen, DuoMsg& m){
-    if(__builtin_amdgcn_readfirstlane(seen) == pt.n){
-        duo_wait_msg(pt);
-        duo_read(pt, m);
-    }
-    duo_consumed(pt);
-}
-// a prefetch issued a while ago: if the message was there, hand the slot back NOW (the base wave can publish the one after it while this
-// wave still works on the current one) and remember that the message is in hand; if not, the next duo_take waits for it
-DEVINL void duo_commit(DuoPort& pt, int& seen, bool& in_hand){
-    in_hand = (__builtin_amdgcn_readfirstlane(seen) != pt.n);
-    if(in_hand) duo_consumed(pt);
-}
-DEVINL void duo_take_committed(DuoPort& pt, bool in_hand, DuoMsg& m){
-    if(!in_hand){
-        duo_wait_msg(pt);
-        duo_read(pt, m);
-        duo_consumed(pt);
-    }
-}
 DEVINL void duo_stage_of(const DuoMsg& m, GlobalStage& S){
     S.n0 = m.v[0]; S.n1 = m.v[1]; S.n2 = m.v[2]; S.inm = m.v[3]; S.cn = m.v[4]; S.icg = m.v[5]; S.dc = m.v[6]; S.du = m.v[7];
     S.dv = m.v[8]; S.v = m.v[9]; S.cg2 = m.v[10]; S.ir = m.v[11]; S.ico = m.v[12]; S.sth = m.v[13]; S.cth = m.v[14]; S.H0 = m.v[15]; S.K2 = m.v[16];
@@ -152,7 +115,8 @@ struct DuoLegEnd { double yn[6], dr_k, dr_g, dnu_r_ds, den; };
 // ------------------------------------------------------------------------------------------------
 // base wave
 // ------------------------------------------------------------------------------------------------
-// V: bit 0 = the aux wave prefetches its next message, bit 1 = the base wave reads the consumed count early, bit 2 = the four stages unrolled
+// V: 2 = the shipped hand-off (the base wave reads the consumed count early); 32, 64 (| 2): timing diagnostics - the base wave alone without
+// any message / messages consumed but nothing computed from them (records NOT valid): what the ray costs, what the hand-off costs
 template <int V>
 DEVINL void duo_base(const GeoacDevParams& P, const double* tab13, DuoPort& pt, int col, int slot, bool mine, bool done0, unsigned long long& steps_out, bool& done_out){
     using EQ = EqGlobal<true>;
@@ -162,7 +126,8 @@ DEVINL void duo_base(const GeoacDevParams& P, const double* tab13, DuoPort& pt, 
     double y[6];
     #pragma unroll
     for(int e = 0; e < 6; e++) y[e] = st[(ST_Y0 + e) * np];
-    long long k = (long long)st[ST_K * np];
+    int k = (int)st[ST_K * np];
+    const int k_lim = (int)(P.step_limit - 1);
     int leg = (int)st[ST_LEG * np];
     double hmax = st[ST_HMAX * np];
     RayCtx C; C.ckey = -1; C.kxy = -1;
@@ -171,6 +136,7 @@ DEVINL void duo_base(const GeoacDevParams& P, const double* tab13, DuoPort& pt, 
     for(int q = 0; q < 6; q++) C.a[q] = st[(ST_AUX0 + q) * np];
     EQ::resume(P, C, y);
     int seg = (int)st[ST_SEG * np] * 13;
+    seg_fetch<13>(tab13, seg, C.rec);
     int nr = 0, nle = 0;
     unsigned long long steps_here = 0;
     auto put_row = [&](int row, const double* v){
@@ -194,9 +160,7 @@ DEVINL void duo_base(const GeoacDevParams& P, const double* tab13, DuoPort& pt, 
             // running turning height (GeoAcGlobal_main.cpp:294) and GeoAc_Set_ds (Global.cpp:210-217)
             const double h = EQ::height(P, y);
             hmax = (hmax < h) ? h : hmax;
-            ds = 0.05 - 0.049 * exp(-EQ::above_ground(P, y) / 0.75);
-            ds = (P.ds_max < ds) ? P.ds_max : ds;
-            ds = (ds < P.ds_min) ? P.ds_min : ds;
+            ds = set_ds(EQ::above_ground(P, y), P.ds_min, P.ds_max);
         }
         // header of the step: what the previous step ended with, whether this lane takes the step, its ds
         if(!(V & 32)){
@@ -217,43 +181,46 @@ DEVINL void duo_base(const GeoacDevParams& P, const double* tab13, DuoPort& pt, 
         double dy[6], yt[6], yn[6];
         #pragma unroll
         for(int e = 0; e < 6; e++){ yt[e] = y[e]; yn[e] = y[e]; }
+        const double ds_2 = 0.5 * ds, ds_6 = (1.0 / 6.0) * ds, ds_3 = (1.0 / 3.0) * ds;
         auto peek_hook = [&](){ if(V & 2) peek = duo_peek_ack(pt); };
         auto stage_body = [&](int stage, auto rot0){
             GlobalStage S;
-            global_base<true, 13, const double*, decltype(peek_hook), decltype(rot0)::value>(tab13, P, seg, yt, C.cur[0], C.cur[1], yt[1] - y[1], dy, S, peek_hook);
+            global_base<true, 13, const double*, decltype(peek_hook), decltype(rot0)::value>(tab13, P, seg, C.rec, yt, C.cur[0], C.cur[1], yt[1] - y[1], dy, S, peek_hook);
             if(!(V & 32)){
                 if(V & 2) duo_wait_free_peeked(pt, peek); else duo_wait_free(pt);
                 duo_put_stage(pt, S);
                 duo_publish(pt);
             }
-            const double wa = ((stage == 2) ? 1.0 : 0.5) * ds;
-            const double wb = ((stage == 0 || stage == 3) ? (1.0 / 6.0) : (1.0 / 3.0)) * ds;
+            if(V & 128){                                          // (timing diagnostic: the stage values to global memory instead - what a base kernel
+                double* g = P.contrib + (size_t)(stage * 18) * np + col;   //  whose derivative systems are integrated by a LATER kernel would cost; one slot per stage, rewritten)
+                const double v[17] = { S.n0, S.n1, S.n2, S.inm, S.cn, S.icg, S.dc, S.du, S.dv, S.v, S.cg2, S.ir, S.ico, S.sth, S.cth, S.H0, S.K2 };
+                #pragma unroll
+                for(int f = 0; f < 17; f++) g[(size_t)f * np] = v[f];
+            }
+            const double wa = (stage == 2) ? ds : ds_2;
+            const double wb = (stage == 0 || stage == 3) ? ds_6 : ds_3;
             #pragma unroll
             for(int e = 0; e < 6; e++){
                 yn[e] = __builtin_fma(dy[e], wb, yn[e]);
                 yt[e] = __builtin_fma(dy[e], wa, y[e]);
             }
         };
-        if(V & 4){
-            stage_body(0, std::true_type()); stage_body(1, std::false_type()); stage_body(2, std::false_type()); stage_body(3, std::false_type());
-        } else {
-            #pragma unroll 1
-            for(int stage = 0; stage < 4; stage++) stage_body(stage, std::false_type());
-        }
+        #pragma unroll 1
+        for(int stage = 0; stage < 4; stage++) stage_body(stage, std::false_type());
 
         if(act){
             k++; steps_here++;
             put_row(nr++, yn);
             bool brk, gnd;
             EQ::checks(P, C, y, yn, k, brk, gnd);
-            const bool lim = (k >= P.step_limit - 1);
+            const bool lim = (k >= k_lim);
             if(V & 2) peek = duo_peek_ack(pt);                    // (for the next step's header, ~100 instructions from here)
             if(brk || gnd || lim){
                 // ---- leg end: the ray's part of the record (GeoAcGlobal_main.cpp:293-317); the aux wave adds the rest ----
                 double* R = P.rec + ((size_t)(P.perm ? P.perm[slot] : slot) * (P.bounces + 1) + leg) * GEOAC_REC_STRIDE;
                 R[GEOAC_REC_STEPS] = (double)((lim && !brk && !gnd) ? k + 1 : k);
                 P.legend[(size_t)nle * np + col] = nr - 1; nle++;
-                if(lim && !brk && !gnd) atomicOr(&P.counters[2], 1ull);
+                if(lim && !brk && !gnd){ atomicOr(&P.counters[2], 1ull); steps_here++; }
                 #pragma unroll
                 for(int e = 0; e < 6; e++){ R[GEOAC_REC_STATE + e] = yn[e]; L.yn[e] = yn[e]; }
                 if(brk){
@@ -261,6 +228,7 @@ DEVINL void duo_base(const GeoacDevParams& P, const double* tab13, DuoPort& pt, 
                     done = true; ev = DUO_EV_BRK;
                 } else {
                     R[GEOAC_REC_VALID] = 1.0;
+                    if(lim && !gnd){ const double hl = EQ::height(P, yn); hmax = (hmax < hl) ? hl : hmax; }   // (as k_rk4)
                     R[GEOAC_REC_TURN] = hmax;
                     EqGlobal<false>::arrival(P, C, slot, yn, R);          // inclination, back azimuth, range: the ray alone
                     if(leg >= P.bounces){
@@ -327,7 +295,6 @@ DEVINL void duo_aux(const GeoacDevParams& P, DuoPort& pt, int col, int slot, boo
         if(mm.v[0] == 1.2345e300) P.counters[31] = 1ull;        // (keeps the reads alive)
         return;
     }
-    constexpr bool PF = (V & 1) != 0;
     const size_t np = (size_t)P.n_pad;
     double* st = P.state + (mine ? slot : 0);
     double y[12], yn[12];
@@ -338,12 +305,7 @@ DEVINL void duo_aux(const GeoacDevParams& P, DuoPort& pt, int col, int slot, boo
     C.c0 = st[ST_C0 * np]; C.nu0 = st[ST_NU0 * np];
     bool prev_act = false;
     DuoMsg m;
-    int seen = 0;
-    bool in_hand = false;
-    auto recv = [&](){                                           // the next message into m (already there when a prefetch was committed)
-        if(PF){ duo_take_committed(pt, in_hand, m); in_hand = false; }
-        else { duo_wait_msg(pt); duo_read(pt, m); duo_consumed(pt); }
-    };
+    auto recv = [&](){ duo_wait_msg(pt); duo_read(pt, m); duo_consumed(pt); };   // the next message into m
 
     for(;;){
         recv();                                                  // header of the step
@@ -397,6 +359,7 @@ DEVINL void duo_aux(const GeoacDevParams& P, DuoPort& pt, int col, int slot, boo
         double yt[12];
         #pragma unroll
         for(int e = 0; e < 12; e++){ yt[e] = y[e]; yn[e] = y[e]; }
+        const double ds_2 = 0.5 * ds, ds_6 = (1.0 / 6.0) * ds, ds_3 = (1.0 / 3.0) * ds;
         auto stage_body = [&](int stage){
             recv();
             GlobalStage S;
@@ -405,22 +368,17 @@ DEVINL void duo_aux(const GeoacDevParams& P, DuoPort& pt, int col, int slot, boo
             global_derive(S, D);
             double dy[12];
             global_aux(S, D, yt, dy);
-            if(PF) duo_prefetch(pt, seen, m);                    // the next stage's message (after the last stage: the next step's header) ...
             global_aux(S, D, yt + 6, dy + 6);
-            if(PF) duo_commit(pt, seen, in_hand);                // ... taken and acknowledged one system later if it was there
-            const double wa = ((stage == 2) ? 1.0 : 0.5) * ds;
-            const double wb = ((stage == 0 || stage == 3) ? (1.0 / 6.0) : (1.0 / 3.0)) * ds;
+            const double wa = (stage == 2) ? ds : ds_2;
+            const double wb = (stage == 0 || stage == 3) ? ds_6 : ds_3;
             #pragma unroll
             for(int e = 0; e < 12; e++){
                 yn[e] = __builtin_fma(dy[e], wb, yn[e]);
                 yt[e] = __builtin_fma(dy[e], wa, y[e]);
             }
         };
-        if(V & 4){ stage_body(0); stage_body(1); stage_body(2); stage_body(3); }
-        else {
-            #pragma unroll 1
-            for(int stage = 0; stage < 4; stage++) stage_body(stage);
-        }
+        #pragma unroll 1
+        for(int stage = 0; stage < 4; stage++) stage_body(stage);
     }
     if(mine && !done0){
         #pragma unroll
@@ -460,8 +418,6 @@ __global__ void __launch_bounds__(256, 1) k_rk4_duo(GeoacDevParams P){
     __syncthreads();
     DuoPort pt;
     pt.slot = slots + pr * GEOAC_DUO_SLOT_BYTES; pt.seq = ctl + 8 * pr; pt.ack = ctl + 8 * pr + 4; pt.n = 0; pt.lane = lane; pt.dead = false;
-    pt.prof = (V & 8) != 0; pt.t_wait = 0; pt.n_spin = 0;
-    const long long t_start = (V & 8) ? clock64() : 0;
     if(is_base){
         unsigned long long steps_here = 0; bool done = true;
         duo_base<V>(P, lds_tab, pt, col, slot, mine, done0, steps_here, done);
@@ -478,13 +434,6 @@ __global__ void __launch_bounds__(256, 1) k_rk4_duo(GeoacDevParams P){
         duo_aux<V>(P, pt, col, slot, mine, done0);
     }
     if(pt.dead && lane == 0) atomicOr(&P.counters[2], 8ull);    // a hand-off timed out: the host reports the fan as failed
-    if((V & 8) && lane == 0){                                     // [16..18] base: ticks in the kernel, ticks waiting, messages that had to wait; [19..21] aux; [22] messages
-        const int o = is_base ? 16 : 19;
-        atomicAdd(&P.counters[o], (unsigned long long)(clock64() - t_start));
-        atomicAdd(&P.counters[o + 1], (unsigned long long)pt.t_wait);
-        atomicAdd(&P.counters[o + 2], (unsigned long long)pt.n_spin);
-        if(is_base) atomicAdd(&P.counters[22], (unsigned long long)pt.n);
-    }
 }
 
 #endif  // GEOAC_DUO_H_

@@ -86,6 +86,15 @@ DEVINL double fexp10(double y){
     r = __builtin_fma(-k, 3.69423907715893078616e-13, r);
     return __builtin_ldexp(exp_poly(r * 2.30258509299404568402e+00), (int)k);
 }
+// GeoAc_Set_ds (Global.cpp:210-217 and twins): 0.05 - 0.049 exp(-h / 0.75), clamped to [ds_min, ds_max]; h = height above the ground.
+// -h / 0.75 as a product with the double next to -4/3 (the quotient differs by at most one unit in the last place; the IEEE division
+// expansion is twelve instructions and a transcendental seed on the serial chain of every step)
+DEVINL double set_ds(double h, double ds_min, double ds_max){
+    const double e = fexp(h * (-1.0 / 0.75));
+    const double ds = 0.05 - 0.049 * e;
+    return __builtin_fmax(__builtin_fmin(ds, ds_max), ds_min);
+}
+
 // rotate (sin a, cos a) by a small angle d.  |d| <= ds_max / r_earth < 1e-4 for every caller (one RK4 stage or step of at most
 // 0.5 km at r >= 6370 km), so sin d = d (1 - d^2/6), cos d = 1 - d^2/2 (1 - d^2/12) are exact to < 1e-17 relative
 DEVINL void rot_small(double sa, double ca, double d, double& s, double& c){
@@ -216,8 +225,40 @@ DEVINL void seg_step_eval(TabPtr tab, const GeoacDevParams& P, double x, int& of
     seg_fetch(tab, off, r);
     seg_resolve(tab, P, x, off, r, a);
 }
+// RK4-stage lookup with the record kept in registers (r[14], filled by seg_fetch when the ray's state is loaded): a ray stays inside a segment
+// for many stages (<= 50 m per stage against ~100 m between nodes; tens of steps for the shallow rays that set a fan's run time), so the usual
+// stage touches no memory at all - the bounds are in hand - and the divergent re-fetch happens once per segment crossing
+// the two halves of it: make r the record of the segment x lies in (the rare, divergent part) / evaluate it
+template <int W = GEOAC_SEGW, typename TabPtr>
+DEVINL void seg_locate(TabPtr tab, const GeoacDevParams& P, double x, int& off, double* r){
+    const int last = (P.nseg - 1) * W;
+    const bool up = (x > r[1]) & (off < last), down = (x < r[0]) & (off > 0);
+    if(up | down){
+        off += (up ? W : 0) - (down ? W : 0);
+        if(!P.seg_safe){
+            const auto* p = tab + off;
+            const double x0 = p[0], x1 = p[W == GEOAC_SEGW ? 1 : 13];
+            if(((x < x0) & (off > 0)) | ((x > x1) & (off < last))){
+                int k = off / W;
+                k = k < 0 ? 0 : (k > P.nseg - 1 ? P.nseg - 1 : k);
+                while(k > 0 && x < tab[k * W]) k--;
+                while(k < P.nseg - 1 && x > tab[k * W + (W == GEOAC_SEGW ? 1 : 13)]) k++;
+                off = k * W;
+            }
+        }
+        seg_fetch<W>(tab, off, r);
+    }
+}
+template <int W = GEOAC_SEGW, typename TabPtr>
+DEVINL void seg_cached_eval(TabPtr tab, const GeoacDevParams& P, double x, int& off, double* r, Atm9& a){
+    seg_locate<W>(tab, P, x, off, r);
+    seg_eval_at(r, x, a);
+}
 
 DEVINL double clampd(double x, double lo, double hi){ double e = (hi < x) ? hi : x; return (e < lo) ? lo : e; }
+// the same through v_min_f64 / v_max_f64 (two instructions instead of six; no NaN reaches it): the stage abscissa of the 1-D kernels.  The grid
+// kernels keep the select form: min / max canonicalise operands that come straight from memory, and those kernels have no register to spare
+DEVINL double clampq(double x, double lo, double hi){ return __builtin_fmax(__builtin_fmin(x, hi), lo); }
 
 // first guess of the segment index for an arbitrary x (uniform-grid guess + walk)
 template <typename TabPtr>
@@ -252,30 +293,24 @@ struct GlobalStage { double n0, n1, n2, inm, cn, icg, dc, du, dv, v, cg2, ir, ic
 struct NoHook { DEVINL void operator()() const {} };
 // HOOK: called once the segment record has arrived (k_rk4_duo reads the consumed-message counter there, so that the answer is back
 // when the stage's message is published); ROT0: stage 0 of a step - the stage latitude IS the step's, no rotation (bit-identical to a rotation by 0)
-template <bool AMP, int W, typename TabPtr, class HOOK = NoHook, bool ROT0 = false>
-DEVINL void global_base(TabPtr tab, const GeoacDevParams& P, int& seg, const double* y, double sth0, double cth0, double dlat, double* dy, GlobalStage& S, const HOOK& hook = HOOK()){
+// LOCATED: rec already is the record of the stage's segment (seg_locate done by the caller: the skewed stage loop of k_rk4)
+template <bool AMP, int W, typename TabPtr, class HOOK = NoHook, bool ROT0 = false, bool LOCATED = false>
+DEVINL void global_base(TabPtr tab, const GeoacDevParams& P, int& seg, double* rec, const double* y, double sth0, double cth0, double dlat, double* dy, GlobalStage& S, const HOOK& hook = HOOK()){
     const double r = y[0];
     const double n0 = y[3], n1 = y[4], n2 = y[5];
-    const double xe = clampd(r, P.x_min, P.x_max);
-    double rec[14];
-    seg_fetch<W>(tab, seg, rec);                                 // LDS loads in flight while the table-independent terms are formed
-    __builtin_amdgcn_sched_barrier(0);                           // (the scheduler would otherwise issue them after that arithmetic)
+    const double xe = clampq(r, P.x_min, P.x_max);
     double sth, cth;
     if(ROT0){ sth = sth0; cth = cth0; }
     else rot_small(sth0, cth0, dlat, sth, cth);                  // sin / cos of the stage latitude from the step's (stage 0: zero angle, exact identity)
     // |nu|   (Global.cpp:249)
     const double nn  = __builtin_fma(n0, n0, __builtin_fma(n1, n1, n2 * n2));
     const double inm0 = frsq(nn);
-    double ir  = frcp(r);
-    double ico = frcp(cth);
-    double inm_ = inm0;
-    // pin these table-independent values HERE, ahead of the bounds check: left alone the compiler sinks them below the (rarely
-    // taken) re-fetch branch and the wave then sits out the LDS round trip with nothing to issue
-    asm volatile("" : "+v"(ir), "+v"(ico), "+v"(inm_), "+v"(sth), "+v"(cth));
+    const double ir  = frcp(r);
+    const double ico = frcp(cth);
     Atm9 a;
-    seg_resolve<W>(tab, P, xe, seg, rec, a);
+    if(LOCATED) seg_eval_at(rec, xe, a); else seg_cached_eval<W>(tab, P, xe, seg, rec, a);
     hook();
-    const double inm = inm_, numag = nn * inm;
+    const double inm = inm0, numag = nn * inm;
     const double u = a.u, v = a.v, du = a.du, dv = a.dv;
 
     // c = sqrt(gamR T), c' = gamR/(2c) T'                      (G2S_GlobalSpline1D.cpp:345-356)
@@ -376,9 +411,9 @@ DEVINL void global_aux(const GlobalStage& S, const GlobalDerived& D, const doubl
 // NQ = number of launch-angle derivative systems carried in y after the 6 base components: 2 = the reference layout
 // (theta then phi), 1 = the two-lanes-per-ray kernel where each lane of a pair carries the base ray and ONE of the two systems.
 template <bool AMP, int NQ, typename TabPtr>
-DEVINL void global_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const double* y, double sth0, double cth0, double dlat, double* dy){
+DEVINL void global_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, double* rec, const double* y, double sth0, double cth0, double dlat, double* dy){
     GlobalStage S;
-    global_base<AMP, GEOAC_SEGW>(tab, P, seg, y, sth0, cth0, dlat, dy, S);
+    global_base<AMP, GEOAC_SEGW>(tab, P, seg, rec, y, sth0, cth0, dlat, dy, S);
     if(AMP){
         GlobalDerived D;
         global_derive(S, D);
@@ -609,6 +644,7 @@ struct RayCtx {
     double t[4];      // Global: proposed sin/cos for the row under test
     double cur[4];    // Global (stratified): sin/cos(lat), sin/cos(lon - lon_src) of the current row - a[] then holds the REFERENCE point they are
                       // rotated from: lat_ref, sin, cos, (lon - lon_src)_ref, sin, cos (EqGlobal::checks)
+    mutable double rec[GEOAC_SEGW];   // 1-D sets: the spline record of the segment the ray is in (x0, x1, cubics of T, u, v), seg_cached_eval
     mutable int ckey; // record-cache kernels: (segment, node) key of the records this lane holds in LDS (-1: none)
     mutable int kxy;  // grid sets: horizontal cell of the previous evaluation, kx << 16 | ky (-1: none), grid_locate's hint
     mutable double cell[4];   // and its node coordinates X1, X2, Y1, Y2
@@ -618,9 +654,9 @@ template <bool AMP, int NQ = 2, typename TabPtr = const double*>
 DEVINL void cart3_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y, double* dy, int q0 = 0){
     const double nz = y[3];
     const double nx = C.a[0], ny = C.a[1];
-    const double xe = clampd(y[2], P.x_min, P.x_max);
+    const double xe = clampq(y[2], P.x_min, P.x_max);
     Atm9 a;
-    seg_step_eval(tab, P, xe, seg, a);
+    seg_cached_eval(tab, P, xe, seg, C.rec, a);
     const double u = a.u, v = a.v, du = a.du, dv = a.dv;
     const double qT = kGamR * a.T;
     const double ic = frsq(qT);
@@ -663,9 +699,9 @@ template <bool AMP, typename TabPtr>
 DEVINL void cart2_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y, double* dy){
     const double nz = y[2];
     const double cph = C.a[0], sph = C.a[1], cth = C.a[2], sth = C.a[3];
-    const double xe = clampd(y[1], P.x_min, P.x_max);
+    const double xe = clampq(y[1], P.x_min, P.x_max);
     Atm9 a;
-    seg_step_eval(tab, P, xe, seg, a);
+    seg_cached_eval(tab, P, xe, seg, C.rec, a);
     const double qT = kGamR * a.T;
     const double ic = frsq(qT);
     const double c  = qT * ic;
@@ -696,6 +732,8 @@ DEVINL void cart2_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCt
 // ================================================================================================
 template <bool AMP_> struct EqGlobal {
     static constexpr bool AMP = AMP_;
+    static constexpr bool SEG1D = true;                             // the ray keeps the spline record of its segment in registers (RayCtx::rec)
+    static constexpr int AUX_SAVE = 6;                              // entries of RayCtx::a the RK4 kernel changes (the reference point of the carried sin / cos)
     static constexpr bool COOP = false; static constexpr bool CACHE = false; static constexpr bool LDS_STATE = false; static constexpr int XCHG_BYTES = 0; static constexpr bool PP_TILE = false; static constexpr bool PP_DEDUP = false; static constexpr int SYS_SHIFT = 0; static constexpr bool ROW_SPLIT = false;
     static constexpr int PP_WAVES = 3;                              // post-pass waves per SIMD (168 registers; at 128 it spills 148 B and runs 1.5 x slower)
     static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 0, LANES = 1;
@@ -745,10 +783,10 @@ template <bool AMP_> struct EqGlobal {
     }
     template <typename TabPtr>
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
-        global_rhs<AMP, 2>(tab, P, seg, yt, C.cur[0], C.cur[1], yt[1] - y0[1], dy);
+        global_rhs<AMP, 2>(tab, P, seg, C.rec, yt, C.cur[0], C.cur[1], yt[1] - y0[1], dy);
     }
     // GeoAc_BreakCheck / GeoAc_GroundCheck on the new row (Global.cpp:500-522)
-    static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, long long k, bool& brk, bool& gnd){
+    static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, int k, bool& brk, bool& gnd){
         const double lon0 = P.src[2] * kPi / 180.0;
         const double dl = yn[1] - C.a[0], pl = yn[2] - lon0, dp = pl - C.a[3];
         if(fabs(dl) > GEOAC_ROT_MAX){ C.a[0] = yn[1]; fsincos(yn[1], C.a[1], C.a[2]); C.t[0] = C.a[1]; C.t[1] = C.a[2]; }   // (rare, per ray)
@@ -864,7 +902,7 @@ struct EqGlobalPair : EqGlobal<true> {
     static constexpr bool SPLIT = true; static constexpr bool ROW_SPLIT = true;      // (the two lanes also store half a path row each)
     template <typename TabPtr>
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
-        global_rhs<true, 1>(tab, P, seg, yt, C.cur[0], C.cur[1], yt[1] - y0[1], dy);
+        global_rhs<true, 1>(tab, P, seg, C.rec, yt, C.cur[0], C.cur[1], yt[1] - y0[1], dy);
     }
     // reflection of the base ray and of this lane's derivative system (Global.cpp:140-205, Q1 linear intercept)
     static DEVINL void reflect(const GeoacDevParams& P, const RayCtx& C, const double* yn, double* y, const double* ym2){
@@ -902,6 +940,8 @@ struct EqGlobalPair : EqGlobal<true> {
 
 // Range-dependent Cartesian set (GeoAc3D.RngDep): EquationSets.3DRngDep.cpp + G2S_MultiDimSpline3D.cpp
 template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struct Eq3DRngDep {
+    static constexpr bool SEG1D = false;
+    static constexpr int AUX_SAVE = 0;
     static constexpr bool CACHE = CACHE_;                           // NL_ = 4, small fans: per-lane record cache and z nodes in LDS (grid_cache_fill)
     static constexpr bool AMP = AMP_;
     static constexpr bool COOP = COOP_;                             // wave-cooperative record gather through LDS (grid_eval3_glds / _coop8): NL_ = 1, every lane of the wave stays in the loop
@@ -957,7 +997,7 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
         rngdep_rhs<AMP, NL_, COOP_, CACHE_>(P, seg, yt, dy, (int)(threadIdx.x & (NL_ - 1)), (char*)tab, &C.ckey, &C.kxy, GEOAC_CELL_REGS(C));
     }
     // 3DRngDep.cpp:451-472
-    static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, long long k, bool& brk, bool& gnd){
+    static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, int k, bool& brk, bool& gnd){
         brk = (yn[0] > P.xy_lim[1]) || (yn[0] < P.xy_lim[0]) || (yn[1] > P.xy_lim[3]) || (yn[1] < P.xy_lim[2]) || (yn[2] > P.vert_limit);
         gnd = yn[2] < P.ground;
     }
@@ -1083,6 +1123,8 @@ struct Eq3DRngDepOct : Eq3DRngDep<true, 4, false, true> {
 // Range-dependent spherical set (GeoAcGlobal.RngDep): EquationSets.GlobalRngDep.cpp + G2S_GlobalMultiDimSpline3D.cpp.
 // Grid axes in table order: x = latitude, y = longitude [rad], z = geocentric radius; xy_lim = lat/lon box of the break check.
 template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struct EqGlobalRngDep {
+    static constexpr bool SEG1D = false;
+    static constexpr int AUX_SAVE = 2;                              // sin / cos of the latitude, carried along the ray
     static constexpr bool CACHE = CACHE_;
     static constexpr bool AMP = AMP_;
     static constexpr bool COOP = COOP_;
@@ -1093,7 +1135,7 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
     static constexpr int SYS_SHIFT = 0; static constexpr bool ROW_SPLIT = false;
     static constexpr bool LDS_STATE = true;
     static constexpr int NB = 6, NS = 6;
-    static constexpr int PP_WAVES = 3;
+    static constexpr int PP_WAVES = 2;                                 // post-pass at two waves per SIMD: 0 scratch (168 registers spill 108 B: the absorption integrand AND its ground-level reference state)
     static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 0, LANES = NL_;
     static constexpr bool SPLIT = false;
     static constexpr bool KM2 = false, KM2_MEM = false, HMAX_PER_LEG = true;         // linear intercept (Q1, GlobalRngDep.cpp:147-148); turning height per leg (Q8)
@@ -1136,7 +1178,7 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
         globalrd_rhs<AMP, NL_, COOP_, CACHE_>(P, seg, yt, s2, c2, dy, (int)(threadIdx.x & (NL_ - 1)), (char*)tab, &C.ckey, &C.kxy, GEOAC_CELL_REGS(C));
     }
     // GeoAc_BreakCheck / GeoAc_GroundCheck: GlobalRngDep.cpp:523-545
-    static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, long long k, bool& brk, bool& gnd){
+    static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, int k, bool& brk, bool& gnd){
         if((k & 63) == 0) fsincos(yn[1], C.t[0], C.t[1]);          // periodic exact re-sync
         else rot_small(C.a[0], C.a[1], yn[1] - y[1], C.t[0], C.t[1]);
         brk = (yn[0] > P.vert_limit) || (yn[1] < P.xy_lim[0]) || (yn[1] > P.xy_lim[1]) || (yn[2] < P.xy_lim[2]) || (yn[2] > P.xy_lim[3]);
@@ -1272,6 +1314,8 @@ struct EqGlobalRngDepOct : EqGlobalRngDep<true, 4, false, true> {
 #pragma clang fp contract(off)           // stratified sets again
 template <bool AMP_> struct Eq3D {
     static constexpr bool AMP = AMP_;
+    static constexpr bool SEG1D = true;
+    static constexpr int AUX_SAVE = 0;                              // (nu_x, nu_y and their launch-angle derivatives: constants of the ray)
     static constexpr bool COOP = false; static constexpr bool CACHE = false; static constexpr bool LDS_STATE = false; static constexpr int XCHG_BYTES = 0; static constexpr bool PP_TILE = false; static constexpr bool PP_DEDUP = false; static constexpr int SYS_SHIFT = 0; static constexpr bool ROW_SPLIT = false;
     static constexpr int PP_WAVES = 4;                              // post-pass at four waves per SIMD (127 registers, 52 B of spill): GeoAc3D 360 x 90 fan 185 -> 168 ms
     static constexpr int E = AMP_ ? 12 : 4, PW = 4, HIDX = 2, LANES = 1;
@@ -1310,7 +1354,7 @@ template <bool AMP_> struct Eq3D {
         cart3_rhs<AMP>(tab, P, seg, C, yt, dy);
     }
     // 3DStratified.cpp:327-343
-    static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, long long k, bool& brk, bool& gnd){
+    static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, int k, bool& brk, bool& gnd){
         double r = sqrt(yn[0] * yn[0] + yn[1] * yn[1]);
         brk = (yn[2] > P.vert_limit) || (r > P.range_limit);
         gnd = yn[2] < P.ground;
@@ -1433,6 +1477,8 @@ struct Eq3DPair : Eq3D<true> {
 
 template <bool AMP_> struct Eq2D {
     static constexpr bool AMP = AMP_;
+    static constexpr bool SEG1D = true;
+    static constexpr int AUX_SAVE = 0;
     static constexpr bool COOP = false; static constexpr bool CACHE = false; static constexpr bool LDS_STATE = false; static constexpr int XCHG_BYTES = 0; static constexpr bool PP_TILE = false; static constexpr bool PP_DEDUP = false; static constexpr int SYS_SHIFT = 0; static constexpr bool ROW_SPLIT = false;
     static constexpr int NB = 3, NS = 3;
     static constexpr int PP_WAVES = 4;
@@ -1458,7 +1504,7 @@ template <bool AMP_> struct Eq2D {
         cart2_rhs<AMP>(tab, P, seg, C, yt, dy);
     }
     // 2DStratified.cpp:194-212
-    static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, long long k, bool& brk, bool& gnd){
+    static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, int k, bool& brk, bool& gnd){
         brk = (yn[1] > P.vert_limit) || (yn[0] > P.range_limit);
         gnd = yn[1] < P.ground;
     }
@@ -1576,9 +1622,9 @@ template <class EQ, bool S = EQ::SPLIT> struct ArrivalOf { static DEVINL void go
 template <class EQ> struct ArrivalOf<EQ, true> { static DEVINL void go(const GeoacDevParams& P, const RayCtx& C, int slot, const double* y, double* R){ EQ::Full::arrival(P, C, slot, y, R); } };
 template <class EQ> DEVINL void arrival_of(const GeoacDevParams& P, const RayCtx& C, int slot, const double* y, double* R){ ArrivalOf<EQ>::go(P, C, slot, y, R); }
 
+// one path row: `p` = this lane's address of the row (component 0; k_rk4 keeps it as a running pointer, one row further per call)
 template <class EQ>
-DEVINL void write_row(const GeoacDevParams& P, int row, int col, int q, const double* y){
-    double* p = P.path + ((size_t)row * EQ::PW) * P.n_pad + col;
+DEVINL void write_row(const GeoacDevParams& P, double* p, int q, const double* y){
     if(!EQ::ROW_SPLIT && EQ::LANES > 1 && q != 0) return;   // multi-lane grid kernels: the lanes hold the same row, lane 0 stores it
     if(EQ::ROW_SPLIT){                    // pair kernels: each lane stores half of the row (Global: r, lat, lon | nu_r, nu_t, nu_p; 3D: x, y | z, nu_z)
         constexpr int H = EQ::PW / 2;
@@ -1685,7 +1731,8 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
         #pragma unroll
         for(int e = 0; e < E; e++) ym2[e] = st[(ST_YM2 + ((EQ::SPLIT && e >= EQ::NB) ? e + EQ::NS * qs : e)) * np];
     }
-    long long k = (long long)st[ST_K * np];
+    int k = (int)st[ST_K * np];                                   // steps of the current leg (step_limit is clamped to 2^31 - 1 on the host)
+    const int k_lim = (int)(P.step_limit - 1);
     int leg = (int)st[ST_LEG * np];
     double hmax = st[ST_HMAX * np];
     RayCtx C;
@@ -1695,12 +1742,22 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
     for(int q = 0; q < 6; q++) C.a[q] = st[(ST_AUX0 + q) * np];
     EQ::resume(P, C, y);
     int seg = P.gtab ? (int)st[ST_SEG * np] : (int)st[ST_SEG * np] * GEOAC_SEGW;   // 1-D sets: element offset of the current spline segment; grid sets: vertical segment index
+    if constexpr (EQ::SEG1D){ if(LDS) seg_fetch(lds_tab, seg, C.rec); else seg_fetch(gtab, seg, C.rec); }
     unsigned long long steps_here = 0;
     int nev = (EQ::COOP && SMP && sub_h > 0 && !idle0) ? P.nev[col] : 0;   // WriteRays / WriteCaustics events of this chunk
     double dprev = SMP ? st[ST_DPREV * np] : 0.0;               // Jacobian of the previous row (caustic detection)
     const bool want_rays = SMP && (P.mode & GEOAC_MODE_WRITE_RAYS), want_caus = SMP && EQ::AMP && (P.mode & GEOAC_MODE_WRITE_CAUSTICS);
 
-    if(!EQ::COOP || (!idle0 && sub_h == 0)) write_row<EQ>(P, nr++, col, q, y);     // carry row: chunk row 0 = current state
+    // this lane's address of chunk row nr: a running pointer in the 1-D kernels (kept in step with nr), recomputed per row in the grid kernels
+    // (two registers they do not have)
+    const size_t row_stride = (size_t)EQ::PW * np;
+    double* prow = P.path + (size_t)nr * row_stride + col;
+    auto put_row = [&](const double* v){
+        if(EQ::SEG1D){ write_row<EQ>(P, prow, q, v); prow += row_stride; }
+        else write_row<EQ>(P, P.path + (size_t)nr * row_stride + col, q, v);
+        nr++;
+    };
+    if(!EQ::COOP || (!idle0 && sub_h == 0)) put_row(y);          // carry row: chunk row 0 = current state
 
     // COOP: wave-uniform loop (every lane stays while any lane of the wave has work; `act` predicates this lane's own work).
     // Other policies: the plain per-lane loop (kept in this form: the latency-bound stratified kernels are sensitive to how the loop is laid out)
@@ -1738,9 +1795,12 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
         }
 
         // ---- GeoAc_Set_ds (Global.cpp:210-217 and twins) ----
-        ds = 0.05 - 0.049 * exp(-EQ::above_ground(P, y) / 0.75);
-        ds = (P.ds_max < ds) ? P.ds_max : ds;
-        ds = (ds < P.ds_min) ? P.ds_min : ds;
+        if constexpr (EQ::SEG1D) ds = set_ds(EQ::above_ground(P, y), P.ds_min, P.ds_max);
+        else {                                                    // (grid kernels: the form they were tuned with - registers)
+            ds = 0.05 - 0.049 * exp(-EQ::above_ground(P, y) / 0.75);
+            ds = (P.ds_max < ds) ? P.ds_max : ds;
+            ds = (ds < P.ds_min) ? P.ds_min : ds;
+        }
         }
 
         // ---- the four RK4 stages as ONE rolled loop (a single copy of the RHS keeps the live set < 256 VGPRs):
@@ -1748,6 +1808,7 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
         double dy[E], yt[E], yn[E];
         #pragma unroll
         for(int e = 0; e < E; e++){ yt[e] = y[e]; yn[e] = y[e]; }
+        const double ds_2 = 0.5 * ds, ds_6 = (1.0 / 6.0) * ds, ds_3 = (1.0 / 3.0) * ds;     // (1-D sets: the products the stages used to form one by one)
         if(EQ::LDS_STATE){
             // the step's base row y and the accumulating new row yn live in LDS ([component][lane], conflict free) while the four stages
             // run: 72 registers less under the table evaluation, which is what spilled (416 B of scratch per lane before)
@@ -1759,8 +1820,9 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
             if(EQ::COOP) EQ::rhs((double*)ldsw, P, seg, C, y, yt, stage, dy);
             else if(EQ::CACHE) EQ::rhs((double*)ldsc, P, seg, C, y, yt, stage, dy);
             else if(LDS) EQ::rhs(lds_tab, P, seg, C, y, yt, stage, dy); else EQ::rhs(gtab, P, seg, C, y, yt, stage, dy);
-            const double wa = ((stage == 2) ? 1.0 : 0.5) * ds;
-            const double wb = ((stage == 0 || stage == 3) ? (1.0 / 6.0) : (1.0 / 3.0)) * ds;
+            // (grid sets: formed per stage - three doubles less to keep alive under the table evaluation)
+            const double wa = EQ::SEG1D ? ((stage == 2) ? ds : ds_2) : ((stage == 2) ? 1.0 : 0.5) * ds;
+            const double wb = EQ::SEG1D ? ((stage == 0 || stage == 3) ? ds_6 : ds_3) : ((stage == 0 || stage == 3) ? (1.0 / 6.0) : (1.0 / 3.0)) * ds;
             if(EQ::LDS_STATE){
                 #pragma unroll
                 for(int e = 0; e < E; e++){
@@ -1782,18 +1844,18 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
 
         if(!EQ::COOP || act){                                     // (a helper lane has nothing of its own to advance)
         k++; steps_here++;
-        write_row<EQ>(P, nr++, col, q, yn);
+        put_row(yn);
 
         bool brk, gnd;
         EQ::checks(P, C, y, yn, k, brk, gnd);
-        bool lim = (k >= P.step_limit - 1);                       // Solver.cpp loop bound; never reached on sane inputs
+        bool lim = (k >= k_lim);                                  // Solver.cpp loop bound; never reached on sane inputs
 
         if(brk || gnd || lim){
             // ---- leg end: record (GeoAcGlobal_main.cpp:293-317 and twins) ----
             double* R = P.rec + ((size_t)(P.perm ? P.perm[slot] : slot) * (P.bounces + 1) + leg) * GEOAC_REC_STRIDE;
             R[GEOAC_REC_STEPS] = (double)((lim && !brk && !gnd) ? k + 1 : k);   // exhausted loop: the reference returns step_limit (= k + 1), Solver.cpp:70
             P.legend[(size_t)nle * np + col] = nr - 1; nle++;
-            if(lim && !brk && !gnd) atomicOr(&P.counters[2], 1ull);
+            if(lim && !brk && !gnd){ atomicOr(&P.counters[2], 1ull); steps_here++; }   // (the step total is the sum of the reference's return values: step_limit for this leg)
             // the leg's last row solution[k][*] (both outcomes: arrival rows read it, and so do the eigenray scans' messages after a break)
             double yf[18];
             if(EQ::SPLIT){
@@ -1820,6 +1882,10 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
                 done = true;
             } else {
                 R[GEOAC_REC_VALID] = 1.0;
+                if(lim && !gnd){                                  // exhausted loop: the reference's row count is one more, its turning height covers the last row too
+                    const double hl = EQ::height(P, yn);
+                    if(!(EQ::PW == 2 && (P.mode & GEOAC_MODE_INTERACTIVE))) hmax = (hmax < hl) ? hl : hmax;
+                }
                 R[GEOAC_REC_TURN] = hmax;
                 arrival_of<EQ>(P, C, slot, EQ::SPLIT ? yf : yn, R);
                 if(leg >= P.bounces){
@@ -1833,7 +1899,7 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
                     } else EQ::reflect(P, C, yn, y, ym2);
                     leg++; k = 0;
                     EQ::restart(P, C, y);
-                    write_row<EQ>(P, nr++, col, q, y);               // leg-start row
+                    put_row(y);                                       // leg-start row
                 }
             }
         } else {
@@ -1863,7 +1929,7 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
     st[ST_K * np] = (double)k; st[ST_LEG * np] = (double)leg; st[ST_DONE * np] = done ? 1.0 : 0.0;
     st[ST_HMAX * np] = hmax; st[ST_SEG * np] = P.gtab ? (double)seg : (double)(seg / GEOAC_SEGW);
     #pragma unroll
-    for(int q = 0; q < 6; q++) st[(ST_AUX0 + q) * np] = C.a[q];
+    for(int q = 0; q < EQ::AUX_SAVE; q++) st[(ST_AUX0 + q) * np] = C.a[q];      // (only what the kernel changes: a value that is merely carried would sit in registers from entry to exit)
     P.nrows[col] = nr; P.nlegend[col] = nle;
     if(SMP){
         st[ST_DPREV * np] = dprev;
@@ -2053,7 +2119,7 @@ __global__ void __launch_bounds__(256) k_postpass_tab(GeoacDevParams P, int rows
             }
             PPGeom G;
             EQ::pp_geom(P, aux, A, B, G);
-            const double xe = clampd(G.x, P.x_min, P.x_max);
+            const double xe = clampq(G.x, P.x_min, P.x_max);
             if(!((xe >= rec[0]) & (xe <= rec[1]))){               // (also the first segment: rec[0] > rec[1])
                 k = seg_find(P.seg, P.nseg, xe, k < 0 ? (int)((xe - P.x_min) * P.seg_per_x) : k);
                 const double* p = P.seg + (size_t)k * GEOAC_SEGW;
@@ -2184,17 +2250,22 @@ __global__ void __launch_bounds__(256) k_accum(GeoacDevParams P){
             S[GEOAC_SMP_RAY] = (double)(P.perm ? P.perm[slot] : slot); S[GEOAC_SMP_LEG] = (double)leg; S[GEOAC_SMP_M] = (double)m; S[GEOAC_SMP_KIND] = (double)kind;
             double amp = P.ev_amp[(size_t)ev * np + col];
             double amp_db = P.calc_amp ? 20.0 * log10(amp) : 0.0;
-            double v[6] = {0, 0, 0, 0, 0, 0};
-            int np3;                                                   // number of position columns
-            if(P.eqset == GEOAC_EQ_GLOBAL || P.eqset == GEOAC_EQ_GLOBAL_RNGDEP){ v[0] = row[0] - P.r_earth; v[1] = row[np] * 180.0 / kPi; v[2] = row[2 * np] * 180.0 / kPi; np3 = 3; }
-            else if(P.eqset == GEOAC_EQ_3D){ v[0] = row[0]; v[1] = row[np]; double z = row[2 * np]; v[2] = (z < 0.0 ? 0.0 : z); np3 = 3; }   // max(z, 0) in both files (GeoAc3D_main.cpp:257,267)
-            else if(P.eqset == GEOAC_EQ_3D_RNGDEP){ v[0] = row[0]; v[1] = row[np]; double z = row[2 * np]; v[2] = (kind == 0) ? (z < 0.0 ? 0.0 : z) : z; np3 = 3;
-                                                    if(kind == 1){ v[3] = 0.0; np3 = 4; } }                 // caustic rows: raw z and a 0.0 column (GeoAc3D.RngDep_main.cpp:279-284)
-            else { v[0] = row[0]; double z = row[np]; v[1] = (kind == 0) ? (z < 0.0 ? 0.0 : z) : z; np3 = 2; }
-            if(kind == 0){ v[np3] = amp_db; v[np3 + 1] = -at; v[np3 + 2] = tt; }
-            else { v[np3] = tt; }
-            #pragma unroll
-            for(int q = 0; q < 6; q++) S[GEOAC_SMP_V0 + q] = v[q];
+            // position columns, then (raypath row) amplitude [dB], -attenuation, travel time or (caustic row) travel time - written out by case: a
+            // register array indexed by a run-time column count would live in scratch memory
+            double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0;
+            const bool sph = (P.eqset == GEOAC_EQ_GLOBAL || P.eqset == GEOAC_EQ_GLOBAL_RNGDEP);
+            if(P.eqset == GEOAC_EQ_2D){
+                v0 = row[0]; const double z = row[np]; v1 = (kind == 0) ? (z < 0.0 ? 0.0 : z) : z;
+                if(kind == 0){ v2 = amp_db; v3 = -at; v4 = tt; } else v2 = tt;
+            } else {
+                if(sph){ v0 = row[0] - P.r_earth; v1 = row[np] * 180.0 / kPi; v2 = row[2 * np] * 180.0 / kPi; }
+                else { v0 = row[0]; v1 = row[np]; const double z = row[2 * np];
+                       v2 = (P.eqset == GEOAC_EQ_3D || kind == 0) ? (z < 0.0 ? 0.0 : z) : z; }       // max(z, 0) in both files of GeoAc3D (GeoAc3D_main.cpp:257,267); RngDep caustic rows: raw z
+                if(kind == 0){ v3 = amp_db; v4 = -at; v5 = tt; }
+                else if(P.eqset == GEOAC_EQ_3D_RNGDEP){ v3 = 0.0; v4 = tt; }                         // caustic rows of GeoAc3D.RngDep: a 0.0 column (GeoAc3D.RngDep_main.cpp:279-284)
+                else v3 = tt;
+            }
+            S[GEOAC_SMP_V0 + 0] = v0; S[GEOAC_SMP_V0 + 1] = v1; S[GEOAC_SMP_V0 + 2] = v2; S[GEOAC_SMP_V0 + 3] = v3; S[GEOAC_SMP_V0 + 4] = v4; S[GEOAC_SMP_V0 + 5] = v5;
         }
         ev++;
     }
@@ -2436,16 +2507,11 @@ static hipError_t launch_rk4_duo(const GeoacDevParams* P, hipStream_t s, unsigne
         hipError_t err = hipFuncSetAttribute((const void*)k_rk4_duo<VV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if(err != hipSuccess) return err; \
         hipLaunchKernelGGL(k_rk4_duo<VV>, g, b, lds, s, *P); } while(0)
-    switch(P->duo){                              // A/B variants of the hand-off (geoac_duo.h); 8 = the shipped one
-        case 1: GEOAC_DUO_LAUNCH(0); break;
-        case 2: GEOAC_DUO_LAUNCH(1); break;
-        case 4: GEOAC_DUO_LAUNCH(3); break;
-        case 16: GEOAC_DUO_LAUNCH(8); break;     // (diagnostic: wait-time counters, variant 0 / variant 7)
-        case 17: GEOAC_DUO_LAUNCH(15); break;
-        case 32: GEOAC_DUO_LAUNCH(32); break;    // (timing diagnostics: base wave alone / messages consumed but not used - records are NOT valid)
-        case 64: GEOAC_DUO_LAUNCH(64); break;
+    switch(P->duo){
+        case 32: GEOAC_DUO_LAUNCH(32); break;    // (timing diagnostics, tools/perf_duo.py: the base wave alone / messages consumed but not used - records are NOT valid)
         case 66: GEOAC_DUO_LAUNCH(66); break;
-        default: GEOAC_DUO_LAUNCH(7); break;
+        case 160: GEOAC_DUO_LAUNCH(160); break;
+        default: GEOAC_DUO_LAUNCH(2); break;
     }
     #undef GEOAC_DUO_LAUNCH
     return hipGetLastError();

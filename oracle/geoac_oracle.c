@@ -287,6 +287,8 @@ int orc_load(orc_ctx* c, const char* met_file, const char* format){
 }
 
 void orc_limits(orc_ctx* c, double* vl, double* rl){ *vl = c->vert_limit; *rl = c->range_limit; }
+/* GeoAc_ray_limit (GeoAc.Parameters{,.Global}.cpp:23): the reference's step bound is ray_limit * int(1 / (10 ds_min)), GeoAc.Solver.cpp:14 */
+void orc_set_ray_limit(orc_ctx* c, double ray_limit){ c->ray_limit = ray_limit; }
 
 /* ------------------------------------------------------------------------------------------ */
 /* Atmo_State.h scalar API on the spline abscissa: G2S_Spline1D.cpp:321-416, Global twin :332-428 */

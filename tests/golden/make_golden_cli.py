@@ -19,6 +19,8 @@ CASES = {
     "2d": ("GeoAc2D", ["theta_min=5", "theta_max=35", "theta_step=15", "azimuth=-80", "bounces=1", "WriteCaustics=True"]),
     "global_norays": ("GeoAcGlobal", ["theta_min=5", "theta_max=45", "theta_step=8", "azimuth=37", "WriteRays=False", "CalcAmp=False",
                                       "lat_src=41.131", "lon_src=-112.896", "z_src=1.0", "freq=0.5", "rng_max=900"]),
+    # BASELINE config 1, the exact command: GeoAc2D -prop ToyAtmo.met theta_min=1 theta_max=10 theta_step=1 (10 rays, defaults otherwise)
+    "cfg1": ("GeoAc2D", ["theta_min=1", "theta_max=10", "theta_step=1"]),
     # range-dependent Cartesian main on the synthetic 5x5 grid (tests/rngdep_data.py): -prop p loc_x.dat loc_y.dat ...
     "3drd": ("GeoAc3D.RngDep", ["theta_min=10", "theta_max=30", "theta_step=20", "phi_min=-90", "phi_max=-45", "phi_step=45",
                                 "bounces=1", "WriteCaustics=True", "WriteAtmo=True", "x_src=50", "y_src=-30", "z_src=0.5"]),
@@ -36,6 +38,9 @@ EIG_CASES = {
     "eig_3d_direct": ("GeoAc3D", "-eig_direct", ["x_rcvr=-252", "y_rcvr=3", "theta_est=8.0", "bounces=0", "verbose=True"]),
     "eig_3drd": ("GeoAc3D.RngDep", "-eig_search", ["x_rcvr=-250", "y_rcvr=20", "theta_min=2", "theta_max=20", "bounces=0", "verbose=True"]),
     "eig_globalrd": ("GeoAcGlobal.RngDep", "-eig_search", ["lat_rcvr=31.0", "lon_rcvr=-2.65", "theta_min=2", "theta_max=20", "bounces=0", "verbose=True"]),
+    # -eig_direct of the two range-dependent mains (GeoAc3D.RngDep_main.cpp:593-660, GeoAcGlobal.RngDep_main.cpp:623-693): start from an estimate
+    "eig_3drd_direct": ("GeoAc3D.RngDep", "-eig_direct", ["x_rcvr=-252", "y_rcvr=23", "theta_est=4.5", "bounces=0", "verbose=True"]),
+    "eig_globalrd_direct": ("GeoAcGlobal.RngDep", "-eig_direct", ["lat_rcvr=31.02", "lon_rcvr=-2.67", "theta_est=5.0", "bounces=0", "verbose=True"]),
 }
 
 

@@ -137,6 +137,10 @@ class Oracle(_FanLib):
         assert m == n
         return dict(zip(("x", "T", "u", "v", "rho", "sT", "su", "sv", "srho"), a))
 
+    def set_ray_limit(self, ray_limit):
+        self.lib.orc_set_ray_limit.argtypes = [ctypes.c_void_p, ctypes.c_double]
+        self.lib.orc_set_ray_limit(self.ctx, float(ray_limit))
+
     def limits(self):
         a = ctypes.c_double(); b = ctypes.c_double()
         self.lib.orc_limits(self.ctx, ctypes.byref(a), ctypes.byref(b))

@@ -40,7 +40,7 @@ def _compare_files(got, want):
     return nsame, ntok
 
 
-@pytest.mark.parametrize("case", ["global", "3d", "2d", "global_norays", "3drd", "globalrd", "global+groups", "3drd+groups", "3drd+sub"])
+@pytest.mark.parametrize("case", ["global", "3d", "2d", "cfg1", "global_norays", "3drd", "globalrd", "global+groups", "3drd+groups", "3drd+sub"])
 def test_cli_files_match_reference_binaries(case, tmp_path):
     """"+groups": the same fan integrated one azimuth group at a time (the path large WriteRays fans take: bounded sample list, text of
     group g written while group g+1 is on the GPU) must give the same files.  "+sub": the launch plan of saturated grid fans forced on the

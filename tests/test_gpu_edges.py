@@ -90,3 +90,38 @@ def test_error_paths():
     grid_ctx = G.FanContext(G.EQ_3D_RNGDEP, device=0)
     with pytest.raises(G.GeoAcError):
         grid_ctx.load_met(H.TOYATMO)                                  # a 1-D profile is not an atmosphere for a grid set
+
+
+def test_step_limit_exhaustion_is_an_ordinary_leg_end():
+    """GeoAc_Propagate_RK4 stops after step_limit - 1 steps (GeoAc.Solver.cpp:14,25) and returns step_limit with check = false: the mains write the
+    leg as an arrival.  With ray_limit = 10 (step_limit = 1000, at most 50 km of path) no ray reaches the ground or the top: every leg's STEPS is the reference's 1000,
+    the launch succeeds, and the condition is reported through geoac_fan_status.  (The arrival row itself is not compared: the reference reads
+    the row solution[step_limit] it never wrote; here the leg ends on the last integrated row.)"""
+    import geoac_amd as G
+    th = np.array([3.0, 17.0, 40.0]); ph = np.array([-90.0, 20.0, 135.0])
+    ctx = _gpu(H.EQ_GLOBAL, bounces=0, calc_amp=1, ray_limit=10.0)
+    rec, steps = ctx.run(th, ph)
+    assert ctx.fan_status() & 1                                       # GEOAC_FAN_STEP_LIMIT
+    O = H.Oracle(H.EQ_GLOBAL)
+    O.set_ray_limit(10.0)
+    so, ro, _, _ = O.fan(H.make_cfg(H.EQ_GLOBAL, bounces=0, calc_amp=True), th, ph)
+    assert steps == so == 3 * 1000
+    for f in ("STEPS", "VALID", "BROKE"):
+        assert np.array_equal(rec[:, :, G.REC[f]], ro[:, :, H.REC[f]]), f
+    assert (rec[:, 0, G.REC["STEPS"]] == 1000).all() and (rec[:, 0, G.REC["VALID"]] == 1).all()
+    np.testing.assert_allclose(rec[:, 0, G.REC["TURN"]], ro[:, 0, H.REC["TURN"]], rtol=1e-9)
+    # an ordinary run on the same context afterwards: the flag is per launch
+    ctx.set_params(ray_limit=10000.0)
+    rec2, _ = ctx.run(th, ph)
+    assert ctx.fan_status() == 0 and (rec2[:, 0, G.REC["STEPS"]] > 1000).all()
+
+
+def test_event_list_overflow_is_reported(monkeypatch):
+    """the per-epoch list of raypath-sample / caustic rows of a ray holds s_rows / stride + a slack for the caustics; with the slack taken away
+    (GEOAC_EV_SLACK=0) a ray with caustics overflows it: the launch must fail with GEOAC_E_CAPACITY, not return a truncated table"""
+    import geoac_amd as G
+    monkeypatch.setenv("GEOAC_EV_SLACK", "0")
+    monkeypatch.setenv("GEOAC_S_ROWS", "64")
+    ctx = _gpu(H.EQ_GLOBAL, bounces=1, calc_amp=1, mode=1 | 2)     # GEOAC_MODE_WRITE_RAYS | GEOAC_MODE_WRITE_CAUSTICS
+    with pytest.raises(G.GeoAcError, match="event list overflowed|capacity"):
+        ctx.run(np.array([5.0, 12.0, 25.0]), np.array([-90.0, -90.0, -90.0]))

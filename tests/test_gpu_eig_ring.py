@@ -34,24 +34,30 @@ def _parse_results(path):
     return out
 
 
-def test_config5_rank0_receivers_vs_reference_binary(tmp_path):
+@pytest.mark.parametrize("which", ["rank0", "ranks1to7"])
+def test_config5_receivers_vs_reference_binary(tmp_path, which):
+    """rank0: the eight receivers rank 0 of the 8-GPU run searches (ring positions 0, 8, ..., 56; fixtures cfg5_r0..r7).  ranks1to7: the first
+    receiver of each of the other seven ranks (ring positions 1..7; fixtures cfg5_r8..r14), searched as one batch of seven."""
     import geoac_amd as G
     import rngdep_data as RD
-    rcv = _ring()
+    if which == "rank0":
+        rcv, names = _ring(), [f"cfg5_r{k}" for k in range(8)]
+    else:
+        rcv, names = _ring(every=1)[1:8], [f"cfg5_r{7 + r}" for r in range(1, 8)]
     # the receivers the fixtures were made for (ARGS hold the exact decimal strings the reference parsed)
     for k in range(len(rcv)):
-        args = open(os.path.join(CLI_GOLD, f"cfg5_r{k}", "ARGS")).read().split()
+        args = open(os.path.join(CLI_GOLD, names[k], "ARGS")).read().split()
         kv = dict(a.split("=") for a in args if "=" in a)
         assert float(kv["lat_rcvr"]) == rcv[k, 0] and float(kv["lon_rcvr"]) == rcv[k, 1]
     ctx = G.FanContext(G.EQ_GLOBAL_RNGDEP, device=0)
     ctx.load_grid(*RD.write_grid_global(str(tmp_path), short_paths=False))
     ctx.set_params(src=(0.0, 31.0, 0.0))
     out = ctx.eig_search(rcv, bnc_min=0, bnc_max=2, verbose=True)
-    print("config 5, 8 receivers:", out["stats"], len(out["eig"]), "eigenrays")
+    print(f"config 5 ({which}), {len(rcv)} receivers:", out["stats"], len(out["eig"]), "eigenrays")
     E = G.EIG
     n_ref = 0
     for k in range(len(rcv)):
-        gold = os.path.join(CLI_GOLD, f"cfg5_r{k}")
+        gold = os.path.join(CLI_GOLD, names[k])
         _compare_logs(out["logs"][k], open(os.path.join(gold, "LOG.txt")).read())
         want = _parse_results(os.path.join(gold, "g_results.dat"))
         got = out["eig"][out["eig"][:, E["RCVR"]] == k]
@@ -64,4 +70,5 @@ def test_config5_rank0_receivers_vs_reference_binary(tmp_path):
                 x, y = float(g[E[col]]), w[f]
                 # 8 printed digits; the deviation is a difference of nearly equal bearings: absolute on the scale of a degree
                 assert abs(x - y) <= 2e-7 * max(abs(x), abs(y)) + (2e-6 if f in ("azdev", "phi", "backaz", "bearing") else 1e-12), (k, f, x, y)
-    assert n_ref >= 5
+    print(f"config 5 ({which}): {n_ref} eigenrays in the reference's result files, all matched; every receiver's iteration log line for line")
+    assert n_ref >= 5 or which != "rank0"          # (the seven receivers of ring positions 1..7 lie in the shadow north of the source: the reference finds none, after the same scans)

@@ -36,7 +36,7 @@ def _compare_logs(got, want):
             assert abs(x - y) <= 1.2e-5 * max(abs(x), abs(y)) + 2e-6, f"log line {i + 1}: {a!r} vs {b!r}\n{g}\n{w}"
 
 
-@pytest.mark.parametrize("case", ["eig_global", "eig_global_direct", "eig_globalrd", "eig_3d", "eig_3d_direct", "eig_3drd"])
+@pytest.mark.parametrize("case", ["eig_global", "eig_global_direct", "eig_globalrd", "eig_globalrd_direct", "eig_3d", "eig_3d_direct", "eig_3drd", "eig_3drd_direct"])
 def test_eigenray_modes_match_reference_binaries(case, tmp_path):
     gold = os.path.join(CLI_GOLD, case)
     args = open(os.path.join(gold, "ARGS")).read().split()

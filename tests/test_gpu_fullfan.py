@@ -8,6 +8,7 @@ inclination, back azimuth, amplitude and range within 1e-6 relative (tests/parit
   cfg3     GeoAcGlobal 720 az x 180 incl, bounces=3: counts for all 129 600 rays x 4 legs, values for every 4th azimuth
   cfg4     GeoAc3D.RngDep, 5x5x1400 grid, the rank-0 share (125 azimuths x 1000 inclinations = 124 000 rays) of the 1000 x 1000 fan:
            the GPU integrates the whole share; the reference's lattice of 2000 of its rays (every 8th azimuth x every 8th inclination)
+           + 250 rays of each of the other seven ranks' shares (five of the rank's azimuths x every 20th inclination)
   cfg5     GeoAcGlobal.RngDep -eig_search, the rank-0 receivers of the 64-ring: tests/test_gpu_eig_ring.py
 """
 import os
@@ -68,6 +69,37 @@ def test_config4_share_on_5x5x1400_grid_vs_reference(G, tmp_path):
     gold = {k: g[k] for k in ("steps", "flags", "vals", "val_fields")}
     err = compare_compact(rec, gold, idx=sel)
     print("cfg4 share:", steps, "ray-steps;", len(sel), "rays vs reference, max rel err", {k: f"{v:.2e}" for k, v in err.items()})
+
+
+def test_config4_other_ranks_shares_vs_reference(G, tmp_path):
+    """the shares of ranks 1..7 of the 8-GPU run (geoac_amd.sharding: rank r integrates the azimuths r, r + 8, ... of the 999): five azimuths of
+    every rank's share x all 1000 inclinations on the GPU (35 000 rays: the cooperative one-lane-per-ray kernel of the full fan), 250 of each
+    rank's rays against the compiled reference (tests/golden/full_cfg4_shares.npz, make_golden_full.py cfg4_shares)"""
+    import rngdep_data as RD
+    g = np.load(os.path.join(H.GOLDEN_DIR, "full_cfg4_shares.npz"))
+    grid = RD.write_grid(str(tmp_path), short_paths=False, thin=1)
+    ctx = G.FanContext(G.EQ_3D_RNGDEP, device=0)
+    ctx.load_grid(*grid)
+    ctx.set_params(bounces=int(g["bounces"]), calc_amp=1, mode=0, src=(0.0, 0.0, 0.0))
+    th, ph = G.fan_enumerate(theta_min=0.05, theta_max=50.0, theta_step=0.05, phi_min=-180.0, phi_max=-180.0 + 999 * 0.36, phi_step=0.36)
+    n_th = int(g["n_theta"])
+    assert len(th) == n_th * int(g["n_phi"])
+    az = np.concatenate([g[f"az{r}"] for r in range(1, 8)])
+    assert all((g[f"az{r}"] % 8 == r).all() for r in range(1, 8))            # each rank's own azimuths
+    rays = (az[:, None] * n_th + np.arange(n_th)[None, :]).ravel()
+    rec, steps = ctx.run(th[rays], ph[rays])
+    assert int(rec[..., H.REC["STEPS"]].sum()) == steps
+    pos = {int(a): i for i, a in enumerate(az)}
+    worst = {}
+    for r in range(1, 8):
+        sel = g[f"sel{r}"]
+        assert np.array_equal(th[sel], g[f"theta{r}"]) and np.array_equal(ph[sel], g[f"phi{r}"])
+        local = np.array([pos[int(q // n_th)] * n_th + int(q % n_th) for q in sel])
+        gold = {"steps": g[f"steps{r}"], "flags": g[f"flags{r}"], "vals": g[f"vals{r}"], "val_fields": g["val_fields"]}
+        err = compare_compact(rec, gold, idx=local)
+        for k, v in err.items():
+            worst[k] = max(worst.get(k, 0.0), v)
+    print("cfg4 shares of ranks 1..7:", steps, "ray-steps on the GPU;", 7 * 250, "rays vs reference, max rel err", {k: f"{v:.2e}" for k, v in worst.items()})
 
 
 def test_config4_share_is_schedule_independent(G, tmp_path):

@@ -131,12 +131,12 @@ def test_full_fan_is_schedule_independent(G, eqname, total):
     ref, steps = run({})
     assert steps == total
     # GEOAC_NO_PAIR: one launch per epoch, which runs over the compacted list of live rays (k_compact); with GEOAC_COMPACT=0 over all slots.
-    # The spherical set's default plan is the wave-specialised kernel (k_rk4_duo: the ray on one wave, its derivative systems on another);
-    # GEOAC_DUO=0 gives the one-wave kernels and their hybrid plan - same bits.
+    # GEOAC_DUO=1 (spherical set): the wave-specialised kernel (k_rk4_duo: the ray on one wave, its derivative systems on another, the
+    # stage values handed over through LDS) with and without compaction and with short epochs - same bits as the one-wave kernels.
     plans = [{"GEOAC_PAIR_FRAC": "0.03"}, {"GEOAC_NO_PAIR": "1"}, {"GEOAC_NO_PAIR": "1", "GEOAC_COMPACT": "0"},
              {"GEOAC_TWO_CHUNKS": "1", "GEOAC_S_ROWS": "4096"}, {"GEOAC_PAIR_FRAC": "1.0"}, {"GEOAC_PAIR_FRAC": "0"}]
     if eqname == "EQ_GLOBAL":
-        plans = [dict(e, GEOAC_DUO="0") for e in plans] + [{"GEOAC_DUO": "0"}, {"GEOAC_COMPACT": "0"}, {"GEOAC_TWO_CHUNKS": "1", "GEOAC_S_ROWS": "3000"}]
+        plans += [{"GEOAC_DUO": "1"}, {"GEOAC_DUO": "1", "GEOAC_COMPACT": "0"}, {"GEOAC_DUO": "1", "GEOAC_TWO_CHUNKS": "1", "GEOAC_S_ROWS": "3000"}]
     for env in plans:
         rec, st = run(env)
         assert st == steps, env
