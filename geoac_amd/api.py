@@ -116,17 +116,61 @@ def default_params(eqset):
     return p
 
 
+# ---------------- launch-plan options (geoac_set_option) ----------------
+# Options every new FanContext / FanPool gets (key without the GEOAC_ prefix -> value); tests and A/B tools set them through options() or
+# directly.  The library itself reads no environment variable (unless GEOAC_DEBUG_ENV=1).
+DEFAULT_OPTIONS = {}
+
+
+class options:
+    """with options(S_ROWS=4096, COMPACT=0): ...  -  contexts created inside carry these launch-plan options"""
+
+    def __init__(self, **kw):
+        self.kw = {str(k): str(v) for k, v in kw.items()}
+
+    def __enter__(self):
+        self.old = dict(DEFAULT_OPTIONS)
+        DEFAULT_OPTIONS.update(self.kw)
+        return self
+
+    def __exit__(self, *exc):
+        DEFAULT_OPTIONS.clear()
+        DEFAULT_OPTIONS.update(self.old)
+        return False
+
+
+def option_names():
+    lib = load_library()
+    lib.geoac_option_names.restype = ctypes.POINTER(ctypes.c_char_p)
+    p, out, i = lib.geoac_option_names(), [], 0
+    while p[i]:
+        out.append(p[i].decode()); i += 1
+    return out
+
+
+def _apply_options(lib, h, opts):
+    lib.geoac_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_char_p]
+    for k, v in opts.items():
+        k = str(k)
+        if k.startswith("GEOAC_"):
+            k = k[6:]
+        rc = lib.geoac_set_option(h, k.encode(), str(v).encode())
+        if rc:
+            raise GeoAcError(f"geoac_set_option({k}={v}): {lib.geoac_strerror(rc).decode()}")
+
+
 # ---------------- the GPU fan context ----------------
 class FanContext:
     """One geoac_ctx: a GPU, a stream, an atmosphere, a parameter set; runs fans of launch angles."""
 
-    def __init__(self, eqset, device=0, stream=None):
+    def __init__(self, eqset, device=0, stream=None, options=None):
         self.lib = load_library()
         self.eqset = eqset
         self._h = ctypes.c_void_p()
         rc = self.lib.geoac_create(ctypes.byref(self._h), eqset, device)
         if rc:
             raise GeoAcError(f"geoac_create: {self.lib.geoac_strerror(rc).decode()}")
+        _apply_options(self.lib, self._h, dict(DEFAULT_OPTIONS, **(options or {})))
         if stream is not None:
             self._chk(self.lib.geoac_set_stream(self._h, ctypes.c_void_p(stream)))
         self.params = default_params(eqset)
@@ -341,7 +385,7 @@ class FanContext:
 class FanPool:
     """geoac_pool: one context per listed device, azimuth groups from a shared queue, records gathered into the caller's table."""
 
-    def __init__(self, eqset, devices):
+    def __init__(self, eqset, devices, options=None):
         self.lib = load_library()
         self.eqset = eqset
         self.devices = [int(d) for d in devices]
@@ -351,6 +395,10 @@ class FanPool:
         if rc:
             raise GeoAcError(f"geoac_pool_create: {self.lib.geoac_strerror(rc).decode()}")
         self.lib.geoac_pool_last_error.restype = ctypes.c_char_p
+        self.lib.geoac_pool_ctx.restype = ctypes.c_void_p
+        self.lib.geoac_pool_ctx.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        for i in range(len(self.devices)):
+            _apply_options(self.lib, ctypes.c_void_p(self.lib.geoac_pool_ctx(self._h, i)), dict(DEFAULT_OPTIONS, **(options or {})))
         self.params = default_params(eqset)
         self._chk(self.lib.geoac_pool_set_params(self._h, ctypes.byref(self.params)))
 

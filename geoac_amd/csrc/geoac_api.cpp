@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <ctype.h>
 #include <algorithm>
 #include <string>
 #include <vector>
@@ -44,14 +45,17 @@ const double kGam = 1.4, kRgas = 287.05, kGamR = 0.00040187;
 
 struct DevBuf {
     void* p = nullptr; size_t bytes = 0;
+    bool owned = true;                 // false: a view of another context's buffer (geoac_clone: the atmosphere tables are shared, read-only)
     hipError_t ensure(size_t need){
         if(need <= bytes && p) return hipSuccess;
-        if(p){ hipFree(p); p = nullptr; bytes = 0; }
+        if(p && owned) hipFree(p);
+        p = nullptr; bytes = 0; owned = true;
         hipError_t e = hipMalloc(&p, need);
         if(e == hipSuccess) bytes = need;
         return e;
     }
-    void release(){ if(p) hipFree(p); p = nullptr; bytes = 0; }
+    void release(){ if(p && owned) hipFree(p); p = nullptr; bytes = 0; owned = true; }
+    void view_of(const DevBuf& o){ release(); p = o.p; bytes = o.bytes; owned = false; }
 };
 
 }  // namespace
@@ -110,11 +114,12 @@ struct geoac_ctx {
                                                   // Measured: a short full-occupancy burst disturbs k_rk4 LESS than a long thin sweep
                                                   // (avg k_rk4 launch 10.9 ms vs 11.7-12.8 ms at 8192-256 blocks).
     double pair_frac = 0.10;                      // hybrid fans: share of the inclination-sorted rays that get two lanes (GEOAC_PAIR_FRAC; >= 1: all)
-    double hybrid_rows = 0.75;                    // hybrid fans: rows per epoch of the one-lane launch relative to the two-lane launch (GEOAC_HYBRID_ROWS)
+    double hybrid_rows = 0.70;                    // hybrid fans: rows per epoch of the one-lane launch relative to the two-lane launch (GEOAC_HYBRID_ROWS)
     bool two_chunks = false;                      // GEOAC_TWO_CHUNKS=1: two path chunks in rotation instead of three (A/B measurements)
     bool trace_epochs = false;                    // GEOAC_TRACE_EPOCHS=1: per-epoch live counts on stderr
     bool no_gate = false;                         // GEOAC_NO_GATE=1: post-pass not held back behind the next RK4 launch (A/B measurements)
     bool no_pair = false;                         // GEOAC_NO_PAIR=1: force one lane per ray (A/B measurements)
+    bool grid_build_host = false;                 // GRID_BUILD=host: evaluation table of the grid sets by the host twin (geoac_grid_table_eq) instead of on the device
     int ev_slack = 72;                            // GEOAC_EV_SLACK: per-epoch event rows of a ray beyond its raypath samples (caustics); tests lower it to reach the overflow path
     int duo = 0;                                  // GEOAC_DUO=1: the wave-specialised kernel k_rk4_duo for Global fans with amplitudes (measured SLOWER than the two-lane
                                                   // kernel on MI355X - 3.0 vs 2.7 us per step, DESIGN 3 - kept for A/B runs and the schedule-independence tests); 32, 66: timing diagnostics
@@ -198,6 +203,46 @@ int geoac_default_params(int eqset, geoac_params* p){
     return GEOAC_OK;
 }
 
+// ---- launch-plan options (A/B measurements, tests; results never depend on them) ----
+static const char* const kOptionNames[] = {
+    "S_ROWS", "NO_OVERLAP", "PP_BLOCKS", "ABS_TABLE", "DUO", "EV_SLACK", "NO_PAIR", "PAIR_FRAC", "HYBRID_ROWS", "TWO_CHUNKS", "TRACE_EPOCHS", "NO_GATE", "SORT",
+    "NO_QUAD", "GRID_LANES", "OCT", "SPREAD", "COMPACT", "QUAD_CACHE", "GRID_COOP", "SUB_EPOCHS", "SUB_MIN_WAVES", "SMP_CAP", "GRID_BUILD", nullptr };
+const char* const* geoac_option_names(void){ return kOptionNames; }
+
+int geoac_set_option(geoac_ctx* ctx, const char* key, const char* value){
+    if(!ctx || !key || !value) return GEOAC_E_INVALID;
+    std::string k(key);
+    if(k.rfind("GEOAC_", 0) == 0) k = k.substr(6);
+    for(char& c : k) c = (char)toupper((unsigned char)c);
+    const int iv = atoi(value); const double dv = atof(value); const long long lv = atoll(value);
+    if(k == "S_ROWS") ctx->s_rows_override = iv;
+    else if(k == "NO_OVERLAP") ctx->no_overlap = iv != 0;
+    else if(k == "PP_BLOCKS"){ if(iv >= 0) ctx->pp_blocks = iv; }
+    else if(k == "ABS_TABLE") ctx->abs_table = iv != 0;
+    else if(k == "DUO") ctx->duo = iv;
+    else if(k == "EV_SLACK"){ if(iv >= 0) ctx->ev_slack = iv; }
+    else if(k == "NO_PAIR") ctx->no_pair = iv != 0;
+    else if(k == "PAIR_FRAC"){ if(dv >= 0.0) ctx->pair_frac = dv; }
+    else if(k == "HYBRID_ROWS"){ if(dv > 0.0 && dv <= 1.0) ctx->hybrid_rows = dv; }
+    else if(k == "TWO_CHUNKS") ctx->two_chunks = iv != 0;
+    else if(k == "TRACE_EPOCHS") ctx->trace_epochs = iv != 0;
+    else if(k == "NO_GATE") ctx->no_gate = iv != 0;
+    else if(k == "SORT") ctx->sort_rays = iv != 0;
+    else if(k == "NO_QUAD") ctx->no_quad = iv != 0;
+    else if(k == "GRID_LANES"){ if(iv == 0 || iv == 1 || iv == 2 || iv == 4 || iv == 8) ctx->grid_lanes = iv; else return fail(ctx, GEOAC_E_INVALID, "GRID_LANES: 0, 1, 2, 4 or 8"); }
+    else if(k == "OCT") ctx->oct = iv != 0;
+    else if(k == "SPREAD"){ if(iv >= 0) ctx->spread_override = iv; }
+    else if(k == "COMPACT") ctx->compact = iv != 0;
+    else if(k == "QUAD_CACHE") ctx->quad_cache = iv != 0;
+    else if(k == "GRID_COOP") ctx->grid_coop = iv != 0;
+    else if(k == "SUB_EPOCHS") ctx->sub_epochs = std::min(16, std::max(1, iv));
+    else if(k == "SUB_MIN_WAVES"){ if(iv >= 0) ctx->sub_min_waves = iv; }
+    else if(k == "SMP_CAP"){ if(lv > 0) ctx->smp_cap = lv; }
+    else if(k == "GRID_BUILD") ctx->grid_build_host = (strcmp(value, "host") == 0);
+    else return fail(ctx, GEOAC_E_INVALID, "set_option: unknown key " + k);
+    return GEOAC_OK;
+}
+
 int geoac_create(geoac_ctx** out, int eqset, int device){
     if(!out) return GEOAC_E_INVALID;
     *out = nullptr;
@@ -224,52 +269,15 @@ int geoac_create(geoac_ctx** out, int eqset, int device){
         ctx->h_counters = nullptr; geoac_destroy(ctx); return GEOAC_E_HIP;
     }
     geoac_default_params(eqset, &ctx->prm);
-    const char* sr = getenv("GEOAC_S_ROWS");
-    if(sr) ctx->s_rows_override = atoi(sr);
-    const char* nov = getenv("GEOAC_NO_OVERLAP");
-    if(nov && atoi(nov) != 0) ctx->no_overlap = true;
-    const char* ppb = getenv("GEOAC_PP_BLOCKS");
-    if(ppb && atoi(ppb) > 0) ctx->pp_blocks = atoi(ppb);
-    const char* abt = getenv("GEOAC_ABS_TABLE");
-    if(abt) ctx->abs_table = (atoi(abt) != 0);
-    const char* du = getenv("GEOAC_DUO");
-    if(du) ctx->duo = atoi(du);
-    const char* evs = getenv("GEOAC_EV_SLACK");
-    if(evs && atoi(evs) >= 0) ctx->ev_slack = atoi(evs);
-    const char* npr = getenv("GEOAC_NO_PAIR");
-    if(npr && atoi(npr) != 0) ctx->no_pair = true;
-    const char* pf = getenv("GEOAC_PAIR_FRAC");
-    if(pf && atof(pf) >= 0.0) ctx->pair_frac = atof(pf);
-    const char* hr = getenv("GEOAC_HYBRID_ROWS");
-    if(hr && atof(hr) > 0.0 && atof(hr) <= 1.0) ctx->hybrid_rows = atof(hr);
-    const char* tc = getenv("GEOAC_TWO_CHUNKS");
-    if(tc && atoi(tc) != 0) ctx->two_chunks = true;
-    const char* te = getenv("GEOAC_TRACE_EPOCHS");
-    if(te && atoi(te) != 0) ctx->trace_epochs = true;
-    const char* ng = getenv("GEOAC_NO_GATE");
-    if(ng && atoi(ng) != 0) ctx->no_gate = true;
-    const char* srt = getenv("GEOAC_SORT");
-    if(srt) ctx->sort_rays = (atoi(srt) != 0);
-    const char* nq = getenv("GEOAC_NO_QUAD");
-    if(nq && atoi(nq) != 0) ctx->no_quad = true;
-    const char* gl = getenv("GEOAC_GRID_LANES");
-    if(gl && (atoi(gl) == 1 || atoi(gl) == 2 || atoi(gl) == 4 || atoi(gl) == 8)) ctx->grid_lanes = atoi(gl);
-    const char* oc = getenv("GEOAC_OCT");
-    if(oc) ctx->oct = (atoi(oc) != 0);
-    const char* nsp = getenv("GEOAC_SPREAD");
-    if(nsp && atoi(nsp) > 0) ctx->spread_override = atoi(nsp);
-    const char* cp = getenv("GEOAC_COMPACT");
-    if(cp) ctx->compact = (atoi(cp) != 0);
-    const char* qc = getenv("GEOAC_QUAD_CACHE");
-    if(qc) ctx->quad_cache = (atoi(qc) != 0);
-    const char* gc = getenv("GEOAC_GRID_COOP");
-    if(gc) ctx->grid_coop = (atoi(gc) != 0);
-    const char* se = getenv("GEOAC_SUB_EPOCHS");
-    if(se){ ctx->sub_epochs = atoi(se); if(ctx->sub_epochs < 1) ctx->sub_epochs = 1; if(ctx->sub_epochs > 16) ctx->sub_epochs = 16; }
-    const char* smw = getenv("GEOAC_SUB_MIN_WAVES");
-    if(smw && atoi(smw) >= 0) ctx->sub_min_waves = atoi(smw);
-    const char* sc = getenv("GEOAC_SMP_CAP");
-    if(sc && atoll(sc) > 0) ctx->smp_cap = atoll(sc);
+    // launch-plan options come through geoac_set_option; the environment is read only when GEOAC_DEBUG_ENV=1 (the drivers' A/B runs)
+    const char* dbg = getenv("GEOAC_DEBUG_ENV");
+    if(dbg && atoi(dbg) != 0){
+        for(const char* const* k = geoac_option_names(); *k; k++){
+            const std::string name = std::string("GEOAC_") + *k;
+            const char* v = getenv(name.c_str());
+            if(v) geoac_set_option(ctx, *k, v);
+        }
+    }
     *out = ctx;
     return GEOAC_OK;
 }
@@ -297,6 +305,34 @@ int geoac_destroy(geoac_ctx* ctx){
     if(ctx->pp_stream) hipStreamDestroy(ctx->pp_stream);
     if(ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
+    return GEOAC_OK;
+}
+
+// A second context on the same device that shares the source's atmosphere tables (device memory, read-only to the kernels) and carries its
+// parameters and launch-plan options: for callers that run several independent fans at once (the eigenray searches integrate the ray groups
+// of a decision round concurrently, each group on its own context and streams).  Valid until the source uploads another atmosphere or is
+// destroyed; destroy the clone first.
+int geoac_clone(geoac_ctx* src, geoac_ctx** out){
+    if(!src || !out) return GEOAC_E_INVALID;
+    if(!src->have_atmo) return fail(src, GEOAC_E_INVALID, "clone: no atmosphere uploaded");
+    geoac_ctx* c = nullptr;
+    int rc = geoac_create(&c, src->eqset, src->device);
+    if(rc) return rc;
+    c->prm = src->prm; c->have_params = src->have_params; c->have_atmo = true; c->have_grid = src->have_grid;
+    c->x = src->x; c->T = src->T; c->u = src->u; c->v = src->v; c->rho = src->rho; c->sl = src->sl; c->n_nodes = src->n_nodes;
+    c->gnx = src->gnx; c->gny = src->gny; c->gx = src->gx; c->gy = src->gy; c->gtab_bytes = src->gtab_bytes;
+    c->seg.view_of(src->seg); c->rhot.view_of(src->rhot);
+    c->d_gx.view_of(src->d_gx); c->d_gy.view_of(src->d_gy); c->d_gz.view_of(src->d_gz); c->d_gtab.view_of(src->d_gtab); c->d_gtab8.view_of(src->d_gtab8);
+    if(src->have_grid){                                           // (k_init writes the absorption model's reference state here: one block per context)
+        hipError_t e = c->d_consts.ensure(sizeof(double) * 8);
+        if(e != hipSuccess){ geoac_destroy(c); return hipfail(src, e, "clone: constants block"); }
+    }
+    c->sort_rays = src->sort_rays; c->no_quad = src->no_quad; c->oct = src->oct; c->grid_lanes = src->grid_lanes; c->spread_override = src->spread_override;
+    c->compact = src->compact; c->quad_cache = src->quad_cache; c->sub_min_waves = src->sub_min_waves; c->sub_epochs = src->sub_epochs; c->grid_coop = src->grid_coop;
+    c->smp_cap = src->smp_cap; c->s_rows_override = src->s_rows_override; c->no_overlap = src->no_overlap; c->pp_blocks = src->pp_blocks; c->pair_frac = src->pair_frac;
+    c->hybrid_rows = src->hybrid_rows; c->two_chunks = src->two_chunks; c->no_gate = src->no_gate; c->no_pair = src->no_pair; c->duo = src->duo; c->abs_table = src->abs_table;
+    c->ev_slack = src->ev_slack; c->grid_build_host = src->grid_build_host;
+    *out = c;
     return GEOAC_OK;
 }
 
@@ -356,8 +392,7 @@ int geoac_upload_atmo_3d(geoac_ctx* ctx, int nx, int ny, int nz, const double* x
     HIPCHK(hipMemcpyAsync(ctx->d_gx.p, x, sizeof(double) * nx, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_gy.p, y, sizeof(double) * ny, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->d_gz.p, z, sizeof(double) * nz, hipMemcpyHostToDevice, ctx->stream));
-    const char* gb = getenv("GEOAC_GRID_BUILD");
-    if(gb && strcmp(gb, "host") == 0){
+    if(ctx->grid_build_host){
         // the host builder (geoac_host.cpp), kept as the checker of the device builder and for A/B timing
         std::vector<double> tab(tab_n);
         geoac_grid_table_eq(ctx->eqset, nx, ny, nz, x, y, z, T, u, v, rho, tab.data());

@@ -621,58 +621,94 @@ struct geoac_eig_result {
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
-// integrate all pending requests: one fan launch per (bounces, calc_amp, mode) group
-static int serve(geoac_ctx* ctx, const geoac_params& base, std::vector<Request*>& reqs, geoac_eig_result* res){
-    std::map<std::tuple<int, int, int>, std::vector<Request*>> groups;
-    for(Request* r : reqs) groups[std::make_tuple(r->bounces, r->calc_amp, r->mode)].push_back(r);
-    for(auto& g : groups){
-        geoac_params p = base;
-        p.bounces = std::get<0>(g.first); p.calc_amp = std::get<1>(g.first); p.mode = std::get<2>(g.first);
-        int rc = geoac_set_params(ctx, &p);
-        if(rc) return rc;
-        std::vector<double> th, ph;
-        for(Request* r : g.second){ th.insert(th.end(), r->th.begin(), r->th.end()); ph.insert(ph.end(), r->ph.begin(), r->ph.end()); }
-        const int n = (int)th.size();
-        const int legs = p.bounces + 1;
-        std::vector<double> rec((size_t)n * legs * GEOAC_REC_STRIDE);
-        uint64_t steps = 0;
-        rc = geoac_fan_run(ctx, n, th.data(), ph.data(), rec.data(), &steps);
-        if(rc) return rc;
-        res->stats[0] += 1; res->stats[1] += (uint64_t)n; res->stats[2] += steps;
-        {   // the launch's longest ray (all legs)
-            double longest = 0.0;
-            for(int i = 0; i < n; i++){
-                double sum = 0.0;
-                for(int l = 0; l < legs; l++) sum += rec[((size_t)i * legs + l) * GEOAC_REC_STRIDE + GEOAC_REC_STEPS];
-                longest = std::max(longest, sum);
-            }
-            res->stats[4] += (uint64_t)longest;
-            if(p.calc_amp) res->stats[5] += 1;
+// one (bounces, calc_amp, mode) group of a decision round as ONE fan launch on context `ctx`; results handed back to the group's requests
+static int serve_group(geoac_ctx* ctx, const geoac_params& base, const std::tuple<int, int, int>& key, std::vector<Request*>& grp, uint64_t st[8]){
+    geoac_params p = base;
+    p.bounces = std::get<0>(key); p.calc_amp = std::get<1>(key); p.mode = std::get<2>(key);
+    int rc = geoac_set_params(ctx, &p);
+    if(rc) return rc;
+    std::vector<double> th, ph;
+    for(Request* r : grp){ th.insert(th.end(), r->th.begin(), r->th.end()); ph.insert(ph.end(), r->ph.begin(), r->ph.end()); }
+    const int n = (int)th.size();
+    const int legs = p.bounces + 1;
+    std::vector<double> rec((size_t)n * legs * GEOAC_REC_STRIDE);
+    uint64_t steps = 0;
+    rc = geoac_fan_run(ctx, n, th.data(), ph.data(), rec.data(), &steps);
+    if(rc) return rc;
+    st[0] += 1; st[1] += (uint64_t)n; st[2] += steps;
+    {   // the launch's longest ray (all legs)
+        double longest = 0.0;
+        for(int i = 0; i < n; i++){
+            double sum = 0.0;
+            for(int l = 0; l < legs; l++) sum += rec[((size_t)i * legs + l) * GEOAC_REC_STRIDE + GEOAC_REC_STEPS];
+            longest = std::max(longest, sum);
         }
-        std::vector<double> smp;
-        if(p.mode){
-            int64_t ns = 0;
-            rc = geoac_fan_sample_count(ctx, &ns); if(rc) return rc;
-            smp.resize((size_t)std::max<int64_t>(ns, 1) * GEOAC_SMP_STRIDE);
-            if(ns > 0){ rc = geoac_fan_fetch_samples(ctx, smp.data(), ns); if(rc) return rc; }
-            smp.resize((size_t)ns * GEOAC_SMP_STRIDE);
+        st[4] = std::max<uint64_t>(st[4], (uint64_t)longest);       // (the caller adds the round's critical path: its groups run side by side)
+        if(p.calc_amp) st[5] += 1;
+    }
+    std::vector<double> smp;
+    if(p.mode){
+        int64_t ns = 0;
+        rc = geoac_fan_sample_count(ctx, &ns); if(rc) return rc;
+        smp.resize((size_t)std::max<int64_t>(ns, 1) * GEOAC_SMP_STRIDE);
+        if(ns > 0){ rc = geoac_fan_fetch_samples(ctx, smp.data(), ns); if(rc) return rc; }
+        smp.resize((size_t)ns * GEOAC_SMP_STRIDE);
+    }
+    size_t off = 0, sp = 0;
+    const size_t nsmp = smp.size() / GEOAC_SMP_STRIDE;
+    for(Request* r : grp){
+        const size_t m = r->th.size();
+        r->rec.assign(rec.begin() + off * legs * GEOAC_REC_STRIDE, rec.begin() + (off + m) * legs * GEOAC_REC_STRIDE);
+        r->smp.clear();
+        while(sp < nsmp && (size_t)smp[sp * GEOAC_SMP_STRIDE + GEOAC_SMP_RAY] < off + m){       // samples are sorted by ray
+            size_t b = r->smp.size();
+            r->smp.insert(r->smp.end(), smp.begin() + sp * GEOAC_SMP_STRIDE, smp.begin() + (sp + 1) * GEOAC_SMP_STRIDE);
+            r->smp[b + GEOAC_SMP_RAY] -= (double)off;
+            sp++;
         }
-        size_t off = 0, sp = 0;
-        const size_t nsmp = smp.size() / GEOAC_SMP_STRIDE;
-        for(Request* r : g.second){
-            const size_t m = r->th.size();
-            r->rec.assign(rec.begin() + off * legs * GEOAC_REC_STRIDE, rec.begin() + (off + m) * legs * GEOAC_REC_STRIDE);
-            r->smp.clear();
-            while(sp < nsmp && (size_t)smp[sp * GEOAC_SMP_STRIDE + GEOAC_SMP_RAY] < off + m){       // samples are sorted by ray
-                size_t b = r->smp.size();
-                r->smp.insert(r->smp.end(), smp.begin() + sp * GEOAC_SMP_STRIDE, smp.begin() + (sp + 1) * GEOAC_SMP_STRIDE);
-                r->smp[b + GEOAC_SMP_RAY] -= (double)off;
-                sp++;
-            }
-            off += m;
-        }
+        off += m;
     }
     return 0;
+}
+
+// Integrate all pending requests of a decision round: one fan launch per (bounces, calc_amp, mode) group, the groups SIDE BY SIDE - each on a
+// context of its own (the caller's, and clones of it that share its atmosphere tables: geoac_clone), from a host thread of its own.  A
+// group of a search round is a handful of rays - a few waves on a chip of 1 024 wave slots - and lasts as long as its longest ray, so the
+// groups of a round overlap almost completely: the round costs its longest group, not the sum of them.
+static int serve(std::vector<geoac_ctx*>& ctxs, const geoac_params& base, std::vector<Request*>& reqs, geoac_eig_result* res){
+    std::map<std::tuple<int, int, int>, std::vector<Request*>> groups;
+    for(Request* r : reqs) groups[std::make_tuple(r->bounces, r->calc_amp, r->mode)].push_back(r);
+    while(ctxs.size() < groups.size() && ctxs.size() < 8){
+        geoac_ctx* c = nullptr;
+        int rc = geoac_clone(ctxs[0], &c);
+        if(rc) break;                                              // (no clone: the groups take turns on the contexts there are)
+        ctxs.push_back(c);
+    }
+    std::vector<std::pair<const std::tuple<int, int, int>*, std::vector<Request*>*>> work;
+    for(auto& g : groups) work.emplace_back(&g.first, &g.second);
+    std::atomic<size_t> next{0};
+    std::atomic<int> first_rc{0};
+    std::mutex mu;
+    uint64_t round_crit = 0;
+    auto worker = [&](geoac_ctx* c){
+        uint64_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for(;;){
+            const size_t i = next.fetch_add(1);
+            if(i >= work.size() || first_rc.load()) break;
+            int rc = serve_group(c, base, *work[i].first, *work[i].second, st);
+            if(rc){ int z = 0; first_rc.compare_exchange_strong(z, rc); break; }
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        res->stats[0] += st[0]; res->stats[1] += st[1]; res->stats[2] += st[2]; res->stats[5] += st[5];
+        round_crit = std::max(round_crit, st[4]);
+    };
+    const size_t nw = std::min(ctxs.size(), work.size());
+    std::vector<std::thread> th;
+    for(size_t w = 1; w < nw; w++) th.emplace_back(worker, ctxs[w]);
+    worker(ctxs[0]);
+    for(auto& t : th) t.join();
+    res->stats[4] += round_crit;
+    return first_rc.load();
 }
 
 static int run_all(geoac_ctx* ctx, const geoac_eig_params* ep, int n_rcvr, const double* rcvr, bool direct,
@@ -695,6 +731,7 @@ static int run_all(geoac_ctx* ctx, const geoac_eig_params* ep, int n_rcvr, const
         mach[0] = m4[1] / m4[0]; mach[1] = m4[2] / m4[0]; mach[2] = 0.0 / m4[0];
     }
     geoac_eig_result* res = new geoac_eig_result();
+    std::vector<geoac_ctx*> ctxs{ ctx };                          // the caller's context and, made on demand, clones of it (serve)
     Shared sh;
     std::vector<std::unique_ptr<SearchBase>> S;
     for(int i = 0; i < n_rcvr; i++){
@@ -742,7 +779,7 @@ static int run_all(geoac_ctx* ctx, const geoac_eig_params* ep, int n_rcvr, const
                 if(sh.active == 0) break;
                 batch.swap(sh.pending);
             }
-            err = serve(ctx, base, batch, res);
+            err = serve(ctxs, base, batch, res);
             res->stats[3] += 1;
             {
                 std::unique_lock<std::mutex> lk(sh.mu);
@@ -754,6 +791,7 @@ static int run_all(geoac_ctx* ctx, const geoac_eig_params* ep, int n_rcvr, const
         }
         for(auto& t : threads) t.join();
     }
+    for(size_t w = 1; w < ctxs.size(); w++) geoac_destroy(ctxs[w]);
     geoac_set_params(ctx, &base);                                  // restore the caller's bounces / calc_amp / mode
     if(err){ delete res; return err; }
     for(int i = 0; i < n_rcvr; i++){

@@ -52,10 +52,44 @@ static bool string2bool(const string& v){          // GeoAc.Interface.cpp:125-12
     return !v.empty() && (strcasecmp(v.c_str(), "true") == 0 || atoi(v.c_str()) != 0);
 }
 
-// GEOAC_DEVICES=0,1,2,...: the HIP devices a -prop fan may use (default: device 0)
+// ---- arguments of this GPU build (not in the reference's grammar; its parsers skip what they do not know, and so do ours for the rest):
+//   gpu_devices=0,1,...      HIP devices an arrivals-only -prop fan is dealt over (default: device 0)
+//   gpu_stats=<file>         run summary as JSON (rays, RK4 ray-steps, GPU seconds, per-device shares)
+//   gpu_rays_per_batch=<n>   rays per azimuth group of a -prop run that keeps raypath / caustic rows (default 8192)
+//   gpu_opt=<KEY>:<value>    a launch-plan option of the library (geoac_set_option), repeatable
+// The environment (GEOAC_DEVICES, GEOAC_STATS, GEOAC_CLI_RAYS_PER_BATCH) is honoured only with GEOAC_DEBUG_ENV=1.
+static string g_devices, g_stats;
+static long g_rays_per_batch = 0;
+static vector<std::pair<string, string>> g_opts;
+static void parse_gpu_args(int argc, char* argv[]){
+    const char* dbg = getenv("GEOAC_DEBUG_ENV");
+    if(dbg && atoi(dbg) != 0){
+        if(const char* e = getenv("GEOAC_DEVICES")) g_devices = e;
+        if(const char* e = getenv("GEOAC_STATS")) g_stats = e;
+        if(const char* e = getenv("GEOAC_CLI_RAYS_PER_BATCH")) g_rays_per_batch = atol(e);
+    }
+    for(int i = 2; i < argc; i++){
+        const char* a = argv[i];
+        if(strncmp(a, "gpu_devices=", 12) == 0) g_devices = a + 12;
+        else if(strncmp(a, "gpu_stats=", 10) == 0) g_stats = a + 10;
+        else if(strncmp(a, "gpu_rays_per_batch=", 19) == 0) g_rays_per_batch = atol(a + 19);
+        else if(strncmp(a, "gpu_opt=", 8) == 0){
+            const char* c = strchr(a + 8, ':');
+            if(c) g_opts.emplace_back(string(a + 8, c), string(c + 1));
+        }
+    }
+}
+static int apply_gpu_opts(geoac_ctx* ctx){
+    for(const auto& kv : g_opts){
+        int rc = geoac_set_option(ctx, kv.first.c_str(), kv.second.c_str());
+        if(rc){ cout << kName << ": gpu_opt=" << kv.first << ": " << geoac_last_error(ctx) << '\n'; return rc; }
+    }
+    return 0;
+}
+
 static vector<int> device_list(){
     vector<int> d;
-    const char* e = getenv("GEOAC_DEVICES");
+    const char* e = g_devices.empty() ? nullptr : g_devices.c_str();
     if(e){
         const char* q = e;
         while(*q){
@@ -73,8 +107,8 @@ static vector<int> device_list(){
 
 static void write_stats(const char* mode, long rays, uint64_t steps, double seconds, const vector<int>& devs,
                         const vector<uint64_t>& d_rays, const vector<uint64_t>& d_steps, const vector<uint64_t>& d_groups){
-    const char* path = getenv("GEOAC_STATS");
-    if(!path || !*path) return;
+    const char* path = g_stats.c_str();
+    if(!*path) return;
     ofstream js(path);
     js << "{\"program\": \"" << kName << "\", \"mode\": \"" << mode << "\", \"rays\": " << rays << ", \"rk4_ray_steps\": " << steps
        << ", \"gpu_seconds\": " << setprecision(9) << seconds << ", \"ray_steps_per_s\": " << (seconds > 0 ? steps / seconds : 0.0) << ", \"devices\": [";
@@ -249,6 +283,7 @@ static int run_prop(char* inputs[], int count){
         else if(strncmp(a, "CalcAmp=", 8) == 0){ CalcAmp = string2bool(a + 8); }
         else if(strncmp(a, "alt_max=", 8) == 0){ P.vert_limit = atof(a + 8); }     // Global: a km altitude compared with a radius (Q9)
         else if(!kRng && strncmp(a, "rng_max=", 8) == 0){ P.range_limit = atof(a + 8); }
+        else if(strncmp(a, "gpu_", 4) == 0){ }                        // arguments of this GPU build (parse_gpu_args)
         else {
             cout << "***WARNING*** Unrecognized parameter entry: " << a << '\n';
             cout << "Continue? (y/n):"; cin >> input_check;
@@ -284,6 +319,7 @@ static int run_prop(char* inputs[], int count){
     if(multi){
         rc = geoac_pool_create(&pool, kEq, (int)devs.size(), devs.data());
         if(rc){ cout << kName << ": " << geoac_strerror(rc) << '\n'; return 2; }
+        for(int d = 0; d < geoac_pool_size(pool); d++) if(apply_gpu_opts(geoac_pool_ctx(pool, d))) return 2;
         if(kRng) rc = geoac_pool_upload_atmo_3d(pool, grid.nx, grid.ny, grid.nz, grid.x.data(), grid.y.data(), grid.z.data(), grid.T.data(), grid.u.data(), grid.v.data(), grid.rho.data());
         else     rc = geoac_pool_upload_atmo_1d(pool, prof.n, prof.x.data(), prof.T.data(), prof.u.data(), prof.v.data(), prof.rho.data(), prof.sl.data());
         if(rc){ cout << kName << ": " << geoac_pool_last_error(pool) << '\n'; return 2; }
@@ -291,6 +327,7 @@ static int run_prop(char* inputs[], int count){
     } else {
     rc = geoac_create(&ctx, kEq, devs[0]);
     if(rc){ cout << kName << ": " << geoac_strerror(rc) << '\n'; return 2; }
+    if(apply_gpu_opts(ctx)) return 2;
     if(kRng) rc = geoac_upload_atmo_3d(ctx, grid.nx, grid.ny, grid.nz, grid.x.data(), grid.y.data(), grid.z.data(), grid.T.data(), grid.u.data(), grid.v.data(), grid.rho.data());
     else     rc = geoac_upload_atmo_1d(ctx, prof.n, prof.x.data(), prof.T.data(), prof.u.data(), prof.v.data(), prof.rho.data(), prof.sl.data());
     if(rc){ cout << kName << ": " << geoac_last_error(ctx) << '\n'; return 2; }
@@ -439,8 +476,7 @@ static int run_prop(char* inputs[], int count){
     long az_per_batch = n_az;
     if(sampling && n_az > 0){
         const long rays_per_az = max(1L, nr / n_az);
-        const char* rpb = getenv("GEOAC_CLI_RAYS_PER_BATCH");               // tests: force several groups on a small fan
-        az_per_batch = max(1L, ((rpb && atol(rpb) > 0) ? atol(rpb) : 8192L) / rays_per_az);
+        az_per_batch = max(1L, (g_rays_per_batch > 0 ? g_rays_per_batch : 8192L) / rays_per_az);    // (gpu_rays_per_batch=: tests force several groups on a small fan)
     }
     struct Batch { long i0 = 0, i1 = 0; vector<double> rec, smp; };
     Batch buf[2];
@@ -593,6 +629,7 @@ static int run_interactive(char* inputs[], int count){
         else if(kRngS && strncmp(a, "lat_max=", 8) == 0){ P.xy_limits[1] = atof(a + 8); }
         else if(kRngS && strncmp(a, "lon_min=", 8) == 0){ P.xy_limits[2] = atof(a + 8); }
         else if(kRngS && strncmp(a, "lon_max=", 8) == 0){ P.xy_limits[3] = atof(a + 8); }
+        else if(strncmp(a, "gpu_", 4) == 0){ }                        // arguments of this GPU build (parse_gpu_args)
         else {
             cout << "***WARNING*** Unrecognized parameter entry: " << a << '\n';
             cout << "Continue? (y/n):"; cin >> input_check;
@@ -621,6 +658,7 @@ static int run_interactive(char* inputs[], int count){
     geoac_ctx* ctx = nullptr;
     int rc = geoac_create(&ctx, kEq, 0);
     if(rc){ cout << kName << ": " << geoac_strerror(rc) << '\n'; return 2; }
+    if(apply_gpu_opts(ctx)) return 2;
     if(kRng) rc = geoac_upload_atmo_3d(ctx, grid.nx, grid.ny, grid.nz, grid.x.data(), grid.y.data(), grid.z.data(), grid.T.data(), grid.u.data(), grid.v.data(), grid.rho.data());
     else     rc = geoac_upload_atmo_1d(ctx, prof.n, prof.x.data(), prof.T.data(), prof.u.data(), prof.v.data(), prof.rho.data(), prof.sl.data());
     if(rc){ cout << kName << ": " << geoac_last_error(ctx) << '\n'; return 2; }
@@ -851,6 +889,7 @@ static int run_eig(char* inputs[], int count, bool direct){
         else if(kRngS && strncmp(a, "lat_max=", 8) == 0){ P.xy_limits[1] = atof(a + 8); }
         else if(kRngS && strncmp(a, "lon_min=", 8) == 0){ P.xy_limits[2] = atof(a + 8); }
         else if(kRngS && strncmp(a, "lon_max=", 8) == 0){ P.xy_limits[3] = atof(a + 8); }
+        else if(strncmp(a, "gpu_", 4) == 0){ }                        // arguments of this GPU build (parse_gpu_args)
         else {
             cout << "***WARNING*** Unrecognized parameter entry: " << a << '\n';
             cout << "Continue? (y/n):"; cin >> input_check;
@@ -863,6 +902,7 @@ static int run_eig(char* inputs[], int count, bool direct){
     geoac_ctx* ctx = nullptr;
     int rc = geoac_create(&ctx, kEq, 0);
     if(rc){ cout << kName << ": " << geoac_strerror(rc) << '\n'; return 2; }
+    if(apply_gpu_opts(ctx)) return 2;
     if(kRng) rc = geoac_upload_atmo_3d(ctx, grid.nx, grid.ny, grid.nz, grid.x.data(), grid.y.data(), grid.z.data(), grid.T.data(), grid.u.data(), grid.v.data(), grid.rho.data());
     else     rc = geoac_upload_atmo_1d(ctx, prof.n, prof.x.data(), prof.T.data(), prof.u.data(), prof.v.data(), prof.rho.data(), prof.sl.data());
     if(rc){ cout << kName << ": " << geoac_last_error(ctx) << '\n'; return 2; }
@@ -969,6 +1009,7 @@ static int run_eig(char* inputs[], int count, bool direct){
 
 int main(int argc, char* argv[]){
     if(argc < (kRng ? 5 : 3)){ usage(); return 0; }
+    parse_gpu_args(argc, argv);
     if(strncmp(argv[1], "-prop", 5) == 0) return run_prop(argv, argc);
     if(kEq != GEOAC_EQ_2D && strncmp(argv[1], "-eig_search", 11) == 0) return run_eig(argv, argc, false);
     if(kEq != GEOAC_EQ_2D && strncmp(argv[1], "-eig_direct", 11) == 0) return run_eig(argv, argc, true);

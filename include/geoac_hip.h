@@ -111,6 +111,16 @@ int  geoac_default_params(int eqset, geoac_params* p);
 
 int  geoac_create(geoac_ctx** out, int eqset, int device);
 int  geoac_destroy(geoac_ctx* ctx);
+/* a second context on the same device sharing src's atmosphere tables (read-only device memory), with src's parameters and options: several
+ * independent fans at once (one fan in flight per context).  Valid until src uploads another atmosphere or is destroyed; destroy clones first. */
+int  geoac_clone(geoac_ctx* src, geoac_ctx** out);
+
+/* Launch-plan options (epoch length, kernel variants, overlap): for A/B measurements and the schedule-independence tests - a fan's records
+ * never depend on them.  key: one of geoac_option_names() (case-insensitive, an optional "GEOAC_" prefix is ignored), value: its decimal
+ * text.  Set before geoac_fan_launch / the atmosphere upload they act on.  The library reads NO environment variable unless
+ * GEOAC_DEBUG_ENV=1 is set, in which case GEOAC_<KEY> is applied through this function when a context is created. */
+int  geoac_set_option(geoac_ctx* ctx, const char* key, const char* value);
+const char* const* geoac_option_names(void);        /* NULL-terminated */
 
 /* use a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own */
 int  geoac_set_stream(geoac_ctx* ctx, void* hip_stream);

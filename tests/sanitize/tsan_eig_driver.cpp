@@ -9,7 +9,9 @@
 #include <vector>
 #include "../../include/geoac_eig.h"
 
+#include <atomic>
 struct geoac_ctx { geoac_params p; int eqset; std::string err; long calls; };
+static std::atomic<long> g_clone_calls{0};
 static const double Pi = 3.141592653589793;
 
 extern "C" {
@@ -18,6 +20,9 @@ int geoac_default_params(int eqset, geoac_params* p){ memset(p, 0, sizeof *p); p
 int geoac_get_params(geoac_ctx* c, geoac_params* p){ *p = c->p; return 0; }
 int geoac_set_params(geoac_ctx* c, const geoac_params* p){ c->p = *p; return 0; }
 int geoac_get_eqset(geoac_ctx* c, int* e){ *e = c->eqset; return 0; }
+// clones: the groups of a decision round are integrated side by side, one context and one host thread each (serve)
+int geoac_clone(geoac_ctx* src, geoac_ctx** out){ geoac_ctx* c = new geoac_ctx(); c->p = src->p; c->eqset = src->eqset; c->calls = 0; *out = c; return 0; }
+int geoac_destroy(geoac_ctx* c){ g_clone_calls += c->calls; delete c; return 0; }
 int geoac_medium_1d(geoac_ctx*, double, double out[4]){ out[0] = 0.34; out[1] = 0.0; out[2] = 0.0; out[3] = 1.2e-3; return 0; }
 int geoac_fan_sample_count(geoac_ctx*, int64_t* n){ *n = 0; return 0; }
 int geoac_fan_fetch_samples(geoac_ctx*, double*, int64_t){ return 0; }

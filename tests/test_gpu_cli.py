@@ -47,12 +47,13 @@ def test_cli_files_match_reference_binaries(case, tmp_path):
     small one - one lane per ray, cooperative LDS-DMA gather, 512-row epochs in four sub-epochs handed from workgroup to workgroup - with the
     raypath samples and caustics on"""
     env = dict(os.environ)
+    gpu_args = []                  # arguments of the GPU build (geoac_cli.cpp: gpu_rays_per_batch=, gpu_opt=KEY:value -> geoac_set_option); the environment is not read
     if case.endswith("+groups"):
         case = case[:-len("+groups")]
-        env["GEOAC_CLI_RAYS_PER_BATCH"] = "2"
+        gpu_args = ["gpu_rays_per_batch=2"]
     if case.endswith("+sub"):
         case = case[:-len("+sub")]
-        env.update({"GEOAC_GRID_LANES": "1", "GEOAC_SPREAD": "1", "GEOAC_SUB_MIN_WAVES": "0", "GEOAC_SUB_EPOCHS": "4", "GEOAC_S_ROWS": "512"})
+        gpu_args = ["gpu_opt=GRID_LANES:1", "gpu_opt=SPREAD:1", "gpu_opt=SUB_MIN_WAVES:0", "gpu_opt=SUB_EPOCHS:4", "gpu_opt=S_ROWS:512"]
     gold = os.path.join(CLI_GOLD, case)
     args = open(os.path.join(gold, "ARGS")).read().split()
     binary, params = args[0], args[1:]
@@ -71,7 +72,7 @@ def test_cli_files_match_reference_binaries(case, tmp_path):
     else:
         shutil.copy(H.TOYATMO, tmp_path / "ToyAtmo.met")
         inputs = ["ToyAtmo.met"]
-    subprocess.run([exe, "-prop"] + inputs + params, cwd=tmp_path, check=True, stdout=subprocess.DEVNULL, env=env)
+    subprocess.run([exe, "-prop"] + inputs + params + gpu_args, cwd=tmp_path, check=True, stdout=subprocess.DEVNULL, env=env)
     want_files = sorted(f for f in os.listdir(gold) if f.endswith(".dat"))
     got_files = sorted(f for f in os.listdir(tmp_path) if f.endswith(".dat") and not f.startswith("loc_"))
     assert got_files == want_files

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import harness as H
+from geoac_amd.api import DEFAULT_OPTIONS as OPT      # launch-plan options of the contexts the tests create (geoac_set_option)
 from parity import compare_records
 
 pytestmark = pytest.mark.gpu
@@ -120,8 +121,36 @@ def test_event_list_overflow_is_reported(monkeypatch):
     """the per-epoch list of raypath-sample / caustic rows of a ray holds s_rows / stride + a slack for the caustics; with the slack taken away
     (GEOAC_EV_SLACK=0) a ray with caustics overflows it: the launch must fail with GEOAC_E_CAPACITY, not return a truncated table"""
     import geoac_amd as G
-    monkeypatch.setenv("GEOAC_EV_SLACK", "0")
-    monkeypatch.setenv("GEOAC_S_ROWS", "64")
+    monkeypatch.setitem(OPT, "EV_SLACK", "0")
+    monkeypatch.setitem(OPT, "S_ROWS", "64")
     ctx = _gpu(H.EQ_GLOBAL, bounces=1, calc_amp=1, mode=1 | 2)     # GEOAC_MODE_WRITE_RAYS | GEOAC_MODE_WRITE_CAUSTICS
     with pytest.raises(G.GeoAcError, match="event list overflowed|capacity"):
         ctx.run(np.array([5.0, 12.0, 25.0]), np.array([-90.0, -90.0, -90.0]))
+
+
+def test_options_go_through_the_abi_not_the_environment(monkeypatch):
+    """launch-plan options reach a context through geoac_set_option (api.FanContext(options=...), api.options()); the library ignores GEOAC_*
+    environment variables unless GEOAC_DEBUG_ENV=1; an unknown key is an error; records do not depend on the option"""
+    import geoac_amd as G
+    assert {"S_ROWS", "COMPACT", "PAIR_FRAC", "GRID_LANES", "ABS_TABLE"} <= set(G.option_names())
+    th = np.array([4.0, 21.0]); ph = np.array([-90.0, 33.0])
+
+    def epochs(**kw):
+        ctx = G.FanContext(H.EQ_GLOBAL, device=0, **kw)
+        ctx.load_met(H.TOYATMO)
+        ctx.set_params(bounces=0, calc_amp=1)
+        rec, _ = ctx.run(th, ph)
+        return rec, ctx.timing()["epochs"]
+    monkeypatch.delenv("GEOAC_DEBUG_ENV", raising=False)
+    monkeypatch.setenv("GEOAC_S_ROWS", "64")
+    rec0, e0 = epochs()                                               # the variable is NOT read
+    rec1, e1 = epochs(options={"S_ROWS": 64})
+    with G.options(S_ROWS=64):
+        rec2, e2 = epochs()
+    assert e0 < 20 < e1 == e2
+    assert np.array_equal(rec0, rec1) and np.array_equal(rec0, rec2)
+    monkeypatch.setenv("GEOAC_DEBUG_ENV", "1")
+    rec3, e3 = epochs()                                               # debug switch: now it is
+    assert e3 == e1 and np.array_equal(rec0, rec3)
+    with pytest.raises(G.GeoAcError):
+        G.FanContext(H.EQ_GLOBAL, device=0, options={"NO_SUCH_KNOB": 1})

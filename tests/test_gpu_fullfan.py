@@ -111,20 +111,12 @@ def test_config4_share_is_schedule_independent(G, tmp_path):
     th, ph = G.fan_enumerate(theta_min=0.05, theta_max=50.0, theta_step=0.05, phi_min=-180.0, phi_max=-180.0 + 124 * 0.36, phi_step=0.36)
 
     def run(env):
-        old = {k: os.environ.get(k) for k in env}
-        os.environ.update(env)
-        try:
+        with G.options(**env):                                # launch-plan options of the contexts created inside (geoac_set_option)
             ctx = G.FanContext(G.EQ_3D_RNGDEP, device=0)      # the knobs are read when the context is created
             ctx.load_grid(*grid)
             ctx.set_params(bounces=1, calc_amp=1, mode=0, src=(0.0, 0.0, 0.0))
             rec, steps = ctx.run(th, ph)
             ctx.close()
-        finally:
-            for k, v in old.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
         return rec, steps
     ref, steps = run({})
     for env in ({"GEOAC_SUB_EPOCHS": "1"}, {"GEOAC_SUB_EPOCHS": "8", "GEOAC_S_ROWS": "4096"}, {"GEOAC_COMPACT": "0"}, {"GEOAC_GRID_COOP": "0"}):

@@ -113,20 +113,12 @@ def test_full_fan_is_schedule_independent(G, eqname, total):
     params = dict(bounces=2, calc_amp=1, mode=0)
 
     def run(env):
-        old = {k: os.environ.get(k) for k in env}
-        os.environ.update(env)
-        try:
+        with G.options(**env):                                # launch-plan options of the contexts created inside (geoac_set_option)
             ctx = G.FanContext(getattr(G, eqname), device=0)   # the knobs are read when the context is created
             ctx.load_met(H.TOYATMO)
             ctx.set_params(**params)
             rec, steps = ctx.run(th, ph)
             ctx.close()
-        finally:
-            for k, v in old.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
         return rec, steps
     ref, steps = run({})
     assert steps == total

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 import harness as H
+from geoac_amd.api import DEFAULT_OPTIONS as OPT      # launch-plan options of the contexts the tests create (geoac_set_option)
 import rngdep_data as RD
 from parity import compare_records, max_rel_errors
 
@@ -73,18 +74,18 @@ def test_every_lanes_per_ray_variant_vs_golden(gold, grid, lanes, monkeypatch):
     if lanes == "coop+sub":
         # the launch plan of saturated fans forced on the small one: cooperative LDS-DMA gather, 512-row epochs in four sub-epochs handed from
         # workgroup to workgroup (sample and caustic events carried across the hand-off)
-        monkeypatch.setenv("GEOAC_SUB_MIN_WAVES", "0")
-        monkeypatch.setenv("GEOAC_SUB_EPOCHS", "4")
-        monkeypatch.setenv("GEOAC_S_ROWS", "512")
+        monkeypatch.setitem(OPT, "SUB_MIN_WAVES", "0")
+        monkeypatch.setitem(OPT, "SUB_EPOCHS", "4")
+        monkeypatch.setitem(OPT, "S_ROWS", "512")
         lanes = "coop"
     if lanes in ("coop", "dense"):
         # one lane per ray without lane thinning, as a large fan runs: "coop" = wave-cooperative table gather through LDS (58 of the
         # wave's 64 lanes are helpers without a ray here), "dense" = the same launch with per-lane gathers
-        monkeypatch.setenv("GEOAC_GRID_LANES", "1")
-        monkeypatch.setenv("GEOAC_SPREAD", "1")
-        monkeypatch.setenv("GEOAC_GRID_COOP", "1" if lanes == "coop" else "0")
+        monkeypatch.setitem(OPT, "GRID_LANES", "1")
+        monkeypatch.setitem(OPT, "SPREAD", "1")
+        monkeypatch.setitem(OPT, "GRID_COOP", "1" if lanes == "coop" else "0")
     else:
-        monkeypatch.setenv("GEOAC_GRID_LANES", str(lanes))
+        monkeypatch.setitem(OPT, "GRID_LANES", str(lanes))
     ctx = _ctx(grid, bounces=1, calc_amp=1, mode=3, src=(0.0, 31.0, 0.0))
     rec, steps = ctx.run(gold["theta"], gold["phi"])
     assert steps == int(gold["steps_amp1_mode3"])
@@ -97,7 +98,7 @@ def test_eight_lane_kernel_gives_the_four_lane_kernels_bits(gold, grid, monkeypa
     GEOAC_OCT=0 keeps them on the four-lane kernel: same records bit for bit, and both within tolerance of the golden ones"""
     out = {}
     for oct_on in ("1", "0"):
-        monkeypatch.setenv("GEOAC_OCT", oct_on)
+        monkeypatch.setitem(OPT, "OCT", oct_on)
         ctx = _ctx(grid, bounces=2, calc_amp=1, mode=0, src=(0.0, 31.0, 0.0))
         out[oct_on] = ctx.run(gold["theta"], gold["phi"])
     assert out["1"][1] == out["0"][1]

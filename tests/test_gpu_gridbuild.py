@@ -114,15 +114,11 @@ def test_fan_on_a_ragged_grid_is_variant_independent(eq, shape, monkeypatch):
     th, ph = G.fan_enumerate(theta_min=2.0, theta_max=46.0, theta_step=4.0, phi_min=-180.0, phi_max=135.0, phi_step=45.0)
 
     def run(env):
-        for k, val in env.items():
-            monkeypatch.setenv(k, val)
-        ctx = G.FanContext(eq, device=0)
+        ctx = G.FanContext(eq, device=0, options=env)            # launch-plan options of this context (geoac_set_option; the GEOAC_ prefix of a key is optional)
         ctx.upload_atmo_3d(x, y, z, T, u, v, rho)
         ctx.set_params(bounces=1, calc_amp=1, mode=0, src=src)
         out = ctx.run(th, ph)
         ctx.close()
-        for k in env:
-            monkeypatch.delenv(k)
         return out
     ref, steps = run({})
     assert steps > 1000 and np.isfinite(ref).all()

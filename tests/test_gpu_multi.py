@@ -75,10 +75,8 @@ def test_prop_driver_on_two_devices_writes_the_same_files(tmp_path):
     for tag, devs in (("one", None), ("two", "0,0")):
         d = tmp_path / tag; d.mkdir()
         shutil.copy(H.TOYATMO, d / "ToyAtmo.met")
-        env = dict(os.environ, GEOAC_STATS=str(d / "stats.json"))
-        if devs:
-            env["GEOAC_DEVICES"] = devs
-        r = subprocess.run([exe] + args, cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        gpu = ["gpu_stats=" + str(d / "stats.json")] + (["gpu_devices=" + devs] if devs else [])        # arguments of the GPU build, not environment
+        r = subprocess.run([exe] + args + gpu, cwd=d, env=dict(os.environ), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
         assert r.returncode == 0, r.stderr.decode()
         outs.append((open(d / "ToyAtmo_results.dat").read(), json.load(open(d / "stats.json"))))
     assert outs[0][0] == outs[1][0] and len(outs[0][0].split("\n")) > 100

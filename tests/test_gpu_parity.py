@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 import harness as H
+from geoac_amd.api import DEFAULT_OPTIONS as OPT      # launch-plan options of the contexts the tests create (geoac_set_option)
 from parity import compare_records, max_rel_errors
 
 pytestmark = pytest.mark.gpu
@@ -135,7 +136,7 @@ def test_epoch_size_invariance(G, golden, monkeypatch, eq):
     g = golden(eq)
     recs = []
     for s_rows in ("64", "777"):
-        monkeypatch.setenv("GEOAC_S_ROWS", s_rows)
+        monkeypatch.setitem(OPT, "S_ROWS", s_rows)
         ctx = _ctx(G, eq, bounces=2, calc_amp=1, mode=0)
         recs.append(ctx.run(g["theta"], g["phi"]))
         ctx.close()

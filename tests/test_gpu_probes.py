@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import harness as H
+from geoac_amd.api import DEFAULT_OPTIONS as OPT      # launch-plan options of the contexts the tests create (geoac_set_option)
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-6
@@ -191,7 +192,7 @@ def test_table_and_exact_post_pass_agree(eq, monkeypatch):
     th, ph = G.fan_enumerate(theta_min=1.0, theta_max=45.0, theta_step=1.0, phi_min=-90.0, phi_max=0.0, phi_step=30.0)
     out = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("GEOAC_ABS_TABLE", mode)
+        monkeypatch.setitem(OPT, "ABS_TABLE", mode)
         ctx = G.FanContext(eq, device=0)
         ctx.load_met(H.TOYATMO)
         ctx.set_params(bounces=2, calc_amp=1, mode=0)

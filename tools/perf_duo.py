@@ -9,8 +9,7 @@ import geoac_amd as G
 import harness as H
 n_az = int(sys.argv[1]) if len(sys.argv) > 1 else 3240
 for v in (sys.argv[2:] or ["0", "1", "32", "66"]):
-    os.environ["GEOAC_DUO"] = v
-    ctx = G.FanContext(G.EQ_GLOBAL, device=0); ctx.load_met(H.TOYATMO)
+    ctx = G.FanContext(G.EQ_GLOBAL, device=0, options={"DUO": v}); ctx.load_met(H.TOYATMO)
     ctx.set_params(bounces=2, calc_amp=1, mode=0, src=(0.0, 30.0, 0.0))
     ph = -180.0 + 360.0 * np.arange(n_az) / n_az
     th = np.full(n_az, 0.5)

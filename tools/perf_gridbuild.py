@@ -10,7 +10,7 @@ from test_gpu_gridbuild import _synthetic_grid
 nx, ny, nz = (int(a) for a in sys.argv[1:4])
 host = len(sys.argv) > 4 and sys.argv[4] == "host"
 if host:
-    os.environ["GEOAC_GRID_BUILD"] = "host"
+    G.DEFAULT_OPTIONS["GRID_BUILD"] = "host"
 x, y, z, T, u, v, rho = _synthetic_grid(nx, ny, nz, False)
 ctx = G.FanContext(G.EQ_3D_RNGDEP, device=0)
 ctx.upload_atmo_3d(x[:2], y[:2], z[:3], T[:2, :2, :3].copy(), u[:2, :2, :3].copy(), v[:2, :2, :3].copy(), rho[:2, :2, :3].copy())   # warm-up: context, kernels

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GEOAC_DEBUG_ENV=1      # A/B sweeps drive the launch-plan options through the environment (read only with this set)
 # config-4 share under launch-plan knobs (sub-epochs, epoch length): one line each.  usage (GPU box): tools/sweep_cfg4.sh
 cd $GRAFT_REPO_ROOT
 for kv in "GEOAC_SUB_EPOCHS=1" "GEOAC_SUB_EPOCHS=4" "GEOAC_SUB_EPOCHS=8" "GEOAC_SUB_EPOCHS=16" "GEOAC_SUB_EPOCHS=8 GEOAC_S_ROWS=4096" "GEOAC_SUB_EPOCHS=4 GEOAC_S_ROWS=3072" "GEOAC_SUB_EPOCHS=16 GEOAC_S_ROWS=12288"; do

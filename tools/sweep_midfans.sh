@@ -1,4 +1,5 @@
 #!/bin/bash
+export GEOAC_DEBUG_ENV=1      # A/B sweeps drive the launch-plan options through the environment (read only with this set)
 # mid-size grid fans (4 097 - 32 768 rays) under the candidate launch plans: the multi-lane kernels without the record cache (the round-2
 # default there) against the cooperative one-lane kernel.  usage: sweep_midfans.sh OUTFILE
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=${1:-$R/gpurun_out/midfans.txt}

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GEOAC_DEBUG_ENV=1      # A/B sweeps drive the launch-plan options through the environment (read only with this set)
 # epoch-length sweep of one tools/bench_configs.py configuration: usage tools/sweep_rows.sh cfg4 1443 2886 5772
 c=$1; shift
 for r in "$@"; do

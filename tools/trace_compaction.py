@@ -4,7 +4,7 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 which = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
 for compact in ("1", "0"):
-    env = dict(os.environ, GEOAC_TRACE_EPOCHS="1", GEOAC_COMPACT=compact)
+    env = dict(os.environ, GEOAC_DEBUG_ENV="1", GEOAC_TRACE_EPOCHS="1", GEOAC_COMPACT=compact)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_configs.py"), which], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     lines = [l for l in r.stderr.decode().split("\n") if l.startswith("[epoch")]
     n = len(lines) // 2                       # bench_configs runs a warm-up and a timed pass: keep the second
