@@ -27,6 +27,7 @@ extern "C" int geoac_kernels_cart_rec(void);
 extern "C" hipError_t geoac_gridbuild_launch(int glob, int nx, int ny, int nz, const double* d_x, const double* d_y, const double* d_z,
                                              const double* d_fields, double* d_work, double* d_tab, hipStream_t s);
 extern "C" hipError_t geoac_launch_accum(const GeoacDevParams* P, hipStream_t s);
+extern "C" hipError_t geoac_launch_arrival(const GeoacDevParams* P, hipStream_t s);
 extern "C" hipError_t geoac_launch_compact(const GeoacDevParams* P, const int* cur, const int* n_cur, int n_first, int* next, int* n_next, hipStream_t s);
 extern "C" hipError_t geoac_launch_probe_atmo1d(const GeoacDevParams* P, int n, const double* x, double* out9, double* rho, hipStream_t s);
 extern "C" hipError_t geoac_launch_probe_absorption(const GeoacDevParams* P, int n, const double* x, const double* f, double* out, hipStream_t s);
@@ -543,9 +544,9 @@ int geoac_fan_launch(geoac_ctx* ctx){
     P.vert_limit = p.vert_limit; P.range_limit = p.range_limit;
     if(is_global){
         double half = p.range_limit / (2.0 * p.r_earth);
-        if(half >= kPi / 2.0) P.range_thresh = 2.0;               // asin saturates: the range test can never fire
-        else if(half <= 0.0) P.range_thresh = -1.0;
-        else { double s = sin(half); P.range_thresh = s * s; }
+        if(half >= kPi / 2.0){ P.range_thresh = 2.0; P.range_skip = 1e300; }      // asin saturates: the range test can never fire
+        else if(half <= 0.0){ P.range_thresh = -1.0; P.range_skip = -1.0; }       // (always fires)
+        else { double s = sin(half); P.range_thresh = s * s; P.range_skip = half * (1.0 - 1e-9); }
     }
     P.src[0] = p.src[0]; P.src[1] = p.src[1]; P.src[2] = p.src[2];
     P.freq = p.freq; P.tweak_abs = p.tweak_abs;
@@ -860,6 +861,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
         }
         if((long long)e > max_epochs) return fail(ctx, GEOAC_E_CAPACITY, "fan_launch: epoch bound exceeded");
     }
+    HIPCHK(geoac_launch_arrival(&P, s));           // stratified sets: inclination, back azimuth, range, amplitude of every arrival (k_arrival), beside the last post-pass
     HIPCHK(hipStreamWaitEvent(s, ctx->evs[4 * (ctx->n_epochs - 1) + 3], 0));
     HIPCHK(hipEventRecord(ctx->ev1, s));
     HIPCHK(hipMemcpyAsync(ctx->h_counters + 8, ctx->counters.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));

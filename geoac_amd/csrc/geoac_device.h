@@ -71,6 +71,7 @@ struct GeoacDevParams {
     double  ground;                 // Global: r_earth + z_grnd ; Cartesian: z_grnd
     double  r_earth, z_grnd;
     double  vert_limit, range_limit, range_thresh;   // range_thresh: sin^2(range_limit/(2 r_earth)) (Global)
+    double  range_skip;             // Global: while (|lat - lat_src| + |lon - lon_src|) / 2 stays below this, the range test cannot fire (EqGlobal::checks)
     double  src[3];                 // as in geoac_params
     double  freq, tweak_abs;
     double  T_o, P_o;               // SuthBass reference temperature / pressure (ground), host-evaluated from the spline

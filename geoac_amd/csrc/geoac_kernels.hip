@@ -89,9 +89,14 @@ DEVINL double fexp10(double y){
 // GeoAc_Set_ds (Global.cpp:210-217 and twins): 0.05 - 0.049 exp(-h / 0.75), clamped to [ds_min, ds_max]; h = height above the ground.
 // -h / 0.75 as a product with the double next to -4/3 (the quotient differs by at most one unit in the last place; the IEEE division
 // expansion is twelve instructions and a transcendental seed on the serial chain of every step)
+// Above 28.5 km the exponential is below 3.2e-17 and 0.049 e below half the spacing of the doubles at 0.05 (3.5e-18): the difference IS 0.05, and
+// a wave whose rays are all up there skips the 45 instructions of the exponential (the same bits either way)
 DEVINL double set_ds(double h, double ds_min, double ds_max){
-    const double e = fexp(h * (-1.0 / 0.75));
-    const double ds = 0.05 - 0.049 * e;
+    double ds = 0.05;
+    if(!(h > 28.5)){
+        const double e = fexp(h * (-1.0 / 0.75));
+        ds = 0.05 - 0.049 * e;
+    }
     return __builtin_fmax(__builtin_fmin(ds, ds_max), ds_min);
 }
 
@@ -410,10 +415,10 @@ DEVINL void global_aux(const GlobalStage& S, const GlobalDerived& D, const doubl
 
 // NQ = number of launch-angle derivative systems carried in y after the 6 base components: 2 = the reference layout
 // (theta then phi), 1 = the two-lanes-per-ray kernel where each lane of a pair carries the base ray and ONE of the two systems.
-template <bool AMP, int NQ, typename TabPtr>
+template <bool AMP, int NQ, bool ROT0 = false, typename TabPtr>
 DEVINL void global_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, double* rec, const double* y, double sth0, double cth0, double dlat, double* dy){
     GlobalStage S;
-    global_base<AMP, GEOAC_SEGW>(tab, P, seg, rec, y, sth0, cth0, dlat, dy, S);
+    global_base<AMP, GEOAC_SEGW, TabPtr, NoHook, ROT0>(tab, P, seg, rec, y, sth0, cth0, dlat, dy, S);
     if(AMP){
         GlobalDerived D;
         global_derive(S, D);
@@ -779,32 +784,43 @@ template <bool AMP_> struct EqGlobal {
     // values of a row depend on the ray's own rows only - not on where an epoch or a kernel began.
     static DEVINL void resume(const GeoacDevParams& P, RayCtx& C, const double* y){   // current row from the reference (kernel entry)
         rot_small(C.a[1], C.a[2], y[1] - C.a[0], C.cur[0], C.cur[1]);
-        rot_small(C.a[4], C.a[5], (y[2] - P.src[2] * kPi / 180.0) - C.a[3], C.cur[2], C.cur[3]);
     }
     template <typename TabPtr>
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
-        global_rhs<AMP, 2>(tab, P, seg, C.rec, yt, C.cur[0], C.cur[1], yt[1] - y0[1], dy);
+        // (stage 0 - a constant where the step loop peels it: the stage latitude is the step's, no rotation)
+        if(stage == 0) global_rhs<AMP, 2, true>(tab, P, seg, C.rec, yt, C.cur[0], C.cur[1], 0.0, dy);
+        else global_rhs<AMP, 2>(tab, P, seg, C.rec, yt, C.cur[0], C.cur[1], yt[1] - y0[1], dy);
     }
     // GeoAc_BreakCheck / GeoAc_GroundCheck on the new row (Global.cpp:500-522)
     static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, int k, bool& brk, bool& gnd){
         const double lon0 = P.src[2] * kPi / 180.0;
-        const double dl = yn[1] - C.a[0], pl = yn[2] - lon0, dp = pl - C.a[3];
+        const double dl = yn[1] - C.a[0], pl = yn[2] - lon0;
         if(fabs(dl) > GEOAC_ROT_MAX){ C.a[0] = yn[1]; fsincos(yn[1], C.a[1], C.a[2]); C.t[0] = C.a[1]; C.t[1] = C.a[2]; }   // (rare, per ray)
         else rot_small(C.a[1], C.a[2], dl, C.t[0], C.t[1]);
-        if(fabs(dp) > GEOAC_ROT_MAX){ C.a[3] = pl; fsincos(pl, C.a[4], C.a[5]); C.t[2] = C.a[4]; C.t[3] = C.a[5]; }
-        else rot_small(C.a[4], C.a[5], dp, C.t[2], C.t[3]);
         // haversine of the great-circle range: hav = sin^2(dlat/2) + cos(lat0) cos(lat) sin^2(dlon/2), with 2 sin^2(x/2) = 1 - cos x;
-        // range = 2 R asin(sqrt(hav)) > limit  <=>  hav > sin^2(limit / 2R)
-        const double sl0 = P.src_trig[0], cl0 = P.src_trig[1];
-        double hav = __builtin_fma(cl0 * C.t[1], 0.5 * (1.0 - C.t[3]), 0.5 * (1.0 - __builtin_fma(C.t[1], cl0, C.t[0] * sl0)));
-        brk = (yn[0] > P.vert_limit) || (hav > P.range_thresh);
+        // range = 2 R asin(sqrt(hav)) > limit  <=>  hav > sin^2(limit / 2R).
+        // hav <= sin^2 a + sin^2 b <= sin^2(a + b) for a = |dlat| / 2, b = |dlon| / 2, a + b <= pi / 2 (the difference is 2 sin a sin b cos(a + b)):
+        // while a + b stays below limit / 2R (less 1e-9 of it: P.range_skip) the test cannot fire, and the ~50 instructions of the longitude
+        // rotation and the haversine are skipped by a wave whose rays are all that close to the source.  The longitude reference point goes
+        // stale meanwhile; the first row that is tested finds it further than GEOAC_ROT_MAX away and takes a new one.
+        bool far = false;
+        if(fabs(yn[1] - P.src[1] * kPi / 180.0) * 0.5 + fabs(pl) * 0.5 >= P.range_skip){
+            const double dp = pl - C.a[3];
+            double tp0, tp1;
+            if(fabs(dp) > GEOAC_ROT_MAX){ C.a[3] = pl; fsincos(pl, C.a[4], C.a[5]); tp0 = C.a[4]; tp1 = C.a[5]; }
+            else rot_small(C.a[4], C.a[5], dp, tp0, tp1);
+            const double sl0 = P.src_trig[0], cl0 = P.src_trig[1];
+            double hav = __builtin_fma(cl0 * C.t[1], 0.5 * (1.0 - tp1), 0.5 * (1.0 - __builtin_fma(C.t[1], cl0, C.t[0] * sl0)));
+            far = hav > P.range_thresh;
+        }
+        brk = (yn[0] > P.vert_limit) || far;
         gnd = yn[0] < P.ground;
     }
-    static DEVINL void accept(RayCtx& C){ C.cur[0] = C.t[0]; C.cur[1] = C.t[1]; C.cur[2] = C.t[2]; C.cur[3] = C.t[3]; }
+    static DEVINL void accept(RayCtx& C){ C.cur[0] = C.t[0]; C.cur[1] = C.t[1]; }
     static DEVINL void restart(const GeoacDevParams& P, RayCtx& C, const double* y){      // start of a leg: the reflected row is the new reference
         C.a[0] = y[1]; fsincos(y[1], C.a[1], C.a[2]);
         C.a[3] = y[2] - P.src[2] * kPi / 180.0; fsincos(C.a[3], C.a[4], C.a[5]);
-        C.cur[0] = C.a[1]; C.cur[1] = C.a[2]; C.cur[2] = C.a[4]; C.cur[3] = C.a[5];
+        C.cur[0] = C.a[1]; C.cur[1] = C.a[2];
     }
     // arrival row: GeoAcGlobal_main.cpp:296-317
     static DEVINL void arrival(const GeoacDevParams& P, const RayCtx& C, int slot, const double* yn, double* R){
@@ -902,7 +918,8 @@ struct EqGlobalPair : EqGlobal<true> {
     static constexpr bool SPLIT = true; static constexpr bool ROW_SPLIT = true;      // (the two lanes also store half a path row each)
     template <typename TabPtr>
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
-        global_rhs<true, 1>(tab, P, seg, C.rec, yt, C.cur[0], C.cur[1], yt[1] - y0[1], dy);
+        if(stage == 0) global_rhs<true, 1, true>(tab, P, seg, C.rec, yt, C.cur[0], C.cur[1], 0.0, dy);
+        else global_rhs<true, 1>(tab, P, seg, C.rec, yt, C.cur[0], C.cur[1], yt[1] - y0[1], dy);
     }
     // reflection of the base ray and of this lane's derivative system (Global.cpp:140-205, Q1 linear intercept)
     static DEVINL void reflect(const GeoacDevParams& P, const RayCtx& C, const double* yn, double* y, const double* ym2){
@@ -1759,27 +1776,20 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
     };
     if(!EQ::COOP || (!idle0 && sub_h == 0)) put_row(y);          // carry row: chunk row 0 = current state
 
-    // COOP: wave-uniform loop (every lane stays while any lane of the wave has work; `act` predicates this lane's own work).
-    // Other policies: the plain per-lane loop (kept in this form: the latency-bound stratified kernels are sensitive to how the loop is laid out)
-    while(EQ::COOP ? (bool)__any((nr + 2 <= row_end) && !done) : ((nr + 2 <= P.s_rows) && !done)){
-        const bool act = EQ::COOP ? ((nr + 2 <= row_end) && !done) : true;
-#ifdef GEOAC_KSTAT
-        C.ckey = act ? 1 : 0;
-#endif
-        double ds = P.ds_min;
-        if(!EQ::COOP || act){
+    // ---- what opens a step on row ya: running turning height, raypath / caustic events of the row ----
+    auto open_step = [&](const double* ya){
         // running turning height: max over rows m < k of the height component   (GeoAcGlobal_main.cpp:294)
         if(EQ::PW == 2 && (P.mode & GEOAC_MODE_INTERACTIVE)){         // GeoAc2D -interactive: max over rows 1..k-1 of solution[m][2] (nu_z)
-            if(k >= 1) hmax = (hmax < y[2]) ? y[2] : hmax;
-        } else { double h = EQ::height(P, y); if(EQ::HMAX_PER_LEG && k == 0) hmax = 0.0; hmax = (hmax < h) ? h : hmax; }
+            if(k >= 1) hmax = (hmax < ya[2]) ? ya[2] : hmax;
+        } else { double h = EQ::height(P, ya); if(EQ::HMAX_PER_LEG && k == 0) hmax = 0.0; hmax = (hmax < h) ? h : hmax; }
 
         if(SMP && k >= 1){
-            // y is row m = k (1 <= m < k_final) at chunk row nr-1: the rows the reference's post-pass loop visits
+            // ya is row m = k (1 <= m < k_final) at chunk row nr-1: the rows the reference's post-pass loop visits
             // (GeoAcGlobal_main.cpp:264-286).  Raypath sample every sample_stride-th row; caustic where the Jacobian changes sign.
             const bool smp_row = want_rays && (k % P.smp_stride == 0);
             if(smp_row || want_caus){
                 double amp = 0.0, D = 0.0;
-                if(EQ::AMP) EQ::amp_jac(P, C, slot, y, amp, D);
+                if(EQ::AMP) EQ::amp_jac(P, C, slot, ya, amp, D);
                 if(smp_row){
                     if(nev < P.ev_cap){ P.ev_row[(size_t)nev * np + col] = nr - 1; P.ev_m[(size_t)nev * np + col] = (int)k; P.ev_amp[(size_t)nev * np + col] = amp; }
                     nev++;
@@ -1793,22 +1803,159 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
                 }
             }
         }
+    };
+    // ---- what closes it: ya = row k-1, yb = the new row k.  The row is stored and tested (GeoAc_BreakCheck / GeoAc_GroundCheck / the loop bound);
+    //      true: it ended the leg ----
+    bool brk = false, gnd = false, lim = false;
+    auto advance = [&](const double* ya, const double* yb) -> bool {
+        k++; steps_here++;
+        put_row(yb);
+        EQ::checks(P, C, ya, yb, k, brk, gnd);
+        lim = (k >= k_lim);                                       // Solver.cpp loop bound; never reached on sane inputs
+        return brk || gnd || lim;
+    };
+    // ---- leg end: ya = row k-1, yb = the leg's last row k, yc = row k-2 (YM2_REG).  The new leg's row 0 (for a finished ray: row k-1) is left in ya ----
+    auto leg_end = [&](double* ya, double* yb, const double* yc){
+        // ---- leg end: record (GeoAcGlobal_main.cpp:293-317 and twins) ----
+        double* R = P.rec + ((size_t)(P.perm ? P.perm[slot] : slot) * (P.bounces + 1) + leg) * GEOAC_REC_STRIDE;
+        R[GEOAC_REC_STEPS] = (double)((lim && !brk && !gnd) ? k + 1 : k);   // exhausted loop: the reference returns step_limit (= k + 1), Solver.cpp:70
+        P.legend[(size_t)nle * np + col] = nr - 1; nle++;
+        if(lim && !brk && !gnd){ atomicOr(&P.counters[2], 1ull); steps_here++; }   // (the step total is the sum of the reference's return values: step_limit for this leg)
+        // the leg's last row solution[k][*] (both outcomes: arrival rows read it, and so do the eigenray scans' messages after a break)
+        double yf[18];
+        if(EQ::SPLIT){
+            // assemble the reference's full row (base + both systems) from the lane pair (both lanes end up with the same row
+            // and store the same record)
+            #pragma unroll
+            for(int e = 0; e < 18; e++) yf[e] = 0.0;
+            #pragma unroll
+            for(int e = 0; e < EQ::NB; e++) yf[e] = yb[e];
+            #pragma unroll
+            for(int e = 0; e < EQ::NS; e++){
+                double mine = yb[EQ::NB + e], other = __shfl_xor(mine, 1 << EQ::SYS_SHIFT);
+                yf[EQ::NB + e]  = qs ? other : mine;
+                yf[EQ::NB + EQ::NS + e] = qs ? mine : other;
+            }
+        } else {
+            #pragma unroll
+            for(int e = 0; e < 18; e++) yf[e] = (e < E) ? yb[e < E ? e : 0] : 0.0;
+        }
+        #pragma unroll
+        for(int e = 0; e < (EQ::SPLIT ? EQ::NB + 2 * EQ::NS : E); e++) R[GEOAC_REC_STATE + e] = yf[e];
+        if(brk){
+            R[GEOAC_REC_BROKE] = 1.0;
+            done = true;
+        } else {
+            R[GEOAC_REC_VALID] = 1.0;
+            if(lim && !gnd){                                  // exhausted loop: the reference's row count is one more, its turning height covers the last row too
+                const double hl = EQ::height(P, yb);
+                if(!(EQ::PW == 2 && (P.mode & GEOAC_MODE_INTERACTIVE))) hmax = (hmax < hl) ? hl : hmax;
+            }
+            R[GEOAC_REC_TURN] = hmax;
+            // stratified sets: the arrival record (inclination, back azimuth, range, amplitude: sin / cos / asin / atan2 of the leg's last row,
+            // which the record holds) is filled in by k_arrival once the fan has finished - ~3 000 instructions and their constants out of this
+            // kernel's registers.  The grid sets, whose kernels are bound by their table gathers, keep it here.
+            if constexpr (!EQ::SEG1D) arrival_of<EQ>(P, C, slot, EQ::SPLIT ? yf : yb, R);
+            if(leg >= P.bounces){
+                done = true;
+            } else {
+                if(EQ::KM2 && EQ::KM2_MEM){
+                    double r2[E];
+                    #pragma unroll
+                    for(int e = 0; e < E; e++) r2[e] = st[(ST_YM2 + ((EQ::SPLIT && e >= EQ::NB) ? e + EQ::NS * qs : e)) * np];
+                    EQ::reflect(P, C, yb, ya, r2);
+                } else EQ::reflect(P, C, yb, ya, yc);
+                leg++; k = 0;
+                EQ::restart(P, C, ya);
+                put_row(ya);                                      // leg-start row
+            }
+        }
+    };
 
-        // ---- GeoAc_Set_ds (Global.cpp:210-217 and twins) ----
-        if constexpr (EQ::SEG1D) ds = set_ds(EQ::above_ground(P, y), P.ds_min, P.ds_max);
-        else {                                                    // (grid kernels: the form they were tuned with - registers)
+    if constexpr (EQ::SEG1D){
+        // ---- stratified sets: the serial chain of one ray IS the run time (one wave per SIMD issues an instruction every ~4.5 cycles whatever its
+        // kind), so the loop is laid out for instruction count:
+        //  * stages 0 and 3 are peeled off the rolled stage loop (four copies of the right-hand side do not fit the registers, three do): stage 0
+        //    reads the row itself (no copy, no rotation of the carried sin / cos), stage 3 forms no further stage input;
+        //  * the new row is written over the old one, component by component, once the tests on its position have passed - no copy of the row at
+        //    the bottom of the loop;
+        //  * a row that ends a leg takes the WHOLE wave out of the loop before that (a vote: a uniform branch), with the row still in its parts
+        //    (row k-1, the three-stage sum, the last slope); the leg end is worked off outside and the wave re-enters.  Inside the loop a row is
+        //    never merged with the outcome of a rare path, which is what cost ~45 register moves per step before (a few hundred leg ends per
+        //    wave and fan against 50 000 steps).
+        while(__any((nr + 2 <= P.s_rows) && !done)){                  // (wave-uniform)
+            bool ev = false, pend = false;
+            double dy[E], ys[E], w6 = 0.0;                            // at a vote: the last slope, the sum of the first three stages, ds / 6
+            while((nr + 2 <= P.s_rows) && !done){
+                open_step(y);
+                const double ds = set_ds(EQ::above_ground(P, y), P.ds_min, P.ds_max);        // GeoAc_Set_ds (Global.cpp:210-217 and twins)
+                const double ds_2 = 0.5 * ds, ds_6 = (1.0 / 6.0) * ds, ds_3 = (1.0 / 3.0) * ds;
+                // k_s = ds f(y + a_s k_{s-1}), a = {0, 1/2, 1/2, 1};  y' = y + k1/6 + k2/3 + k3/3 + k4/6  (Solver.cpp:33-54)
+                double yt[E];
+                if(LDS) EQ::rhs(lds_tab, P, seg, C, y, y, 0, dy); else EQ::rhs(gtab, P, seg, C, y, y, 0, dy);
+                #pragma unroll
+                for(int e = 0; e < E; e++){ ys[e] = __builtin_fma(dy[e], ds_6, y[e]); yt[e] = __builtin_fma(dy[e], ds_2, y[e]); }
+                #pragma unroll 1
+                for(int stage = 1; stage < 3; stage++){
+                    if(LDS) EQ::rhs(lds_tab, P, seg, C, y, yt, stage, dy); else EQ::rhs(gtab, P, seg, C, y, yt, stage, dy);
+                    const double wa = (stage == 2) ? ds : ds_2;
+                    #pragma unroll
+                    for(int e = 0; e < E; e++){ ys[e] = __builtin_fma(dy[e], ds_3, ys[e]); yt[e] = __builtin_fma(dy[e], wa, y[e]); }
+                }
+                if(LDS) EQ::rhs(lds_tab, P, seg, C, y, yt, 3, dy); else EQ::rhs(gtab, P, seg, C, y, yt, 3, dy);      // (the last slope stays in dy)
+                // the position part of the new row and the tests on it (GeoAc_BreakCheck / GeoAc_GroundCheck / the loop bound)
+                double t[EQ::NB];
+                #pragma unroll
+                for(int e = 0; e < EQ::NB; e++) t[e] = __builtin_fma(dy[e], ds_6, ys[e]);
+                EQ::checks(P, C, y, t, k + 1, brk, gnd);
+                lim = (k + 1 >= k_lim);                               // Solver.cpp loop bound; never reached on sane inputs
+                ev = brk || gnd || lim;
+                if(__any(ev)){ pend = true; w6 = ds_6; break; }
+                #pragma unroll
+                for(int e = 0; e < E; e++){
+                    if(YM2_REG) ym2[e] = y[e];
+                    y[e] = __builtin_fma(dy[e], ds_6, ys[e]);
+                }
+                k++; steps_here++;
+                put_row(y);
+                EQ::accept(C);
+            }
+            if(pend){                                                 // (rare) the row that was voted on
+                #pragma unroll
+                for(int e = 0; e < E; e++) ys[e] = __builtin_fma(dy[e], w6, ys[e]);
+                k++; steps_here++;
+                put_row(ys);
+                EQ::accept(C);                                        // (a leg end sets the carried values anew: restart)
+                if(ev) leg_end(y, ys, ym2);
+                else {
+                    #pragma unroll
+                    for(int e = 0; e < E; e++){ if(YM2_REG) ym2[e] = y[e]; y[e] = ys[e]; }
+                }
+            }
+        }
+    } else {
+    // COOP: wave-uniform loop (every lane stays while any lane of the wave has work; `act` predicates this lane's own work).
+    // Other policies: the plain per-lane loop
+    double yn[E];
+    while(EQ::COOP ? (bool)__any((nr + 2 <= row_end) && !done) : ((nr + 2 <= P.s_rows) && !done)){
+        const bool act = EQ::COOP ? ((nr + 2 <= row_end) && !done) : true;
+#ifdef GEOAC_KSTAT
+        C.ckey = act ? 1 : 0;
+#endif
+        double ds = P.ds_min;
+        if(!EQ::COOP || act){
+            open_step(y);
+            // ---- GeoAc_Set_ds (Global.cpp:210-217 and twins); the form the grid kernels were tuned with (registers) ----
             ds = 0.05 - 0.049 * exp(-EQ::above_ground(P, y) / 0.75);
             ds = (P.ds_max < ds) ? P.ds_max : ds;
             ds = (ds < P.ds_min) ? P.ds_min : ds;
         }
-        }
 
         // ---- the four RK4 stages as ONE rolled loop (a single copy of the RHS keeps the live set < 256 VGPRs):
         //      k_s = ds f(y + a_s k_{s-1}), a = {0, 1/2, 1/2, 1};  y' = y + k1/6 + k2/3 + k3/3 + k4/6  (Solver.cpp:33-54)
-        double dy[E], yt[E], yn[E];
+        double dy[E], yt[E];
         #pragma unroll
         for(int e = 0; e < E; e++){ yt[e] = y[e]; yn[e] = y[e]; }
-        const double ds_2 = 0.5 * ds, ds_6 = (1.0 / 6.0) * ds, ds_3 = (1.0 / 3.0) * ds;     // (1-D sets: the products the stages used to form one by one)
         if(EQ::LDS_STATE){
             // the step's base row y and the accumulating new row yn live in LDS ([component][lane], conflict free) while the four stages
             // run: 72 registers less under the table evaluation, which is what spilled (416 B of scratch per lane before)
@@ -1820,9 +1967,9 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
             if(EQ::COOP) EQ::rhs((double*)ldsw, P, seg, C, y, yt, stage, dy);
             else if(EQ::CACHE) EQ::rhs((double*)ldsc, P, seg, C, y, yt, stage, dy);
             else if(LDS) EQ::rhs(lds_tab, P, seg, C, y, yt, stage, dy); else EQ::rhs(gtab, P, seg, C, y, yt, stage, dy);
-            // (grid sets: formed per stage - three doubles less to keep alive under the table evaluation)
-            const double wa = EQ::SEG1D ? ((stage == 2) ? ds : ds_2) : ((stage == 2) ? 1.0 : 0.5) * ds;
-            const double wb = EQ::SEG1D ? ((stage == 0 || stage == 3) ? ds_6 : ds_3) : ((stage == 0 || stage == 3) ? (1.0 / 6.0) : (1.0 / 3.0)) * ds;
+            // (formed per stage - three doubles less to keep alive under the table evaluation)
+            const double wa = ((stage == 2) ? 1.0 : 0.5) * ds;
+            const double wb = ((stage == 0 || stage == 3) ? (1.0 / 6.0) : (1.0 / 3.0)) * ds;
             if(EQ::LDS_STATE){
                 #pragma unroll
                 for(int e = 0; e < E; e++){
@@ -1843,79 +1990,22 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
         }
 
         if(!EQ::COOP || act){                                     // (a helper lane has nothing of its own to advance)
-        k++; steps_here++;
-        put_row(yn);
-
-        bool brk, gnd;
-        EQ::checks(P, C, y, yn, k, brk, gnd);
-        bool lim = (k >= k_lim);                                  // Solver.cpp loop bound; never reached on sane inputs
-
-        if(brk || gnd || lim){
-            // ---- leg end: record (GeoAcGlobal_main.cpp:293-317 and twins) ----
-            double* R = P.rec + ((size_t)(P.perm ? P.perm[slot] : slot) * (P.bounces + 1) + leg) * GEOAC_REC_STRIDE;
-            R[GEOAC_REC_STEPS] = (double)((lim && !brk && !gnd) ? k + 1 : k);   // exhausted loop: the reference returns step_limit (= k + 1), Solver.cpp:70
-            P.legend[(size_t)nle * np + col] = nr - 1; nle++;
-            if(lim && !brk && !gnd){ atomicOr(&P.counters[2], 1ull); steps_here++; }   // (the step total is the sum of the reference's return values: step_limit for this leg)
-            // the leg's last row solution[k][*] (both outcomes: arrival rows read it, and so do the eigenray scans' messages after a break)
-            double yf[18];
-            if(EQ::SPLIT){
-                // assemble the reference's full row (base + both systems) from the lane pair (both lanes end up with the same row
-                // and store the same record)
-                #pragma unroll
-                for(int e = 0; e < 18; e++) yf[e] = 0.0;
-                #pragma unroll
-                for(int e = 0; e < EQ::NB; e++) yf[e] = yn[e];
-                #pragma unroll
-                for(int e = 0; e < EQ::NS; e++){
-                    double mine = yn[EQ::NB + e], other = __shfl_xor(mine, 1 << EQ::SYS_SHIFT);
-                    yf[EQ::NB + e]  = qs ? other : mine;
-                    yf[EQ::NB + EQ::NS + e] = qs ? mine : other;
+            if(advance(y, yn)) leg_end(y, yn, ym2);
+            else {
+                if(YM2_REG){
+                    #pragma unroll
+                    for(int e = 0; e < E; e++) ym2[e] = y[e];
+                } else if(EQ::KM2 && (EQ::LANES == 1 || (EQ::SPLIT ? (q & ((1 << EQ::SYS_SHIFT) - 1)) == 0 : q == 0))){
+                    // KM2_MEM: one coalesced row per step, stored by the ray's first lane (split state: by the first lane of each launch-angle system, its part)
+                    #pragma unroll
+                    for(int e = 0; e < E; e++) st[(ST_YM2 + ((EQ::SPLIT && e >= EQ::NB) ? e + EQ::NS * qs : e)) * np] = y[e];
                 }
-            } else {
                 #pragma unroll
-                for(int e = 0; e < 18; e++) yf[e] = (e < E) ? yn[e < E ? e : 0] : 0.0;
+                for(int e = 0; e < E; e++) y[e] = yn[e];
+                EQ::accept(C);
             }
-            #pragma unroll
-            for(int e = 0; e < (EQ::SPLIT ? EQ::NB + 2 * EQ::NS : E); e++) R[GEOAC_REC_STATE + e] = yf[e];
-            if(brk){
-                R[GEOAC_REC_BROKE] = 1.0;
-                done = true;
-            } else {
-                R[GEOAC_REC_VALID] = 1.0;
-                if(lim && !gnd){                                  // exhausted loop: the reference's row count is one more, its turning height covers the last row too
-                    const double hl = EQ::height(P, yn);
-                    if(!(EQ::PW == 2 && (P.mode & GEOAC_MODE_INTERACTIVE))) hmax = (hmax < hl) ? hl : hmax;
-                }
-                R[GEOAC_REC_TURN] = hmax;
-                arrival_of<EQ>(P, C, slot, EQ::SPLIT ? yf : yn, R);
-                if(leg >= P.bounces){
-                    done = true;
-                } else {
-                    if(EQ::KM2 && EQ::KM2_MEM){
-                        double r2[E];
-                        #pragma unroll
-                        for(int e = 0; e < E; e++) r2[e] = st[(ST_YM2 + ((EQ::SPLIT && e >= EQ::NB) ? e + EQ::NS * qs : e)) * np];
-                        EQ::reflect(P, C, yn, y, r2);
-                    } else EQ::reflect(P, C, yn, y, ym2);
-                    leg++; k = 0;
-                    EQ::restart(P, C, y);
-                    put_row(y);                                       // leg-start row
-                }
-            }
-        } else {
-            if(YM2_REG){
-                #pragma unroll
-                for(int e = 0; e < E; e++) ym2[e] = y[e];
-            } else if(EQ::KM2 && (EQ::LANES == 1 || (EQ::SPLIT ? (q & ((1 << EQ::SYS_SHIFT) - 1)) == 0 : q == 0))){
-                // KM2_MEM: one coalesced row per step, stored by the ray's first lane (split state: by the first lane of each launch-angle system, its part)
-                #pragma unroll
-                for(int e = 0; e < E; e++) st[(ST_YM2 + ((EQ::SPLIT && e >= EQ::NB) ? e + EQ::NS * qs : e)) * np] = y[e];
-            }
-            #pragma unroll
-            for(int e = 0; e < E; e++) y[e] = yn[e];
-            EQ::accept(C);
         }
-        }
+    }
     }
 
     // ---- save state (pair kernel: both lanes store the identical base ray; each stores its own derivative system) ----
@@ -2216,6 +2306,31 @@ __global__ void __launch_bounds__(64) k_atab_build(GeoacDevParams P, double* __r
     }
     if(!ok) o[0] = -o[0];                                       // flagged: not served
     o[GEOAC_ATABW - 1] = worst;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_arrival (stratified sets): the arrival part of the records (GeoAcGlobal_main.cpp:296-317 and twins) from the leg's last row, which
+// k_rk4 left in the record.  One thread per (ray, leg); runs once, behind the fan's last RK4 launch.
+// ------------------------------------------------------------------------------------------------
+template <class EQ>
+__global__ void __launch_bounds__(256) k_arrival(GeoacDevParams P){
+    const int legs = P.bounces + 1;
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if(id >= (long long)P.n_rays * legs) return;
+    const int slot = (int)(id / legs), leg = (int)(id % legs);
+    double* R = P.rec + ((size_t)(P.perm ? P.perm[slot] : slot) * legs + leg) * GEOAC_REC_STRIDE;
+    if(R[GEOAC_REC_VALID] == 0.0) return;
+    const size_t np = (size_t)P.n_pad;
+    const double* st = P.state + slot;
+    RayCtx C;
+    C.ckey = -1; C.kxy = -1;
+    C.c0 = st[ST_C0 * np]; C.nu0 = st[ST_NU0 * np];
+    #pragma unroll
+    for(int q = 0; q < 6; q++) C.a[q] = st[(ST_AUX0 + q) * np];     // (3-D / 2-D: the constants of the ray; Global: not read)
+    double yl[18];
+    #pragma unroll
+    for(int e = 0; e < 18; e++) yl[e] = R[GEOAC_REC_STATE + e];
+    EQ::arrival(P, C, slot, yl, R);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2608,6 +2723,18 @@ extern "C" hipError_t geoac_launch_compact(const GeoacDevParams* P, const int* c
     return hipGetLastError();
 }
 
+extern "C" hipError_t geoac_launch_arrival(const GeoacDevParams* P, hipStream_t s){
+    if(P->gtab) return hipSuccess;                               // (grid sets: k_rk4 fills the records in)
+    dim3 b(256), g((unsigned)(((long long)P->n_rays * (P->bounces + 1) + 255) / 256));
+    const bool amp = P->calc_amp != 0;
+    switch(P->eqset){
+        case GEOAC_EQ_GLOBAL: if(amp) hipLaunchKernelGGL(k_arrival<EqGlobal<true>>, g, b, 0, s, *P); else hipLaunchKernelGGL(k_arrival<EqGlobal<false>>, g, b, 0, s, *P); break;
+        case GEOAC_EQ_3D:     if(amp) hipLaunchKernelGGL(k_arrival<Eq3D<true>>, g, b, 0, s, *P);     else hipLaunchKernelGGL(k_arrival<Eq3D<false>>, g, b, 0, s, *P); break;
+        case GEOAC_EQ_2D:     if(amp) hipLaunchKernelGGL(k_arrival<Eq2D<true>>, g, b, 0, s, *P);     else hipLaunchKernelGGL(k_arrival<Eq2D<false>>, g, b, 0, s, *P); break;
+        default: return hipSuccess;
+    }
+    return hipGetLastError();
+}
 extern "C" hipError_t geoac_launch_accum(const GeoacDevParams* P, hipStream_t s){
     dim3 b(256), g2((P->n_cols_bound + 255) / 256);
     hipLaunchKernelGGL(k_accum, g2, b, 0, s, *P);
