@@ -115,7 +115,7 @@ struct geoac_ctx {
                                                   // Measured: a short full-occupancy burst disturbs k_rk4 LESS than a long thin sweep
                                                   // (avg k_rk4 launch 10.9 ms vs 11.7-12.8 ms at 8192-256 blocks).
     double pair_frac = 0.10;                      // hybrid fans: share of the inclination-sorted rays that get two lanes (GEOAC_PAIR_FRAC; >= 1: all)
-    double hybrid_rows = 0.70;                    // hybrid fans: rows per epoch of the one-lane launch relative to the two-lane launch (GEOAC_HYBRID_ROWS)
+    double hybrid_rows = 0.75;                    // hybrid fans: rows per epoch of the one-lane launch relative to the two-lane launch (GEOAC_HYBRID_ROWS)
     bool two_chunks = false;                      // GEOAC_TWO_CHUNKS=1: two path chunks in rotation instead of three (A/B measurements)
     bool trace_epochs = false;                    // GEOAC_TRACE_EPOCHS=1: per-epoch live counts on stderr
     bool no_gate = false;                         // GEOAC_NO_GATE=1: post-pass not held back behind the next RK4 launch (A/B measurements)

@@ -90,13 +90,13 @@ DEVINL double fexp10(double y){
 // -h / 0.75 as a product with the double next to -4/3 (the quotient differs by at most one unit in the last place; the IEEE division
 // expansion is twelve instructions and a transcendental seed on the serial chain of every step)
 // Above 28.5 km the exponential is below 3.2e-17 and 0.049 e below half the spacing of the doubles at 0.05 (3.5e-18): the difference IS 0.05, and
-// a wave whose rays are all up there skips the 45 instructions of the exponential (the same bits either way)
+// a wave whose rays are all up there skips the exponential (the same bits either way).
+// (Measured and dropped, round 3: exp(-h / 0.75) as a table value at the 1/64 km marks times a degree-6 polynomial - 25 instructions less, 2.5 % MORE
+// time, with the table value loaded at the top of the step or a step ahead: the constants the full routine moves into place between its dependent
+// multiply-adds fill issue slots that would stay empty anyway, the load and its wait do not.)
 DEVINL double set_ds(double h, double ds_min, double ds_max){
     double ds = 0.05;
-    if(!(h > 28.5)){
-        const double e = fexp(h * (-1.0 / 0.75));
-        ds = 0.05 - 0.049 * e;
-    }
+    if(!(h > 28.5)) ds = 0.05 - 0.049 * fexp(h * (-1.0 / 0.75));
     return __builtin_fmax(__builtin_fmin(ds, ds_max), ds_min);
 }
 
@@ -1879,14 +1879,14 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
         //    reads the row itself (no copy, no rotation of the carried sin / cos), stage 3 forms no further stage input;
         //  * the new row is written over the old one, component by component, once the tests on its position have passed - no copy of the row at
         //    the bottom of the loop;
-        //  * a row that ends a leg takes the WHOLE wave out of the loop before that (a vote: a uniform branch), with the row still in its parts
+        //  * a row that ends a leg (or fills a lane's chunk) takes the WHOLE wave out of the loop before that (a vote: a uniform branch), with the row still in its parts
         //    (row k-1, the three-stage sum, the last slope); the leg end is worked off outside and the wave re-enters.  Inside the loop a row is
         //    never merged with the outcome of a rare path, which is what cost ~45 register moves per step before (a few hundred leg ends per
         //    wave and fan against 50 000 steps).
         while(__any((nr + 2 <= P.s_rows) && !done)){                  // (wave-uniform)
             bool ev = false, pend = false;
             double dy[E], ys[E], w6 = 0.0;                            // at a vote: the last slope, the sum of the first three stages, ds / 6
-            while((nr + 2 <= P.s_rows) && !done){
+            if((nr + 2 <= P.s_rows) && !done) for(;;){                // (every lane that enters leaves at the same vote: no exec-mask bookkeeping inside)
                 open_step(y);
                 const double ds = set_ds(EQ::above_ground(P, y), P.ds_min, P.ds_max);        // GeoAc_Set_ds (Global.cpp:210-217 and twins)
                 const double ds_2 = 0.5 * ds, ds_6 = (1.0 / 6.0) * ds, ds_3 = (1.0 / 3.0) * ds;
@@ -1910,7 +1910,8 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
                 EQ::checks(P, C, y, t, k + 1, brk, gnd);
                 lim = (k + 1 >= k_lim);                               // Solver.cpp loop bound; never reached on sane inputs
                 ev = brk || gnd || lim;
-                if(__any(ev)){ pend = true; w6 = ds_6; break; }
+                const bool full = !(nr + 3 <= P.s_rows);                // this lane's chunk has no room for another step after this one
+                if(__any(ev || full)){ pend = true; w6 = ds_6; break; }
                 #pragma unroll
                 for(int e = 0; e < E; e++){
                     if(YM2_REG) ym2[e] = y[e];

@@ -1,4 +1,4 @@
-"""A/B of two builds of libgeoac_hip.so on the metric fan, same box, same process order: usage ab_metric.py <libA.so> <libB.so> [passes]"""
+"""A/B of builds of libgeoac_hip.so on the metric fan, same box, same process, each build twice in turn: usage ab_metric.py <passes> <libA.so> <libB.so> [...]"""
 import ctypes, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,6 +23,6 @@ def run(lib_path, passes):
 
 
 if __name__ == "__main__":
-    n = int(sys.argv[3]) if len(sys.argv) > 3 else 8
-    for p in (sys.argv[1], sys.argv[2], sys.argv[1], sys.argv[2]):
+    n = int(sys.argv[1])
+    for p in sys.argv[2:] + sys.argv[2:]:
         run(os.path.abspath(p), n)
