@@ -39,7 +39,8 @@ class EigParams(ctypes.Structure):
 
 
 def library_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libgeoac_hip.so")
+    """the in-tree build; GEOAC_LIB names another build of the same library (A/B and diagnostic builds: tools/ab_metric.py, -DGEOAC_KSTAT)"""
+    return os.environ.get("GEOAC_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libgeoac_hip.so")
 
 
 _lib = None

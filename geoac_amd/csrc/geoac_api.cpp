@@ -879,6 +879,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
             fprintf(stderr, "[kstat] wave-stages %llu; K = 1: %.3f, 2: %.3f, 3-4: %.3f, 5-6: %.3f, 7-8: %.3f, 9-12: %.3f, 13-16: %.3f, > 16: %.3f; mean K %.2f, mean kz span %.2f\n", tot,
                     (double)h[0] / tot, (double)h[1] / tot, (double)h[2] / tot, (double)h[3] / tot, (double)h[4] / tot, (double)h[5] / tot, (double)h[6] / tot, (double)h[7] / tot,
                     (double)h[8] / tot, (double)h[9] / tot);
+            if(h[11]) fprintf(stderr, "[kstat] lane-stages %llu, of them with a (segment, cell) key other than the lane's key of the stage before: %.4f\n", h[11], (double)h[10] / (double)h[11]);
         }
     }
 #endif

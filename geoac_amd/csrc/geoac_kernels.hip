@@ -100,6 +100,14 @@ DEVINL double set_ds(double h, double ds_min, double ds_max){
     return __builtin_fmax(__builtin_fmin(ds, ds_max), ds_min);
 }
 
+// the same for |d| <= 4e-3 rad: two more terms (d^7 / 5040 < 2e-20)
+DEVINL void rot_fifth(double sa, double ca, double d, double& s, double& c){
+    const double d2 = d * d;
+    const double sd = d * __builtin_fma(d2, __builtin_fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
+    const double cd = __builtin_fma(d2, __builtin_fma(d2, __builtin_fma(d2, -1.0 / 720.0, 1.0 / 24.0), -0.5), 1.0);
+    s = __builtin_fma(sa, cd, ca * sd);
+    c = __builtin_fma(ca, cd, -sa * sd);
+}
 // rotate (sin a, cos a) by a small angle d.  |d| <= ds_max / r_earth < 1e-4 for every caller (one RK4 stage or step of at most
 // 0.5 km at r >= 6370 km), so sin d = d (1 - d^2/6), cos d = 1 - d^2/2 (1 - d^2/12) are exact to < 1e-17 relative
 DEVINL void rot_small(double sa, double ca, double d, double& s, double& c){
@@ -878,11 +886,19 @@ template <bool AMP_> struct EqGlobal {
     // one path segment: travel time (Global.cpp:527-589) and attenuation (Global.cpp:634-670, sin(lat) in ds: Q3); A, B = its two path rows
     static DEVINL void pp_aux(const GeoacDevParams& P, const double* st, size_t np, double* aux){}
     // k_postpass_tab: the segment's geometry (G.x = the abscissa of its midpoint) and, once the medium there is known, its travel time
-    static DEVINL void pp_geom(const GeoacDevParams& P, const double* aux, const double* A, const double* B, PPGeom& G){
+    static DEVINL void pp_geom(const GeoacDevParams& P, const double* aux, const double* A, const double* B, PPGeom& G, double* ref = nullptr){
         double ar = A[0], at_ = A[1], ap = A[2], an0 = A[3], an1 = A[4], an2 = A[5];
         double dr = B[0] - ar, dt = B[1] - at_, dp = B[2] - ap;
         double r = ar + dr / 2.0, t = at_ + dt / 2.0;
-        double sn, cs; fsincos(t, sn, cs);
+        // sin / cos of the midpoint latitude.  ref (k_postpass_tab; angle, sin, cos): from the multiple of 2^-7 rad next to it - a function of the
+        // segment alone, whatever thread holds it - by a rotation of at most 2^-8 rad (rot_fifth: exact to 1e-19); a thread's consecutive segments
+        // share that point for ~50 km of travel, so the full routine (70 instructions) runs once per thread and crossing
+        double sn, cs;
+        if(ref){
+            const double tq = __builtin_rint(t * 128.0) * (1.0 / 128.0);
+            if(tq != ref[0]){ ref[0] = tq; fsincos(tq, ref[1], ref[2]); }
+            rot_fifth(ref[1], ref[2], t - tq, sn, cs);
+        } else fsincos(t, sn, cs);
         double rdt = r * dt;
         double e1 = r * cs * dp, e2 = r * sn * dp;
         G.ds_tt = fsqrt(dr * dr + rdt * rdt + e1 * e1);
@@ -1439,7 +1455,7 @@ template <bool AMP_> struct Eq3D {
     }
     // 3DStratified.cpp:348-405 (c(0,0,0) instead of c0, w ignored: Q5) and :456-490; A, B = the segment's two path rows, aux = nu_x, nu_y of the ray
     static DEVINL void pp_aux(const GeoacDevParams& P, const double* st, size_t np, double* aux){ aux[0] = st[(ST_AUX0 + 0) * np]; aux[1] = st[(ST_AUX0 + 1) * np]; }
-    static DEVINL void pp_geom(const GeoacDevParams& P, const double* aux, const double* A, const double* B, PPGeom& G){
+    static DEVINL void pp_geom(const GeoacDevParams& P, const double* aux, const double* A, const double* B, PPGeom& G, double* ref = nullptr){
         double ax = A[0], ay = A[1], az = A[2], anz = A[3];
         double dx = B[0] - ax, dy = B[1] - ay, dz = B[2] - az;
         G.ds_tt = G.ds_at = fsqrt(dx * dx + dy * dy + dz * dz);
@@ -1569,7 +1585,7 @@ template <bool AMP_> struct Eq2D {
     }
     // 2DStratified.cpp:217-286; A, B = the segment's two path rows, aux = cos / sin of the ray's azimuth
     static DEVINL void pp_aux(const GeoacDevParams& P, const double* st, size_t np, double* aux){ aux[0] = st[(ST_AUX0 + 0) * np]; aux[1] = st[(ST_AUX0 + 1) * np]; }
-    static DEVINL void pp_geom(const GeoacDevParams& P, const double* aux, const double* A, const double* B, PPGeom& G){
+    static DEVINL void pp_geom(const GeoacDevParams& P, const double* aux, const double* A, const double* B, PPGeom& G, double* ref = nullptr){
         double ar = A[0], az = A[1];
         double dr = B[0] - ar, dz = B[1] - az;
         G.x = az + dz / 2.0;
@@ -1941,7 +1957,7 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
     while(EQ::COOP ? (bool)__any((nr + 2 <= row_end) && !done) : ((nr + 2 <= P.s_rows) && !done)){
         const bool act = EQ::COOP ? ((nr + 2 <= row_end) && !done) : true;
 #ifdef GEOAC_KSTAT
-        C.ckey = act ? 1 : 0;
+        C.ckey = (C.ckey & ~1) | (act ? 1 : 0);                 // (bit 0: live; the rest: the lane's key of the stage before, rngdep_rhs)
 #endif
         double ds = P.ds_min;
         if(!EQ::COOP || act){
@@ -2190,26 +2206,27 @@ __global__ void __launch_bounds__(256) k_postpass_tab(GeoacDevParams P, int rows
         EQ::pp_aux(P, P.state + slot, np, aux);
         const int i1 = min(i0 + R, nr - 1);                       // segments i0 .. i1 - 1
         const double* a = P.path + ((size_t)i0 * PW) * np + col;
-        double A[PW], B[PW], Bn[PW];
+        // three row buffers in rotation (rows i, i + 1 and the prefetched i + 2): no copies between segments
+        double Ra[PW], Rb[PW], Rc[PW];
         #pragma unroll
-        for(int c = 0; c < PW; c++){ A[c] = a[(size_t)c * np]; Bn[c] = a[(size_t)(PW + c) * np]; }
+        for(int c = 0; c < PW; c++){ Ra[c] = a[(size_t)c * np]; Rb[c] = a[(size_t)(PW + c) * np]; Rc[c] = 0.0; }
         double rec[GEOAC_SEGW], tb[19];                           // the spline record and the table entry in hand (k, ent: which)
         int k = -1, ent = -1;
+        double ref[3] = { 1e300, 0.0, 1.0 };                      // Global: reference point of the midpoint latitudes' sin / cos (pp_geom)
         rec[0] = 1.0; rec[1] = 0.0;
         #pragma unroll
         for(int c = 2; c < GEOAC_SEGW; c++) rec[c] = 0.0;
         #pragma unroll
         for(int c = 0; c < 19; c++) tb[c] = 0.0;
-        for(int i = i0; i < i1; i++){
-            #pragma unroll
-            for(int c = 0; c < PW; c++) B[c] = Bn[c];
-            if(i + 2 <= i1){                                      // the row after next, while this segment is evaluated
+        // segment i: rows A (i) and B (i + 1); row i + 2 goes to Cn while the segment is evaluated
+        auto segment = [&](const double (&A)[PW], const double (&B)[PW], double (&Cn)[PW], int i){
+            if(i + 2 <= i1){
                 const double* b = P.path + ((size_t)(i + 2) * PW) * np + col;
                 #pragma unroll
-                for(int c = 0; c < PW; c++) Bn[c] = b[(size_t)c * np];
+                for(int c = 0; c < PW; c++) Cn[c] = b[(size_t)c * np];
             }
             PPGeom G;
-            EQ::pp_geom(P, aux, A, B, G);
+            EQ::pp_geom(P, aux, A, B, G, ref);
             const double xe = clampq(G.x, P.x_min, P.x_max);
             if(!((xe >= rec[0]) & (xe <= rec[1]))){               // (also the first segment: rec[0] > rec[1])
                 k = seg_find(P.seg, P.nseg, xe, k < 0 ? (int)((xe - P.x_min) * P.seg_per_x) : k);
@@ -2237,8 +2254,11 @@ __global__ void __launch_bounds__(256) k_postpass_tab(GeoacDevParams P, int rows
             o[0]  = tt;
             o[np] = at;
             flagged += bad ? 1u : 0u;
-            #pragma unroll
-            for(int c = 0; c < PW; c++) A[c] = B[c];
+        };
+        for(int i = i0; i < i1; ){
+            segment(Ra, Rb, Rc, i); if(++i >= i1) break;
+            segment(Rb, Rc, Ra, i); if(++i >= i1) break;
+            segment(Rc, Ra, Rb, i); ++i;
         }
     }
     if(flagged) atomicAdd(&P.counters[GEOAC_CNT_PPFLAG + 1], (unsigned long long)flagged);     // (statistics: geoac_abs_table_info)

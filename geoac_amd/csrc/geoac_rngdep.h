@@ -747,8 +747,12 @@ DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double
     // three copies of the evaluator: M[][] stays in registers (rolled, the dynamic index f put it in scratch: 240 B written and read back per stage)
 #ifdef GEOAC_KSTAT
     if(COOP){   // diagnostic build: histogram of the number of DISTINCT (segment, cell) keys among the live lanes of a wave-stage
-        const bool live = (*ckey != 0);
+        const bool live = (*ckey & 1) != 0;
         const unsigned key = (unsigned)L.kz * 4096u + (unsigned)L.n00;
+        // ... and how often a lane's own key differs from its key of the stage before (what a per-lane record cache would have to refetch)
+        const bool moved = live && ((unsigned)(*ckey >> 1) != key + 1u);
+        *ckey = (int)(((key + 1u) << 1) | (live ? 1u : 0u));
+        const unsigned long long nmov = __popcll(__ballot(moved)), nliv = __popcll(__ballot(live));
         unsigned long long rem = __ballot(live); int K = 0;
         while(rem){ const int l = __ffsll((long long)rem) - 1; const unsigned k0 = (unsigned)__shfl((int)key, l); rem &= ~__ballot(live && key == k0); K++; }
         int kzmin = live ? L.kz : 1 << 30, kzmax = live ? L.kz : -1;
@@ -756,6 +760,7 @@ DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double
         if((threadIdx.x & 63) == 0 && K > 0){
             const int bin = K == 1 ? 0 : K == 2 ? 1 : K <= 4 ? 2 : K <= 6 ? 3 : K <= 8 ? 4 : K <= 12 ? 5 : K <= 16 ? 6 : 7;
             atomicAdd(&P.counters[16 + bin], 1ull); atomicAdd(&P.counters[24], (unsigned long long)K); atomicAdd(&P.counters[25], (unsigned long long)(kzmax - kzmin + 1));
+            atomicAdd(&P.counters[26], nmov); atomicAdd(&P.counters[27], nliv);
         }
     }
 #endif
