@@ -1,17 +1,23 @@
 // geoac_eigenray.cpp - batched eigenray searches on top of the ray-fan C ABI (include/geoac_eig.h): spherical sets
 // (GeoAc.Eigenray.Global.cpp) and 3-D Cartesian sets (GeoAc.Eigenray.cpp).
 //
-// Every receiver's search is the reference's straight-line logic (GeoAc.Eigenray.Global.cpp) running in its own host thread; wherever
-// the reference would propagate a ray the thread posts a request and sleeps.  When every live search is waiting, the calling thread
-// groups the requests by (bounces, CalcAmp, output mode), integrates each group as ONE fan launch on the GPU and wakes the searches
-// with their arrival records.  An inclination scan whose step does not depend on earlier arrivals (the first three passes of
-// GeoAc_EstimateEigenray) is requested as a whole and replayed in the reference's order afterwards.
+// A search is a set of TASKS - resumable state machines that post rays and consume arrival records:
+//   ScanChain   one per (receiver, bounce count): header, then estimate -> (refinement spawned) -> estimate -> ... over the inclination range
+//   Estimator   GeoAc_EstimateEigenray: up to five inclination scans; a scan whose step does not depend on earlier arrivals (the first
+//               three) is posted as ONE request and replayed in the reference's order, the adaptive ones ray by ray
+//   Refiner     GeoAc_3DEigenray_LM: the damped Newton iteration on the launch angles, one ray per iteration, then the eigenray's own
+//               ray with the raypath samples
+// What differs between the spherical and the Cartesian mains - geometry, the derivative matrix, the wording of the log - sits in a Family.
+// The scheduler (run_all) is a plain loop on the calling thread: advance every task until it waits for a ray or ends, integrate all posted
+// requests of the round - grouped by (bounces, CalcAmp, output mode), one fan launch per group, the groups side by side on clones of the
+// context - hand the records back, repeat.  Nothing an estimate or a refinement computes depends on another bounce count or receiver, so
+// all of them share the rounds; the text each task would have written to the reference's cout is kept per task and rendered in the
+// reference's order at the end.
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
 #include <atomic>
-#include <condition_variable>
 #include <deque>
 #include <iomanip>
 #include <map>
@@ -33,20 +39,9 @@ struct Request {
     std::vector<double> th, ph;            // launch inclination, azimuth from north [deg]
     std::vector<double> rec;               // [n][bounces+1][GEOAC_REC_STRIDE]
     std::vector<double> smp;               // sample rows of these rays (GEOAC_SMP_RAY = index within the request)
-    bool done = false;
-    int  error = 0;
 };
 
 struct Eigenray { double v[GEOAC_EIG_STRIDE]; std::vector<double> smp; };
-
-struct Shared {
-    std::mutex mu;
-    std::condition_variable cv_work, cv_done;
-    std::vector<Request*> pending;
-    int active = 0;                        // searches still running
-    int waiting = 0;                       // searches blocked in trace()
-    std::atomic<bool> failed{false};     // written by the coordinator under the mutex, read by the scan-chain threads without it
-};
 
 struct Geo {                               // spherical helpers of GeoAc.Eigenray.Global.cpp:25-43
     double r_earth;
@@ -68,10 +63,9 @@ double modify_d_theta(double dr, double dr_dtheta){           // :40-44
     return d_theta_big - (d_theta_big - d_theta_small) * exp(-dr * dr / width);
 }
 
-// Deferred log: what a search task would have written to the reference's cout, kept as operations and rendered at the end
-// into ONE stream per receiver in the reference's order - the tasks of a receiver (one scan chain per bounce count, one task per
-// refinement) run concurrently, but a std::setprecision of an earlier block must still stick to the later ones, and the running
-// eigenray number is only known once the earlier blocks are complete.
+// Deferred log: what a task would have written to the reference's cout, kept as operations and rendered at the end into ONE stream per
+// receiver in the reference's order - the tasks of a receiver advance side by side, but a std::setprecision of an earlier block must
+// still stick to the later ones, and the running eigenray number is only known once the earlier blocks are complete.
 struct DLog {
     enum Kind { TEXT, NUM, INT, PREC, COUNT, INCR };
     struct Op { Kind k; std::string s; double d; long long i; };
@@ -101,15 +95,25 @@ struct DLog {
     }
 };
 
-struct Eigenray;
-struct Segment;                            // one task's output: its log and the eigenrays it identified
-thread_local DLog* tl_log = nullptr;
-thread_local std::vector<Eigenray>* tl_found = nullptr;
-#define LOG (*tl_log)
-#define FOUND (*tl_found)
+// one task's output: its log and the eigenrays it identified
+struct Segment { DLog log; std::vector<Eigenray> found; };
 
-struct SearchBase {
-    Shared* sh = nullptr;
+// outcome of ray i of a request: BreakCheck of the reference's leg loop, last row solution[k][*]
+bool broke(const Request& rq, int i){
+    const int legs = rq.bounces + 1;
+    const double* R = &rq.rec[((size_t)i * legs + (legs - 1)) * GEOAC_REC_STRIDE];
+    return R[GEOAC_REC_VALID] == 0.0;
+}
+const double* last_row(const Request& rq, int i){
+    const int legs = rq.bounces + 1;
+    // the row the reference reads after a break is the breaking leg's last row; only used for messages there
+    int l = legs - 1;
+    while(l > 0 && rq.rec[((size_t)i * legs + l) * GEOAC_REC_STRIDE + GEOAC_REC_STEPS] == 0.0) l--;
+    return &rq.rec[((size_t)i * legs + l) * GEOAC_REC_STRIDE];
+}
+
+// what every task of one receiver reads
+struct Site {
     int eqset = GEOAC_EQ_GLOBAL;
     int rcvr_index = 0;
     double src[3] = {0, 0, 0};             // Source_Loc of the reference: (lat, lon [deg], z) or (x, y, z) [km]
@@ -117,499 +121,516 @@ struct SearchBase {
     double z_grnd = 0.0;
     geoac_eig_params prm{};
     bool verbose = false;
-    std::ostringstream log;                // the reference's cout for this receiver (sticky precision and all), rendered at the end
-    std::vector<Eigenray> found;
-    int eigenray_count = 0;
-    bool self_released = false;            // run_search took this thread out of Shared::active before waiting for its tasks
-    virtual ~SearchBase(){}
-    virtual void run_direct(double theta_est, double phi_from_north, int bounces) = 0;
-    // the pieces of the reference's -eig_search loop (GeoAcGlobal_main.cpp:566-580, GeoAc3D_main.cpp:531-543) the two families differ in
-    virtual void header(int n_bnc) = 0;
-    virtual void footer() = 0;
-    virtual bool estimate(double theta_min, double theta_max, double& theta_estimate, double& phi_estimate, double& theta_next, int bounces) = 0;
-    virtual void refine(double& lt, double& lp, int bnc_cnt, int iterate_limit) = 0;
-
-    // ---- tasks.  The reference runs, per bounce count, estimate -> refine -> estimate -> ... one ray at a time.  Nothing an
-    //      estimate or a refinement computes depends on another bounce count, and a refinement depends only on the estimate it
-    //      starts from; so every bounce count is its own scan chain and every refinement its own task, all posting rays to the same
-    //      rounds (fewer, fuller fan launches), and the output is put back in the reference's order afterwards. ----
-    struct Segment { DLog log; std::vector<Eigenray> found; };
-    void task_started(int n = 1){ std::unique_lock<std::mutex> lk(sh->mu); sh->active += n; }
-    void task_ended(){ std::unique_lock<std::mutex> lk(sh->mu); sh->active--; sh->cv_work.notify_all(); }
-    static std::atomic<int>& live_tasks(){ static std::atomic<int> n{0}; return n; }
-
-    void run_search(){
-        const int nb = std::max(0, prm.bnc_max - prm.bnc_min + 1);
-        std::vector<std::deque<Segment>> segs((size_t)nb);           // per bounce count, in the reference's order: header, E1, R1, E2, R2, ...
-        std::vector<std::thread> chains;
-        task_started(nb);
-        for(int b = 0; b < nb; b++){
-            chains.emplace_back([this, b, &segs]{
-                const int n_bnc = prm.bnc_min + b;
-                std::deque<Segment>& mine = segs[(size_t)b];
-                std::vector<std::thread> refiners;
-                mine.emplace_back();
-                tl_log = &mine.back().log; tl_found = &mine.back().found;
-                header(n_bnc);
-                double theta_start = prm.theta_min, theta_next = prm.theta_max, theta_est = 0, phi_est = 0;
-                while(theta_start < prm.theta_max && !sh->failed){
-                    mine.emplace_back();
-                    tl_log = &mine.back().log; tl_found = &mine.back().found;
-                    bool ok = estimate(theta_start, prm.theta_max, theta_est, phi_est, theta_next, n_bnc);
-                    if(sh->failed) break;
-                    if(ok){
-                        mine.emplace_back();
-                        Segment* seg = &mine.back();                 // deque: the address stays valid while later segments are appended
-                        const double lt0 = theta_est, lp0 = phi_est;
-                        if(live_tasks().load() < 384){
-                            live_tasks()++;
-                            task_started();
-                            refiners.emplace_back([this, seg, lt0, lp0, n_bnc]{
-                                tl_log = &seg->log; tl_found = &seg->found;
-                                double lt = lt0, lp = lp0;
-                                refine(lt, lp, n_bnc, prm.iterations);
-                                live_tasks()--;
-                                task_ended();
-                            });
-                        } else {                                       // very many receivers: refine in line, as the reference does
-                            tl_log = &seg->log; tl_found = &seg->found;
-                            double lt = lt0, lp = lp0;
-                            refine(lt, lp, n_bnc, prm.iterations);
-                        }
-                    }
-                    theta_start = theta_next;
-                }
-                task_ended();                                          // nothing more to trace from this thread: it only waits now
-                for(auto& t : refiners) t.join();
-            });
-        }
-        task_ended();                                                  // this receiver's own thread only waits for its chains
-        self_released = true;
-        for(auto& t : chains) t.join();
-        // ---- put the output in the reference's order ----
-        for(auto& per_bnc : segs) for(Segment& g : per_bnc){
-            g.log.render(log, eigenray_count);
-            for(Eigenray& e : g.found){ e.v[GEOAC_EIG_INDEX] = (double)found.size(); found.push_back(e); }
-        }
-        Segment tail;
-        tl_log = &tail.log; tl_found = &tail.found;
-        footer();
-        tail.log.render(log, eigenray_count);
-    }
-    // -eig_direct: one refinement, on this thread
-    void direct_refine(double lt, double lp, int bounces){
-        Segment g;
-        tl_log = &g.log; tl_found = &g.found;
-        refine(lt, lp, bounces, prm.iterations);
-        g.log.render(log, eigenray_count);
-        for(Eigenray& e : g.found){ e.v[GEOAC_EIG_INDEX] = (double)found.size(); found.push_back(e); }
-    }
-
-    // ---- post a request and wait for the coordinator ----
-    bool trace(Request& rq){
-        std::unique_lock<std::mutex> lk(sh->mu);
-        rq.done = false;
-        sh->pending.push_back(&rq);
-        sh->waiting++;
-        sh->cv_work.notify_all();
-        sh->cv_done.wait(lk, [&]{ return rq.done || sh->failed; });
-        return rq.done && rq.error == 0 && !sh->failed;
-    }
-    // outcome of ray i of a request: BreakCheck of the reference's leg loop, last row solution[k][*]
-    static bool broke(const Request& rq, int i){
-        const int legs = rq.bounces + 1;
-        const double* R = &rq.rec[((size_t)i * legs + (legs - 1)) * GEOAC_REC_STRIDE];
-        return R[GEOAC_REC_VALID] == 0.0;
-    }
-    static const double* last_row(const Request& rq, int i){
-        const int legs = rq.bounces + 1;
-        // the row the reference reads after a break is the breaking leg's last row; only used for messages there
-        int l = legs - 1;
-        while(l > 0 && rq.rec[((size_t)i * legs + l) * GEOAC_REC_STRIDE + GEOAC_REC_STEPS] == 0.0) l--;
-        return &rq.rec[((size_t)i * legs + l) * GEOAC_REC_STRIDE];
-    }
 };
 
-// ================= spherical sets: GeoAc.Eigenray.Global.cpp =================
-struct Search : SearchBase {
+// the numbers a refinement carries from one iteration to the next (GeoAc_3DEigenray_LM's locals; the long doubles are the reference's)
+struct Newton {
+    double lt = 0, lp = 0;                 // launch inclination and azimuth [deg] as the routine carries them (spherical: lp = 90 - azimuth from north; Cartesian: azimuth from east)
+    double dr = 0, dr_prev = 10000.0, step_scalar = 1.0;
+    long double dlt = 0, dlp = 0;          // the last full step
+    long double p = 0, q = 0;              // arrival: (lat, lon) [rad] or (x, y) [km]
+    double nu0_xy[2] = {0, 0};             // Cartesian stratified set: horizontal slowness of the launch direction
+};
+
+// ================= what the spherical and the Cartesian mains do differently =================
+struct Family {
+    Site site;
+    virtual ~Family(){}
+    // the text around the -eig_search driver loop
+    virtual void header(DLog& log, int n_bnc) const = 0;
+    virtual void footer(DLog& log) const = 0;
+    // ---- GeoAc_EstimateEigenray ----
+    virtual double range_to_receiver() const = 0;
+    virtual double first_azimuth() const = 0;                                      // the azimuth the scans start with, in the routine's own convention
+    virtual double azimuth_from_north(double phi) const = 0;                       // ... as the fan ABI wants it
+    virtual double azimuth_estimate(double phi) const = 0;                         // ... as the refinement wants it
+    virtual bool scan_goes_on(double theta, double theta_max) const = 0;
+    virtual void announce(DLog& log, double range0, double phi, double theta_min, double theta_max) const = 0;
+    virtual double arrival(DLog& log, double theta, int bounces, bool left_region, const double* Rk, double range0) const = 0;   // range of one ray of a scan + its line
+    virtual double azimuth_deviation(const double* Rk) const = 0;
+    virtual void verdict(DLog& log, bool acceptable, double d_phi, double limit) const = 0;
+    virtual double next_step(double dr, double dr_dtheta) const = 0;
+    virtual void gave_up(DLog& log) const = 0;
+    // ---- GeoAc_3DEigenray_LM ----
+    virtual void launch_direction(Newton& N) const {}
+    virtual void left_region(DLog& log) const {}
+    virtual void maxed_out(DLog& log) const = 0;
+    virtual double miss(DLog& log, Newton& N, const double* S, int bounces) const = 0;          // distance between arrival and receiver + its line
+    virtual void full_step(Newton& N, const double* S) const = 0;                                // the Newton step on (lt, lp), clamped: N.dlt, N.dlp
+    virtual void identified(Segment& out, const Newton& N, const Request& fin, int bounces) const = 0;   // the eigenray's record and its block of the log
+};
+
+// ---- spherical sets: GeoAc.Eigenray.Global.cpp ----
+struct SphericalFamily : Family {
     Geo geo{6370.0};
-
-    // ---- GeoAc_EstimateEigenray: GeoAc.Eigenray.Global.cpp:46-136 ----
-    bool estimate(double theta_min, double theta_max, double& theta_estimate, double& phi_estimate, double& theta_next, int bounces) override {
-        const double azimuth_error_limit = prm.azimuth_err_lim;
-        double GC_r_rcvr = geo.gc_distance(src[0], src[1], rcv[0], rcv[1]);
-        double phi = geo.bearing(src[0], src[1], rcv[0], rcv[1]);
-        if(verbose){
-            LOG << '\t' << "Estimating eigenray angles for source-receiver separated by great circle distance " << GC_r_rcvr << " km, and azimuth " << phi;
-            LOG << " degrees from N.  Inclination limits: [" << theta_min << ", " << theta_max << "]." << '\n';
-        }
-        int iterations = 0;
-        theta_estimate = theta_max;
-        double r, r_prev, d_theta = d_theta_big, d_phi = 10.0;
-        bool theta_max_reached = false;
-        while(fabs(d_phi) > azimuth_error_limit && iterations < 5){
-            r = GC_r_rcvr; r_prev = GC_r_rcvr;
-            // the scan of this pass: with a fixed step all its rays are known now -> one request, replayed below
-            Request scan; scan.bounces = bounces; scan.calc_amp = 0; scan.mode = 0;
-            const bool batched = (iterations < 3);
-            if(batched){
-                for(double theta = theta_min; theta < theta_max; theta += d_theta){ scan.th.push_back(theta); scan.ph.push_back(phi); }
-                if(!scan.th.empty() && !trace(scan)) return false;
-            }
-            int j = 0;
-            bool crossed = false;
-            for(double theta = theta_min; theta < theta_max; theta += d_theta, j++){
-                if(theta + d_theta >= theta_max) theta_max_reached = true;
-                Request one; const Request* rq = &scan; int idx = j;
-                if(!batched){                                           // step depends on the previous arrival (:122): one ray at a time
-                    one.bounces = bounces; one.calc_amp = 0; one.mode = 0; one.th.push_back(theta); one.ph.push_back(phi);
-                    if(!trace(one)) return false;
-                    rq = &one; idx = 0;
-                }
-                const bool BreakCheck = broke(*rq, idx);
-                const double* Rk = last_row(*rq, idx);
-                const double lat_k = Rk[GEOAC_REC_STATE + 1] * 180.0 / Pi, lon_k = Rk[GEOAC_REC_STATE + 2] * 180.0 / Pi;
-                if(BreakCheck){ r = GC_r_rcvr; r_prev = GC_r_rcvr; }
-                else r = geo.gc_distance(src[0], src[1], lat_k, lon_k);
-                if(verbose){
-                    LOG << '\t' << '\t' << "Ray launched at inclination=" << (theta * Pi / 180.0) * 180.0 / Pi << " degrees arrives at range " << r;
-                    LOG << " km after " << bounces << " bounces.  Exact arrival at " << lat_k << " degrees N latitude, " << lon_k << " degrees E longitude" << '\n';
-                }
-                if((r - GC_r_rcvr) * (r_prev - GC_r_rcvr) < 0.0){
-                    if(iterations == 0) theta_next = theta;
-                    d_phi  = geo.bearing(src[0], src[1], rcv[0], rcv[1]);
-                    d_phi -= geo.bearing(src[0], src[1], lat_k, lon_k);
-                    while(d_phi > 180.0){ d_phi -= 360.0; }
-                    while(d_phi < -180.0){ d_phi += 360.0; }
-                    if(fabs(d_phi) < azimuth_error_limit){
-                        if(verbose) LOG << '\t' << '\t' << "Azimuth deviation less than " << azimuth_error_limit << " degrees.  Estimates acceptable." << '\n' << '\n';
-                        theta_estimate = theta - d_theta;
-                        phi_estimate = 90.0 - phi;
-                        return true;
-                    } else {
-                        if(verbose) LOG << '\t' << '\t' << "Azimuth deviation greater than " << azimuth_error_limit << " degrees.  Compensating and searching inclinations again." << '\n' << '\n';
-                        phi += d_phi * 0.9;
-                        theta_min = std::max(theta - 7.5, theta_min);
-                    }
-                    crossed = true;
-                    break;
-                }
-                if(iterations >= 3){ d_theta = modify_d_theta(r - GC_r_rcvr, (r - r_prev) / (2.0 * d_theta)); }
-                r_prev = r;
-            }
-            (void)crossed;
-            if(theta_max_reached){
-                theta_next = theta_max;
-                break;
-            }
-            iterations++;
-            if(iterations >= 1 && iterations < 3){ d_theta = d_theta_big / 2.0; }
-        }
-        if(verbose) LOG << '\t' << '\t' << "Reached maximum inclination angle or iteration limit." << '\n' << '\n';
-        return false;
+    void header(DLog& log, int n_bnc) const override { log << "Searching for " << n_bnc << " bounce eigenrays." << '\n'; }      // GeoAcGlobal_main.cpp:566-580
+    void footer(DLog& log) const override { log << "Identified " << DLog::Count{} << " eigenray(s)." << '\n'; }
+    // GeoAc_EstimateEigenray: GeoAc.Eigenray.Global.cpp:46-136
+    double range_to_receiver() const override { return geo.gc_distance(site.src[0], site.src[1], site.rcv[0], site.rcv[1]); }
+    double first_azimuth() const override { return geo.bearing(site.src[0], site.src[1], site.rcv[0], site.rcv[1]); }
+    double azimuth_from_north(double phi) const override { return phi; }
+    double azimuth_estimate(double phi) const override { return 90.0 - phi; }
+    bool scan_goes_on(double theta, double theta_max) const override { return theta < theta_max; }
+    void announce(DLog& log, double range0, double phi, double theta_min, double theta_max) const override {
+        log << '\t' << "Estimating eigenray angles for source-receiver separated by great circle distance " << range0 << " km, and azimuth " << phi;
+        log << " degrees from N.  Inclination limits: [" << theta_min << ", " << theta_max << "]." << '\n';
     }
-
-    // ---- GeoAc_3DEigenray_LM: GeoAc.Eigenray.Global.cpp:139-319 ----
-    void refine(double& lt, double& lp, int bnc_cnt, int iterate_limit) override {
-        double dr, dr_prev = 10000.0;
-        const double tolerance = 0.1;
+    double arrival(DLog& log, double theta, int bounces, bool left, const double* Rk, double range0) const override {
+        const double lat_k = Rk[GEOAC_REC_STATE + 1] * 180.0 / Pi, lon_k = Rk[GEOAC_REC_STATE + 2] * 180.0 / Pi;
+        const double r = left ? range0 : geo.gc_distance(site.src[0], site.src[1], lat_k, lon_k);
+        if(site.verbose){
+            log << '\t' << '\t' << "Ray launched at inclination=" << (theta * Pi / 180.0) * 180.0 / Pi << " degrees arrives at range " << r;
+            log << " km after " << bounces << " bounces.  Exact arrival at " << lat_k << " degrees N latitude, " << lon_k << " degrees E longitude" << '\n';
+        }
+        return r;
+    }
+    double azimuth_deviation(const double* Rk) const override {
+        const double lat_k = Rk[GEOAC_REC_STATE + 1] * 180.0 / Pi, lon_k = Rk[GEOAC_REC_STATE + 2] * 180.0 / Pi;
+        double d_phi = geo.bearing(site.src[0], site.src[1], site.rcv[0], site.rcv[1]);
+        d_phi -= geo.bearing(site.src[0], site.src[1], lat_k, lon_k);
+        return d_phi;
+    }
+    void verdict(DLog& log, bool ok, double d_phi, double limit) const override {
+        if(ok) log << '\t' << '\t' << "Azimuth deviation less than " << limit << " degrees.  Estimates acceptable." << '\n' << '\n';
+        else   log << '\t' << '\t' << "Azimuth deviation greater than " << limit << " degrees.  Compensating and searching inclinations again." << '\n' << '\n';
+    }
+    double next_step(double dr, double dr_dtheta) const override { return modify_d_theta(dr, dr_dtheta); }
+    void gave_up(DLog& log) const override { log << '\t' << '\t' << "Reached maximum inclination angle or iteration limit." << '\n' << '\n'; }
+    // GeoAc_3DEigenray_LM: GeoAc.Eigenray.Global.cpp:139-319
+    void maxed_out(DLog& log) const override { log << '\t' << '\t' << '\t' << "Search for exact eigenray maxed out iterations.  No eigneray idenfied." << '\n'; }
+    double miss(DLog& log, Newton& N, const double* S, int) const override {
+        N.p = S[1]; N.q = S[2];
+        const double dr = geo.gc_distance((double)(N.p * 180.0 / Pi), (double)(N.q * 180.0 / Pi), site.rcv[0], site.rcv[1]);
+        if(site.verbose) log << '\t' << '\t' << "Arrival at (" << DLog::Prec{8} << (double)(N.p * 180.0 / Pi) << ", " << (double)(N.q * 180.0 / Pi) << "), distance to receiver = " << dr << " km." << '\n';
+        return dr;
+    }
+    void full_step(Newton& N, const double* S) const override {
+        const long double lat = N.p, lon = N.q;
+        long double d_lat, d_lon, d_lat_dlt, d_lon_dlt, d_lat_dlp, d_lon_dlp, det;
         const double lt_lim_step = 0.2, lp_lim_step = 0.2;
-        double step_scalar = 1.0;
-        long double lat, lon, d_lat, d_lon, d_lat_dlt, d_lon_dlt, d_lat_dlp, d_lon_dlp, det, dlt = 0, dlp = 0;
-        if(verbose) LOG << '\t' << '\t' << "Searching for exact eigenray using auxiliary parameters." << '\n';
-        for(int n = 0; n <= iterate_limit; n++){
-            if(n == iterate_limit){
-                if(verbose){ LOG << '\t' << '\t' << '\t' << "Search for exact eigenray maxed out iterations.  No eigneray idenfied." << '\n'; }
-                break;
-            }
-            Request rq; rq.bounces = bnc_cnt; rq.calc_amp = 1; rq.mode = 0;
-            rq.th.push_back(lt); rq.ph.push_back(90.0 - lp);
-            if(verbose) LOG << '\t' << '\t' << "Plotting ray path with theta = " << lt << ", phi = " << 90.0 - lp;
-            if(!trace(rq)) return;
-            if(broke(rq, 0)) break;
-            const double* S = &rq.rec[((size_t)bnc_cnt) * GEOAC_REC_STRIDE + GEOAC_REC_STATE];        // solution[k][*] of the last leg
-            lat = S[1]; lon = S[2];
-            dr = geo.gc_distance((double)(lat * 180.0 / Pi), (double)(lon * 180.0 / Pi), rcv[0], rcv[1]);
-            if(verbose) LOG << '\t' << '\t' << "Arrival at (" << DLog::Prec{8} << (double)(lat * 180.0 / Pi) << ", " << (double)(lon * 180.0 / Pi) << "), distance to receiver = " << dr << " km." << '\n';
-
-            if(dr < tolerance){
-                // the reference re-propagates and accumulates travel time / attenuation with the raypath-writing loop (:198-238):
-                // same ray again with WriteRays on (segment form of Q7, samples every 25th step)
-                Request fin; fin.bounces = bnc_cnt; fin.calc_amp = 1; fin.mode = GEOAC_MODE_WRITE_RAYS;
-                fin.th.push_back(lt); fin.ph.push_back(90.0 - lp);
-                if(!trace(fin)) return;
-                const double* R = &fin.rec[((size_t)bnc_cnt) * GEOAC_REC_STRIDE];
-                const double* Sk = R + GEOAC_REC_STATE;
-                Eigenray e; memset(e.v, 0, sizeof e.v);
-                const double travel_time = R[GEOAC_REC_TTIME], attenuation = R[GEOAC_REC_ATTEN];
-                // arrival inclination: -asin(c_k / c_src nu_r) (:241); the fan record of the range-dependent main carries the opposite sign (Q10)
-                double arrival_incl = (eqset == GEOAC_EQ_GLOBAL_RNGDEP) ? -R[GEOAC_REC_INCL] : R[GEOAC_REC_INCL];
-                double bearing_back = geo.bearing(rcv[0], rcv[1], src[0], src[1]);
-                double back_az = 90.0 - atan2(-Sk[4], -Sk[5]) * 180.0 / Pi;
-                double back_az_dev = back_az - bearing_back;
-                if(back_az_dev > 180.0)  back_az_dev -= 360.0;
-                if(back_az_dev < -180.0) back_az_dev += 360.0;
-                e.v[GEOAC_EIG_RCVR] = rcvr_index; e.v[GEOAC_EIG_INDEX] = 0;  /* numbered when the receiver's segments are put in order */ e.v[GEOAC_EIG_BOUNCES] = bnc_cnt;
-                e.v[GEOAC_EIG_THETA] = lt; e.v[GEOAC_EIG_PHI] = 90.0 - lp;
-                e.v[GEOAC_EIG_TTIME] = travel_time;
-                e.v[GEOAC_EIG_CELERITY] = geo.gc_distance(src[0], src[1], rcv[0], rcv[1]) / travel_time;
-                e.v[GEOAC_EIG_AMP_DB] = 20.0 * log10(R[GEOAC_REC_AMP]);
-                e.v[GEOAC_EIG_ATTEN_DB] = -attenuation;
-                e.v[GEOAC_EIG_INCL] = arrival_incl; e.v[GEOAC_EIG_BEARING] = bearing_back; e.v[GEOAC_EIG_BACKAZ] = back_az; e.v[GEOAC_EIG_AZDEV] = back_az_dev;
-                e.smp = fin.smp;
-                e.v[GEOAC_EIG_NSMP] = (double)(e.smp.size() / GEOAC_SMP_STRIDE);
-                if(verbose){
-                    LOG << '\t' << '\t' << "Eigenray-" << DLog::Count{} << ".  " << bnc_cnt << " bounce(s)." << '\n';
-                    LOG << '\t' << '\t' << '\t' << "theta, phi = " << DLog::Prec{8} << lt << ", " << 90.0 - lp << " degrees." << '\n';
-                    LOG << '\t' << '\t' << '\t' << "Travel Time = " << travel_time << " seconds." << '\n';
-                    LOG << '\t' << '\t' << '\t' << "Celerity = " << e.v[GEOAC_EIG_CELERITY] << " km/s." << '\n';
-                    LOG << '\t' << '\t' << '\t' << "Amplitude = " << e.v[GEOAC_EIG_AMP_DB] << " dB." << '\n';
-                    LOG << '\t' << '\t' << '\t' << "Atmospheric Attenuation = " << -attenuation << " dB." << '\n';
-                    LOG << '\t' << '\t' << '\t' << "Arrival inclination = " << arrival_incl << " degrees." << '\n';
-                    LOG << '\t' << '\t' << '\t' << "Bearing to source = " << bearing_back << " degrees." << '\n';
-                    LOG << '\t' << '\t' << '\t' << "Back azimuth of arrival = " << back_az << " degrees." << '\n';
-                    LOG << '\t' << '\t' << '\t' << "Azimuth Deviation = " << back_az_dev << " degrees." << '\n' << '\n';
-                } else {
-                    LOG << '\t' << "Eigenray identified:" << '\t' << "theta, phi = " << DLog::Prec{8} << lt << ", " << 90.0 - lp << " degrees." << '\n';
-                }
-                FOUND.push_back(e);
-                LOG.incr();
-                break;
-            } else if(n > 0 && dr > dr_prev){
-                lt -= dlt * step_scalar;
-                lp -= dlp * step_scalar;
-                step_scalar /= 2.0;
-                if(sqrt(dlt * dlt + dlp * dlp) * step_scalar < 1.0e-12){
-                    if(verbose) LOG << '\t' << '\t' << '\t' << "Step size too small, psuedo-critical ray path likely." << '\n' << '\n';
-                    break;
-                }
-            } else {
-                step_scalar = std::min(1.0, step_scalar * 1.25);
-                d_lat = rcv[0] * Pi / 180.0 - lat;
-                d_lon = rcv[1] * Pi / 180.0 - lon;
-                const double rg = geo.r_earth + z_grnd;
-                d_lat_dlt = S[7]  - 1.0 / rg * S[4] / S[3] * S[6];
-                d_lat_dlp = S[13] - 1.0 / rg * S[4] / S[3] * S[12];
-                d_lon_dlt = S[8]  - 1.0 / (rg * cos(lat)) * S[5] / S[3] * S[6];
-                d_lon_dlp = S[14] - 1.0 / (rg * cos(lat)) * S[5] / S[3] * S[12];
-                det = d_lat_dlt * d_lon_dlp - d_lat_dlp * d_lon_dlt;
-                dlt = (d_lon_dlp * d_lat - d_lat_dlp * d_lon) / det * 180.0 / Pi;
-                dlp = (-d_lon_dlt * d_lat + d_lat_dlt * d_lon) / det * 180.0 / Pi;
-                if(dlt >  lt_lim_step) dlt =  lt_lim_step;
-                if(dlt < -lt_lim_step) dlt = -lt_lim_step;
-                if(dlp >  lp_lim_step) dlp =  lp_lim_step;
-                if(dlp < -lp_lim_step) dlp = -lp_lim_step;
-                lt += dlt * step_scalar;
-                lp += dlp * step_scalar;
-                dr_prev = dr;
-            }
-        }
+        d_lat = site.rcv[0] * Pi / 180.0 - lat;
+        d_lon = site.rcv[1] * Pi / 180.0 - lon;
+        const double rg = geo.r_earth + site.z_grnd;
+        d_lat_dlt = S[7]  - 1.0 / rg * S[4] / S[3] * S[6];
+        d_lat_dlp = S[13] - 1.0 / rg * S[4] / S[3] * S[12];
+        d_lon_dlt = S[8]  - 1.0 / (rg * cos(lat)) * S[5] / S[3] * S[6];
+        d_lon_dlp = S[14] - 1.0 / (rg * cos(lat)) * S[5] / S[3] * S[12];
+        det = d_lat_dlt * d_lon_dlp - d_lat_dlp * d_lon_dlt;
+        N.dlt = (d_lon_dlp * d_lat - d_lat_dlp * d_lon) / det * 180.0 / Pi;
+        N.dlp = (-d_lon_dlt * d_lat + d_lat_dlt * d_lon) / det * 180.0 / Pi;
+        if(N.dlt >  lt_lim_step) N.dlt =  lt_lim_step;
+        if(N.dlt < -lt_lim_step) N.dlt = -lt_lim_step;
+        if(N.dlp >  lp_lim_step) N.dlp =  lp_lim_step;
+        if(N.dlp < -lp_lim_step) N.dlp = -lp_lim_step;
     }
-
-    // ---- the text around the -eig_search driver loop: GeoAcGlobal_main.cpp:566-580 ----
-    void header(int n_bnc) override { LOG << "Searching for " << n_bnc << " bounce eigenrays." << '\n'; }
-    void footer() override { LOG << "Identified " << DLog::Count{} << " eigenray(s)." << '\n'; }
-    void run_direct(double theta_est, double phi_from_north, int bounces) override { direct_refine(theta_est, 90.0 - phi_from_north, bounces); }
+    void identified(Segment& out, const Newton& N, const Request& fin, int bnc_cnt) const override {
+        // the reference re-propagates and accumulates travel time / attenuation with the raypath-writing loop (:198-238): the request was the
+        // same ray again with WriteRays on (segment form of Q7, samples every 25th step)
+        DLog& log = out.log;
+        const double lt = N.lt, lp = N.lp;
+        const double* R = &fin.rec[((size_t)bnc_cnt) * GEOAC_REC_STRIDE];
+        const double* Sk = R + GEOAC_REC_STATE;
+        Eigenray e; memset(e.v, 0, sizeof e.v);
+        const double travel_time = R[GEOAC_REC_TTIME], attenuation = R[GEOAC_REC_ATTEN];
+        // arrival inclination: -asin(c_k / c_src nu_r) (:241); the fan record of the range-dependent main carries the opposite sign (Q10)
+        double arrival_incl = (site.eqset == GEOAC_EQ_GLOBAL_RNGDEP) ? -R[GEOAC_REC_INCL] : R[GEOAC_REC_INCL];
+        double bearing_back = geo.bearing(site.rcv[0], site.rcv[1], site.src[0], site.src[1]);
+        double back_az = 90.0 - atan2(-Sk[4], -Sk[5]) * 180.0 / Pi;
+        double back_az_dev = back_az - bearing_back;
+        if(back_az_dev > 180.0)  back_az_dev -= 360.0;
+        if(back_az_dev < -180.0) back_az_dev += 360.0;
+        e.v[GEOAC_EIG_RCVR] = site.rcvr_index; e.v[GEOAC_EIG_INDEX] = 0;  /* numbered when the receiver's segments are put in order */ e.v[GEOAC_EIG_BOUNCES] = bnc_cnt;
+        e.v[GEOAC_EIG_THETA] = lt; e.v[GEOAC_EIG_PHI] = 90.0 - lp;
+        e.v[GEOAC_EIG_TTIME] = travel_time;
+        e.v[GEOAC_EIG_CELERITY] = geo.gc_distance(site.src[0], site.src[1], site.rcv[0], site.rcv[1]) / travel_time;
+        e.v[GEOAC_EIG_AMP_DB] = 20.0 * log10(R[GEOAC_REC_AMP]);
+        e.v[GEOAC_EIG_ATTEN_DB] = -attenuation;
+        e.v[GEOAC_EIG_INCL] = arrival_incl; e.v[GEOAC_EIG_BEARING] = bearing_back; e.v[GEOAC_EIG_BACKAZ] = back_az; e.v[GEOAC_EIG_AZDEV] = back_az_dev;
+        e.smp = fin.smp;
+        e.v[GEOAC_EIG_NSMP] = (double)(e.smp.size() / GEOAC_SMP_STRIDE);
+        if(site.verbose){
+            log << '\t' << '\t' << "Eigenray-" << DLog::Count{} << ".  " << bnc_cnt << " bounce(s)." << '\n';
+            log << '\t' << '\t' << '\t' << "theta, phi = " << DLog::Prec{8} << lt << ", " << 90.0 - lp << " degrees." << '\n';
+            log << '\t' << '\t' << '\t' << "Travel Time = " << travel_time << " seconds." << '\n';
+            log << '\t' << '\t' << '\t' << "Celerity = " << e.v[GEOAC_EIG_CELERITY] << " km/s." << '\n';
+            log << '\t' << '\t' << '\t' << "Amplitude = " << e.v[GEOAC_EIG_AMP_DB] << " dB." << '\n';
+            log << '\t' << '\t' << '\t' << "Atmospheric Attenuation = " << -attenuation << " dB." << '\n';
+            log << '\t' << '\t' << '\t' << "Arrival inclination = " << arrival_incl << " degrees." << '\n';
+            log << '\t' << '\t' << '\t' << "Bearing to source = " << bearing_back << " degrees." << '\n';
+            log << '\t' << '\t' << '\t' << "Back azimuth of arrival = " << back_az << " degrees." << '\n';
+            log << '\t' << '\t' << '\t' << "Azimuth Deviation = " << back_az_dev << " degrees." << '\n' << '\n';
+        } else {
+            log << '\t' << "Eigenray identified:" << '\t' << "theta, phi = " << DLog::Prec{8} << lt << ", " << 90.0 - lp << " degrees." << '\n';
+        }
+        out.found.push_back(e);
+        log.incr();
+    }
 };
 
-// ================= 3-D Cartesian sets: GeoAc.Eigenray.cpp =================
+// ---- 3-D Cartesian sets: GeoAc.Eigenray.cpp ----
 double modify_d_theta_cart(double dr, double dr_dtheta){       // GeoAc.Eigenray.cpp:24-28
     double width = 2.0 * pow(dr_dtheta, 2);
     return d_theta_big - (d_theta_big - d_theta_small) * exp(-dr * dr / width);
 }
 
-struct SearchCart : SearchBase {
+struct CartesianFamily : Family {
     bool strat = true;                     // GeoAc_AtmoStrat: GeoAc3D (12-component rows) vs GeoAc3D.RngDep (18)
     double M_Comps[3] = {0, 0, 0};         // wind Mach numbers at the source (stratified set only, :130-134)
-
-    // ---- GeoAc_EstimateEigenray: GeoAc.Eigenray.cpp:30-121 ----
-    bool estimate(double theta_min, double theta_max, double& theta_estimate, double& phi_estimate, double& theta_next, int bounces) override {
-        const double azimuth_error_limit = prm.azimuth_err_lim;
-        double r_rcvr = sqrt(pow(rcv[0] - src[0], 2) + pow(rcv[1] - src[1], 2));
-        double phi = 180.0 / 3.14159 * atan2(rcv[1] - src[1], rcv[0] - src[0]);
-        if(verbose){
-            LOG << '\t' << "Estimating eigenray angles for source-receiver separated by " << r_rcvr << " km, and azimuth " << 90.0 - phi;
-            LOG << " degrees from N.  Inclination limits: [" << theta_min << ", " << theta_max << "]." << '\n';
+    const double* src() const { return site.src; }
+    const double* rcv() const { return site.rcv; }
+    void header(DLog& log, int n_bnc) const override { log << "Searching for " << n_bnc << " bounce eigenray(s) between " << site.prm.theta_min << " and " << site.prm.theta_max << "." << '\n'; }   // GeoAc3D_main.cpp:531-543
+    void footer(DLog& log) const override { log << '\t' << "Identified " << DLog::Count{} << " eigenray(s)." << '\n'; }
+    // GeoAc_EstimateEigenray: GeoAc.Eigenray.cpp:30-121
+    double range_to_receiver() const override { return sqrt(pow(rcv()[0] - src()[0], 2) + pow(rcv()[1] - src()[1], 2)); }
+    double first_azimuth() const override { return 180.0 / 3.14159 * atan2(rcv()[1] - src()[1], rcv()[0] - src()[0]); }
+    double azimuth_from_north(double phi) const override { return 90.0 - phi; }
+    double azimuth_estimate(double phi) const override { return phi; }
+    bool scan_goes_on(double theta, double theta_max) const override { return theta <= theta_max; }
+    void announce(DLog& log, double range0, double phi, double theta_min, double theta_max) const override {
+        log << '\t' << "Estimating eigenray angles for source-receiver separated by " << range0 << " km, and azimuth " << 90.0 - phi;
+        log << " degrees from N.  Inclination limits: [" << theta_min << ", " << theta_max << "]." << '\n';
+    }
+    double arrival(DLog& log, double theta, int bounces, bool left, const double* Rk, double range0) const override {
+        const double xk = Rk[GEOAC_REC_STATE + 0], yk = Rk[GEOAC_REC_STATE + 1];
+        if(site.verbose){
+            log << '\t' << '\t' << "Ray launched at " << theta << " degrees arrives at range " << sqrt(pow(xk - src()[0], 2) + pow(yk - src()[1], 2));
+            log << " km after " << bounces << " reflections." << '\t' << "Exact arrival at " << xk << " km East, " << yk << " km North" << '\n';
         }
-        int iterations = 0;
-        theta_estimate = theta_max;
-        double r, r_prev, d_theta = d_theta_big, d_phi = 10.0;
-        bool theta_max_reached = false;
-        while(fabs(d_phi) > azimuth_error_limit && iterations < 5){
-            r = r_rcvr; r_prev = r_rcvr;
-            Request scan; scan.bounces = bounces; scan.calc_amp = 0; scan.mode = 0;
-            const bool batched = (iterations < 3);
-            if(batched){
-                for(double theta = theta_min; theta <= theta_max; theta += d_theta){ scan.th.push_back(theta); scan.ph.push_back(90.0 - phi); }
-                if(!scan.th.empty() && !trace(scan)) return false;
+        return left ? range0 : sqrt(pow(xk - src()[0], 2) + pow(yk - src()[1], 2));
+    }
+    double azimuth_deviation(const double* Rk) const override {
+        const double xk = Rk[GEOAC_REC_STATE + 0], yk = Rk[GEOAC_REC_STATE + 1];
+        return (atan2(rcv()[1] - src()[1], rcv()[0] - src()[0]) - atan2(yk - src()[1], xk - src()[0])) * 180.0 / Pi;
+    }
+    void verdict(DLog& log, bool ok, double d_phi, double limit) const override {
+        if(ok) log << '\t' << '\t' << "Azimuth deviation = " << d_phi << ".  Less than " << limit << " degrees.  Estimates acceptable." << '\n' << '\n';
+        else   log << '\t' << '\t' << "Azimuth deviation = " << d_phi << ".  Greater than " << limit << " degrees.  Compensating and searching inclinations again." << '\n' << '\n';
+    }
+    double next_step(double dr, double dr_dtheta) const override { return modify_d_theta_cart(dr, dr_dtheta); }
+    void gave_up(DLog& log) const override { log << '\t' << '\t' << "Reached maximum inclination angle or iteration limit." << '\n'; }
+    // GeoAc_3DEigenray_LM: GeoAc.Eigenray.cpp:123-335
+    void launch_direction(Newton& N) const override {
+        if(!strat) return;
+        const double GeoAc_theta = N.lt * Pi / 180.0, GeoAc_phi = N.lp * Pi / 180.0;
+        double nu0[3], M;
+        nu0[0] = cos(GeoAc_theta) * cos(GeoAc_phi);
+        nu0[1] = cos(GeoAc_theta) * sin(GeoAc_phi);
+        nu0[2] = sin(GeoAc_theta);
+        M = 1.0 + (nu0[0] * M_Comps[0] + nu0[1] * M_Comps[1] + nu0[2] * M_Comps[2]);
+        N.nu0_xy[0] = nu0[0] / M;
+        N.nu0_xy[1] = nu0[1] / M;
+    }
+    void left_region(DLog& log) const override { log << '\t' << "Ray path left propagation region." << '\n'; }
+    void maxed_out(DLog& log) const override { log << '\t' << '\t' << '\t' << "Search for exact eigenray maxed out iterations.  No eigneray idenfied." << '\n' << '\n'; }
+    double miss(DLog& log, Newton& N, const double* S, int bnc_cnt) const override {
+        long double dx, dy;
+        N.p = S[0]; dx = rcv()[0] - N.p;
+        N.q = S[1]; dy = rcv()[1] - N.q;
+        const double dr = (double)sqrtl(dx * dx + dy * dy);
+        if(site.verbose) log << '\t' << '\t' << "Arrival after " << bnc_cnt << " reflections at (" << (double)N.p << ", " << (double)N.q << "), distance to receiver = " << dr << " km." << '\n';
+        return dr;
+    }
+    void full_step(Newton& N, const double* S) const override {
+        const double theta_lim_step = 0.2, phi_lim_step = 0.2;
+        long double dx = rcv()[0] - N.p, dy = rcv()[1] - N.q;
+        long double dx_dt, dy_dt, dx_dp, dy_dp, det;
+        if(strat){
+            dx_dt = S[4] - N.nu0_xy[0] / S[3] * S[6];
+            dy_dt = S[5] - N.nu0_xy[1] / S[3] * S[6];
+            dx_dp = S[8] - N.nu0_xy[0] / S[3] * S[10];
+            dy_dp = S[9] - N.nu0_xy[1] / S[3] * S[10];
+        } else {
+            dx_dt = S[6] - S[3] / S[5] * S[8];
+            dy_dt = S[7] - S[4] / S[5] * S[8];
+            dx_dp = S[12] - S[3] / S[5] * S[14];
+            dy_dp = S[13] - S[4] / S[5] * S[14];
+        }
+        det = dx_dt * dy_dp - dx_dp * dy_dt;
+        N.dlt = 1.0 / det * (dy_dp * dx - dx_dp * dy) * 180.0 / Pi;
+        N.dlp = 1.0 / det * (dx_dt * dy - dy_dt * dx) * 180.0 / Pi;
+        if(N.dlt > theta_lim_step)  N.dlt =  theta_lim_step;
+        if(N.dlp > phi_lim_step)    N.dlp =  phi_lim_step;
+        if(N.dlt < -theta_lim_step) N.dlt = -theta_lim_step;
+        if(N.dlp < -phi_lim_step)   N.dlp = -phi_lim_step;
+    }
+    void identified(Segment& out, const Newton& N, const Request& fin, int bnc_cnt) const override {
+        DLog& log = out.log;
+        const double theta = N.lt, phi = N.lp;
+        const double GeoAc_phi = phi * Pi / 180.0;
+        const double* R = &fin.rec[((size_t)bnc_cnt) * GEOAC_REC_STRIDE];
+        const double* Sk = R + GEOAC_REC_STATE;
+        Eigenray e; memset(e.v, 0, sizeof e.v);
+        const double travel_time = R[GEOAC_REC_TTIME], attenuation = R[GEOAC_REC_ATTEN];
+        double back_az = strat ? (90.0 - GeoAc_phi * 180.0 / Pi) + 180.0 : 90.0 - atan2(-Sk[4], -Sk[3]) * 180.0 / Pi;
+        double arrival_incl = R[GEOAC_REC_INCL];          // -asin(c(x_k, y_k, z_grnd) / c(src) nu_z) in both mains' records
+        double az_to_src = 90.0 - atan2(src()[1] - rcv()[1], src()[0] - rcv()[0]) * 180.0 / Pi;
+        double back_az_dev = back_az - az_to_src;
+        while(back_az > 180.0)      back_az -= 360.0;
+        while(back_az < -180.0)     back_az += 360.0;
+        while(back_az_dev > 180.0)  back_az_dev -= 360.0;
+        while(back_az_dev < -180.0) back_az_dev += 360.0;
+        e.v[GEOAC_EIG_RCVR] = site.rcvr_index; e.v[GEOAC_EIG_INDEX] = 0;  /* numbered when the receiver's segments are put in order */ e.v[GEOAC_EIG_BOUNCES] = bnc_cnt;
+        e.v[GEOAC_EIG_THETA] = theta; e.v[GEOAC_EIG_PHI] = 90.0 - phi;
+        e.v[GEOAC_EIG_TTIME] = travel_time;
+        e.v[GEOAC_EIG_CELERITY] = sqrt(pow(Sk[0] - src()[0], 2) + pow(Sk[1] - src()[1], 2)) / travel_time;
+        e.v[GEOAC_EIG_AMP_DB] = 20.0 * log10(R[GEOAC_REC_AMP]);
+        e.v[GEOAC_EIG_ATTEN_DB] = -attenuation;
+        e.v[GEOAC_EIG_INCL] = arrival_incl; e.v[GEOAC_EIG_BEARING] = az_to_src; e.v[GEOAC_EIG_BACKAZ] = back_az; e.v[GEOAC_EIG_AZDEV] = back_az_dev;
+        e.smp = fin.smp;
+        e.v[GEOAC_EIG_NSMP] = (double)(e.smp.size() / GEOAC_SMP_STRIDE);
+        if(!site.verbose) log << '\t' << "Eigenray identified:" << '\t' << "theta, phi = " << DLog::Prec{8} << theta << ", " << 90.0 - phi << " degrees." << '\n';
+        if(site.verbose){
+            log << '\t' << '\t' << "Eigenray Identified:" << '\n';
+            log << '\t' << '\t' << '\t' << "theta, phi = " << DLog::Prec{8} << theta << ", " << 90.0 - phi << " degrees." << '\n';
+            log << '\t' << '\t' << '\t' << "Travel Time = " << travel_time << " seconds." << '\n';
+            log << '\t' << '\t' << '\t' << "Celerity = " << e.v[GEOAC_EIG_CELERITY] << " km/s." << '\n';
+            log << '\t' << '\t' << '\t' << "Amplitude (geometric) = " << e.v[GEOAC_EIG_AMP_DB] << " dB." << '\n';
+            log << '\t' << '\t' << '\t' << "Atmospheric Attenuation = " << -attenuation << " dB." << '\n';
+            log << '\t' << '\t' << '\t' << "Arrival inclination = " << arrival_incl << " degrees." << '\n';
+            log << '\t' << '\t' << '\t' << "Azimuth to source = " << az_to_src << '\n';
+            log << '\t' << '\t' << '\t' << "Back Azimuth of arrival = " << back_az << '\n';
+            log << '\t' << '\t' << '\t' << "Azimuth Deviation = " << back_az_dev << " degrees." << '\n' << '\n';
+        }
+        out.found.push_back(e);
+        log.incr();
+    }
+};
+
+// ================= tasks =================
+// advance(): run until the task needs a ray (returns the request, which it owns and reads at its next call) or has ended (nullptr).
+struct Task {
+    virtual ~Task(){}
+    virtual Request* advance(std::vector<std::unique_ptr<Task>>& spawned) = 0;
+};
+
+// ---- GeoAc_EstimateEigenray as a state machine: up to five scans of the inclination range, the azimuth corrected between them ----
+struct Estimator {
+    enum State { PASS_BEGIN, SCAN_POSTED, RAY_NEXT, RAY_POSTED, PASS_END, DONE };
+    const Family& fam; DLog& log;
+    State st = PASS_BEGIN;
+    const int bounces;
+    double theta_min; const double theta_max;
+    double range0, phi;
+    int iterations = 0;
+    double r = 0, r_prev = 0, d_theta = d_theta_big, d_phi = 10.0;
+    bool theta_max_reached = false;
+    double theta = 0;                       // scan position (adaptive passes)
+    Request rq;                             // the posted scan or single ray
+    // results
+    bool ok = false;
+    double theta_estimate, phi_estimate = 0, theta_next;
+
+    Estimator(const Family& f, DLog& l, double tmin, double tmax, double tnext, int bnc)
+        : fam(f), log(l), bounces(bnc), theta_min(tmin), theta_max(tmax), theta_estimate(tmax), theta_next(tnext) {
+        range0 = fam.range_to_receiver();
+        phi = fam.first_azimuth();
+        if(fam.site.verbose) fam.announce(log, range0, phi, theta_min, theta_max);
+    }
+    void post(double th){ rq.th.push_back(th); rq.ph.push_back(fam.azimuth_from_north(phi)); }
+    void fresh_request(){ rq = Request(); rq.bounces = bounces; rq.calc_amp = 0; rq.mode = 0; }
+
+    enum Visit { GO_ON, ACCEPTED, RESCAN };
+    // one ray of a scan, in the scan's order: does the arrival range cross the receiver's between this ray and the one before?
+    Visit visit(double th, int idx){
+        const double limit = fam.site.prm.azimuth_err_lim;
+        const bool left = broke(rq, idx);
+        const double* Rk = last_row(rq, idx);
+        r = fam.arrival(log, th, bounces, left, Rk, range0);
+        if(left) r_prev = range0;
+        if((r - range0) * (r_prev - range0) < 0.0){
+            if(iterations == 0) theta_next = th;
+            d_phi = fam.azimuth_deviation(Rk);
+            while(d_phi > 180.0){ d_phi -= 360.0; }
+            while(d_phi < -180.0){ d_phi += 360.0; }
+            if(fabs(d_phi) < limit){
+                if(fam.site.verbose) fam.verdict(log, true, d_phi, limit);
+                theta_estimate = th - d_theta;
+                phi_estimate = fam.azimuth_estimate(phi);
+                return ACCEPTED;
             }
+            if(fam.site.verbose) fam.verdict(log, false, d_phi, limit);
+            phi += d_phi * 0.9;
+            theta_min = std::max(th - 7.5, theta_min);
+            return RESCAN;
+        }
+        if(iterations >= 3){ d_theta = fam.next_step(r - range0, (r - r_prev) / (2.0 * d_theta)); }
+        r_prev = r;
+        return GO_ON;
+    }
+
+    // nullptr: finished (ok, theta_estimate, phi_estimate, theta_next are set)
+    Request* advance(){
+        const double limit = fam.site.prm.azimuth_err_lim;
+        for(;;) switch(st){
+        case PASS_BEGIN:
+            if(!(fabs(d_phi) > limit && iterations < 5)){ if(fam.site.verbose) fam.gave_up(log); ok = false; st = DONE; return nullptr; }
+            r = range0; r_prev = range0;
+            fresh_request();
+            if(iterations < 3){
+                // the scan of this pass: with a fixed step all its rays are known now -> one request, replayed when it comes back
+                for(double th = theta_min; fam.scan_goes_on(th, theta_max); th += d_theta) post(th);
+                st = SCAN_POSTED;
+                if(!rq.th.empty()) return &rq;
+                break;
+            }
+            theta = theta_min;
+            st = RAY_NEXT;
+            break;
+        case SCAN_POSTED: {
+            Visit v = GO_ON;
             int j = 0;
-            for(double theta = theta_min; theta <= theta_max; theta += d_theta, j++){
-                if(theta + d_theta >= theta_max) theta_max_reached = true;
-                Request one; const Request* rq = &scan; int idx = j;
-                if(!batched){
-                    one.bounces = bounces; one.calc_amp = 0; one.mode = 0; one.th.push_back(theta); one.ph.push_back(90.0 - phi);
-                    if(!trace(one)) return false;
-                    rq = &one; idx = 0;
-                }
-                const bool BreakCheck = broke(*rq, idx);
-                const double* Rk = last_row(*rq, idx);
-                const double xk = Rk[GEOAC_REC_STATE + 0], yk = Rk[GEOAC_REC_STATE + 1];
-                if(verbose){
-                    LOG << '\t' << '\t' << "Ray launched at " << theta << " degrees arrives at range " << sqrt(pow(xk - src[0], 2) + pow(yk - src[1], 2));
-                    LOG << " km after " << bounces << " reflections." << '\t' << "Exact arrival at " << xk << " km East, " << yk << " km North" << '\n';
-                }
-                if(BreakCheck){ r = r_rcvr; r_prev = r_rcvr; }
-                else { r = sqrt(pow(xk - src[0], 2) + pow(yk - src[1], 2)); }
-                if((r - r_rcvr) * (r_prev - r_rcvr) < 0.0){
-                    if(iterations == 0) theta_next = theta;
-                    d_phi = (atan2(rcv[1] - src[1], rcv[0] - src[0]) - atan2(yk - src[1], xk - src[0])) * 180.0 / Pi;
-                    while(d_phi > 180.0)  d_phi -= 360.0;
-                    while(d_phi < -180.0) d_phi += 360.0;
-                    if(fabs(d_phi) < azimuth_error_limit){
-                        if(verbose) LOG << '\t' << '\t' << "Azimuth deviation = " << d_phi << ".  Less than " << azimuth_error_limit << " degrees.  Estimates acceptable." << '\n' << '\n';
-                        theta_estimate = theta - d_theta;
-                        phi_estimate = phi;
-                        return true;
-                    } else {
-                        if(verbose) LOG << '\t' << '\t' << "Azimuth deviation = " << d_phi << ".  Greater than " << azimuth_error_limit << " degrees.  Compensating and searching inclinations again." << '\n' << '\n';
-                        phi += d_phi * 0.9;
-                        theta_min = std::max(theta - 7.5, theta_min);
-                    }
-                    break;
-                }
-                if(iterations >= 3){ d_theta = modify_d_theta_cart(r - r_rcvr, (r - r_prev) / (2.0 * d_theta)); }
-                r_prev = r;
+            for(double th = theta_min; fam.scan_goes_on(th, theta_max); th += d_theta, j++){
+                if(th + d_theta >= theta_max) theta_max_reached = true;
+                v = visit(th, j);
+                if(v != GO_ON) break;
             }
+            if(v == ACCEPTED){ ok = true; st = DONE; return nullptr; }
+            st = PASS_END;
+            break;
+        }
+        case RAY_NEXT:                                              // the step depends on the previous arrival (:122): one ray at a time
+            if(!fam.scan_goes_on(theta, theta_max)){ st = PASS_END; break; }
+            if(theta + d_theta >= theta_max) theta_max_reached = true;
+            fresh_request();
+            post(theta);
+            st = RAY_POSTED;
+            return &rq;
+        case RAY_POSTED: {
+            const Visit v = visit(theta, 0);
+            if(v == ACCEPTED){ ok = true; st = DONE; return nullptr; }
+            if(v == RESCAN){ st = PASS_END; break; }
+            theta += d_theta;
+            st = RAY_NEXT;
+            break;
+        }
+        case PASS_END:
             if(theta_max_reached){
                 theta_next = theta_max;
-                break;
+                if(fam.site.verbose) fam.gave_up(log);
+                ok = false; st = DONE; return nullptr;
             }
             iterations++;
             if(iterations >= 1 && iterations < 3){ d_theta = d_theta_big / 2.0; }
+            st = PASS_BEGIN;
+            break;
+        case DONE:
+            return nullptr;
         }
-        if(verbose) LOG << '\t' << '\t' << "Reached maximum inclination angle or iteration limit." << '\n';
-        return false;
     }
+};
 
-    // ---- GeoAc_3DEigenray_LM: GeoAc.Eigenray.cpp:123-335 ----
-    void refine(double& theta, double& phi, int bnc_cnt, int iterate_limit) override {
-        double dr, dr_prev = 10000.0;
+// ---- GeoAc_3DEigenray_LM as a state machine: damped Newton steps on the launch angles until the arrival is within 100 m of the receiver ----
+struct Refiner : Task {
+    enum State { ITERATE, RAY_POSTED, FINAL_POSTED, DONE };
+    const Family& fam; Segment& out;
+    State st = ITERATE;
+    const int bounces, iterate_limit;
+    int n = 0;
+    Newton N;
+    Request rq;
+
+    Refiner(const Family& f, Segment& o, double lt, double lp, int bnc, int limit) : fam(f), out(o), bounces(bnc), iterate_limit(limit) {
+        N.lt = lt; N.lp = lp;
+        if(fam.site.verbose) out.log << '\t' << '\t' << "Searching for exact eigenray using auxiliary parameters." << '\n';
+    }
+    void post(int mode){
+        rq = Request(); rq.bounces = bounces; rq.calc_amp = 1; rq.mode = mode;
+        rq.th.push_back(N.lt); rq.ph.push_back(90.0 - N.lp);
+    }
+    Request* advance(std::vector<std::unique_ptr<Task>>&) override {
+        DLog& log = out.log;
+        const bool verbose = fam.site.verbose;
         const double tolerance = 0.1;
-        const double theta_lim_step = 0.2, phi_lim_step = 0.2;
-        double step_scalar = 1.0;
-        double nu0[3], M, nu0_xy[2] = {0, 0};
-        long double x, y, dx, dy, dx_dt, dy_dt, dx_dp, dy_dp;
-        long double det, dt = 0, dp = 0;
-        if(verbose) LOG << '\t' << '\t' << "Searching for exact eigenray using auxiliary parameters." << '\n';
-        for(int n = 0; n <= iterate_limit; n++){
-            if(n == iterate_limit){
-                if(verbose){ LOG << '\t' << '\t' << '\t' << "Search for exact eigenray maxed out iterations.  No eigneray idenfied." << '\n' << '\n'; }
-                break;
-            }
-            const double GeoAc_theta = theta * Pi / 180.0, GeoAc_phi = phi * Pi / 180.0;
-            if(strat){
-                nu0[0] = cos(GeoAc_theta) * cos(GeoAc_phi);
-                nu0[1] = cos(GeoAc_theta) * sin(GeoAc_phi);
-                nu0[2] = sin(GeoAc_theta);
-                M = 1.0 + (nu0[0] * M_Comps[0] + nu0[1] * M_Comps[1] + nu0[2] * M_Comps[2]);
-                nu0_xy[0] = nu0[0] / M;
-                nu0_xy[1] = nu0[1] / M;
-            }
-            Request rq; rq.bounces = bnc_cnt; rq.calc_amp = 1; rq.mode = 0;
-            rq.th.push_back(theta); rq.ph.push_back(90.0 - phi);
-            if(verbose) LOG << '\t' << '\t' << "Plotting ray path with theta = " << theta << ", phi = " << 90.0 - phi;
-            if(!trace(rq)) return;
-            if(broke(rq, 0)){
-                if(verbose) LOG << '\t' << "Ray path left propagation region." << '\n';
-                break;
-            }
-            const double* S = &rq.rec[((size_t)bnc_cnt) * GEOAC_REC_STRIDE + GEOAC_REC_STATE];
-            x = S[0]; dx = rcv[0] - x;
-            y = S[1]; dy = rcv[1] - y;
-            dr = (double)sqrtl(dx * dx + dy * dy);
-            if(verbose) LOG << '\t' << '\t' << "Arrival after " << bnc_cnt << " reflections at (" << (double)x << ", " << (double)y << "), distance to receiver = " << dr << " km." << '\n';
-
-            if(dr < tolerance){
-                Request fin; fin.bounces = bnc_cnt; fin.calc_amp = 1; fin.mode = GEOAC_MODE_WRITE_RAYS;
-                fin.th.push_back(theta); fin.ph.push_back(90.0 - phi);
-                if(!trace(fin)) return;
-                const double* R = &fin.rec[((size_t)bnc_cnt) * GEOAC_REC_STRIDE];
-                const double* Sk = R + GEOAC_REC_STATE;
-                Eigenray e; memset(e.v, 0, sizeof e.v);
-                const double travel_time = R[GEOAC_REC_TTIME], attenuation = R[GEOAC_REC_ATTEN];
-                double back_az = strat ? (90.0 - GeoAc_phi * 180.0 / Pi) + 180.0 : 90.0 - atan2(-Sk[4], -Sk[3]) * 180.0 / Pi;
-                double arrival_incl = R[GEOAC_REC_INCL];          // -asin(c(x_k, y_k, z_grnd) / c(src) nu_z) in both mains' records
-                double az_to_src = 90.0 - atan2(src[1] - rcv[1], src[0] - rcv[0]) * 180.0 / Pi;
-                double back_az_dev = back_az - az_to_src;
-                while(back_az > 180.0)      back_az -= 360.0;
-                while(back_az < -180.0)     back_az += 360.0;
-                while(back_az_dev > 180.0)  back_az_dev -= 360.0;
-                while(back_az_dev < -180.0) back_az_dev += 360.0;
-                e.v[GEOAC_EIG_RCVR] = rcvr_index; e.v[GEOAC_EIG_INDEX] = 0;  /* numbered when the receiver's segments are put in order */ e.v[GEOAC_EIG_BOUNCES] = bnc_cnt;
-                e.v[GEOAC_EIG_THETA] = theta; e.v[GEOAC_EIG_PHI] = 90.0 - phi;
-                e.v[GEOAC_EIG_TTIME] = travel_time;
-                e.v[GEOAC_EIG_CELERITY] = sqrt(pow(Sk[0] - src[0], 2) + pow(Sk[1] - src[1], 2)) / travel_time;
-                e.v[GEOAC_EIG_AMP_DB] = 20.0 * log10(R[GEOAC_REC_AMP]);
-                e.v[GEOAC_EIG_ATTEN_DB] = -attenuation;
-                e.v[GEOAC_EIG_INCL] = arrival_incl; e.v[GEOAC_EIG_BEARING] = az_to_src; e.v[GEOAC_EIG_BACKAZ] = back_az; e.v[GEOAC_EIG_AZDEV] = back_az_dev;
-                e.smp = fin.smp;
-                e.v[GEOAC_EIG_NSMP] = (double)(e.smp.size() / GEOAC_SMP_STRIDE);
-                if(!verbose) LOG << '\t' << "Eigenray identified:" << '\t' << "theta, phi = " << DLog::Prec{8} << theta << ", " << 90.0 - phi << " degrees." << '\n';
-                if(verbose){
-                    LOG << '\t' << '\t' << "Eigenray Identified:" << '\n';
-                    LOG << '\t' << '\t' << '\t' << "theta, phi = " << DLog::Prec{8} << theta << ", " << 90.0 - phi << " degrees." << '\n';
-                    LOG << '\t' << '\t' << '\t' << "Travel Time = " << travel_time << " seconds." << '\n';
-                    LOG << '\t' << '\t' << '\t' << "Celerity = " << e.v[GEOAC_EIG_CELERITY] << " km/s." << '\n';
-                    LOG << '\t' << '\t' << '\t' << "Amplitude (geometric) = " << e.v[GEOAC_EIG_AMP_DB] << " dB." << '\n';
-                    LOG << '\t' << '\t' << '\t' << "Atmospheric Attenuation = " << -attenuation << " dB." << '\n';
-                    LOG << '\t' << '\t' << '\t' << "Arrival inclination = " << arrival_incl << " degrees." << '\n';
-                    LOG << '\t' << '\t' << '\t' << "Azimuth to source = " << az_to_src << '\n';
-                    LOG << '\t' << '\t' << '\t' << "Back Azimuth of arrival = " << back_az << '\n';
-                    LOG << '\t' << '\t' << '\t' << "Azimuth Deviation = " << back_az_dev << " degrees." << '\n' << '\n';
-                }
-                FOUND.push_back(e);
-                LOG.incr();
-                break;
-            } else if(n > 0 && dr > dr_prev){
-                theta -= dt * step_scalar;
-                phi -= dp * step_scalar;
-                step_scalar /= 2.0;
-                if(sqrt(dt * dt + dp * dp) * step_scalar < 1.0e-12){
-                    if(verbose) LOG << '\t' << '\t' << '\t' << "Step size too small, psuedo-critical ray path likely." << '\n' << '\n';
-                    break;
+        for(;;) switch(st){
+        case ITERATE:
+            if(n == iterate_limit){ if(verbose) fam.maxed_out(log); st = DONE; break; }
+            fam.launch_direction(N);
+            post(0);
+            if(verbose) log << '\t' << '\t' << "Plotting ray path with theta = " << N.lt << ", phi = " << 90.0 - N.lp;
+            st = RAY_POSTED;
+            return &rq;
+        case RAY_POSTED: {
+            if(broke(rq, 0)){ if(verbose) fam.left_region(log); st = DONE; break; }
+            const double* S = &rq.rec[((size_t)bounces) * GEOAC_REC_STRIDE + GEOAC_REC_STATE];        // solution[k][*] of the last leg
+            N.dr = fam.miss(log, N, S, bounces);
+            if(N.dr < tolerance){
+                post(GEOAC_MODE_WRITE_RAYS);                             // the same ray once more, with its raypath
+                st = FINAL_POSTED;
+                return &rq;
+            } else if(n > 0 && N.dr > N.dr_prev){
+                N.lt -= N.dlt * N.step_scalar;
+                N.lp -= N.dlp * N.step_scalar;
+                N.step_scalar /= 2.0;
+                if(sqrt(N.dlt * N.dlt + N.dlp * N.dlp) * N.step_scalar < 1.0e-12){
+                    if(verbose) log << '\t' << '\t' << '\t' << "Step size too small, psuedo-critical ray path likely." << '\n' << '\n';
+                    st = DONE; break;
                 }
             } else {
-                step_scalar = std::min(1.0, step_scalar * 1.25);
-                if(strat){
-                    dx_dt = S[4] - nu0_xy[0] / S[3] * S[6];
-                    dy_dt = S[5] - nu0_xy[1] / S[3] * S[6];
-                    dx_dp = S[8] - nu0_xy[0] / S[3] * S[10];
-                    dy_dp = S[9] - nu0_xy[1] / S[3] * S[10];
-                } else {
-                    dx_dt = S[6] - S[3] / S[5] * S[8];
-                    dy_dt = S[7] - S[4] / S[5] * S[8];
-                    dx_dp = S[12] - S[3] / S[5] * S[14];
-                    dy_dp = S[13] - S[4] / S[5] * S[14];
-                }
-                det = dx_dt * dy_dp - dx_dp * dy_dt;
-                dt = 1.0 / det * (dy_dp * dx - dx_dp * dy) * 180.0 / Pi;
-                dp = 1.0 / det * (dx_dt * dy - dy_dt * dx) * 180.0 / Pi;
-                if(dt > theta_lim_step)  dt =  theta_lim_step;
-                if(dp > phi_lim_step)    dp =  phi_lim_step;
-                if(dt < -theta_lim_step) dt = -theta_lim_step;
-                if(dp < -phi_lim_step)   dp = -phi_lim_step;
-                theta += dt * step_scalar;
-                phi += dp * step_scalar;
-                dr_prev = dr;
+                N.step_scalar = std::min(1.0, N.step_scalar * 1.25);
+                fam.full_step(N, S);
+                N.lt += N.dlt * N.step_scalar;
+                N.lp += N.dlp * N.step_scalar;
+                N.dr_prev = N.dr;
             }
+            n++;
+            st = ITERATE;
+            break;
+        }
+        case FINAL_POSTED:
+            fam.identified(out, N, rq, bounces);
+            st = DONE;
+            break;
+        case DONE:
+            return nullptr;
         }
     }
+};
 
-    // ---- the text around the -eig_search driver loop: GeoAc3D_main.cpp:531-543 ----
-    void header(int n_bnc) override { LOG << "Searching for " << n_bnc << " bounce eigenray(s) between " << prm.theta_min << " and " << prm.theta_max << "." << '\n'; }
-    void footer() override { LOG << '\t' << "Identified " << DLog::Count{} << " eigenray(s)." << '\n'; }
-    void run_direct(double theta_est, double phi_from_north, int bounces) override { direct_refine(theta_est, 90.0 - phi_from_north, bounces); }
+// ---- one bounce count of one receiver: the -eig_search loop body (GeoAcGlobal_main.cpp:566-580, GeoAc3D_main.cpp:531-543).  Every estimate
+//      and every refinement writes into a segment of its own; the refinements run as tasks beside the scan, the segments keep the reference's
+//      order: header, E1, R1, E2, R2, ... ----
+struct ScanChain : Task {
+    const Family& fam;
+    const int n_bnc;
+    std::deque<Segment> segs;                // (deque: addresses stay valid while segments are appended)
+    std::unique_ptr<Estimator> est;
+    double theta_start, theta_next;
+    ScanChain(const Family& f, int bnc) : fam(f), n_bnc(bnc), theta_start(f.site.prm.theta_min), theta_next(f.site.prm.theta_max) {
+        segs.emplace_back();
+        fam.header(segs.back().log, n_bnc);
+    }
+    Request* advance(std::vector<std::unique_ptr<Task>>& spawned) override {
+        const geoac_eig_params& prm = fam.site.prm;
+        for(;;){
+            if(!est){
+                if(!(theta_start < prm.theta_max)) return nullptr;
+                segs.emplace_back();
+                est.reset(new Estimator(fam, segs.back().log, theta_start, prm.theta_max, theta_next, n_bnc));
+            }
+            if(Request* rq = est->advance()) return rq;
+            theta_next = est->theta_next;
+            if(est->ok){
+                segs.emplace_back();
+                spawned.emplace_back(new Refiner(fam, segs.back(), est->theta_estimate, est->phi_estimate, n_bnc, prm.iterations));
+            }
+            theta_start = theta_next;
+            est.reset();
+        }
+    }
+};
+
+// one receiver: its family (site data), its scan chains or its -eig_direct refinement, and the output put back in order
+struct Receiver {
+    std::unique_ptr<Family> fam;
+    std::vector<ScanChain*> chains;          // (owned by the scheduler's task list)
+    Segment direct;                          // -eig_direct: the one refinement's output
+    std::ostringstream log;                  // the reference's cout for this receiver (sticky precision and all), rendered at the end
+    std::vector<Eigenray> found;
+    int eigenray_count = 0;
+    void collect(Segment& g){
+        g.log.render(log, eigenray_count);
+        for(Eigenray& e : g.found){ e.v[GEOAC_EIG_INDEX] = (double)found.size(); found.push_back(e); }
+    }
 };
 
 }  // namespace
@@ -730,73 +751,66 @@ static int run_all(geoac_ctx* ctx, const geoac_eig_params* ep, int n_rcvr, const
         if(rc) return rc;
         mach[0] = m4[1] / m4[0]; mach[1] = m4[2] / m4[0]; mach[2] = 0.0 / m4[0];
     }
+    // ---- the receivers and their first tasks ----
+    std::vector<Receiver> R((size_t)n_rcvr);
+    std::vector<std::unique_ptr<Task>> all;                         // every task ever made (the scan chains hold the output until the end)
+    std::vector<Task*> active;
+    for(int i = 0; i < n_rcvr; i++){
+        Receiver& rv = R[(size_t)i];
+        if(sph){
+            SphericalFamily* q = new SphericalFamily(); q->geo.r_earth = base.r_earth; rv.fam.reset(q);
+            q->site.src[0] = base.src[1]; q->site.src[1] = base.src[2]; q->site.src[2] = std::max(base.src[0], base.z_grnd);   // Source_Loc = (lat, lon, max(z, z_grnd))
+        } else {
+            CartesianFamily* q = new CartesianFamily(); q->strat = (eqset == GEOAC_EQ_3D); rv.fam.reset(q);
+            for(int c = 0; c < 3; c++) q->M_Comps[c] = mach[c];
+            q->site.src[0] = base.src[0]; q->site.src[1] = base.src[1]; q->site.src[2] = std::max(base.src[2], base.z_grnd);   // Source_Loc = (x, y, max(z, z_grnd))
+        }
+        Site& s = rv.fam->site;
+        s.eqset = eqset; s.rcvr_index = i; s.z_grnd = base.z_grnd;
+        s.rcv[0] = rcvr[2 * i]; s.rcv[1] = rcvr[2 * i + 1];
+        s.prm = *ep; s.verbose = ep->verbose != 0;
+        if(direct){
+            all.emplace_back(new Refiner(*rv.fam, rv.direct, theta_est[i], 90.0 - phi_est[i], bounces, ep->iterations));
+            active.push_back(all.back().get());
+        } else {
+            for(int b = ep->bnc_min; b <= ep->bnc_max; b++){
+                ScanChain* c = new ScanChain(*rv.fam, b);
+                all.emplace_back(c); active.push_back(c); rv.chains.push_back(c);
+            }
+        }
+    }
+    // ---- rounds: every task runs until it needs a ray; the rays of the round are integrated together; the tasks read their records ----
     geoac_eig_result* res = new geoac_eig_result();
     std::vector<geoac_ctx*> ctxs{ ctx };                          // the caller's context and, made on demand, clones of it (serve)
-    Shared sh;
-    std::vector<std::unique_ptr<SearchBase>> S;
-    for(int i = 0; i < n_rcvr; i++){
-        std::unique_ptr<SearchBase> sp;
-        if(sph){
-            Search* q = new Search(); q->geo.r_earth = base.r_earth; sp.reset(q);
-            q->src[0] = base.src[1]; q->src[1] = base.src[2]; q->src[2] = std::max(base.src[0], base.z_grnd);   // Source_Loc = (lat, lon, max(z, z_grnd))
-        } else {
-            SearchCart* q = new SearchCart(); q->strat = (eqset == GEOAC_EQ_3D); sp.reset(q);
-            for(int c = 0; c < 3; c++) q->M_Comps[c] = mach[c];
-            q->src[0] = base.src[0]; q->src[1] = base.src[1]; q->src[2] = std::max(base.src[2], base.z_grnd);   // Source_Loc = (x, y, max(z, z_grnd))
-        }
-        sp->sh = &sh; sp->eqset = eqset; sp->rcvr_index = i; sp->z_grnd = base.z_grnd;
-        sp->rcv[0] = rcvr[2 * i]; sp->rcv[1] = rcvr[2 * i + 1];
-        sp->prm = *ep; sp->verbose = ep->verbose != 0;
-        S.push_back(std::move(sp));
-    }
-    // receivers go through in groups of at most 96 (each receiver is a thread plus one per bounce count plus its refinement tasks, all
-    // of them only waiting for rays: the group size keeps the process well under a thousand threads whatever n_rcvr is)
     int err = 0;
-    const int group = 96;
-    for(int g0 = 0; g0 < n_rcvr && !err; g0 += group){
-        const int g1 = std::min(n_rcvr, g0 + group);
-        {
-            std::unique_lock<std::mutex> lk(sh.mu);
-            sh.active = g1 - g0; sh.waiting = 0; sh.pending.clear();
+    while(!active.empty() && !err){
+        std::vector<Request*> batch;
+        std::vector<Task*> waiting;
+        for(size_t i = 0; i < active.size(); i++){                  // (tasks spawned in this round join it)
+            std::vector<std::unique_ptr<Task>> spawned;
+            Request* rq = active[i]->advance(spawned);
+            for(auto& t : spawned){ active.push_back(t.get()); all.push_back(std::move(t)); }
+            if(rq){ batch.push_back(rq); waiting.push_back(active[i]); }
         }
-        std::vector<std::thread> threads;
-        for(int i = g0; i < g1; i++){
-            threads.emplace_back([&, i]{
-                SearchBase& s = *S[(size_t)i];
-                if(direct) s.run_direct(theta_est[i], phi_est[i], bounces); else s.run_search();
-                if(!s.self_released){                              // run_search released this thread before waiting for its tasks
-                    std::unique_lock<std::mutex> lk(sh.mu);
-                    sh.active--;
-                    sh.cv_work.notify_all();
-                }
-            });
-        }
-        for(;;){
-            std::vector<Request*> batch;
-            {
-                std::unique_lock<std::mutex> lk(sh.mu);
-                sh.cv_work.wait(lk, [&]{ return sh.active == 0 || sh.waiting == sh.active; });
-                if(sh.active == 0) break;
-                batch.swap(sh.pending);
-            }
-            err = serve(ctxs, base, batch, res);
-            res->stats[3] += 1;
-            {
-                std::unique_lock<std::mutex> lk(sh.mu);
-                if(err) sh.failed = true;
-                for(Request* r : batch){ r->done = true; r->error = err; }
-                sh.waiting -= (int)batch.size();
-                sh.cv_done.notify_all();
-            }
-        }
-        for(auto& t : threads) t.join();
+        if(batch.empty()) break;
+        err = serve(ctxs, base, batch, res);
+        res->stats[3] += 1;
+        active.swap(waiting);
     }
     for(size_t w = 1; w < ctxs.size(); w++) geoac_destroy(ctxs[w]);
     geoac_set_params(ctx, &base);                                  // restore the caller's bounces / calc_amp / mode
     if(err){ delete res; return err; }
+    // ---- the output in the reference's order ----
     for(int i = 0; i < n_rcvr; i++){
-        SearchBase& s = *S[(size_t)i];
-        for(Eigenray& e : s.found){
+        Receiver& rv = R[(size_t)i];
+        if(direct) rv.collect(rv.direct);
+        else {
+            for(ScanChain* c : rv.chains) for(Segment& g : c->segs) rv.collect(g);
+            Segment tail;
+            rv.fam->footer(tail.log);
+            tail.log.render(rv.log, rv.eigenray_count);
+        }
+        for(Eigenray& e : rv.found){
             e.v[GEOAC_EIG_SMP0] = (double)(res->smp.size() / GEOAC_SMP_STRIDE);
             const size_t idx = res->eig.size() / GEOAC_EIG_STRIDE;
             res->eig.insert(res->eig.end(), e.v, e.v + GEOAC_EIG_STRIDE);
@@ -806,7 +820,7 @@ static int run_all(geoac_ctx* ctx, const geoac_eig_params* ep, int n_rcvr, const
                 res->smp[b + GEOAC_SMP_RAY] = (double)idx;
             }
         }
-        res->logs.push_back(s.log.str());
+        res->logs.push_back(rv.log.str());
     }
     *out = res;
     return 0;

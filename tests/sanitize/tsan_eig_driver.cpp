@@ -1,7 +1,8 @@
 // CPU-only ThreadSanitizer driver (tests/test_sanitizers.py): the eigenray scheduler of libgeoac_hip (geoac_amd/csrc/geoac_eigenray.cpp:
-// one host thread per scan chain / refinement, requests collected into rounds by the caller's thread) compiled with -fsanitize=thread
-// on top of a STUB of the fan ABI - a closed-form "ray" (arrival range grows with the inclination, bearing = launch azimuth) in place
-// of the GPU.  No physics is checked here: the point is the queue / condition-variable / deferred-log machinery under TSan.
+// tasks advanced in rounds by the caller's thread; the (bounces, CalcAmp, mode) groups of a round integrated side by side, one host thread
+// and one context clone each) compiled with -fsanitize=thread on top of a STUB of the fan ABI - a closed-form "ray" (arrival range grows
+// with the inclination, bearing = launch azimuth) in place of the GPU.  No physics is checked here: the point is the round / worker-thread /
+// deferred-log machinery under TSan.
 #include <cmath>
 #include <cstdio>
 #include <cstring>

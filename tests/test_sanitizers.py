@@ -31,8 +31,8 @@ def test_oracle_under_asan_ubsan(tmp_path):
 
 
 def test_eigenray_scheduler_under_tsan(tmp_path):
-    """the search threads / round coordinator of geoac_eigenray.cpp under ThreadSanitizer, on a closed-form stub of the fan ABI
-    (tests/sanitize/tsan_eig_driver.cpp): 12 receivers x 2 bounce counts, scans and refinements running concurrently"""
+    """the round scheduler of geoac_eigenray.cpp and its per-group worker threads (one context clone each) under ThreadSanitizer, on a
+    closed-form stub of the fan ABI (tests/sanitize/tsan_eig_driver.cpp): 12 receivers x 2 bounce counts, scans and refinements sharing rounds"""
     exe = str(tmp_path / "tsan_eig")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread", "-o", exe,
                            os.path.join(H.ROOT, "tests", "sanitize", "tsan_eig_driver.cpp"), os.path.join(H.ROOT, "geoac_amd", "csrc", "geoac_eigenray.cpp")])
