@@ -15,6 +15,7 @@
 // reference's order at the end.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <atomic>
@@ -155,7 +156,7 @@ struct Family {
     virtual void launch_direction(Newton& N) const {}
     virtual void left_region(DLog& log) const {}
     virtual void maxed_out(DLog& log) const = 0;
-    virtual double miss(DLog& log, Newton& N, const double* S, int bounces) const = 0;          // distance between arrival and receiver + its line
+    virtual double miss(DLog* log, Newton& N, const double* S, int bounces) const = 0;          // distance between arrival and receiver (+ its line of the log)
     virtual void full_step(Newton& N, const double* S) const = 0;                                // the Newton step on (lt, lp), clamped: N.dlt, N.dlp
     virtual void identified(Segment& out, const Newton& N, const Request& fin, int bounces) const = 0;   // the eigenray's record and its block of the log
 };
@@ -198,10 +199,10 @@ struct SphericalFamily : Family {
     void gave_up(DLog& log) const override { log << '\t' << '\t' << "Reached maximum inclination angle or iteration limit." << '\n' << '\n'; }
     // GeoAc_3DEigenray_LM: GeoAc.Eigenray.Global.cpp:139-319
     void maxed_out(DLog& log) const override { log << '\t' << '\t' << '\t' << "Search for exact eigenray maxed out iterations.  No eigneray idenfied." << '\n'; }
-    double miss(DLog& log, Newton& N, const double* S, int) const override {
+    double miss(DLog* log, Newton& N, const double* S, int) const override {
         N.p = S[1]; N.q = S[2];
         const double dr = geo.gc_distance((double)(N.p * 180.0 / Pi), (double)(N.q * 180.0 / Pi), site.rcv[0], site.rcv[1]);
-        if(site.verbose) log << '\t' << '\t' << "Arrival at (" << DLog::Prec{8} << (double)(N.p * 180.0 / Pi) << ", " << (double)(N.q * 180.0 / Pi) << "), distance to receiver = " << dr << " km." << '\n';
+        if(site.verbose && log) *log << '\t' << '\t' << "Arrival at (" << DLog::Prec{8} << (double)(N.p * 180.0 / Pi) << ", " << (double)(N.q * 180.0 / Pi) << "), distance to receiver = " << dr << " km." << '\n';
         return dr;
     }
     void full_step(Newton& N, const double* S) const override {
@@ -322,12 +323,12 @@ struct CartesianFamily : Family {
     }
     void left_region(DLog& log) const override { log << '\t' << "Ray path left propagation region." << '\n'; }
     void maxed_out(DLog& log) const override { log << '\t' << '\t' << '\t' << "Search for exact eigenray maxed out iterations.  No eigneray idenfied." << '\n' << '\n'; }
-    double miss(DLog& log, Newton& N, const double* S, int bnc_cnt) const override {
+    double miss(DLog* log, Newton& N, const double* S, int bnc_cnt) const override {
         long double dx, dy;
         N.p = S[0]; dx = rcv()[0] - N.p;
         N.q = S[1]; dy = rcv()[1] - N.q;
         const double dr = (double)sqrtl(dx * dx + dy * dy);
-        if(site.verbose) log << '\t' << '\t' << "Arrival after " << bnc_cnt << " reflections at (" << (double)N.p << ", " << (double)N.q << "), distance to receiver = " << dr << " km." << '\n';
+        if(site.verbose && log) *log << '\t' << '\t' << "Arrival after " << bnc_cnt << " reflections at (" << (double)N.p << ", " << (double)N.q << "), distance to receiver = " << dr << " km." << '\n';
         return dr;
     }
     void full_step(Newton& N, const double* S) const override {
@@ -519,60 +520,116 @@ struct Estimator {
     }
 };
 
-// ---- GeoAc_3DEigenray_LM as a state machine: damped Newton steps on the launch angles until the arrival is within 100 m of the receiver ----
+// ---- GeoAc_3DEigenray_LM as a state machine: damped Newton steps on the launch angles until the arrival is within 100 m of the receiver.
+//      A step that takes the arrival further away is undone and halved: the routine goes back to the point before (the same angles, bit for bit,
+//      almost always) and tries again with 0.625 of the step - two rays, one after the other, for every such step, and the searches that end at
+//      the iteration limit consist of little else.  So (a) every ray of the refinement is remembered and a ray whose angles it has seen is not
+//      integrated again, and (b) beside the trial ray the request carries the trials that would follow if it (and the next, and the next) were
+//      undone - computed by running the same transition on a copy of the state.  Consumed in the routine's order, with its log; a guess that
+//      is not needed is a few lanes of a fan that was going to be launched anyway. ----
 struct Refiner : Task {
     enum State { ITERATE, RAY_POSTED, FINAL_POSTED, DONE };
+    enum { SPECULATE = 3 };                 // trials posted ahead
     const Family& fam; Segment& out;
     State st = ITERATE;
     const int bounces, iterate_limit;
     int n = 0;
     Newton N;
     Request rq;
+    struct Known { double lt, lp; std::vector<double> rec; };      // a ray of this refinement (CalcAmp on, no samples) and its leg records
+    std::vector<Known> known;
+    std::vector<double> rq_lp;              // the azimuths of the posted rays as the routine carries them (the request has 90 - lp)
 
     Refiner(const Family& f, Segment& o, double lt, double lp, int bnc, int limit) : fam(f), out(o), bounces(bnc), iterate_limit(limit) {
         N.lt = lt; N.lp = lp;
         if(fam.site.verbose) out.log << '\t' << '\t' << "Searching for exact eigenray using auxiliary parameters." << '\n';
     }
-    void post(int mode){
-        rq = Request(); rq.bounces = bounces; rq.calc_amp = 1; rq.mode = mode;
-        rq.th.push_back(N.lt); rq.ph.push_back(90.0 - N.lp);
+    const double* lookup(double lt, double lp) const {
+        for(const Known& k : known) if(k.lt == lt && k.lp == lp) return k.rec.data();
+        return nullptr;
+    }
+    bool left_region(const double* rec) const { return rec[(size_t)bounces * GEOAC_REC_STRIDE + GEOAC_REC_VALID] == 0.0; }
+    const double* last_state(const double* rec) const { return rec + (size_t)bounces * GEOAC_REC_STRIDE + GEOAC_REC_STATE; }   // solution[k][*] of the last leg
+
+    // the routine's reaction to the arrival of the ray at (M.lt, M.lp), iteration m; log: the real run (nullptr: a look ahead)
+    enum Next { TRIAL, FINAL, STOP };
+    void undo_step(Newton& M) const { M.lt -= M.dlt * M.step_scalar; M.lp -= M.dlp * M.step_scalar; M.step_scalar /= 2.0; }
+    bool step_too_small(const Newton& M) const { return sqrt(M.dlt * M.dlt + M.dlp * M.dlp) * M.step_scalar < 1.0e-12; }
+    Next react(Newton& M, int& m, const double* rec, DLog* log) const {
+        const bool verbose = fam.site.verbose && log;
+        const double tolerance = 0.1;
+        if(left_region(rec)){ if(verbose) fam.left_region(*log); return STOP; }
+        const double* S = last_state(rec);
+        M.dr = fam.miss(log, M, S, bounces);
+        if(M.dr < tolerance) return FINAL;
+        if(m > 0 && M.dr > M.dr_prev){
+            undo_step(M);
+            if(step_too_small(M)){
+                if(verbose) *log << '\t' << '\t' << '\t' << "Step size too small, psuedo-critical ray path likely." << '\n' << '\n';
+                return STOP;
+            }
+        } else {
+            M.step_scalar = std::min(1.0, M.step_scalar * 1.25);
+            fam.full_step(M, S);
+            M.lt += M.dlt * M.step_scalar;
+            M.lp += M.dlp * M.step_scalar;
+            M.dr_prev = M.dr;
+        }
+        m++;
+        return TRIAL;
+    }
+    void add_ray(double lt, double lp){ rq.th.push_back(lt); rq.ph.push_back(90.0 - lp); rq_lp.push_back(lp); }
+    // the trials that follow if the ray just posted - iteration n, angles (N.lt, N.lp) - is undone, and the one after it, ...
+    void look_ahead(){
+        Newton M = N; int m = n;
+        for(int k = 0; k < SPECULATE; k++){
+            if(m == 0) return;                                       // the first ray is never undone
+            undo_step(M);
+            if(step_too_small(M)) return;
+            m++;
+            if(m == iterate_limit) return;
+            fam.launch_direction(M);
+            const double* back = lookup(M.lt, M.lp);                 // the point before, if the subtraction gave its angles back
+            if(!back) return;
+            if(react(M, m, back, nullptr) != TRIAL || m == iterate_limit) return;
+            if(M.dr_prev != M.dr) return;                            // (it was undone again at once: not the pattern looked for)
+            fam.launch_direction(M);
+            bool posted = false;
+            for(size_t i = 0; i < rq.th.size(); i++) posted = posted || (rq.th[i] == M.lt && rq_lp[i] == M.lp);
+            if(!lookup(M.lt, M.lp) && !posted) add_ray(M.lt, M.lp);
+        }
     }
     Request* advance(std::vector<std::unique_ptr<Task>>&) override {
         DLog& log = out.log;
         const bool verbose = fam.site.verbose;
-        const double tolerance = 0.1;
         for(;;) switch(st){
-        case ITERATE:
+        case ITERATE: {
             if(n == iterate_limit){ if(verbose) fam.maxed_out(log); st = DONE; break; }
             fam.launch_direction(N);
-            post(0);
             if(verbose) log << '\t' << '\t' << "Plotting ray path with theta = " << N.lt << ", phi = " << 90.0 - N.lp;
             st = RAY_POSTED;
+            if(lookup(N.lt, N.lp)) break;                            // seen before: no ray
+            rq = Request(); rq_lp.clear(); rq.bounces = bounces; rq.calc_amp = 1; rq.mode = 0;
+            add_ray(N.lt, N.lp);
+            look_ahead();
             return &rq;
+        }
         case RAY_POSTED: {
-            if(broke(rq, 0)){ if(verbose) fam.left_region(log); st = DONE; break; }
-            const double* S = &rq.rec[((size_t)bounces) * GEOAC_REC_STRIDE + GEOAC_REC_STATE];        // solution[k][*] of the last leg
-            N.dr = fam.miss(log, N, S, bounces);
-            if(N.dr < tolerance){
-                post(GEOAC_MODE_WRITE_RAYS);                             // the same ray once more, with its raypath
+            if(!rq.th.empty()){                                      // what came back: remember all of it
+                const size_t per = (size_t)(bounces + 1) * GEOAC_REC_STRIDE;
+                for(size_t i = 0; i < rq.th.size(); i++)
+                    known.push_back(Known{ rq.th[i], rq_lp[i], std::vector<double>(rq.rec.begin() + i * per, rq.rec.begin() + (i + 1) * per) });
+                rq = Request(); rq_lp.clear();
+            }
+            const double* rec = lookup(N.lt, N.lp);
+            const Next nx = react(N, n, rec, &log);
+            if(nx == STOP){ st = DONE; break; }
+            if(nx == FINAL){
+                rq = Request(); rq_lp.clear(); rq.bounces = bounces; rq.calc_amp = 1; rq.mode = GEOAC_MODE_WRITE_RAYS;      // the same ray once more, with its raypath
+                add_ray(N.lt, N.lp);
                 st = FINAL_POSTED;
                 return &rq;
-            } else if(n > 0 && N.dr > N.dr_prev){
-                N.lt -= N.dlt * N.step_scalar;
-                N.lp -= N.dlp * N.step_scalar;
-                N.step_scalar /= 2.0;
-                if(sqrt(N.dlt * N.dlt + N.dlp * N.dlp) * N.step_scalar < 1.0e-12){
-                    if(verbose) log << '\t' << '\t' << '\t' << "Step size too small, psuedo-critical ray path likely." << '\n' << '\n';
-                    st = DONE; break;
-                }
-            } else {
-                N.step_scalar = std::min(1.0, N.step_scalar * 1.25);
-                fam.full_step(N, S);
-                N.lt += N.dlt * N.step_scalar;
-                N.lp += N.dlp * N.step_scalar;
-                N.dr_prev = N.dr;
             }
-            n++;
             st = ITERATE;
             break;
         }
@@ -783,6 +840,8 @@ static int run_all(geoac_ctx* ctx, const geoac_eig_params* ep, int n_rcvr, const
     geoac_eig_result* res = new geoac_eig_result();
     std::vector<geoac_ctx*> ctxs{ ctx };                          // the caller's context and, made on demand, clones of it (serve)
     int err = 0;
+    const char* dbg = getenv("GEOAC_DEBUG_ENV");
+    const bool trace = dbg && dbg[0] == '1' && getenv("GEOAC_EIG_TRACE") != nullptr;
     while(!active.empty() && !err){
         std::vector<Request*> batch;
         std::vector<Task*> waiting;
@@ -793,6 +852,14 @@ static int run_all(geoac_ctx* ctx, const geoac_eig_params* ep, int n_rcvr, const
             if(rq){ batch.push_back(rq); waiting.push_back(active[i]); }
         }
         if(batch.empty()) break;
+        if(trace){                                                  // (GEOAC_DEBUG_ENV=1 GEOAC_EIG_TRACE=1) what this round is made of
+            size_t scans = 0, scan_rays = 0, singles = 0, newton = 0, finals = 0;
+            for(Request* r : batch){
+                if(r->mode) finals++; else if(r->calc_amp) newton++; else if(r->th.size() > 1){ scans++; scan_rays += r->th.size(); } else singles++;
+            }
+            fprintf(stderr, "[eig round %llu] tasks %zu: %zu scans (%zu rays), %zu single scan rays, %zu refinement rays, %zu eigenray rays\n",
+                    (unsigned long long)res->stats[3], active.size(), scans, scan_rays, singles, newton, finals);
+        }
         err = serve(ctxs, base, batch, res);
         res->stats[3] += 1;
         active.swap(waiting);
