@@ -1,5 +1,10 @@
 // geoac_duo.h - k_rk4_duo: the wave-specialised RK4 kernel of the stratified Global set with amplitudes (included by geoac_kernels.hip).
 //
+// STATUS (round 3): built, bit-identical to the one-wave kernels (tests/test_gpu_fullsize.py), and measured SLOWER than the two-lane kernel - the
+// base wave alone takes 1.91 us per step, but handing 17 doubles per lane and stage to the other wave costs 0.5-0.9 us more (3.0 us against
+// 2.56 us then, 2.23 us now; through HBM rows instead of LDS 2.4 us plus the consumer's lag).  It is NOT on the launch plan: option DUO=1
+// selects it (diagnostic values 32 / 66 / 160 switch parts of the hand-off off for timing).  Kept because it documents what the hand-off costs.
+//
 // GeoAc_Propagate_RK4 (GeoAc.Solver.cpp:12-72) integrates 18 equations per ray: the ray itself (r, lat, lon, nu) and two launch-angle
 // derivative systems of 6 (Global.cpp:273-367).  The derivative systems read the ray, the ray never reads them.  The time of a fan is the
 // serial time of its longest ray (54 130 steps on the metric fan) at one wave per SIMD - every instruction of that wave costs four cycles

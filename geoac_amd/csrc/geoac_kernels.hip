@@ -246,7 +246,7 @@ template <int W = GEOAC_SEGW, typename TabPtr>
 DEVINL void seg_locate(TabPtr tab, const GeoacDevParams& P, double x, int& off, double* r){
     const int last = (P.nseg - 1) * W;
     const bool up = (x > r[1]) & (off < last), down = (x < r[0]) & (off > 0);
-    if(up | down){
+    if(__builtin_expect(up | down, 0)){
         off += (up ? W : 0) - (down ? W : 0);
         if(!P.seg_safe){
             const auto* p = tab + off;
@@ -803,7 +803,7 @@ template <bool AMP_> struct EqGlobal {
     static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, int k, bool& brk, bool& gnd){
         const double lon0 = P.src[2] * kPi / 180.0;
         const double dl = yn[1] - C.a[0], pl = yn[2] - lon0;
-        if(fabs(dl) > GEOAC_ROT_MAX){ C.a[0] = yn[1]; fsincos(yn[1], C.a[1], C.a[2]); C.t[0] = C.a[1]; C.t[1] = C.a[2]; }   // (rare, per ray)
+        if(__builtin_expect(fabs(dl) > GEOAC_ROT_MAX, 0)){ C.a[0] = yn[1]; fsincos(yn[1], C.a[1], C.a[2]); C.t[0] = C.a[1]; C.t[1] = C.a[2]; }   // (rare, per ray)
         else rot_small(C.a[1], C.a[2], dl, C.t[0], C.t[1]);
         // haversine of the great-circle range: hav = sin^2(dlat/2) + cos(lat0) cos(lat) sin^2(dlon/2), with 2 sin^2(x/2) = 1 - cos x;
         // range = 2 R asin(sqrt(hav)) > limit  <=>  hav > sin^2(limit / 2R).
@@ -815,7 +815,7 @@ template <bool AMP_> struct EqGlobal {
         if(fabs(yn[1] - P.src[1] * kPi / 180.0) * 0.5 + fabs(pl) * 0.5 >= P.range_skip){
             const double dp = pl - C.a[3];
             double tp0, tp1;
-            if(fabs(dp) > GEOAC_ROT_MAX){ C.a[3] = pl; fsincos(pl, C.a[4], C.a[5]); tp0 = C.a[4]; tp1 = C.a[5]; }
+            if(__builtin_expect(fabs(dp) > GEOAC_ROT_MAX, 0)){ C.a[3] = pl; fsincos(pl, C.a[4], C.a[5]); tp0 = C.a[4]; tp1 = C.a[5]; }
             else rot_small(C.a[4], C.a[5], dp, tp0, tp1);
             const double sl0 = P.src_trig[0], cl0 = P.src_trig[1];
             double hav = __builtin_fma(cl0 * C.t[1], 0.5 * (1.0 - tp1), 0.5 * (1.0 - __builtin_fma(C.t[1], cl0, C.t[0] * sl0)));
@@ -1927,7 +1927,7 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
                 lim = (k + 1 >= k_lim);                               // Solver.cpp loop bound; never reached on sane inputs
                 ev = brk || gnd || lim;
                 const bool full = !(nr + 3 <= P.s_rows);                // this lane's chunk has no room for another step after this one
-                if(__any(ev || full)){ pend = true; w6 = ds_6; break; }
+                if(__builtin_expect(__any(ev || full), 0)){ pend = true; w6 = ds_6; break; }
                 #pragma unroll
                 for(int e = 0; e < E; e++){
                     if(YM2_REG) ym2[e] = y[e];
