@@ -542,6 +542,8 @@ int geoac_fan_launch(geoac_ctx* ctx){
     P.r_earth = is_sph ? p.r_earth : 0.0; P.z_grnd = p.z_grnd;
     P.ground = P.r_earth + p.z_grnd;
     P.vert_limit = p.vert_limit; P.range_limit = p.range_limit;
+    if(p.range_limit >= 0.0){ const double l2 = p.range_limit * p.range_limit; P.range_sq[0] = l2 * (1.0 - 1e-12); P.range_sq[1] = l2 * (1.0 + 1e-12); }
+    else { P.range_sq[0] = 0.0; P.range_sq[1] = -1.0; }              // (a negative limit: every row is beyond it, as r > limit says)
     if(is_global){
         double half = p.range_limit / (2.0 * p.r_earth);
         if(half >= kPi / 2.0){ P.range_thresh = 2.0; P.range_skip = 1e300; }      // asin saturates: the range test can never fire

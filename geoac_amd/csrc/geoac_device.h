@@ -71,6 +71,7 @@ struct GeoacDevParams {
     double  ground;                 // Global: r_earth + z_grnd ; Cartesian: z_grnd
     double  r_earth, z_grnd;
     double  vert_limit, range_limit, range_thresh;   // range_thresh: sin^2(range_limit/(2 r_earth)) (Global)
+    double  range_sq[2];            // 3-D stratified set: range_limit^2 (1 -/+ 1e-12): the horizontal range is compared squared outside this band (Eq3D::checks)
     double  range_skip;             // Global: while (|lat - lat_src| + |lon - lon_src|) / 2 stays below this, the range test cannot fire (EqGlobal::checks)
     double  src[3];                 // as in geoac_params
     double  freq, tweak_abs;

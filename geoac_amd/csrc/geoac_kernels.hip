@@ -1388,8 +1388,12 @@ template <bool AMP_> struct Eq3D {
     }
     // 3DStratified.cpp:327-343
     static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, int k, bool& brk, bool& gnd){
-        double r = sqrt(yn[0] * yn[0] + yn[1] * yn[1]);
-        brk = (yn[2] > P.vert_limit) || (r > P.range_limit);
+        // r = sqrt(x^2 + y^2) > limit, decided on the square except within 1e-12 of the limit (there the reference's own expression): the root
+        // is ~20 instructions on the serial chain of every step
+        const double s2 = yn[0] * yn[0] + yn[1] * yn[1];
+        bool far = s2 > P.range_sq[1];
+        if(__builtin_expect((s2 >= P.range_sq[0]) & (s2 <= P.range_sq[1]), 0)) far = sqrt(s2) > P.range_limit;
+        brk = (yn[2] > P.vert_limit) || far;
         gnd = yn[2] < P.ground;
     }
     static DEVINL void accept(RayCtx& C){}
