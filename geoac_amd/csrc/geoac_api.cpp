@@ -114,8 +114,8 @@ struct geoac_ctx {
     int pp_blocks = 0;                            // GEOAC_PP_BLOCKS: post-pass grid (256-thread blocks); 0 = one block per 256 segments.
                                                   // Measured: a short full-occupancy burst disturbs k_rk4 LESS than a long thin sweep
                                                   // (avg k_rk4 launch 10.9 ms vs 11.7-12.8 ms at 8192-256 blocks).
-    double pair_frac = 0.10;                      // hybrid fans: share of the inclination-sorted rays that get two lanes (GEOAC_PAIR_FRAC; >= 1: all)
-    double hybrid_rows = 0.75;                    // hybrid fans: rows per epoch of the one-lane launch relative to the two-lane launch (GEOAC_HYBRID_ROWS)
+    double pair_frac = -1.0;                      // hybrid fans: share of the inclination-sorted rays that get two lanes (PAIR_FRAC; >= 1: all; < 0: the set's own default, plan_pair_frac)
+    double hybrid_rows = -1.0;                    // hybrid fans: rows per epoch of the one-lane launch relative to the two-lane launch (HYBRID_ROWS; < 0: the set's own default, plan_hybrid_rows)
     bool two_chunks = false;                      // GEOAC_TWO_CHUNKS=1: two path chunks in rotation instead of three (A/B measurements)
     bool trace_epochs = false;                    // GEOAC_TRACE_EPOCHS=1: per-epoch live counts on stderr
     bool no_gate = false;                         // GEOAC_NO_GATE=1: post-pass not held back behind the next RK4 launch (A/B measurements)
@@ -704,10 +704,14 @@ int geoac_fan_launch(geoac_ctx* ctx){
     //      lanes, the rest one lane (a concurrent launch on a second stream with proportionally fewer rows per epoch so that both
     //      finish an epoch together), and the CUs that stay free run the post-pass throughout. ----
     int n_pair = 0;                                   // slots [0, n_pair): two lanes per ray; [n_pair, n_pad): one lane
-    const bool hybrid = (P.lanes_per_ray == 2 && !is_grid && ctx->have_perm && ctx->pair_frac < 1.0 && !ctx->no_overlap &&
+    // launch-plan defaults, measured in one process per set (tools/sweep_hybrid.py): the spherical set's long rays are its shallow tenth
+    // (0.10 / 0.75: 121.8 ms; 0.15: 124.7, 0.20: 126.9); the 3-D set's are spread over the inclinations (0.25 / 0.80: 108 ms; 0.10 / 0.75: 125)
+    const double plan_pair_frac = ctx->pair_frac >= 0.0 ? ctx->pair_frac : (P.eqset == GEOAC_EQ_3D ? 0.25 : 0.10);
+    const double plan_hybrid_rows = ctx->hybrid_rows > 0.0 ? ctx->hybrid_rows : (P.eqset == GEOAC_EQ_3D ? 0.80 : 0.75);
+    const bool hybrid = (P.lanes_per_ray == 2 && !is_grid && ctx->have_perm && plan_pair_frac < 1.0 && !ctx->no_overlap &&
                          (long long)P.n_pad * 2 / 64 > 512);   // a fan that leaves half the SIMDs idle anyway keeps two lanes for every ray
     if(hybrid){
-        n_pair = (int)(((long long)(ctx->pair_frac * ctx->n_rays) + 127) / 128 * 128);
+        n_pair = (int)(((long long)(plan_pair_frac * ctx->n_rays) + 127) / 128 * 128);
         if(n_pair >= P.n_pad) n_pair = P.n_pad;
     }
     bool split = hybrid && n_pair > 0 && n_pair < P.n_pad;      // n_pair == 0 (GEOAC_PAIR_FRAC=0): everything on the one-lane kernel, one launch
@@ -818,7 +822,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
         if(split){
             GeoacDevParams P1 = Pe;                   // one lane per ray, fewer rows: on the second RK4 stream
             P1.lanes_per_ray = 1; P1.slot_lo = n_pair; P1.slot_hi = P.n_pad; P1.live_slot = 6;
-            P1.s_rows = std::max(8, (int)(ctx->hybrid_rows * rows_now));
+            P1.s_rows = std::max(8, (int)(plan_hybrid_rows * rows_now));
             HIPCHK(hipStreamWaitEvent(ctx->rk4b_stream, ctx->evs[eb], 0));
             HIPCHK(geoac_launch_rk4(&P1, 256, ctx->rk4b_stream, &n_wg1));
             HIPCHK(hipEventRecord(ctx->evj[2 * e], ctx->rk4b_stream));
