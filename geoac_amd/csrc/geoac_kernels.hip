@@ -260,6 +260,8 @@ DEVINL void seg_locate(TabPtr tab, const GeoacDevParams& P, double x, int& off, 
             }
         }
         seg_fetch<W>(tab, off, r);
+        // (measured, round 3: waiting for the whole record here, so that the common path carries no counted waits, costs 7 % - the uses' own waits
+        //  let the first cubic start while the last pieces are still on their way)
     }
 }
 template <int W = GEOAC_SEGW, typename TabPtr>
