@@ -127,6 +127,9 @@ struct geoac_ctx {
     // absorption table of the stratified sets (k_atab_build): rebuilt when the atmosphere or one of the parameters it depends on changes
     bool abs_table = true;                        // GEOAC_ABS_TABLE=0: exact Sutherland-Bass evaluation at every segment midpoint (A/B runs, equivalence test)
     DevBuf atab;
+    DevBuf ppfix;                                 // fix-up list of the table post-pass (k_postpass_tab -> k_ppfix)
+    double atab_tol = 1e-10;                      // ABS_TABLE_TOL: relative error at its check points above which a table entry is flagged
+    int ppfix_cap = 1 << 20;                      // PPFIX_CAP: segments per epoch the table may leave to k_ppfix (8 MB); more: the fan is repeated with the exact post-pass
     unsigned long long atmo_version = 0, atab_version = ~0ull;
     double atab_key[7] = {0, 0, 0, 0, 0, 0, 0};   // freq, tweak_abs, T_o, P_o, r_earth, strip width, tolerance
     int atab_entries = 0, atab_flagged = 0;       // of the current table
@@ -206,7 +209,7 @@ int geoac_default_params(int eqset, geoac_params* p){
 
 // ---- launch-plan options (A/B measurements, tests; results never depend on them) ----
 static const char* const kOptionNames[] = {
-    "S_ROWS", "NO_OVERLAP", "PP_BLOCKS", "ABS_TABLE", "DUO", "EV_SLACK", "NO_PAIR", "PAIR_FRAC", "HYBRID_ROWS", "TWO_CHUNKS", "TRACE_EPOCHS", "NO_GATE", "SORT",
+    "S_ROWS", "NO_OVERLAP", "PP_BLOCKS", "ABS_TABLE", "ABS_TABLE_TOL", "PPFIX_CAP", "DUO", "EV_SLACK", "NO_PAIR", "PAIR_FRAC", "HYBRID_ROWS", "TWO_CHUNKS", "TRACE_EPOCHS", "NO_GATE", "SORT",
     "NO_QUAD", "GRID_LANES", "OCT", "SPREAD", "COMPACT", "QUAD_CACHE", "GRID_COOP", "SUB_EPOCHS", "SUB_MIN_WAVES", "SMP_CAP", "GRID_BUILD", nullptr };
 const char* const* geoac_option_names(void){ return kOptionNames; }
 
@@ -220,6 +223,8 @@ int geoac_set_option(geoac_ctx* ctx, const char* key, const char* value){
     else if(k == "NO_OVERLAP") ctx->no_overlap = iv != 0;
     else if(k == "PP_BLOCKS"){ if(iv >= 0) ctx->pp_blocks = iv; }
     else if(k == "ABS_TABLE") ctx->abs_table = iv != 0;
+    else if(k == "ABS_TABLE_TOL"){ if(dv > 0.0) ctx->atab_tol = dv; }
+    else if(k == "PPFIX_CAP"){ if(iv > 0) ctx->ppfix_cap = iv; }
     else if(k == "DUO") ctx->duo = iv;
     else if(k == "EV_SLACK"){ if(iv >= 0) ctx->ev_slack = iv; }
     else if(k == "NO_PAIR") ctx->no_pair = iv != 0;
@@ -293,7 +298,7 @@ int geoac_destroy(geoac_ctx* ctx){
                        &ctx->nlegend[0], &ctx->nlegend[1], &ctx->nlegend[2],
                        &ctx->ev_row[0], &ctx->ev_row[1], &ctx->ev_row[2], &ctx->ev_m[0], &ctx->ev_m[1], &ctx->ev_m[2],
                        &ctx->ev_amp[0], &ctx->ev_amp[1], &ctx->ev_amp[2], &ctx->nev[0], &ctx->nev[1], &ctx->nev[2], &ctx->smp_out,
-                       &ctx->d_gx, &ctx->d_gy, &ctx->d_gz, &ctx->d_gtab, &ctx->d_gtab8, &ctx->d_consts, &ctx->sub_flags, &ctx->colmap[0], &ctx->colmap[1], &ctx->colmap[2], &ctx->ncols, &ctx->atab };
+                       &ctx->d_gx, &ctx->d_gy, &ctx->d_gz, &ctx->d_gtab, &ctx->d_gtab8, &ctx->d_consts, &ctx->sub_flags, &ctx->colmap[0], &ctx->colmap[1], &ctx->colmap[2], &ctx->ncols, &ctx->atab, &ctx->ppfix };
     for(DevBuf* b : bufs) b->release();
     if(ctx->h_counters) hipHostFree(ctx->h_counters);
     if(ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -332,7 +337,7 @@ int geoac_clone(geoac_ctx* src, geoac_ctx** out){
     c->compact = src->compact; c->quad_cache = src->quad_cache; c->sub_min_waves = src->sub_min_waves; c->sub_epochs = src->sub_epochs; c->grid_coop = src->grid_coop;
     c->smp_cap = src->smp_cap; c->s_rows_override = src->s_rows_override; c->no_overlap = src->no_overlap; c->pp_blocks = src->pp_blocks; c->pair_frac = src->pair_frac;
     c->hybrid_rows = src->hybrid_rows; c->two_chunks = src->two_chunks; c->no_gate = src->no_gate; c->no_pair = src->no_pair; c->duo = src->duo; c->abs_table = src->abs_table;
-    c->ev_slack = src->ev_slack; c->grid_build_host = src->grid_build_host;
+    c->ev_slack = src->ev_slack; c->grid_build_host = src->grid_build_host; c->atab_tol = src->atab_tol; c->ppfix_cap = src->ppfix_cap;
     *out = c;
     return GEOAC_OK;
 }
@@ -619,10 +624,10 @@ int geoac_fan_launch(geoac_ctx* ctx){
     P.state = (double*)ctx->state.p;
     P.rec = (double*)ctx->rec.p; P.counters = (unsigned long long*)ctx->counters.p;
     // absorption table (stratified sets; k_atab_build): alpha is a function of the height coordinate alone there
-    P.atab = nullptr; P.atab_on = 0; P.atab_D = 0.0;
+    P.atab = nullptr; P.atab_on = 0; P.atab_D = 0.0; P.ppfix = nullptr; P.ppfix_cap = 0;
     P.seg_per_x = (double)P.nseg / (P.x_max - P.x_min);
     if(!is_grid && ctx->abs_table){
-        const double D = std::max(std::min(0.05, p.ds_max), p.ds_min), tol = 1e-10;
+        const double D = std::max(std::min(0.05, p.ds_max), p.ds_min), tol = ctx->atab_tol;
         const double key[7] = { P.freq, P.tweak_abs, P.T_o, P.P_o, P.r_earth, D, tol };
         P.atab_D = D;
         if(ctx->atab_version != ctx->atmo_version || memcmp(key, ctx->atab_key, sizeof(key)) != 0){
@@ -641,7 +646,12 @@ int geoac_fan_launch(geoac_ctx* ctx){
             ctx->atab_version = ctx->atmo_version;
         }
         // a profile most of whose segments the interpolant cannot serve (very long segments) keeps the exact post-pass
-        if(4 * ctx->atab_flagged <= ctx->atab_entries){ P.atab = (const double*)ctx->atab.p; P.atab_on = 1; }
+        if(4 * ctx->atab_flagged <= ctx->atab_entries){
+            P.atab = (const double*)ctx->atab.p; P.atab_on = 1;
+            P.ppfix_cap = ctx->ppfix_cap;
+            HIPCHK(ctx->ppfix.ensure(sizeof(int) * 2 * (size_t)P.ppfix_cap));
+            P.ppfix = (int*)ctx->ppfix.p;
+        }
     }
 
     // two lanes per ray (EqGlobalPair) for the Global set with amplitudes when no sample capture is requested
@@ -768,11 +778,16 @@ int geoac_fan_launch(geoac_ctx* ctx){
     const long long max_epochs = (P.step_limit * (long long)ctx->legs) / (rows_late > 4 ? (rows_late - 3) : 1) + ctx->legs + 2;
     unsigned long long live = 1, live_bound = (unsigned long long)P.n_pad;
     // post-pass of one epoch on the second stream; gate_expected > 0: only after that many RK4 workgroups of this fan are resident
-    auto enqueue_post = [&](const GeoacDevParams& Pq, size_t e, unsigned long long gate_expected) -> int {
+    auto enqueue_post = [&](GeoacDevParams Pq, size_t e, unsigned long long gate_expected) -> int {
         HIPCHK(hipStreamWaitEvent(sp, ctx->evs[4 * e + 1], 0));
         if(gate_expected > 0 && sp != s && !ctx->no_gate) HIPCHK(geoac_launch_gate(&Pq, gate_expected, sp));
         HIPCHK(hipEventRecord(ctx->evs[4 * e + 2], sp));
-        if(Pq.atab_on) HIPCHK(geoac_launch_postpass_tab(&Pq, Pq.s_rows, sp));
+        if(Pq.atab_on){
+            // (see geoac_launch_postpass_tab) hybrid fans: the post-pass off the RK4 CUs, one (spherical set) or two (Cartesian sets) workgroups per free CU
+            Pq.pp_lds_pad = !Pq.table_in_lds ? 0 : (hybrid ? (Pq.eqset == GEOAC_EQ_GLOBAL ? 96 : 64) * 1024 : 8 * 1024);
+            HIPCHK(hipMemsetAsync((char*)ctx->counters.p + GEOAC_CNT_PPFLAG * sizeof(unsigned long long), 0, sizeof(unsigned long long), sp));   // the fix-up list is empty
+            HIPCHK(geoac_launch_postpass_tab(&Pq, Pq.s_rows, sp));
+        }
         else HIPCHK(geoac_launch_postpass(&Pq, Pq.s_rows, sp));
         // the per-ray running sums (one thread per ray, latency-bound, 106 VGPRs: fits beside an RK4 wave) on their own stream, in
         // epoch order, so that the next epoch's post-pass does not queue behind them
@@ -911,6 +926,11 @@ int geoac_fan_launch(geoac_ctx* ctx){
         // without sub-epochs (this context keeps them off from now on).
         if(ctx->sub_epochs > 1){ ctx->sub_epochs = 1; fprintf(stderr, "libgeoac_hip: sub-epoch hand-off timed out, repeating the fan without sub-epochs\n"); return geoac_fan_launch(ctx); }
         return fail(ctx, GEOAC_E_HIP, "sub-epoch hand-off timed out");
+    }
+    if(ctx->err_flags & 16ull){
+        // more segments outside the absorption table than its fix-up list holds: this context keeps the exact post-pass from now on
+        if(ctx->abs_table){ ctx->abs_table = 0; fprintf(stderr, "libgeoac_hip: the absorption table leaves too many segments to the fix-up pass, repeating the fan with the exact post-pass\n"); return geoac_fan_launch(ctx); }
+        return fail(ctx, GEOAC_E_CAPACITY, "fix-up list of the table post-pass overflowed");
     }
     if(ctx->err_flags & 8ull) return fail(ctx, GEOAC_E_HIP, "k_rk4_duo: a wave waited more than a second for the other wave of its pair");
     if(ctx->err_flags & 2ull) return fail(ctx, GEOAC_E_CAPACITY, "per-epoch sample/caustic event list overflowed");

@@ -22,7 +22,7 @@
 #define GEOAC_MAXLEGS   64      // legs per ray supported by the per-epoch leg-end event list
 #define GEOAC_ATABW     20      // doubles per entry of the absorption table: 2 / h (negative: flagged), 3 x 6 coefficients, worst check-point error
 #define GEOAC_PP_ROWS   16      // path segments per thread of k_postpass_tab (consecutive rows of one ray: each row is read once)
-#define GEOAC_CNT_PPFLAG 28     // counters[+1]: path segments of the fan the absorption table did not serve (evaluated exactly by k_postpass_tab)
+#define GEOAC_CNT_PPFLAG 28     // counters[+0]: entries of the fix-up list of the current k_postpass_tab launch; counters[+1]: path segments of the fan the absorption table did not serve (evaluated exactly by k_ppfix)
 
 // per-ray state slots (SoA rows of the state buffer)
 enum {
@@ -85,6 +85,9 @@ struct GeoacDevParams {
     const double* rho;              // [nseg][4]
     // stratified sets: absorption table (k_atab_build): Sutherland-Bass alpha is a function of the height coordinate alone there, so it is
     // tabulated per spline segment instead of being evaluated at every path-segment midpoint (k_postpass_tab)
+    int*    ppfix;                  // fix-up list of k_postpass_tab: (column, chunk row) of the segments the table did not serve, ppfix_cap pairs (k_ppfix evaluates them exactly)
+    int     ppfix_cap;
+    int     pp_lds_pad;             // bytes of LDS a k_postpass_tab workgroup asks for without using them: keeps it off CUs that hold an RK4 workgroup (> 7 KiB) / to one workgroup per CU (> 80 KiB)
     const double* atab;             // [nseg + 2][GEOAC_ATABW]: 2/h (negative: flagged), 3 x six coefficients in s = 2 t / h - 1 (atab_eval); entries nseg / nseg + 1: the
                                     // strips of width atab_D below the first / above the last node (medium clamped there, height not)
     int           atab_on;          // 1: k_postpass_tab + fix-up of the flagged segments; 0: exact evaluation at every midpoint (k_postpass)

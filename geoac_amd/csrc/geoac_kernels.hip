@@ -2193,8 +2193,10 @@ __global__ void __launch_bounds__(256, EQ::PP_WAVES) k_postpass(GeoacDevParams P
 // table entry of the midpoint stay in registers from one segment to the next - consecutive steps of a ray are 1 - 50 m apart, the nodes
 // ~100 m - so the usual segment has no dependent memory access at all: geometry, one spline evaluation, three degree-5 polynomials and
 // two square roots (~200 instructions per 64 segments instead of ~1 500).
+// (compiled for two waves per SIMD for the spherical set - 172 registers; at 168 it spills two -, four for the Cartesian ones; the exact fall-back lives in k_ppfix:
+//  inlined here it took the kernel to 256 + 12 registers, one wave per SIMD)
 template <class EQ>
-__global__ void __launch_bounds__(256) k_postpass_tab(GeoacDevParams P, int rows){
+__global__ void __launch_bounds__(256, EQ::PW == 6 ? 2 : 4) k_postpass_tab(GeoacDevParams P, int rows){
     constexpr int PW = EQ::PW, R = GEOAC_PP_ROWS;
     const size_t np = (size_t)P.n_pad;
     const int bx = (P.n_cols_bound + 255) / 256;
@@ -2212,10 +2214,11 @@ __global__ void __launch_bounds__(256) k_postpass_tab(GeoacDevParams P, int rows
         EQ::pp_aux(P, P.state + slot, np, aux);
         const int i1 = min(i0 + R, nr - 1);                       // segments i0 .. i1 - 1
         const double* a = P.path + ((size_t)i0 * PW) * np + col;
-        // three row buffers in rotation (rows i, i + 1 and the prefetched i + 2): no copies between segments
-        double Ra[PW], Rb[PW], Rc[PW];
+        // rows i, i + 1 and the prefetched i + 2.  (Three buffers in rotation - three copies of the body, no row copies - were measured in round 3:
+        // 12 moves fewer per segment, but the exact fall-back inlined three times takes the kernel from 164 to 268 registers, one wave per SIMD.)
+        double A[PW], B[PW], Bn[PW];
         #pragma unroll
-        for(int c = 0; c < PW; c++){ Ra[c] = a[(size_t)c * np]; Rb[c] = a[(size_t)(PW + c) * np]; Rc[c] = 0.0; }
+        for(int c = 0; c < PW; c++){ A[c] = a[(size_t)c * np]; Bn[c] = a[(size_t)(PW + c) * np]; }
         double rec[GEOAC_SEGW], tb[19];                           // the spline record and the table entry in hand (k, ent: which)
         int k = -1, ent = -1;
         double ref[3] = { 1e300, 0.0, 1.0 };                      // Global: reference point of the midpoint latitudes' sin / cos (pp_geom)
@@ -2224,12 +2227,13 @@ __global__ void __launch_bounds__(256) k_postpass_tab(GeoacDevParams P, int rows
         for(int c = 2; c < GEOAC_SEGW; c++) rec[c] = 0.0;
         #pragma unroll
         for(int c = 0; c < 19; c++) tb[c] = 0.0;
-        // segment i: rows A (i) and B (i + 1); row i + 2 goes to Cn while the segment is evaluated
-        auto segment = [&](const double (&A)[PW], const double (&B)[PW], double (&Cn)[PW], int i){
-            if(i + 2 <= i1){
+        for(int i = i0; i < i1; i++){
+            #pragma unroll
+            for(int c = 0; c < PW; c++) B[c] = Bn[c];
+            if(i + 2 <= i1){                                      // the row after next, while this segment is evaluated
                 const double* b = P.path + ((size_t)(i + 2) * PW) * np + col;
                 #pragma unroll
-                for(int c = 0; c < PW; c++) Cn[c] = b[(size_t)c * np];
+                for(int c = 0; c < PW; c++) Bn[c] = b[(size_t)c * np];
             }
             PPGeom G;
             EQ::pp_geom(P, aux, A, B, G, ref);
@@ -2251,23 +2255,49 @@ __global__ void __launch_bounds__(256) k_postpass_tab(GeoacDevParams P, int rows
             double T, u, v; seg_eval_f(rec, xe, T, u, v);
             const double tt = EQ::pp_tt(P, aux, G, T, u, v);
             const bool bad = out | (tb[0] < 0.0);
-            double at = atab_eval(tb, t) * G.ds_at;
-            if(bad){                                              // not served by the table (rare, divergent): the exact routine, as k_postpass calls it
-                const double qT = kGamR * T;
-                at = suthbass_alpha(P, G.x - P.r_earth, qT * frsq(qT), rho_eval(P, k, xe), P.freq, P.T_o, P.P_o, P.cbrt_To) * G.ds_at;
+            const double at = atab_eval(tb, t) * G.ds_at;
+            if(bad){                                              // not served by the table (rare): listed for k_ppfix, which evaluates it exactly
+                const unsigned long long q = atomicAdd(&P.counters[GEOAC_CNT_PPFLAG], 1ull);
+                if(q < (unsigned long long)P.ppfix_cap){ P.ppfix[2 * q] = col; P.ppfix[2 * q + 1] = i; }
+                else atomicOr(&P.counters[2], 16ull);             // (list full: the host repeats the fan with the exact post-pass)
             }
             double* o = P.contrib + ((size_t)i * 2) * np + col;
             o[0]  = tt;
             o[np] = at;
             flagged += bad ? 1u : 0u;
-        };
-        for(int i = i0; i < i1; ){
-            segment(Ra, Rb, Rc, i); if(++i >= i1) break;
-            segment(Rb, Rc, Ra, i); if(++i >= i1) break;
-            segment(Rc, Ra, Rb, i); ++i;
+            #pragma unroll
+            for(int c = 0; c < PW; c++) A[c] = B[c];
         }
     }
     if(flagged) atomicAdd(&P.counters[GEOAC_CNT_PPFLAG + 1], (unsigned long long)flagged);     // (statistics: geoac_abs_table_info)
+}
+
+// k_ppfix: the segments k_postpass_tab listed (the table did not serve them: a flagged entry, a midpoint beyond the strips) - attenuation by
+// the exact routine, as k_postpass computes it, with the segment geometry of k_postpass_tab.  One thread per list entry; usually none.
+template <class EQ>
+__global__ void __launch_bounds__(256) k_ppfix(GeoacDevParams P){
+    constexpr int PW = EQ::PW;
+    const size_t np = (size_t)P.n_pad;
+    unsigned long long n = P.counters[GEOAC_CNT_PPFLAG];
+    if(n > (unsigned long long)P.ppfix_cap) n = (unsigned long long)P.ppfix_cap;
+    for(unsigned long long q = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (unsigned long long)gridDim.x * blockDim.x){
+        const int col = P.ppfix[2 * q], i = P.ppfix[2 * q + 1];
+        const int slot = P.colmap ? P.colmap[col] : col;
+        double aux[2] = { 0.0, 0.0 };
+        EQ::pp_aux(P, P.state + slot, np, aux);
+        const double* a = P.path + ((size_t)i * PW) * np + col;
+        double A[PW], B[PW];
+        #pragma unroll
+        for(int c = 0; c < PW; c++){ A[c] = a[(size_t)c * np]; B[c] = a[(size_t)(PW + c) * np]; }
+        double ref[3] = { 1e300, 0.0, 1.0 };
+        PPGeom G;
+        EQ::pp_geom(P, aux, A, B, G, ref);
+        const double xe = clampq(G.x, P.x_min, P.x_max);
+        const int k = seg_find(P.seg, P.nseg, xe, (int)((xe - P.x_min) * P.seg_per_x));
+        double T, u, v; seg_eval_f(P.seg + (size_t)k * GEOAC_SEGW, xe, T, u, v);
+        const double qT = kGamR * T;
+        P.contrib[((size_t)i * 2 + 1) * np + col] = suthbass_alpha(P, G.x - P.r_earth, qT * frsq(qT), rho_eval(P, k, xe), P.freq, P.T_o, P.P_o, P.cbrt_To) * G.ds_at;
+    }
 }
 
 // k_atab_build: one thread per table entry (see atab_eval).  Entry e < nseg: spline segment e; nseg: the strip [x_min - D, x_min];
@@ -2698,22 +2728,60 @@ extern "C" hipError_t geoac_launch_postpass(const GeoacDevParams* P, int rows, h
     return hipGetLastError();
 }
 
-// post-pass of a stratified set through the absorption table (k_postpass_tab; the few segments the table does not serve are evaluated
-// exactly inside the same kernel)
+// post-pass of a stratified set through the absorption table (k_postpass_tab; the few segments the table does not serve are listed and
+// evaluated exactly by k_ppfix behind it)
 extern "C" hipError_t geoac_launch_postpass_tab(const GeoacDevParams* P, int rows, hipStream_t s){
     if(rows < 2) return hipSuccess;
     if(!P->atab || P->gtab) return hipErrorInvalidValue;
     long long total = (long long)((P->n_cols_bound + 255) / 256) * ((rows - 1 + GEOAC_PP_ROWS - 1) / GEOAC_PP_ROWS);
     if(total > 0x7fffffffLL) total = 0x7fffffffLL;
     dim3 b(256), g((unsigned)total);
+    // LDS the kernel never touches (GeoacDevParams::pp_lds_pad, set by the launch plan): a workgroup that asks for more than 7 KiB cannot be placed
+    // on a CU that holds an RK4 workgroup with its table (153 KiB of the 160), one that asks for more than 80 KiB is alone on its CU (one wave per
+    // SIMD).  With the exact fall-back out of the kernel its waves are small enough to sit beside an RK4 wave on the same SIMD and to run at three
+    // or four waves per SIMD: right for a fan whose RK4 launches fill the chip (config 3: +11 %), wrong for the fans whose time is the serial chain of
+    // one ray (GeoAc3D 360 x 90: +6 % per pass beside the RK4 waves, +2.5 % at full occupancy on the free CUs, 0 at one wave per SIMD there)
+    const unsigned pad = (unsigned)P->pp_lds_pad;
+    if(pad > 65536u){
+        static bool raised[6] = { false, false, false, false, false, false };
+        const int v = P->eqset * 2 + (P->calc_amp ? 1 : 0);
+        const void* f = nullptr;
+        switch(v){
+            case GEOAC_EQ_GLOBAL * 2 + 1: f = (const void*)k_postpass_tab<EqGlobal<true>>; break;
+            case GEOAC_EQ_GLOBAL * 2 + 0: f = (const void*)k_postpass_tab<EqGlobal<false>>; break;
+            case GEOAC_EQ_3D * 2 + 1:     f = (const void*)k_postpass_tab<Eq3D<true>>; break;
+            case GEOAC_EQ_3D * 2 + 0:     f = (const void*)k_postpass_tab<Eq3D<false>>; break;
+            case GEOAC_EQ_2D * 2 + 1:     f = (const void*)k_postpass_tab<Eq2D<true>>; break;
+            case GEOAC_EQ_2D * 2 + 0:     f = (const void*)k_postpass_tab<Eq2D<false>>; break;
+            default: break;
+        }
+        if(f && v >= 0 && v < 6 && !raised[v]){
+            hipError_t err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if(err != hipSuccess) return err;
+            raised[v] = true;
+        }
+    }
     switch(P->eqset * 2 + (P->calc_amp ? 1 : 0)){
-        case GEOAC_EQ_GLOBAL * 2 + 1: hipLaunchKernelGGL(k_postpass_tab<EqGlobal<true>>, g, b, 0, s, *P, rows); break;
-        case GEOAC_EQ_GLOBAL * 2 + 0: hipLaunchKernelGGL(k_postpass_tab<EqGlobal<false>>, g, b, 0, s, *P, rows); break;
-        case GEOAC_EQ_3D * 2 + 1:     hipLaunchKernelGGL(k_postpass_tab<Eq3D<true>>, g, b, 0, s, *P, rows); break;
-        case GEOAC_EQ_3D * 2 + 0:     hipLaunchKernelGGL(k_postpass_tab<Eq3D<false>>, g, b, 0, s, *P, rows); break;
-        case GEOAC_EQ_2D * 2 + 1:     hipLaunchKernelGGL(k_postpass_tab<Eq2D<true>>, g, b, 0, s, *P, rows); break;
-        case GEOAC_EQ_2D * 2 + 0:     hipLaunchKernelGGL(k_postpass_tab<Eq2D<false>>, g, b, 0, s, *P, rows); break;
+        case GEOAC_EQ_GLOBAL * 2 + 1: hipLaunchKernelGGL(k_postpass_tab<EqGlobal<true>>, g, b, pad, s, *P, rows); break;
+        case GEOAC_EQ_GLOBAL * 2 + 0: hipLaunchKernelGGL(k_postpass_tab<EqGlobal<false>>, g, b, pad, s, *P, rows); break;
+        case GEOAC_EQ_3D * 2 + 1:     hipLaunchKernelGGL(k_postpass_tab<Eq3D<true>>, g, b, pad, s, *P, rows); break;
+        case GEOAC_EQ_3D * 2 + 0:     hipLaunchKernelGGL(k_postpass_tab<Eq3D<false>>, g, b, pad, s, *P, rows); break;
+        case GEOAC_EQ_2D * 2 + 1:     hipLaunchKernelGGL(k_postpass_tab<Eq2D<true>>, g, b, pad, s, *P, rows); break;
+        case GEOAC_EQ_2D * 2 + 0:     hipLaunchKernelGGL(k_postpass_tab<Eq2D<false>>, g, b, pad, s, *P, rows); break;
         default: return hipErrorNotSupported;
+    }
+    hipError_t e = hipGetLastError();
+    if(e != hipSuccess) return e;
+    // the listed segments, exactly (the list's counter was zeroed on this stream before the launch above: geoac_api.cpp)
+    dim3 gf(64);
+    switch(P->eqset * 2 + (P->calc_amp ? 1 : 0)){
+        case GEOAC_EQ_GLOBAL * 2 + 1: hipLaunchKernelGGL(k_ppfix<EqGlobal<true>>, gf, b, 0, s, *P); break;
+        case GEOAC_EQ_GLOBAL * 2 + 0: hipLaunchKernelGGL(k_ppfix<EqGlobal<false>>, gf, b, 0, s, *P); break;
+        case GEOAC_EQ_3D * 2 + 1:     hipLaunchKernelGGL(k_ppfix<Eq3D<true>>, gf, b, 0, s, *P); break;
+        case GEOAC_EQ_3D * 2 + 0:     hipLaunchKernelGGL(k_ppfix<Eq3D<false>>, gf, b, 0, s, *P); break;
+        case GEOAC_EQ_2D * 2 + 1:     hipLaunchKernelGGL(k_ppfix<Eq2D<true>>, gf, b, 0, s, *P); break;
+        case GEOAC_EQ_2D * 2 + 0:     hipLaunchKernelGGL(k_ppfix<Eq2D<false>>, gf, b, 0, s, *P); break;
+        default: break;
     }
     return hipGetLastError();
 }

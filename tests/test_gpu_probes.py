@@ -210,3 +210,34 @@ def test_table_and_exact_post_pass_agree(eq, monkeypatch):
     other = [k for k in G.REC if k not in ("TTIME", "ATTEN")]
     for k in other:
         np.testing.assert_array_equal(r1[:, :, G.REC[k]], r0[:, :, G.REC[k]])
+
+
+@pytest.mark.parametrize("cap", [1 << 20, 64])
+def test_segments_the_table_does_not_serve_go_through_the_fix_up_pass(cap, monkeypatch, capfd):
+    """A table built with a tolerance tighter than the interpolants reach (ABS_TABLE_TOL) flags part of its entries; the path segments that fall into
+    them are listed by k_postpass_tab and evaluated exactly by k_ppfix - the fan still agrees with the exact post-pass to 1e-10.  With a list of 64
+    entries (PPFIX_CAP) the list overflows: the library repeats the fan with the exact post-pass and says so."""
+    import geoac_amd as G
+    th, ph = G.fan_enumerate(theta_min=1.0, theta_max=45.0, theta_step=1.0, phi_min=-90.0, phi_max=0.0, phi_step=30.0)
+    monkeypatch.setitem(OPT, "ABS_TABLE", "0")
+    ctx = G.FanContext(H.EQ_GLOBAL, device=0); ctx.load_met(H.TOYATMO); ctx.set_params(bounces=2, calc_amp=1, mode=0)
+    r0, s0 = ctx.run(th, ph); r0 = r0.copy(); ctx.close()
+    monkeypatch.setitem(OPT, "ABS_TABLE", "1")
+    got = None
+    for tol in ("2e-11", "1e-11", "5e-12", "2e-12"):                 # (the spherical set's worst check-point error is ~3e-11: some tolerance below it flags a part, not all)
+        monkeypatch.setitem(OPT, "ABS_TABLE_TOL", tol); monkeypatch.setitem(OPT, "PPFIX_CAP", str(cap))
+        ctx = G.FanContext(H.EQ_GLOBAL, device=0); ctx.load_met(H.TOYATMO); ctx.set_params(bounces=2, calc_amp=1, mode=0)
+        r1, s1 = ctx.run(th, ph); info = ctx.abs_table_info(); r1 = r1.copy(); ctx.close()
+        if cap == 64 and info["entries"] == 0 and "exact post-pass" in capfd.readouterr().err:
+            got = (tol, r1, s1, info); break                         # (the overflow was reported and the fan repeated without the table)
+        if info["entries"] and 0 < info["flagged"] and info["fixup_segments"] > 0:
+            got = (tol, r1, s1, info); break
+    assert got is not None, "no tolerance flagged a part of the table"
+    tol, r1, s1, info = got
+    print("tolerance", tol, info)
+    assert s1 == s0
+    valid = r0[:, :, G.REC["VALID"]] == 1.0
+    at1, at0 = r1[:, :, G.REC["ATTEN"]][valid], r0[:, :, G.REC["ATTEN"]][valid]
+    assert np.abs(at1 / at0 - 1).max() <= 1e-10
+    np.testing.assert_array_equal(r1[:, :, G.REC["TTIME"]], r0[:, :, G.REC["TTIME"]]) if info["entries"] == 0 else None
+
