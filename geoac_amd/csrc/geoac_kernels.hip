@@ -898,7 +898,7 @@ template <bool AMP_> struct EqGlobal {
         double sn, cs;
         if(ref){
             const double tq = __builtin_rint(t * 128.0) * (1.0 / 128.0);
-            if(tq != ref[0]){ ref[0] = tq; fsincos(tq, ref[1], ref[2]); }
+            if(__builtin_expect(tq != ref[0], 0)){ ref[0] = tq; fsincos(tq, ref[1], ref[2]); }
             rot_fifth(ref[1], ref[2], t - tq, sn, cs);
         } else fsincos(t, sn, cs);
         double rdt = r * dt;
@@ -2195,14 +2195,16 @@ __global__ void __launch_bounds__(256, EQ::PP_WAVES) k_postpass(GeoacDevParams P
 // two square roots (~200 instructions per 64 segments instead of ~1 500).
 // (compiled for two waves per SIMD for the spherical set - 172 registers; at 168 it spills two -, four for the Cartesian ones; the exact fall-back lives in k_ppfix:
 //  inlined here it took the kernel to 256 + 12 registers, one wave per SIMD)
+#ifndef GEOAC_PPTAB_GLOBAL_WAVES
+#define GEOAC_PPTAB_GLOBAL_WAVES 2
+#endif
 template <class EQ>
-__global__ void __launch_bounds__(256, EQ::PW == 6 ? 2 : 4) k_postpass_tab(GeoacDevParams P, int rows){
+__global__ void __launch_bounds__(256, EQ::PW == 6 ? GEOAC_PPTAB_GLOBAL_WAVES : 4) k_postpass_tab(GeoacDevParams P, int rows){
     constexpr int PW = EQ::PW, R = GEOAC_PP_ROWS;
     const size_t np = (size_t)P.n_pad;
     const int bx = (P.n_cols_bound + 255) / 256;
     const long long total = (long long)bx * ((rows - 1 + R - 1) / R);
     const int ncol = P.colmap ? *P.n_cols : P.n_pad;
-    unsigned flagged = 0;
     for(long long w = blockIdx.x; w < total; w += gridDim.x){
         const int col = (int)(w % bx) * 256 + (int)threadIdx.x;
         const int i0 = (int)(w / bx) * R;
@@ -2257,6 +2259,7 @@ __global__ void __launch_bounds__(256, EQ::PW == 6 ? 2 : 4) k_postpass_tab(Geoac
             const bool bad = out | (tb[0] < 0.0);
             const double at = atab_eval(tb, t) * G.ds_at;
             if(bad){                                              // not served by the table (rare): listed for k_ppfix, which evaluates it exactly
+                atomicAdd(&P.counters[GEOAC_CNT_PPFLAG + 1], 1ull);                     // (statistics: geoac_abs_table_info)
                 const unsigned long long q = atomicAdd(&P.counters[GEOAC_CNT_PPFLAG], 1ull);
                 if(q < (unsigned long long)P.ppfix_cap){ P.ppfix[2 * q] = col; P.ppfix[2 * q + 1] = i; }
                 else atomicOr(&P.counters[2], 16ull);             // (list full: the host repeats the fan with the exact post-pass)
@@ -2264,12 +2267,10 @@ __global__ void __launch_bounds__(256, EQ::PW == 6 ? 2 : 4) k_postpass_tab(Geoac
             double* o = P.contrib + ((size_t)i * 2) * np + col;
             o[0]  = tt;
             o[np] = at;
-            flagged += bad ? 1u : 0u;
             #pragma unroll
             for(int c = 0; c < PW; c++) A[c] = B[c];
         }
     }
-    if(flagged) atomicAdd(&P.counters[GEOAC_CNT_PPFLAG + 1], (unsigned long long)flagged);     // (statistics: geoac_abs_table_info)
 }
 
 // k_ppfix: the segments k_postpass_tab listed (the table did not serve them: a flagged entry, a midpoint beyond the strips) - attenuation by
