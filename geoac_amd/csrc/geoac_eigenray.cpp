@@ -402,6 +402,7 @@ struct CartesianFamily : Family {
 struct Task {
     virtual ~Task(){}
     virtual Request* advance(std::vector<std::unique_ptr<Task>>& spawned) = 0;
+    virtual Request* also(){ return nullptr; }      // a second request for the same round (asked for right after advance() returned one)
 };
 
 // ---- GeoAc_EstimateEigenray as a state machine: up to five scans of the inclination range, the azimuth corrected between them ----
@@ -539,6 +540,9 @@ struct Refiner : Task {
     struct Known { double lt, lp; std::vector<double> rec; };      // a ray of this refinement (CalcAmp on, no samples) and its leg records
     std::vector<Known> known;
     std::vector<double> rq_lp;              // the azimuths of the posted rays as the routine carries them (the request has 90 - lp)
+    Request fin;                            // the eigenray's own ray (with raypath samples), posted ahead beside a trial that is likely to be the last
+    double fin_lt = 0, fin_lp = 0;
+    bool fin_posted = false, fin_valid = false;
 
     Refiner(const Family& f, Segment& o, double lt, double lp, int bnc, int limit) : fam(f), out(o), bounces(bnc), iterate_limit(limit) {
         N.lt = lt; N.lp = lp;
@@ -599,6 +603,24 @@ struct Refiner : Task {
             if(!lookup(M.lt, M.lp) && !posted) add_ray(M.lt, M.lp);
         }
     }
+    // ... and the trials that follow if the step just taken - the full step, cut to the routine's limit of 0.2 degrees in BOTH angles - is taken again:
+    // far from the receiver the routine walks towards it in exactly these steps, one ray and one round each
+    void walk_ahead(){
+        const long double lim = 0.2;
+        if(n == 0 || N.step_scalar != 1.0 || (N.dlt != lim && N.dlt != -lim) || (N.dlp != lim && N.dlp != -lim)) return;
+        Newton M = N; int m = n;
+        for(int k = 0; k < SPECULATE; k++){
+            M.step_scalar = std::min(1.0, M.step_scalar * 1.25);
+            M.lt += M.dlt * M.step_scalar;
+            M.lp += M.dlp * M.step_scalar;
+            m++;
+            if(m == iterate_limit) return;
+            bool posted = false;
+            for(size_t i = 0; i < rq.th.size(); i++) posted = posted || (rq.th[i] == M.lt && rq_lp[i] == M.lp);
+            if(!lookup(M.lt, M.lp) && !posted) add_ray(M.lt, M.lp);
+        }
+    }
+    Request* also() override { return (fin_posted && st == RAY_POSTED) ? &fin : nullptr; }
     Request* advance(std::vector<std::unique_ptr<Task>>&) override {
         DLog& log = out.log;
         const bool verbose = fam.site.verbose;
@@ -612,9 +634,19 @@ struct Refiner : Task {
             rq = Request(); rq_lp.clear(); rq.bounces = bounces; rq.calc_amp = 1; rq.mode = 0;
             add_ray(N.lt, N.lp);
             look_ahead();
+            walk_ahead();
+            // the arrival before this one missed the receiver by less than 500 m and the iteration converges quadratically there: this trial is
+            // probably within the 100 m that end the search - its raypath ray goes out in the same round (another group, beside this one)
+            fin_posted = fin_valid = false;
+            if(n > 0 && N.dr_prev < 0.5){
+                fin = Request(); fin.bounces = bounces; fin.calc_amp = 1; fin.mode = GEOAC_MODE_WRITE_RAYS;
+                fin.th.push_back(N.lt); fin.ph.push_back(90.0 - N.lp);
+                fin_lt = N.lt; fin_lp = N.lp; fin_posted = true;
+            }
             return &rq;
         }
         case RAY_POSTED: {
+            if(fin_posted){ fin_valid = true; fin_posted = false; }   // (it came back with this round)
             if(!rq.th.empty()){                                      // what came back: remember all of it
                 const size_t per = (size_t)(bounces + 1) * GEOAC_REC_STRIDE;
                 for(size_t i = 0; i < rq.th.size(); i++)
@@ -625,9 +657,10 @@ struct Refiner : Task {
             const Next nx = react(N, n, rec, &log);
             if(nx == STOP){ st = DONE; break; }
             if(nx == FINAL){
+                st = FINAL_POSTED;
+                if(fin_valid && fin_lt == N.lt && fin_lp == N.lp){ rq = fin; break; }      // already here
                 rq = Request(); rq_lp.clear(); rq.bounces = bounces; rq.calc_amp = 1; rq.mode = GEOAC_MODE_WRITE_RAYS;      // the same ray once more, with its raypath
                 add_ray(N.lt, N.lp);
-                st = FINAL_POSTED;
                 return &rq;
             }
             st = ITERATE;
@@ -849,7 +882,7 @@ static int run_all(geoac_ctx* ctx, const geoac_eig_params* ep, int n_rcvr, const
             std::vector<std::unique_ptr<Task>> spawned;
             Request* rq = active[i]->advance(spawned);
             for(auto& t : spawned){ active.push_back(t.get()); all.push_back(std::move(t)); }
-            if(rq){ batch.push_back(rq); waiting.push_back(active[i]); }
+            if(rq){ batch.push_back(rq); waiting.push_back(active[i]); if(Request* more = active[i]->also()) batch.push_back(more); }
         }
         if(batch.empty()) break;
         if(trace){                                                  // (GEOAC_DEBUG_ENV=1 GEOAC_EIG_TRACE=1) what this round is made of
