@@ -69,6 +69,7 @@ struct geoac_ctx {
                                      // instead of every wave waiting for its one long ray: the post-pass then lands on idle SIMDs (metric fan +13 %)
     DevBuf perm; bool have_perm = false;
     bool no_quad = false;            // GEOAC_NO_QUAD=1: never use the multi-lane grid kernels
+    bool hex = true;                 // HEX=0: the smallest spherical grid fans with amplitudes on the eight-lane kernel instead of the sixteen-lane one
     bool oct = true;                 // GEOAC_OCT=0: small spherical grid fans with amplitudes on the four-lane kernel instead of the eight-lane one
     int  grid_lanes = 0;             // GEOAC_GRID_LANES=1|2|4: force the lanes-per-ray variant of the grid kernels (tests); 0 = by fan size
     int  spread_override = 0;        // GEOAC_SPREAD=n: force n-way lane thinning of the grid-set RK4 waves (1 = dense); 0 = automatic
@@ -210,7 +211,7 @@ int geoac_default_params(int eqset, geoac_params* p){
 // ---- launch-plan options (A/B measurements, tests; results never depend on them) ----
 static const char* const kOptionNames[] = {
     "S_ROWS", "NO_OVERLAP", "PP_BLOCKS", "ABS_TABLE", "ABS_TABLE_TOL", "PPFIX_CAP", "DUO", "EV_SLACK", "NO_PAIR", "PAIR_FRAC", "HYBRID_ROWS", "TWO_CHUNKS", "TRACE_EPOCHS", "NO_GATE", "SORT",
-    "NO_QUAD", "GRID_LANES", "OCT", "SPREAD", "COMPACT", "QUAD_CACHE", "GRID_COOP", "SUB_EPOCHS", "SUB_MIN_WAVES", "SMP_CAP", "GRID_BUILD", nullptr };
+    "NO_QUAD", "GRID_LANES", "OCT", "HEX", "SPREAD", "COMPACT", "QUAD_CACHE", "GRID_COOP", "SUB_EPOCHS", "SUB_MIN_WAVES", "SMP_CAP", "GRID_BUILD", nullptr };
 const char* const* geoac_option_names(void){ return kOptionNames; }
 
 int geoac_set_option(geoac_ctx* ctx, const char* key, const char* value){
@@ -235,8 +236,9 @@ int geoac_set_option(geoac_ctx* ctx, const char* key, const char* value){
     else if(k == "NO_GATE") ctx->no_gate = iv != 0;
     else if(k == "SORT") ctx->sort_rays = iv != 0;
     else if(k == "NO_QUAD") ctx->no_quad = iv != 0;
-    else if(k == "GRID_LANES"){ if(iv == 0 || iv == 1 || iv == 2 || iv == 4 || iv == 8) ctx->grid_lanes = iv; else return fail(ctx, GEOAC_E_INVALID, "GRID_LANES: 0, 1, 2, 4 or 8"); }
+    else if(k == "GRID_LANES"){ if(iv == 0 || iv == 1 || iv == 2 || iv == 4 || iv == 8 || iv == 16) ctx->grid_lanes = iv; else return fail(ctx, GEOAC_E_INVALID, "GRID_LANES: 0, 1, 2, 4, 8 or 16"); }
     else if(k == "OCT") ctx->oct = iv != 0;
+    else if(k == "HEX") ctx->hex = iv != 0;
     else if(k == "SPREAD"){ if(iv >= 0) ctx->spread_override = iv; }
     else if(k == "COMPACT") ctx->compact = iv != 0;
     else if(k == "QUAD_CACHE") ctx->quad_cache = iv != 0;
@@ -333,7 +335,7 @@ int geoac_clone(geoac_ctx* src, geoac_ctx** out){
         hipError_t e = c->d_consts.ensure(sizeof(double) * 8);
         if(e != hipSuccess){ geoac_destroy(c); return hipfail(src, e, "clone: constants block"); }
     }
-    c->sort_rays = src->sort_rays; c->no_quad = src->no_quad; c->oct = src->oct; c->grid_lanes = src->grid_lanes; c->spread_override = src->spread_override;
+    c->sort_rays = src->sort_rays; c->no_quad = src->no_quad; c->oct = src->oct; c->hex = src->hex; c->grid_lanes = src->grid_lanes; c->spread_override = src->spread_override;
     c->compact = src->compact; c->quad_cache = src->quad_cache; c->sub_min_waves = src->sub_min_waves; c->sub_epochs = src->sub_epochs; c->grid_coop = src->grid_coop;
     c->smp_cap = src->smp_cap; c->s_rows_override = src->s_rows_override; c->no_overlap = src->no_overlap; c->pp_blocks = src->pp_blocks; c->pair_frac = src->pair_frac;
     c->hybrid_rows = src->hybrid_rows; c->two_chunks = src->two_chunks; c->no_gate = src->no_gate; c->no_pair = src->no_pair; c->duo = src->duo; c->abs_table = src->abs_table;
@@ -683,6 +685,10 @@ int geoac_fan_launch(geoac_ctx* ctx){
     const bool oct_ok = is_grid && p.calc_amp && !sampling && ctx->quad_cache && (long long)P.n_pad * 8 / 64 <= 256;
     if(P.lanes_per_ray == 8 && !oct_ok) P.lanes_per_ray = 4;
     if(is_grid && !ctx->grid_lanes && !ctx->no_quad && ctx->oct && oct_ok && P.lanes_per_ray == 4) P.lanes_per_ray = 8;
+    // ... and sixteen - four corners x (three fields + one) x ... the two systems on the halves - for the spherical set while THAT is at most one wave per CU (EqGlobalRngDepHex)
+    const bool hex_ok = oct_ok && ctx->eqset == GEOAC_EQ_GLOBAL_RNGDEP && (long long)P.n_pad * 16 / 64 <= 256;
+    if(P.lanes_per_ray == 16 && !hex_ok) P.lanes_per_ray = oct_ok ? 8 : 4;
+    if(P.lanes_per_ray == 8 && !ctx->grid_lanes && ctx->hex && hex_ok) P.lanes_per_ray = 16;
     // RK4 workgroup shape: with the table in LDS one workgroup owns a CU, so spread the waves over the 256 CUs
     int waves = P.n_pad * P.lanes_per_ray / 64;
     int wpb = (waves + 255) / 256;
@@ -700,9 +706,9 @@ int geoac_fan_launch(geoac_ctx* ctx){
         if(ctx->spread_override > 0){ P.spread = 1; while(P.spread * 2 <= ctx->spread_override && P.spread < 64) P.spread *= 2; }
     }
     // small four-lane fans (at most one wave per CU): records and z nodes cached in LDS, the stage latency is what such a fan costs
-    P.quad_cache = (is_grid && (P.lanes_per_ray == 4 || P.lanes_per_ray == 8) && ctx->quad_cache && (long long)P.n_pad * P.lanes_per_ray / 64 <= 256 &&
+    P.quad_cache = (is_grid && (P.lanes_per_ray == 4 || P.lanes_per_ray == 8 || P.lanes_per_ray == 16) && ctx->quad_cache && (long long)P.n_pad * P.lanes_per_ray / 64 <= 256 &&
                     2 * GEOAC_MAXE * 64 * sizeof(double) + 64 * 976 + (size_t)(P.nseg + 1) * sizeof(double) <= 160 * 1024) ? 1 : 0;
-    if(P.lanes_per_ray == 8 && !P.quad_cache){ P.lanes_per_ray = 4; P.quad_cache = (is_grid && (P.lanes_per_ray == 4 || P.lanes_per_ray == 8) && ctx->quad_cache && (long long)P.n_pad * P.lanes_per_ray / 64 <= 256 &&
+    if((P.lanes_per_ray == 8 || P.lanes_per_ray == 16) && !P.quad_cache){ P.lanes_per_ray = 4; P.quad_cache = (is_grid && (P.lanes_per_ray == 4 || P.lanes_per_ray == 8) && ctx->quad_cache && (long long)P.n_pad * P.lanes_per_ray / 64 <= 256 &&
                     2 * GEOAC_MAXE * 64 * sizeof(double) + 64 * 976 + (size_t)(P.nseg + 1) * sizeof(double) <= 160 * 1024) ? 1 : 0; }      // (the eight-lane kernel exists with the record cache only)
     // dense one-lane-per-ray grid fans (more waves than SIMDs): the quads of a wave fetch the table records together (grid_eval3_coop)
     P.coop = (is_grid && P.lanes_per_ray == 1 && P.spread == 1 && ctx->grid_coop && ctx->gtab_bytes < (4ull << 30)) ? 1 : 0;   // (32-bit record offsets)

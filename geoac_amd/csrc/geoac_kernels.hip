@@ -1346,6 +1346,20 @@ struct EqGlobalRngDepOct : EqGlobalRngDep<true, 4, false, true> {
     }
 };
 
+// Sixteen lanes per ray for the same fans when they are smaller still (at most four rays per wave and one wave per CU: the refinement rounds of an
+// eigenray search are a handful of rays): lane q evaluates cell corner q & 3 of ONE field, (q >> 2) & 3, and carries the base ray plus the
+// launch-angle system q >> 3 (globalrd_rhs<..., FSPLIT>).  A third of the table evaluation per lane; the fields change hands through LDS.
+struct EqGlobalRngDepHex : EqGlobalRngDepOct {
+    static constexpr int LANES = 16;
+    static constexpr int SYS_SHIFT = 3;
+    template <typename TabPtr>
+    static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
+        double s2, c2;
+        rot_small(C.a[0], C.a[1], yt[1] - y0[1], s2, c2);
+        globalrd_rhs<true, 4, false, true, 1, true>(P, seg, yt, s2, c2, dy, (int)(threadIdx.x & 3), (char*)tab, &C.ckey, &C.kxy, C.cell);
+    }
+};
+
 #pragma clang fp contract(off)           // stratified sets again
 template <bool AMP_> struct Eq3D {
     static constexpr bool AMP = AMP_;
@@ -2593,7 +2607,10 @@ __global__ void __launch_bounds__(64) k_probe_grid(GeoacDevParams P, int n, cons
 
 // RK4 only: the grid sets have four-lanes-per-ray variants (small fans)
 #define GEOAC_DISPATCH_EQ_RK4(P, CALL) \
-    if((P)->lanes_per_ray == 8){ \
+    if((P)->lanes_per_ray == 16){ \
+        if((P)->eqset == GEOAC_EQ_GLOBAL_RNGDEP && (P)->calc_amp && (P)->quad_cache){ using EQ = EqGlobalRngDepHex; CALL; } \
+        else return hipErrorNotSupported; \
+    } else if((P)->lanes_per_ray == 8){ \
         if((P)->eqset == GEOAC_EQ_GLOBAL_RNGDEP && (P)->calc_amp && (P)->quad_cache){ using EQ = EqGlobalRngDepOct; CALL; } \
         else if((P)->eqset == GEOAC_EQ_3D_RNGDEP && (P)->calc_amp && (P)->quad_cache){ using EQ = Eq3DRngDepOct; CALL; } \
         else return hipErrorNotSupported; \

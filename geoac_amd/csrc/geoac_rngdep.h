@@ -649,6 +649,28 @@ DEVINL const double* grid_cache_fill(const GeoacDevParams& P, const GridLoc& L, 
     return (const double*)mine;
 }
 
+// sixteen lanes per ray: the lane keeps ONE record - field `field` of its corner - at the head of its slot
+template <bool GLB>
+DEVINL const double* grid_cache_fill_one(const GeoacDevParams& P, const GridLoc& L, int cq, int field, char* cache, int* ckey){
+    constexpr int RB = GRec<GLB>::N * (int)sizeof(double), NCH = RB / 16;
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned nn = (unsigned)(P.gnx * P.gny);
+    const int key = L.kz * (int)nn + corner_node(L, cq >> 1, cq & 1);
+    char* mine = cache + lane * GEOAC_CACHE_SLOT;
+    if(key != *ckey){                                              // (the sixteen lanes of a ray change cell / segment together)
+        const size_t fstride = (size_t)P.nseg * nn * RB;
+        const char* __restrict__ src = (const char*)P.gtab + (size_t)key * RB + (size_t)field * fstride;
+        geoac_d2 v[NCH];
+        #pragma unroll
+        for(int j = 0; j < NCH; j++) v[j] = *(const geoac_d2*)(src + 16 * j);
+        #pragma unroll
+        for(int j = 0; j < NCH; j++) *(geoac_d2*)(mine + 16 * j) = v[j];
+        *ckey = key;
+    }
+    return (const double*)mine;
+}
+#define GEOAC_HEX_XCHG 336            // byte offset of a ray's exchange area in the slot of its first lane (behind that lane's 320-byte record)
+
 // Eval_Spline_f (:806-863): scalar value, y rows scaled by dx_scalar (Q11; the spherical twin :755-807 uses dp_scalar)
 template <bool GLB>
 DEVINL double grid_eval_f(const GeoacDevParams& P, int field, const GridLoc& L){
@@ -843,7 +865,11 @@ DEVINL void rngdep_rhs(const GeoacDevParams& P, int& kz, const double* y, double
 // the algebra of global_rhs (geoac_kernels.hip) with the full gradient and second-derivative matrices of c, u, v (w = 0).
 // y: r, lat, lon, nu_r, nu_t, nu_p | R_lt(3), mu_lt(3) | R_lp(3), mu_lp(3);  sth/cth = sin/cos(lat) from the caller.
 // NSYS = 1 (the eight-lane kernel, EqGlobalRngDepOct): y = base ray | ONE launch-angle system, the lane's own
-template <bool AMP, int NL = 1, bool COOP = false, bool CACHE = false, int NSYS = 2>
+// FSPLIT (sixteen lanes per ray: EqGlobalRngDepHex): the quad (lane >> 2) & 3 of a ray's sixteen lanes evaluates ONE field (T, u, v; the fourth quad
+// repeats T and keeps its result to itself) - a third of the table evaluation per lane - and the three fields' ten values each change hands
+// through 240 bytes of LDS in the slot of the ray's first lane.  Per field the same corner sums in the same order as the four- and eight-lane
+// kernels: the same bits.
+template <bool AMP, int NL = 1, bool COOP = false, bool CACHE = false, int NSYS = 2, bool FSPLIT = false>
 DEVINL void globalrd_rhs(const GeoacDevParams& P, int& kz, const double* y, double sth, double cth, double* dy, int cq = 0, char* ldsw = nullptr, int* ckey = nullptr, int* kxy = nullptr, double* cell = nullptr){
     const double r = y[0];
     const double te = clampd(y[1], P.g_lo[0], P.g_hi[0]), pe = clampd(y[2], P.g_lo[1], P.g_hi[1]), re = clampd(r, P.x_min, P.x_max);
@@ -853,6 +879,31 @@ DEVINL void globalrd_rhs(const GeoacDevParams& P, int& kz, const double* y, doub
     if(COOP){
         if constexpr (GEOAC_COOP_GLDS != 0) grid_eval3_glds<AMP, true>(P, L, M, ldsw);
         else grid_eval3_coop<AMP, true>(P, L, M, ldsw);
+    }
+    else if(CACHE && FSPLIT){
+        const unsigned lane = threadIdx.x & 63u;
+        const int fq = (int)((lane >> 2) & 3u), fm = fq < 3 ? fq : 0;
+        const double* rec = grid_cache_fill_one<true>(P, L, cq, fm, ldsw, ckey);
+        unsigned off = (unsigned)(size_t)(geoac_lds_char*)rec;      // (explicit LDS reads, offset laundered per stage: as in the eight-lane kernel)
+        asm volatile("" : "+v"(off));
+        double o[10];
+        grid_eval_all<AMP, true, NL, true>(P, fm, L, o, cq, rec, off);
+        // the quad's totals (identical in its four lanes) to the ray's exchange area, then every lane reads all three fields
+        char* const xa = ldsw + (lane & ~15u) * GEOAC_CACHE_SLOT + GEOAC_HEX_XCHG + 16u * (lane >> 4);
+        if(cq == 0 && fq < 3){
+            #pragma unroll
+            for(int i = 0; i < 5; i++){ geoac_d2 w; w.x = o[2 * i]; w.y = o[2 * i + 1]; *(geoac_d2*)(xa + 80 * fq + 16 * i) = w; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        #pragma unroll
+        for(int f = 0; f < 3; f++){
+            #pragma unroll
+            for(int i = 0; i < 5; i++){ const geoac_d2 w = *(const geoac_d2*)(xa + 80 * f + 16 * i); M[f][2 * i] = w.x; M[f][2 * i + 1] = w.y; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");              // the next stage's stores stay behind these reads
+        __builtin_amdgcn_wave_barrier();
     }
     else if(CACHE){
         const double* rec = grid_cache_fill<true>(P, L, cq, ldsw, ckey);

@@ -97,9 +97,24 @@ def test_eight_lane_kernel_gives_the_four_lane_kernels_bits(gold, grid, monkeypa
     """small arrivals-only fans with amplitudes run eight lanes per ray (four cell corners x the two launch-angle systems, EqGlobalRngDepOct);
     GEOAC_OCT=0 keeps them on the four-lane kernel: same records bit for bit, and both within tolerance of the golden ones"""
     out = {}
+    monkeypatch.setitem(OPT, "HEX", "0")
     for oct_on in ("1", "0"):
         monkeypatch.setitem(OPT, "OCT", oct_on)
         ctx = _ctx(grid, bounces=2, calc_amp=1, mode=0, src=(0.0, 31.0, 0.0))
         out[oct_on] = ctx.run(gold["theta"], gold["phi"])
     assert out["1"][1] == out["0"][1]
     assert np.array_equal(out["1"][0], out["0"][0])
+    # ... and the sixteen-lane kernel (one field of one corner per lane, EqGlobalRngDepHex: the default for fans this small) the same bits again
+    monkeypatch.setitem(OPT, "OCT", "1"); monkeypatch.setitem(OPT, "HEX", "1")
+    ctx = _ctx(grid, bounces=2, calc_amp=1, mode=0, src=(0.0, 31.0, 0.0))
+    rec16, steps16 = ctx.run(gold["theta"], gold["phi"])
+    assert steps16 == out["1"][1]
+    assert np.array_equal(rec16, out["1"][0])
+    # a fan that is not a multiple of four rays (part-filled wave), and one ray alone
+    for n in (5, 1):
+        got = {}
+        for hx in ("1", "0"):
+            monkeypatch.setitem(OPT, "HEX", hx)
+            ctx = _ctx(grid, bounces=2, calc_amp=1, mode=0, src=(0.0, 31.0, 0.0))
+            got[hx] = ctx.run(gold["theta"][:n], gold["phi"][:n])
+        assert got["1"][1] == got["0"][1] and np.array_equal(got["1"][0], got["0"][0])
