@@ -2458,6 +2458,8 @@ __global__ void __launch_bounds__(256) k_accum(GeoacDevParams P){
     }
     };
     emit_events(0);             // events on the carry row (the row a previous epoch ended on)
+    // (measured, round 3: a separate summation loop for arrivals-only fans with eight rows' loads in flight - config 3 373 -> 388 ms per pass: the sums
+    //  run beside the next epoch's RK4 and post-pass, and pulling their rows faster only takes bandwidth from those)
     for(int i = 0; i + 1 < nr; i++){
         if(i == cur_end) continue;                              // (leg-end row -> next leg's start row): not a segment
         const double* cpt = P.contrib + ((size_t)i * 2) * np + col;

@@ -11,8 +11,13 @@ def run(lib_path, passes):
     A._lib = None
     A.library_path = lambda: lib_path
     import geoac_amd as G
-    th, ph = A.fan_enumerate(phi_min=-180.0, phi_max=179.0, phi_step=1.0)
-    ctx = A.FanContext(A.EQ_3D if os.environ.get("GEOAC_AB_SET") == "3d" else A.EQ_GLOBAL, device=0); ctx.load_met(H.TOYATMO); ctx.set_params(bounces=2, calc_amp=1, mode=0)
+    which = os.environ.get("GEOAC_AB_SET", "")
+    if which == "cfg3":
+        th, ph = A.fan_enumerate(theta_min=0.25, theta_max=45.0, theta_step=0.25, phi_min=-180.0, phi_max=179.5, phi_step=0.5)
+        ctx = A.FanContext(A.EQ_GLOBAL, device=0); ctx.load_met(H.TOYATMO); ctx.set_params(bounces=3, calc_amp=1, mode=0, src=(0.0, 30.0, 0.0))
+    else:
+        th, ph = A.fan_enumerate(phi_min=-180.0, phi_max=179.0, phi_step=1.0)
+        ctx = A.FanContext(A.EQ_3D if which == "3d" else A.EQ_GLOBAL, device=0); ctx.load_met(H.TOYATMO); ctx.set_params(bounces=2, calc_amp=1, mode=0)
     ctx.set_angles(th, ph); ctx.launch(); ctx.launch()
     ts = []
     for _ in range(passes):
