@@ -699,10 +699,13 @@ int geoac_fan_launch(geoac_ctx* ctx){
     // grid sets are bound by divergent table gathers (one cache line per active lane and load): while the fan has fewer waves than
     // the chip has SIMDs, thin the waves out (1 wave per SIMD is what the kernel's register budget allows)
     P.spread = 1;
+    const bool coop_able = is_grid && ctx->grid_coop && ctx->gtab_bytes < (4ull << 30);
     if(is_grid && P.lanes_per_ray == 1){
         // measured (tools/perf_rngdep.py, GEOAC_SPREAD sweep): 2-4 way thinning gains 5-20 %, 8+ loses again (path stores and the
-        // post-pass reads scatter), more waves than SIMDs loses a lot
-        while(P.spread < 4 && (long long)P.n_pad * (P.spread * 2) / 64 <= 1024) P.spread *= 2;
+        // post-pass reads scatter), more waves than SIMDs loses a lot.  Only for the per-lane-gather kernel (GRID_COOP=0): a fan that
+        // comes here on the default plan has more than 16 384 rays and takes the cooperative kernel unthinned (24 000-ray fan on the
+        // 5 x 5 x 1400 grid: 5.1e8 ray-steps/s against 3.9e8 thinned two-way on the per-lane kernel, profiles/r03_c_midfans.txt)
+        while(!coop_able && P.spread < 4 && (long long)P.n_pad * (P.spread * 2) / 64 <= 1024) P.spread *= 2;
         if(ctx->spread_override > 0){ P.spread = 1; while(P.spread * 2 <= ctx->spread_override && P.spread < 64) P.spread *= 2; }
     }
     // small four-lane fans (at most one wave per CU): records and z nodes cached in LDS, the stage latency is what such a fan costs
@@ -888,7 +891,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
         }
         if((long long)e > max_epochs) return fail(ctx, GEOAC_E_CAPACITY, "fan_launch: epoch bound exceeded");
     }
-    HIPCHK(geoac_launch_arrival(&P, s));           // stratified sets: inclination, back azimuth, range, amplitude of every arrival (k_arrival), beside the last post-pass
+    HIPCHK(geoac_launch_arrival(&P, s));           // inclination, back azimuth, range, amplitude of every arrival (k_arrival), beside the last post-pass
     HIPCHK(hipStreamWaitEvent(s, ctx->evs[4 * (ctx->n_epochs - 1) + 3], 0));
     HIPCHK(hipEventRecord(ctx->ev1, s));
     HIPCHK(hipMemcpyAsync(ctx->h_counters + 8, ctx->counters.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));

@@ -1888,10 +1888,9 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
                 if(!(EQ::PW == 2 && (P.mode & GEOAC_MODE_INTERACTIVE))) hmax = (hmax < hl) ? hl : hmax;
             }
             R[GEOAC_REC_TURN] = hmax;
-            // stratified sets: the arrival record (inclination, back azimuth, range, amplitude: sin / cos / asin / atan2 of the leg's last row,
-            // which the record holds) is filled in by k_arrival once the fan has finished - ~3 000 instructions and their constants out of this
-            // kernel's registers.  The grid sets, whose kernels are bound by their table gathers, keep it here.
-            if constexpr (!EQ::SEG1D) arrival_of<EQ>(P, C, slot, EQ::SPLIT ? yf : yb, R);
+            // the arrival part of the record (inclination, back azimuth, range, amplitude, Jacobian: sin / cos / asin / atan2 and - grid sets - table
+            // evaluations at the leg's last row, which the record holds) is filled in by k_arrival once the fan has finished: thousands of
+            // instructions and the constants hipcc hoists out of them stay out of this kernel's registers
             if(leg >= P.bounces){
                 done = true;
             } else {
@@ -2381,7 +2380,7 @@ __global__ void __launch_bounds__(64) k_atab_build(GeoacDevParams P, double* __r
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_arrival (stratified sets): the arrival part of the records (GeoAcGlobal_main.cpp:296-317 and twins) from the leg's last row, which
+// k_arrival: the arrival part of the records (GeoAcGlobal_main.cpp:296-317 and twins) from the leg's last row, which
 // k_rk4 left in the record.  One thread per (ray, leg); runs once, behind the fan's last RK4 launch.
 // ------------------------------------------------------------------------------------------------
 template <class EQ>
@@ -2839,13 +2838,14 @@ extern "C" hipError_t geoac_launch_compact(const GeoacDevParams* P, const int* c
 }
 
 extern "C" hipError_t geoac_launch_arrival(const GeoacDevParams* P, hipStream_t s){
-    if(P->gtab) return hipSuccess;                               // (grid sets: k_rk4 fills the records in)
     dim3 b(256), g((unsigned)(((long long)P->n_rays * (P->bounces + 1) + 255) / 256));
     const bool amp = P->calc_amp != 0;
     switch(P->eqset){
         case GEOAC_EQ_GLOBAL: if(amp) hipLaunchKernelGGL(k_arrival<EqGlobal<true>>, g, b, 0, s, *P); else hipLaunchKernelGGL(k_arrival<EqGlobal<false>>, g, b, 0, s, *P); break;
         case GEOAC_EQ_3D:     if(amp) hipLaunchKernelGGL(k_arrival<Eq3D<true>>, g, b, 0, s, *P);     else hipLaunchKernelGGL(k_arrival<Eq3D<false>>, g, b, 0, s, *P); break;
         case GEOAC_EQ_2D:     if(amp) hipLaunchKernelGGL(k_arrival<Eq2D<true>>, g, b, 0, s, *P);     else hipLaunchKernelGGL(k_arrival<Eq2D<false>>, g, b, 0, s, *P); break;
+        case GEOAC_EQ_3D_RNGDEP:     if(amp) hipLaunchKernelGGL(k_arrival<Eq3DRngDep<true>>, g, b, 0, s, *P);     else hipLaunchKernelGGL(k_arrival<Eq3DRngDep<false>>, g, b, 0, s, *P); break;
+        case GEOAC_EQ_GLOBAL_RNGDEP: if(amp) hipLaunchKernelGGL(k_arrival<EqGlobalRngDep<true>>, g, b, 0, s, *P); else hipLaunchKernelGGL(k_arrival<EqGlobalRngDep<false>>, g, b, 0, s, *P); break;
         default: return hipSuccess;
     }
     return hipGetLastError();

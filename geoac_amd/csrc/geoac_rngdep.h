@@ -202,7 +202,7 @@ DEVINL void grid_eval_all(const GeoacDevParams& P, int field, const GridLoc& L, 
     for(int cn = cq * (4 / NL); cn < (cq + 1) * (4 / NL); cn++){
         {
             const int a = cn >> 1, b = cn & 1;
-            const double* r = rec_lds ? rec_lds : base + (size_t)(NL > 1 ? corner_node_sel(L, a, b) : corner_node(L, a, b)) * R::N;
+            const double* r = rec_lds ? rec_lds : base + (size_t)corner_node(L, a, b) * R::N;      // (by arithmetic: a select over n00 .. n11 with a lane-dependent corner becomes a table in scratch memory)
             Cub c[R::NCUB];                                        // all loads of the corner in flight before the first use
             #pragma unroll
             for(int i = 0; i < R::NCUB; i++) c[i] = LDSOFF ? load_cubic_lds(lds_off + 32u * i) : load_cubic(r + 4 * i);

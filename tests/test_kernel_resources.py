@@ -20,10 +20,9 @@ NOT_ON_THE_LAUNCH_PLAN = [
 ]
 
 
-# ON the launch plan and still spilling - the one known exception, with the measurement that keeps it there: grid fans of 4 097 - 16 384 rays
-# (more waves than the record-cache kernels' LDS allows, fewer than the cooperative gather needs to fill the chip).  8 000-ray fan on the
-# 5 x 5 x 1400 grid, CalcAmp on (profiles/r03_midfans.txt): this kernel 2.9e8 ray-steps/s, cooperative one-lane kernel 1.9e8, two lanes 2.1e8.
-KNOWN_ON_THE_PLAN = [r"k_rk4<Eq(3D|Global)RngDep<(true|false), 4, false, false>"]
+# ON the launch plan and still using scratch: none.  (Until round 3 the four-lane per-lane-gather kernels of the grid sets - fans of 4 097 - 16 384 rays - kept an
+# 88-byte table there: a select over the four corner nodes with a lane-dependent corner; the node index is computed by arithmetic now.)
+KNOWN_ON_THE_PLAN = []
 
 
 def _rows():
@@ -61,7 +60,7 @@ def test_launch_plan_kernels_use_no_scratch():
             known.append(r["name"])
             continue
         offenders.append(f'{r["name"]}: {r["ScratchSize"]} B/lane scratch, {r.get("VGPRs Spill", 0)} spilled VGPRs')
-    print(f"{len(rows)} kernels, {excused} A/B-only or set-up kernels with scratch, {len(known)} known exceptions on the plan (4 097 - 16 384-ray grid fans), "
+    print(f"{len(rows)} kernels, {excused} A/B-only or set-up kernels with scratch, {len(known)} known exceptions on the plan, "
           f"{len(offenders)} other launch-plan kernels with scratch")
-    assert len(known) <= 16                                           # 2 sets x CalcAmp on / off x the LDS / sample-capture variants of one kernel
+    assert not known
     assert not offenders, "\n".join(offenders)
