@@ -3,7 +3,8 @@
 # cfg2 / cfg3 / cfg4 / cfg5, one SQ PMC pass each for cfg2 / cfg3 / cfg5 and the six passes of tools/pmc_cfg.sh for cfg4, the whole 64-receiver
 # ring of config 5 on one GPU (tools/perf_eigenray.py).  Everything lands in gpurun_out/<tag>/; the summaries to keep are copied to profiles/.
 R=$GRAFT_REPO_ROOT; TAG=${1:-r03_cfg}; O=$R/gpurun_out/$TAG; mkdir -p $O
-cd $R && timeout -k 10 500 python3 tools/bench_configs.py cfg1 cfg2 cfg3 cfg4_350 cfg4 cfg4_full cfg5 > $O/configs.jsonl 2> $O/configs.err
+# (one process per configuration: the eigenray share measured behind the 1 M-ray fan in the same process reads 40 % high - allocator state)
+cd $R && : > $O/configs.jsonl && for c in cfg1 cfg2 cfg3 cfg4_350 cfg4 cfg4_full cfg5; do timeout -k 10 300 python3 tools/bench_configs.py $c >> $O/configs.jsonl 2>> $O/configs.err; done
 echo "configs done"
 cd /tmp && export TMPDIR=/tmp
 for c in cfg2 cfg3 cfg4 cfg5; do
@@ -20,5 +21,6 @@ done
 cd $R && bash tools/pmc_cfg.sh cfg4 $TAG/pmc_cfg4 > $O/pmc_cfg4.txt 2>&1 || true
 echo "pmc cfg4 done"
 cd $R && (timeout -k 10 200 python3 tools/perf_eigenray.py global; timeout -k 10 300 python3 tools/perf_eigenray.py globalrd) > $O/ring64.txt 2>&1 || true
+rm -f $O/midfans.txt; timeout -k 10 400 bash tools/sweep_midfans.sh $O/midfans.txt > /dev/null 2>&1 || true
 find $O -name "*kernel_trace.csv" -size +2M -delete; find $O -name "*counter_collection.csv" -size +1M -delete
 cut -c1-300 $O/configs.jsonl; tail -5 $O/ring64.txt
