@@ -708,11 +708,19 @@ int geoac_fan_launch(geoac_ctx* ctx){
         while(!coop_able && P.spread < 4 && (long long)P.n_pad * (P.spread * 2) / 64 <= 1024) P.spread *= 2;
         if(ctx->spread_override > 0){ P.spread = 1; while(P.spread * 2 <= ctx->spread_override && P.spread < 64) P.spread *= 2; }
     }
-    // small four-lane fans (at most one wave per CU): records and z nodes cached in LDS, the stage latency is what such a fan costs
-    P.quad_cache = (is_grid && (P.lanes_per_ray == 4 || P.lanes_per_ray == 8 || P.lanes_per_ray == 16) && ctx->quad_cache && (long long)P.n_pad * P.lanes_per_ray / 64 <= 256 &&
-                    2 * GEOAC_MAXE * 64 * sizeof(double) + 64 * 976 + (size_t)(P.nseg + 1) * sizeof(double) <= 160 * 1024) ? 1 : 0;
-    if((P.lanes_per_ray == 8 || P.lanes_per_ray == 16) && !P.quad_cache){ P.lanes_per_ray = 4; P.quad_cache = (is_grid && (P.lanes_per_ray == 4 || P.lanes_per_ray == 8) && ctx->quad_cache && (long long)P.n_pad * P.lanes_per_ray / 64 <= 256 &&
-                    2 * GEOAC_MAXE * 64 * sizeof(double) + 64 * 976 + (size_t)(P.nseg + 1) * sizeof(double) <= 160 * 1024) ? 1 : 0; }      // (the eight-lane kernel exists with the record cache only)
+    // small multi-lane fans: records and z nodes cached in LDS (one wave per workgroup), the stage latency is what such a fan costs.  A wave needs its
+    // step rows (2 x E x 512 B), 64 record slots of 976 B and the z nodes: one wave per CU with amplitudes (E = 18, or 12 per lane in the eight- and
+    // sixteen-lane kernels), TWO without (E = 6: 80 KB each on a 1400-segment grid) - the inclination scans of an eigenray search (4 272 rays x 4
+    // lanes = 267 waves for the 8-receiver share of config 5) stay on the cached kernel that way
+    auto cache_fits = [&](int lanes){
+        const int e_rows = !p.calc_amp ? 6 : ((lanes == 8 || lanes == 16) ? 12 : 18);
+        const size_t per_wave = 2 * (size_t)e_rows * 64 * sizeof(double) + 64 * 976 + (size_t)(P.nseg + 1) * sizeof(double);
+        if(!(is_grid && (lanes == 4 || lanes == 8 || lanes == 16) && ctx->quad_cache) || per_wave > 160 * 1024) return false;
+        const long long waves_per_cu = (long long)((160 * 1024) / per_wave);
+        return (long long)P.n_pad * lanes / 64 <= 256 * waves_per_cu;
+    };
+    P.quad_cache = cache_fits(P.lanes_per_ray) ? 1 : 0;
+    if((P.lanes_per_ray == 8 || P.lanes_per_ray == 16) && !P.quad_cache){ P.lanes_per_ray = 4; P.quad_cache = cache_fits(4) ? 1 : 0; }      // (the eight- and sixteen-lane kernels exist with the record cache only)
     // dense one-lane-per-ray grid fans (more waves than SIMDs): the quads of a wave fetch the table records together (grid_eval3_coop)
     P.coop = (is_grid && P.lanes_per_ray == 1 && P.spread == 1 && ctx->grid_coop && ctx->gtab_bytes < (4ull << 30)) ? 1 : 0;   // (32-bit record offsets)
 

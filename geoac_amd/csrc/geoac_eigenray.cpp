@@ -19,6 +19,7 @@
 #include <string.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <deque>
 #include <iomanip>
 #include <map>
@@ -893,7 +894,9 @@ static int run_all(geoac_ctx* ctx, const geoac_eig_params* ep, int n_rcvr, const
             fprintf(stderr, "[eig round %llu] tasks %zu: %zu scans (%zu rays), %zu single scan rays, %zu refinement rays, %zu eigenray rays\n",
                     (unsigned long long)res->stats[3], active.size(), scans, scan_rays, singles, newton, finals);
         }
+        const auto t0 = std::chrono::steady_clock::now();
         err = serve(ctxs, base, batch, res);
+        if(trace) fprintf(stderr, "[eig round %llu] integrated in %.1f ms\n", (unsigned long long)res->stats[3], std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         res->stats[3] += 1;
         active.swap(waiting);
     }

@@ -1755,7 +1755,7 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
     const bool idle0 = done;                                     // finished before this epoch: nothing of this lane's is written
     // record-cache kernels (one wave per workgroup): behind the state rows, 64 x 976 B of per-lane records, then a copy of the z nodes,
     // staged by ALL 64 lanes before the lanes without a live ray leave
-    constexpr int LDS_STATE_BYTES = (EQ::COOP ? EQ::XCHG_BYTES : 0) + (EQ::LDS_STATE ? 2 * GEOAC_MAXE * 64 * (int)sizeof(double) : 0);
+    constexpr int LDS_STATE_BYTES = (EQ::COOP ? EQ::XCHG_BYTES : 0) + (EQ::LDS_STATE ? 2 * E * 64 * (int)sizeof(double) : 0);      // (rows of E components: an amplitude-less kernel's 6 leave room for a second wave per CU beside the record cache)
     char* const ldsc = (char*)lds_tab + (threadIdx.x >> 6) * LDS_STATE_BYTES + LDS_STATE_BYTES;
     if(EQ::CACHE){
         double* gzl = (double*)(ldsc + GEOAC_CACHE_BYTES);
@@ -1767,10 +1767,10 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
     if(!EQ::COOP && done) return;
     // per wave: (COOP) the 64 x 176 B exchange buffer of the cooperative gather, then (LDS_STATE) y[E][64] and yn[E][64]
     constexpr int LDS_XCHG_BYTES = EQ::COOP ? EQ::XCHG_BYTES : 0;
-    constexpr int LDS_WAVE_BYTES = LDS_XCHG_BYTES + (EQ::LDS_STATE ? 2 * GEOAC_MAXE * 64 * (int)sizeof(double) : 0);
+    constexpr int LDS_WAVE_BYTES = LDS_XCHG_BYTES + (EQ::LDS_STATE ? 2 * E * 64 * (int)sizeof(double) : 0);
     char* const ldsw = (char*)lds_tab + (threadIdx.x >> 6) * LDS_WAVE_BYTES;
     double* const ly = (double*)(ldsw + LDS_XCHG_BYTES) + (threadIdx.x & 63);
-    double* const lyn = ly + GEOAC_MAXE * 64;
+    double* const lyn = ly + E * 64;
 
     int nr = 0, nle = 0;
     if(EQ::COOP && sub_h > 0 && !idle0){ nr = P.nrows[col]; nle = P.nlegend[col]; }   // continue the chunk where the previous sub-epoch stopped
@@ -2666,7 +2666,7 @@ static hipError_t launch_rk4_t(const GeoacDevParams* P, int block, hipStream_t s
     }
     if(n_wg) *n_wg = g.x;
     size_t lds = P->table_in_lds ? (size_t)P->nseg * GEOAC_SEGW * sizeof(double) : 0;
-    if(EQ::LDS_STATE) lds = (size_t)(block / 64) * ((EQ::COOP ? EQ::XCHG_BYTES : 0) + 2 * GEOAC_MAXE * 64 * sizeof(double));   // per wave: exchange buffer, y and yn rows (k_rk4)
+    if(EQ::LDS_STATE) lds = (size_t)(block / 64) * ((EQ::COOP ? EQ::XCHG_BYTES : 0) + 2 * EQ::E * 64 * sizeof(double));   // per wave: exchange buffer, y and yn rows (k_rk4)
     if(EQ::CACHE){
         if(block != 64) return hipErrorInvalidValue;
         lds += GEOAC_CACHE_BYTES + (size_t)(P->nseg + 1) * sizeof(double);                 // per-lane records, z nodes
