@@ -687,8 +687,13 @@ int geoac_fan_launch(geoac_ctx* ctx){
     if(is_grid && !ctx->grid_lanes && !ctx->no_quad && ctx->oct && oct_ok && P.lanes_per_ray == 4) P.lanes_per_ray = 8;
     // ... and sixteen - four corners x (three fields + one) x ... the two systems on the halves - for the spherical set while THAT is at most one wave per CU (EqGlobalRngDepHex)
     const bool hex_ok = oct_ok && ctx->eqset == GEOAC_EQ_GLOBAL_RNGDEP && (long long)P.n_pad * 16 / 64 <= 256;
-    if(P.lanes_per_ray == 16 && !hex_ok) P.lanes_per_ray = oct_ok ? 8 : 4;
+    if(P.lanes_per_ray == 16 && p.calc_amp && !hex_ok) P.lanes_per_ray = oct_ok ? 8 : 4;
     if(P.lanes_per_ray == 8 && !ctx->grid_lanes && ctx->hex && hex_ok) P.lanes_per_ray = 16;
+    // ... and amplitude-less fans of the spherical set that leave room for sixteen lanes on the cached kernel at two waves per CU (EqGlobalRngDepScan16: the
+    // inclination scans of a search with few receivers; cache_fits below has the last word)
+    const bool scan16_ok = is_grid && ctx->eqset == GEOAC_EQ_GLOBAL_RNGDEP && !p.calc_amp && !sampling && ctx->quad_cache && (long long)P.n_pad * 16 / 64 <= 512;
+    if(P.lanes_per_ray == 16 && !p.calc_amp && !scan16_ok) P.lanes_per_ray = 4;
+    if(P.lanes_per_ray == 4 && !ctx->grid_lanes && !ctx->no_quad && ctx->hex && scan16_ok) P.lanes_per_ray = 16;
     // RK4 workgroup shape: with the table in LDS one workgroup owns a CU, so spread the waves over the 256 CUs
     int waves = P.n_pad * P.lanes_per_ray / 64;
     int wpb = (waves + 255) / 256;

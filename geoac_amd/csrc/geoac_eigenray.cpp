@@ -745,8 +745,15 @@ static int serve_group(geoac_ctx* ctx, const geoac_params& base, const std::tupl
     const int legs = p.bounces + 1;
     std::vector<double> rec((size_t)n * legs * GEOAC_REC_STRIDE);
     uint64_t steps = 0;
+    const auto t0 = std::chrono::steady_clock::now();
     rc = geoac_fan_run(ctx, n, th.data(), ph.data(), rec.data(), &steps);
     if(rc) return rc;
+    if(st[7]){                                                      // (trace: GEOAC_EIG_TRACE)
+        double longest = 0.0;
+        for(int i = 0; i < n; i++){ double sum = 0.0; for(int l = 0; l < legs; l++) sum += rec[((size_t)i * legs + l) * GEOAC_REC_STRIDE + GEOAC_REC_STEPS]; longest = std::max(longest, sum); }
+        fprintf(stderr, "    [group bounces %d amp %d mode %d] %d rays, longest %.0f steps, %.1f ms\n", p.bounces, p.calc_amp, p.mode, n, longest,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
     st[0] += 1; st[1] += (uint64_t)n; st[2] += steps;
     {   // the launch's longest ray (all legs)
         double longest = 0.0;
@@ -787,7 +794,7 @@ static int serve_group(geoac_ctx* ctx, const geoac_params& base, const std::tupl
 // context of its own (the caller's, and clones of it that share its atmosphere tables: geoac_clone), from a host thread of its own.  A
 // group of a search round is a handful of rays - a few waves on a chip of 1 024 wave slots - and lasts as long as its longest ray, so the
 // groups of a round overlap almost completely: the round costs its longest group, not the sum of them.
-static int serve(std::vector<geoac_ctx*>& ctxs, const geoac_params& base, std::vector<Request*>& reqs, geoac_eig_result* res){
+static int serve(std::vector<geoac_ctx*>& ctxs, const geoac_params& base, std::vector<Request*>& reqs, geoac_eig_result* res, bool trace_groups = false){
     std::map<std::tuple<int, int, int>, std::vector<Request*>> groups;
     for(Request* r : reqs) groups[std::make_tuple(r->bounces, r->calc_amp, r->mode)].push_back(r);
     while(ctxs.size() < groups.size() && ctxs.size() < 8){
@@ -803,7 +810,7 @@ static int serve(std::vector<geoac_ctx*>& ctxs, const geoac_params& base, std::v
     std::mutex mu;
     uint64_t round_crit = 0;
     auto worker = [&](geoac_ctx* c){
-        uint64_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint64_t st[8] = {0, 0, 0, 0, 0, 0, 0, trace_groups ? 1ull : 0ull};
         for(;;){
             const size_t i = next.fetch_add(1);
             if(i >= work.size() || first_rc.load()) break;
@@ -895,7 +902,7 @@ static int run_all(geoac_ctx* ctx, const geoac_eig_params* ep, int n_rcvr, const
                     (unsigned long long)res->stats[3], active.size(), scans, scan_rays, singles, newton, finals);
         }
         const auto t0 = std::chrono::steady_clock::now();
-        err = serve(ctxs, base, batch, res);
+        err = serve(ctxs, base, batch, res, trace);
         if(trace) fprintf(stderr, "[eig round %llu] integrated in %.1f ms\n", (unsigned long long)res->stats[3], std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         res->stats[3] += 1;
         active.swap(waiting);

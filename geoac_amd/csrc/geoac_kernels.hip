@@ -1360,6 +1360,18 @@ struct EqGlobalRngDepHex : EqGlobalRngDepOct {
     }
 };
 
+// ... and the amplitude-less fans of that size - the inclination scans of an eigenray search once the receivers are few: the same split of the
+// table evaluation over sixteen lanes (every lane carries the whole six-component ray; nothing to split there)
+struct EqGlobalRngDepScan16 : EqGlobalRngDep<false, 4, false, true> {
+    static constexpr int LANES = 16;
+    template <typename TabPtr>
+    static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
+        double s2, c2;
+        rot_small(C.a[0], C.a[1], yt[1] - y0[1], s2, c2);
+        globalrd_rhs<false, 4, false, true, 2, true>(P, seg, yt, s2, c2, dy, (int)(threadIdx.x & 3), (char*)tab, &C.ckey, &C.kxy, C.cell);
+    }
+};
+
 #pragma clang fp contract(off)           // stratified sets again
 template <bool AMP_> struct Eq3D {
     static constexpr bool AMP = AMP_;
@@ -2610,6 +2622,7 @@ __global__ void __launch_bounds__(64) k_probe_grid(GeoacDevParams P, int n, cons
 #define GEOAC_DISPATCH_EQ_RK4(P, CALL) \
     if((P)->lanes_per_ray == 16){ \
         if((P)->eqset == GEOAC_EQ_GLOBAL_RNGDEP && (P)->calc_amp && (P)->quad_cache){ using EQ = EqGlobalRngDepHex; CALL; } \
+        else if((P)->eqset == GEOAC_EQ_GLOBAL_RNGDEP && !(P)->calc_amp && (P)->quad_cache){ using EQ = EqGlobalRngDepScan16; CALL; } \
         else return hipErrorNotSupported; \
     } else if((P)->lanes_per_ray == 8){ \
         if((P)->eqset == GEOAC_EQ_GLOBAL_RNGDEP && (P)->calc_amp && (P)->quad_cache){ using EQ = EqGlobalRngDepOct; CALL; } \

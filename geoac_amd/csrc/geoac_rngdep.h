@@ -890,9 +890,10 @@ DEVINL void globalrd_rhs(const GeoacDevParams& P, int& kz, const double* y, doub
         grid_eval_all<AMP, true, NL, true>(P, fm, L, o, cq, rec, off);
         // the quad's totals (identical in its four lanes) to the ray's exchange area, then every lane reads all three fields
         char* const xa = ldsw + (lane & ~15u) * GEOAC_CACHE_SLOT + GEOAC_HEX_XCHG + 16u * (lane >> 4);
+        constexpr int NX = AMP ? 5 : 2;                            // 16-byte pieces per field: ten values with the second derivatives, four without
         if(cq == 0 && fq < 3){
             #pragma unroll
-            for(int i = 0; i < 5; i++){ geoac_d2 w; w.x = o[2 * i]; w.y = o[2 * i + 1]; *(geoac_d2*)(xa + 80 * fq + 16 * i) = w; }
+            for(int i = 0; i < NX; i++){ geoac_d2 w; w.x = o[2 * i]; w.y = o[2 * i + 1]; *(geoac_d2*)(xa + 80 * fq + 16 * i) = w; }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
@@ -900,7 +901,9 @@ DEVINL void globalrd_rhs(const GeoacDevParams& P, int& kz, const double* y, doub
         #pragma unroll
         for(int f = 0; f < 3; f++){
             #pragma unroll
-            for(int i = 0; i < 5; i++){ const geoac_d2 w = *(const geoac_d2*)(xa + 80 * f + 16 * i); M[f][2 * i] = w.x; M[f][2 * i + 1] = w.y; }
+            for(int i = 0; i < NX; i++){ const geoac_d2 w = *(const geoac_d2*)(xa + 80 * f + 16 * i); M[f][2 * i] = w.x; M[f][2 * i + 1] = w.y; }
+            #pragma unroll
+            for(int i = 2 * NX; i < 10; i++) M[f][i] = 0.0;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");              // the next stage's stores stay behind these reads
         __builtin_amdgcn_wave_barrier();

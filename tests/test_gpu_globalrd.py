@@ -118,3 +118,16 @@ def test_eight_lane_kernel_gives_the_four_lane_kernels_bits(gold, grid, monkeypa
             ctx = _ctx(grid, bounces=2, calc_amp=1, mode=0, src=(0.0, 31.0, 0.0))
             got[hx] = ctx.run(gold["theta"][:n], gold["phi"][:n])
         assert got["1"][1] == got["0"][1] and np.array_equal(got["1"][0], got["0"][0])
+
+
+def test_sixteen_lane_scan_kernel_gives_the_four_lane_kernels_bits(gold, grid, monkeypatch):
+    """amplitude-less arrivals-only fans of a few hundred rays (the inclination scans of an eigenray search) split the table evaluation over sixteen lanes
+    (EqGlobalRngDepScan16); HEX=0 keeps them on the four-lane kernel: the same records bit for bit, also for a part-filled wave and a single ray"""
+    for n in (len(gold["theta"]), 5, 1):
+        got = {}
+        for hx in ("1", "0"):
+            monkeypatch.setitem(OPT, "HEX", hx)
+            ctx = _ctx(grid, bounces=2, calc_amp=0, mode=0, src=(0.0, 31.0, 0.0))
+            got[hx] = ctx.run(gold["theta"][:n], gold["phi"][:n])
+        assert got["1"][1] == got["0"][1] and np.array_equal(got["1"][0], got["0"][0])
+
