@@ -1352,6 +1352,10 @@ struct EqGlobalRngDepOct : EqGlobalRngDep<true, 4, false, true> {
 struct EqGlobalRngDepHex : EqGlobalRngDepOct {
     static constexpr int LANES = 16;
     static constexpr int SYS_SHIFT = 3;
+#ifndef GEOAC_HEX_LDS_STATE
+#define GEOAC_HEX_LDS_STATE 0
+#endif
+    static constexpr bool LDS_STATE = GEOAC_HEX_LDS_STATE != 0;    // the step's rows in registers: a third of the evaluation leaves room for them, and 24 LDS operations per stage go
     template <typename TabPtr>
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
         double s2, c2;
