@@ -21,6 +21,9 @@
 #include "../../include/geoac_hip.h"
 
 #define DEVINL __device__ __forceinline__
+#ifndef GEOAC_OCT_LDS_STATE
+#define GEOAC_OCT_LDS_STATE 0         // eight-lane grid kernels: the step's rows in LDS (1) or in registers (0: since the arrival evaluation left k_rk4 they fit)
+#endif
 #define GEOAC_ROT_MAX 1.0e-3             // largest angle rot_small is asked to rotate by (EqGlobal::checks)
 
 // Floating-point contraction: OFF for the stratified sets' code (from here to the include of geoac_rngdep.h, and again from geoac_duo.h
@@ -1129,6 +1132,7 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
 struct Eq3DRngDepOct : Eq3DRngDep<true, 4, false, true> {
     using Full = Eq3DRngDep<true, 4, false, true>;
     static constexpr int E = 12, LANES = 8;
+    static constexpr bool LDS_STATE = GEOAC_OCT_LDS_STATE != 0;
     static constexpr bool SPLIT = true; static constexpr bool ROW_SPLIT = false;
     static constexpr int SYS_SHIFT = 2;
     template <typename TabPtr>
@@ -1317,6 +1321,7 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
 struct EqGlobalRngDepOct : EqGlobalRngDep<true, 4, false, true> {
     using Full = EqGlobalRngDep<true, 4, false, true>;
     static constexpr int E = 12, LANES = 8;
+    static constexpr bool LDS_STATE = GEOAC_OCT_LDS_STATE != 0;
     static constexpr bool SPLIT = true; static constexpr bool ROW_SPLIT = false;
     static constexpr int SYS_SHIFT = 2;
     template <typename TabPtr>
