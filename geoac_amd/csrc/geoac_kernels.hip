@@ -21,6 +21,9 @@
 #include "../../include/geoac_hip.h"
 
 #define DEVINL __device__ __forceinline__
+#ifndef GEOAC_CACHE_REG_STATE
+#define GEOAC_CACHE_REG_STATE 0       // record-cache kernels (four lanes per ray, small fans): the step rows in registers (1) or in LDS (0; measured: the 64-receiver ring 4.4 s against 4.7 s with 1)
+#endif
 #ifndef GEOAC_OCT_LDS_STATE
 #define GEOAC_OCT_LDS_STATE 0         // eight-lane grid kernels: the step's rows in LDS (1) or in registers (0: since the arrival evaluation left k_rk4 they fit)
 #endif
@@ -988,7 +991,7 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
     static constexpr bool PP_DEDUP = GEOAC_PP_TILE && GEOAC_PP_DEDUP;  // and one table read per distinct (cell, segment) key of a wave
     static constexpr bool PP_TWO = false, GLOBAL = false;
     static constexpr int SYS_SHIFT = 0; static constexpr bool ROW_SPLIT = false;
-    static constexpr bool LDS_STATE = true;                         // the step's rows y and yn live in LDS while the four stages run (the grid kernels use no LDS otherwise)
+    static constexpr bool LDS_STATE = !(CACHE_ && GEOAC_CACHE_REG_STATE);   // the step's rows y and yn live in LDS while the four stages run (GEOAC_CACHE_REG_STATE: the record-cache kernels could keep them in registers since the arrival evaluation left k_rk4 - measured slower on the ring)
     static constexpr int NB = 6, NS = 6;
     static constexpr int PP_WAVES = 3;
     static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 2, LANES = NL_;            // NL_ = 1, 2 or 4 lanes per ray, each evaluating 4/NL_ of the cell corners (identical state otherwise)
@@ -1172,7 +1175,7 @@ template <bool AMP_, int NL_ = 1, bool COOP_ = false, bool CACHE_ = false> struc
     static constexpr bool PP_DEDUP = GEOAC_PP_TILE && GEOAC_PP_DEDUP;
     static constexpr bool PP_TWO = true, GLOBAL = true;             // (a second point per segment: the absorption's reference state at ground level)
     static constexpr int SYS_SHIFT = 0; static constexpr bool ROW_SPLIT = false;
-    static constexpr bool LDS_STATE = true;
+    static constexpr bool LDS_STATE = !(CACHE_ && GEOAC_CACHE_REG_STATE);
     static constexpr int NB = 6, NS = 6;
     static constexpr int PP_WAVES = 2;                                 // post-pass at two waves per SIMD: 0 scratch (168 registers spill 108 B: the absorption integrand AND its ground-level reference state)
     static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 0, LANES = NL_;
