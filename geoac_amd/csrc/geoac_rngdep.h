@@ -468,6 +468,11 @@ DEVINL void grid_eval3_coop8(const GeoacDevParams& P, const GridLoc& L, double (
 // counted here: s_waitcnt vmcnt(12) before round rho is read leaves the three younger rounds in flight.  A slot is refilled one whole
 // iteration after it was read, behind a register dependence on what those reads returned.  Arithmetic: the statements of grid_eval_all, one dot4 per accumulator and corner
 // in the same order - the same bits.
+// Measured and dropped (round 3): a SHARED gather - the wave numbers its distinct (segment, cell) keys (26 of 64 on the tiled config-4 fan), a round
+// fetches each KEY's quarter record once (lanes without a key masked off by EXEC, four loads per round so that the vmcnt arithmetic stays
+// static) and every lane reads its key's 64 bytes.  Same bits, config-4 share 1.24 -> 1.71 s: a load instruction costs the texture path the
+// same with 17 lanes as with 64, the numbering loop is ~29 instructions per key, and the reads of 64-byte key slots conflict in the banks.
+// With the loads of absent keys skipped by scalar branches (vmcnt by a four-way branch per round) the allocator spilt 750 registers.
 #define GEOAC_GLDS_RING 5
 #define GEOAC_GLDS_BYTES (GEOAC_GLDS_RING * 4096)
 

@@ -101,3 +101,22 @@ def test_eight_lane_kernel_gives_the_four_lane_kernels_bits(gold, grid, monkeypa
         out[oct_on] = ctx.run(gold["theta"], gold["phi"])
     assert out["1"][1] == out["0"][1]
     assert np.array_equal(out["1"][0], out["0"][0])
+
+
+def test_tiled_slot_order_gives_the_inclination_orders_bits(grid, monkeypatch):
+    """the grid sets integrate a fan in Z-order over (inclination rank, azimuth rank) - 8 x 8 tiles of the fan per wave, fewer distinct
+    (segment, cell) records per gather - and hand the records back in the caller's order; TILE=0 keeps the inclination order, SORT=0 the caller's:
+    the same records bit for bit (a fan with a ragged edge: 37 inclinations x 11 azimuths, cooperative kernel forced by GRID_LANES=1)"""
+    th = np.repeat(np.linspace(2.0, 38.0, 37)[None, :], 11, axis=0).reshape(-1)
+    ph = np.repeat((-120.0 + 7.5 * np.arange(11))[:, None], 37, axis=1).reshape(-1)
+    out = {}
+    for name, opts in (("tile", {}), ("incl", {"TILE": "0"}), ("caller", {"SORT": "0"})):
+        for k in ("TILE", "SORT"):
+            monkeypatch.delitem(OPT, k, raising=False)
+        for k, v in opts.items():
+            monkeypatch.setitem(OPT, k, v)
+        monkeypatch.setitem(OPT, "GRID_LANES", "1")
+        ctx = _ctx(grid, bounces=1, calc_amp=1, mode=0, src=(0.0, 0.0, 0.0))
+        out[name] = ctx.run(th, ph)
+    assert out["tile"][1] == out["incl"][1] == out["caller"][1]
+    assert np.array_equal(out["tile"][0], out["incl"][0]) and np.array_equal(out["tile"][0], out["caller"][0])
