@@ -64,6 +64,7 @@ struct DevBuf {
 struct geoac_ctx {
     int eqset = 0, device = 0;
     GeoacDevParams lastP{};          // parameter block of the last completed launch (device-function probes, include/geoac_probe.h)
+    int  pp_onetrip = -1;            // table post-pass: record + table entry of the neighbouring segment in one trip (PP_ONETRIP; < 0: every fan but the hybrid ones)
     bool tile_rays = true;           // grid sets: Z-order over (inclination, azimuth) ranks instead of the inclination order (GEOAC_TILE=0)
     bool sort_rays = true;           // integrate the rays in order of launch inclination, results in caller order (GEOAC_SORT=0: caller order).
                                      // Ray length is mostly a function of inclination (ground-hugging rays take 1 m steps), so whole waves finish early
@@ -211,7 +212,7 @@ int geoac_default_params(int eqset, geoac_params* p){
 
 // ---- launch-plan options (A/B measurements, tests; results never depend on them) ----
 static const char* const kOptionNames[] = {
-    "S_ROWS", "NO_OVERLAP", "PP_BLOCKS", "ABS_TABLE", "ABS_TABLE_TOL", "PPFIX_CAP", "DUO", "EV_SLACK", "NO_PAIR", "PAIR_FRAC", "HYBRID_ROWS", "TWO_CHUNKS", "TRACE_EPOCHS", "NO_GATE", "SORT", "TILE",
+    "S_ROWS", "NO_OVERLAP", "PP_BLOCKS", "ABS_TABLE", "ABS_TABLE_TOL", "PPFIX_CAP", "DUO", "EV_SLACK", "NO_PAIR", "PAIR_FRAC", "HYBRID_ROWS", "TWO_CHUNKS", "TRACE_EPOCHS", "NO_GATE", "SORT", "TILE", "PP_ONETRIP",
     "NO_QUAD", "GRID_LANES", "OCT", "HEX", "SPREAD", "COMPACT", "QUAD_CACHE", "GRID_COOP", "SUB_EPOCHS", "SUB_MIN_WAVES", "SMP_CAP", "GRID_BUILD", nullptr };
 const char* const* geoac_option_names(void){ return kOptionNames; }
 
@@ -237,6 +238,7 @@ int geoac_set_option(geoac_ctx* ctx, const char* key, const char* value){
     else if(k == "NO_GATE") ctx->no_gate = iv != 0;
     else if(k == "SORT") ctx->sort_rays = iv != 0;
     else if(k == "TILE") ctx->tile_rays = iv != 0;
+    else if(k == "PP_ONETRIP") ctx->pp_onetrip = iv;
     else if(k == "NO_QUAD") ctx->no_quad = iv != 0;
     else if(k == "GRID_LANES"){ if(iv == 0 || iv == 1 || iv == 2 || iv == 4 || iv == 8 || iv == 16) ctx->grid_lanes = iv; else return fail(ctx, GEOAC_E_INVALID, "GRID_LANES: 0, 1, 2, 4, 8 or 16"); }
     else if(k == "OCT") ctx->oct = iv != 0;
@@ -337,7 +339,7 @@ int geoac_clone(geoac_ctx* src, geoac_ctx** out){
         hipError_t e = c->d_consts.ensure(sizeof(double) * 8);
         if(e != hipSuccess){ geoac_destroy(c); return hipfail(src, e, "clone: constants block"); }
     }
-    c->sort_rays = src->sort_rays; c->tile_rays = src->tile_rays; c->no_quad = src->no_quad; c->oct = src->oct; c->hex = src->hex; c->grid_lanes = src->grid_lanes; c->spread_override = src->spread_override;
+    c->sort_rays = src->sort_rays; c->tile_rays = src->tile_rays; c->pp_onetrip = src->pp_onetrip; c->no_quad = src->no_quad; c->oct = src->oct; c->hex = src->hex; c->grid_lanes = src->grid_lanes; c->spread_override = src->spread_override;
     c->compact = src->compact; c->quad_cache = src->quad_cache; c->sub_min_waves = src->sub_min_waves; c->sub_epochs = src->sub_epochs; c->grid_coop = src->grid_coop;
     c->smp_cap = src->smp_cap; c->s_rows_override = src->s_rows_override; c->no_overlap = src->no_overlap; c->pp_blocks = src->pp_blocks; c->pair_frac = src->pair_frac;
     c->hybrid_rows = src->hybrid_rows; c->two_chunks = src->two_chunks; c->no_gate = src->no_gate; c->no_pair = src->no_pair; c->duo = src->duo; c->abs_table = src->abs_table;
@@ -826,6 +828,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
         if(Pq.atab_on){
             // (see geoac_launch_postpass_tab) hybrid fans: the post-pass off the RK4 CUs, one (spherical set) or two (Cartesian sets) workgroups per free CU
             Pq.pp_lds_pad = !Pq.table_in_lds ? 0 : (hybrid ? (Pq.eqset == GEOAC_EQ_GLOBAL ? 96 : 64) * 1024 : 8 * 1024);
+            Pq.pp_onetrip = ctx->pp_onetrip >= 0 ? (ctx->pp_onetrip ? 1 : 0) : (hybrid ? 0 : 1);
             HIPCHK(hipMemsetAsync((char*)ctx->counters.p + GEOAC_CNT_PPFLAG * sizeof(unsigned long long), 0, sizeof(unsigned long long), sp));   // the fix-up list is empty
             HIPCHK(geoac_launch_postpass_tab(&Pq, Pq.s_rows, sp));
         }

@@ -2235,7 +2235,7 @@ __global__ void __launch_bounds__(256, EQ::PP_WAVES) k_postpass(GeoacDevParams P
 #ifndef GEOAC_PPTAB_GLOBAL_WAVES
 #define GEOAC_PPTAB_GLOBAL_WAVES 2
 #endif
-template <class EQ>
+template <class EQ, bool ONETRIP>
 __global__ void __launch_bounds__(256, EQ::PW == 6 ? GEOAC_PPTAB_GLOBAL_WAVES : 4) k_postpass_tab(GeoacDevParams P, int rows){
     constexpr int PW = EQ::PW, R = GEOAC_PP_ROWS;
     const size_t np = (size_t)P.n_pad;
@@ -2278,10 +2278,35 @@ __global__ void __launch_bounds__(256, EQ::PW == 6 ? GEOAC_PPTAB_GLOBAL_WAVES : 
             EQ::pp_geom(P, aux, A, B, G, ref);
             const double xe = clampq(G.x, P.x_min, P.x_max);
             if(!((xe >= rec[0]) & (xe <= rec[1]))){               // (also the first segment: rec[0] > rec[1])
-                k = seg_find(P.seg, P.nseg, xe, k < 0 ? (int)((xe - P.x_min) * P.seg_per_x) : k);
-                const double* p = P.seg + (size_t)k * GEOAC_SEGW;
-                #pragma unroll
-                for(int c = 0; c < GEOAC_SEGW; c++) rec[c] = p[c];
+                if constexpr (ONETRIP){   // (GeoacDevParams::pp_onetrip picks the instantiation)
+                    // ONE trip to memory instead of five dependent ones (the walk's node reads, the record, the table entry): the neighbour the midpoint
+                    // left towards (first segment: the guess by multiplication) is almost always the answer of seg_find, so its record AND its table
+                    // entry are fetched together and the walk runs only if the record does not hold xe (then from there: the same k, the same bits).
+                    // For the fans that fill the chip (config 3: 375 -> 357 ms per pass).  Hybrid fans keep the slow form below: their post-pass is
+                    // hidden either way, and the faster it runs beside the RK4 launches the slower THOSE run (metric fan: post-pass 133 -> 108 ms,
+                    // RK4 launch 13.38 -> 13.71 ms, pass 123.4 -> 126.4 ms, A/B in turn on one box)
+                    const int kg = k < 0 ? (int)((xe - P.x_min) * P.seg_per_x) : (xe > rec[1] ? k + 1 : k - 1);
+                    const int kn = kg < 0 ? 0 : (kg > P.nseg - 1 ? P.nseg - 1 : kg);
+                    const int eg = G.x < P.x_min ? P.nseg : (G.x > P.x_max ? P.nseg + 1 : kn);
+                    const double* p = P.seg + (size_t)kn * GEOAC_SEGW;
+                    const double* q = P.atab + (size_t)eg * GEOAC_ATABW;
+                    #pragma unroll
+                    for(int c = 0; c < GEOAC_SEGW; c++) rec[c] = p[c];
+                    #pragma unroll
+                    for(int c = 0; c < 19; c++) tb[c] = q[c];
+                    ent = eg; k = kn;
+                    if(__builtin_expect(!(((xe >= rec[0]) | (kn == 0)) & ((xe <= rec[1]) | (kn == P.nseg - 1))), 0)){
+                        k = seg_find(P.seg, P.nseg, xe, kn);
+                        const double* p2 = P.seg + (size_t)k * GEOAC_SEGW;
+                        #pragma unroll
+                        for(int c = 0; c < GEOAC_SEGW; c++) rec[c] = p2[c];
+                    }
+                } else {
+                    k = seg_find(P.seg, P.nseg, xe, k < 0 ? (int)((xe - P.x_min) * P.seg_per_x) : k);
+                    const double* p = P.seg + (size_t)k * GEOAC_SEGW;
+                    #pragma unroll
+                    for(int c = 0; c < GEOAC_SEGW; c++) rec[c] = p[c];
+                }
             }
             double t; bool out;
             const int e = atab_locate(P, G.x, xe, k, rec[0], t, out);
@@ -2786,34 +2811,32 @@ extern "C" hipError_t geoac_launch_postpass_tab(const GeoacDevParams* P, int row
     // or four waves per SIMD: right for a fan whose RK4 launches fill the chip (config 3: +11 %), wrong for the fans whose time is the serial chain of
     // one ray (GeoAc3D 360 x 90: +6 % per pass beside the RK4 waves, +2.5 % at full occupancy on the free CUs, 0 at one wave per SIMD there)
     const unsigned pad = (unsigned)P->pp_lds_pad;
+    const int v = (P->eqset * 2 + (P->calc_amp ? 1 : 0)) * 2 + (P->pp_onetrip ? 1 : 0);
+    void (*f)(GeoacDevParams, int) = nullptr;
+    switch(v){
+        case (GEOAC_EQ_GLOBAL * 2 + 1) * 2 + 0: f = k_postpass_tab<EqGlobal<true>, false>; break;
+        case (GEOAC_EQ_GLOBAL * 2 + 1) * 2 + 1: f = k_postpass_tab<EqGlobal<true>, true>; break;
+        case (GEOAC_EQ_GLOBAL * 2 + 0) * 2 + 0: f = k_postpass_tab<EqGlobal<false>, false>; break;
+        case (GEOAC_EQ_GLOBAL * 2 + 0) * 2 + 1: f = k_postpass_tab<EqGlobal<false>, true>; break;
+        case (GEOAC_EQ_3D * 2 + 1) * 2 + 0:     f = k_postpass_tab<Eq3D<true>, false>; break;
+        case (GEOAC_EQ_3D * 2 + 1) * 2 + 1:     f = k_postpass_tab<Eq3D<true>, true>; break;
+        case (GEOAC_EQ_3D * 2 + 0) * 2 + 0:     f = k_postpass_tab<Eq3D<false>, false>; break;
+        case (GEOAC_EQ_3D * 2 + 0) * 2 + 1:     f = k_postpass_tab<Eq3D<false>, true>; break;
+        case (GEOAC_EQ_2D * 2 + 1) * 2 + 0:     f = k_postpass_tab<Eq2D<true>, false>; break;
+        case (GEOAC_EQ_2D * 2 + 1) * 2 + 1:     f = k_postpass_tab<Eq2D<true>, true>; break;
+        case (GEOAC_EQ_2D * 2 + 0) * 2 + 0:     f = k_postpass_tab<Eq2D<false>, false>; break;
+        case (GEOAC_EQ_2D * 2 + 0) * 2 + 1:     f = k_postpass_tab<Eq2D<false>, true>; break;
+        default: return hipErrorNotSupported;
+    }
     if(pad > 65536u){
-        static bool raised[6] = { false, false, false, false, false, false };
-        const int v = P->eqset * 2 + (P->calc_amp ? 1 : 0);
-        const void* f = nullptr;
-        switch(v){
-            case GEOAC_EQ_GLOBAL * 2 + 1: f = (const void*)k_postpass_tab<EqGlobal<true>>; break;
-            case GEOAC_EQ_GLOBAL * 2 + 0: f = (const void*)k_postpass_tab<EqGlobal<false>>; break;
-            case GEOAC_EQ_3D * 2 + 1:     f = (const void*)k_postpass_tab<Eq3D<true>>; break;
-            case GEOAC_EQ_3D * 2 + 0:     f = (const void*)k_postpass_tab<Eq3D<false>>; break;
-            case GEOAC_EQ_2D * 2 + 1:     f = (const void*)k_postpass_tab<Eq2D<true>>; break;
-            case GEOAC_EQ_2D * 2 + 0:     f = (const void*)k_postpass_tab<Eq2D<false>>; break;
-            default: break;
-        }
-        if(f && v >= 0 && v < 6 && !raised[v]){
-            hipError_t err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        static bool raised[32] = {};
+        if(v >= 0 && v < 32 && !raised[v]){
+            hipError_t err = hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if(err != hipSuccess) return err;
             raised[v] = true;
         }
     }
-    switch(P->eqset * 2 + (P->calc_amp ? 1 : 0)){
-        case GEOAC_EQ_GLOBAL * 2 + 1: hipLaunchKernelGGL(k_postpass_tab<EqGlobal<true>>, g, b, pad, s, *P, rows); break;
-        case GEOAC_EQ_GLOBAL * 2 + 0: hipLaunchKernelGGL(k_postpass_tab<EqGlobal<false>>, g, b, pad, s, *P, rows); break;
-        case GEOAC_EQ_3D * 2 + 1:     hipLaunchKernelGGL(k_postpass_tab<Eq3D<true>>, g, b, pad, s, *P, rows); break;
-        case GEOAC_EQ_3D * 2 + 0:     hipLaunchKernelGGL(k_postpass_tab<Eq3D<false>>, g, b, pad, s, *P, rows); break;
-        case GEOAC_EQ_2D * 2 + 1:     hipLaunchKernelGGL(k_postpass_tab<Eq2D<true>>, g, b, pad, s, *P, rows); break;
-        case GEOAC_EQ_2D * 2 + 0:     hipLaunchKernelGGL(k_postpass_tab<Eq2D<false>>, g, b, pad, s, *P, rows); break;
-        default: return hipErrorNotSupported;
-    }
+    hipLaunchKernelGGL(f, g, b, pad, s, *P, rows);
     hipError_t e = hipGetLastError();
     if(e != hipSuccess) return e;
     // the listed segments, exactly (the list's counter was zeroed on this stream before the launch above: geoac_api.cpp)

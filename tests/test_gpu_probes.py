@@ -241,3 +241,21 @@ def test_segments_the_table_does_not_serve_go_through_the_fix_up_pass(cap, monke
     assert np.abs(at1 / at0 - 1).max() <= 1e-10
     np.testing.assert_array_equal(r1[:, :, G.REC["TTIME"]], r0[:, :, G.REC["TTIME"]]) if info["entries"] == 0 else None
 
+
+
+@pytest.mark.parametrize("eq", ["global", "3d"])
+def test_one_trip_and_walking_forms_of_the_table_post_pass_give_the_same_bits(eq, monkeypatch):
+    """k_postpass_tab finds the spline segment of a path segment's midpoint either by the hinted walk (hybrid fans) or by fetching the neighbouring
+    record and table entry in one trip and walking only when that record does not hold the midpoint (PP_ONETRIP; default on the fans that fill
+    the chip): the same segment, the same records bit for bit - steep rays included (up to 85 deg: a node every two or three steps)"""
+    import geoac_amd as G
+    th, ph = G.fan_enumerate(theta_min=1.0, theta_max=85.0, theta_step=2.0, phi_min=-90.0, phi_max=90.0, phi_step=45.0)
+    EQ = H.EQ_GLOBAL if eq == "global" else H.EQ_3D
+    out = {}
+    for v in ("0", "1"):
+        monkeypatch.setitem(OPT, "PP_ONETRIP", v)
+        ctx = G.FanContext(EQ, device=0); ctx.load_met(H.TOYATMO); ctx.set_params(bounces=2, calc_amp=1, mode=0)
+        r, s = ctx.run(th, ph); out[v] = (r.copy(), s, ctx.abs_table_info()); ctx.close()
+    assert out["0"][2]["entries"] > 0 and out["1"][2]["entries"] > 0
+    assert out["0"][1] == out["1"][1]
+    assert np.array_equal(out["0"][0].view(np.uint64), out["1"][0].view(np.uint64))
