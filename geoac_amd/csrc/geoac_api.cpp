@@ -8,6 +8,7 @@
 #include <string.h>
 #include <ctype.h>
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -44,12 +45,33 @@ namespace {
 const double kPi = 3.141592653589793238462643;
 const double kGam = 1.4, kRgas = 287.05, kGamR = 0.00040187;
 
+// A buffer that has to grow is not freed on the spot when it is small: hipFree waits for the whole device, i.e. for the launches of the OTHER
+// contexts of an eigenray search round (a 4-ray refinement group measured at 324 instead of 190 ms when its context's buffers had to grow
+// beside the other groups' launches).  The old allocation goes to a process-wide list that is emptied when a context is destroyed or when the
+// list holds more than 256 MB.  Large buffers (the path chunks of a big fan) are freed at once, as before: their memory is needed.
+struct DeferredFrees {
+    std::mutex mu; std::vector<void*> ptrs; size_t bytes = 0;
+    void add(void* p, size_t n){
+        std::vector<void*> now;
+        {   std::lock_guard<std::mutex> lk(mu);
+            ptrs.push_back(p); bytes += n;
+            if(bytes > (256ull << 20)){ now.swap(ptrs); bytes = 0; } }
+        for(void* q : now) hipFree(q);
+    }
+    void drain(){
+        std::vector<void*> now;
+        {   std::lock_guard<std::mutex> lk(mu); now.swap(ptrs); bytes = 0; }
+        for(void* q : now) hipFree(q);
+    }
+};
+DeferredFrees g_deferred;
+
 struct DevBuf {
     void* p = nullptr; size_t bytes = 0;
     bool owned = true;                 // false: a view of another context's buffer (geoac_clone: the atmosphere tables are shared, read-only)
     hipError_t ensure(size_t need){
         if(need <= bytes && p) return hipSuccess;
-        if(p && owned) hipFree(p);
+        if(p && owned){ if(bytes <= (32ull << 20)) g_deferred.add(p, bytes); else hipFree(p); }
         p = nullptr; bytes = 0; owned = true;
         hipError_t e = hipMalloc(&p, need);
         if(e == hipSuccess) bytes = need;
@@ -306,6 +328,7 @@ int geoac_destroy(geoac_ctx* ctx){
                        &ctx->ev_amp[0], &ctx->ev_amp[1], &ctx->ev_amp[2], &ctx->nev[0], &ctx->nev[1], &ctx->nev[2], &ctx->smp_out,
                        &ctx->d_gx, &ctx->d_gy, &ctx->d_gz, &ctx->d_gtab, &ctx->d_gtab8, &ctx->d_consts, &ctx->sub_flags, &ctx->colmap[0], &ctx->colmap[1], &ctx->colmap[2], &ctx->ncols, &ctx->atab, &ctx->ppfix };
     for(DevBuf* b : bufs) b->release();
+    g_deferred.drain();
     if(ctx->h_counters) hipHostFree(ctx->h_counters);
     if(ctx->ev0) hipEventDestroy(ctx->ev0);
     if(ctx->ev1) hipEventDestroy(ctx->ev1);

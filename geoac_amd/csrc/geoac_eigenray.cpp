@@ -794,7 +794,29 @@ static int serve_group(geoac_ctx* ctx, const geoac_params& base, const std::tupl
 // context of its own (the caller's, and clones of it that share its atmosphere tables: geoac_clone), from a host thread of its own.  A
 // group of a search round is a handful of rays - a few waves on a chip of 1 024 wave slots - and lasts as long as its longest ray, so the
 // groups of a round overlap almost completely: the round costs its longest group, not the sum of them.
-static int serve(std::vector<geoac_ctx*>& ctxs, const geoac_params& base, std::vector<Request*>& reqs, geoac_eig_result* res, bool trace_groups = false){
+static int serve(std::vector<geoac_ctx*>& ctxs, const geoac_params& base, std::vector<Request*>& reqs, geoac_eig_result* res, bool trace_groups = false, bool merge = true){
+    // Requests of one round that launch the SAME rays and differ only in the bounce count are integrated once, with the largest count: a ray with b
+    // bounces goes through the states of the ray with fewer, its records of legs 0 .. a ARE the a-bounce ray's (bit for bit:
+    // test_leg_records_do_not_depend_on_the_number_of_bounces).  The first inclination scans of a search are such requests - one per bounce count
+    // over the same inclinations towards the same receiver (GeoAc.Eigenray.Global.cpp:46-70 runs them one after the other): config 5's first round
+    // is one fan instead of three.  Arrivals only (mode 0: sample rows are per launch).
+    std::vector<std::pair<Request*, Request*>> riders;              // (request, the request whose launch carries its rays)
+    {
+        std::vector<Request*> lead;                                // per distinct (calc_amp, ray list): the request with the most bounces so far
+        std::vector<Request*> kept;
+        for(Request* r : reqs){
+            if(r->mode != 0 || !merge){ kept.push_back(r); continue; }
+            Request** slot = nullptr;
+            for(Request*& l : lead) if(l->calc_amp == r->calc_amp && l->th == r->th && l->ph == r->ph){ slot = &l; break; }
+            if(!slot){ lead.push_back(r); continue; }
+            if(r->bounces > (*slot)->bounces){ riders.emplace_back(*slot, nullptr); *slot = r; }
+            else riders.emplace_back(r, nullptr);
+        }
+        for(auto& rd : riders)
+            for(Request* l : lead) if(l->calc_amp == rd.first->calc_amp && l->th == rd.first->th && l->ph == rd.first->ph){ rd.second = l; break; }
+        for(Request* l : lead) kept.push_back(l);
+        reqs.swap(kept);                                           // (the riders are filled in below, after the launches)
+    }
     std::map<std::tuple<int, int, int>, std::vector<Request*>> groups;
     for(Request* r : reqs) groups[std::make_tuple(r->bounces, r->calc_amp, r->mode)].push_back(r);
     while(ctxs.size() < groups.size() && ctxs.size() < 8){
@@ -803,6 +825,9 @@ static int serve(std::vector<geoac_ctx*>& ctxs, const geoac_params& base, std::v
         if(rc) break;                                              // (no clone: the groups take turns on the contexts there are)
         ctxs.push_back(c);
     }
+    // (a HOME context per kind of group - so that a context's buffers, which only grow, and grow by hipFree + hipMalloc, fit its kind of fan - was
+    //  measured: nine kinds for bounces 0 .. 2, nine contexts to create and warm instead of five or six: config 5 1.75 -> 2.13 s.  Groups go to the
+    //  first free context.)
     std::vector<std::pair<const std::tuple<int, int, int>*, std::vector<Request*>*>> work;
     for(auto& g : groups) work.emplace_back(&g.first, &g.second);
     std::atomic<size_t> next{0};
@@ -827,6 +852,16 @@ static int serve(std::vector<geoac_ctx*>& ctxs, const geoac_params& base, std::v
     worker(ctxs[0]);
     for(auto& t : th) t.join();
     res->stats[4] += round_crit;
+    if(!first_rc.load()){
+        for(auto& rd : riders){                                    // legs 0 .. a of the carrier's records
+            Request* r = rd.first; const Request* c = rd.second;
+            const size_t n = r->th.size(), la = (size_t)r->bounces + 1, lc = (size_t)c->bounces + 1;
+            r->rec.resize(n * la * GEOAC_REC_STRIDE);
+            for(size_t i = 0; i < n; i++)
+                std::copy(c->rec.begin() + (i * lc) * GEOAC_REC_STRIDE, c->rec.begin() + (i * lc + la) * GEOAC_REC_STRIDE, r->rec.begin() + (i * la) * GEOAC_REC_STRIDE);
+            r->smp.clear();
+        }
+    }
     return first_rc.load();
 }
 
@@ -883,6 +918,8 @@ static int run_all(geoac_ctx* ctx, const geoac_eig_params* ep, int n_rcvr, const
     int err = 0;
     const char* dbg = getenv("GEOAC_DEBUG_ENV");
     const bool trace = dbg && dbg[0] == '1' && getenv("GEOAC_EIG_TRACE") != nullptr;
+    const char* mg = (dbg && dbg[0] == '1') ? getenv("GEOAC_EIG_MERGE") : nullptr;      // (A/B: 0 = every request its own rays)
+    const bool merge = !(mg && mg[0] == '0');
     while(!active.empty() && !err){
         std::vector<Request*> batch;
         std::vector<Task*> waiting;
@@ -902,7 +939,7 @@ static int run_all(geoac_ctx* ctx, const geoac_eig_params* ep, int n_rcvr, const
                     (unsigned long long)res->stats[3], active.size(), scans, scan_rays, singles, newton, finals);
         }
         const auto t0 = std::chrono::steady_clock::now();
-        err = serve(ctxs, base, batch, res, trace);
+        err = serve(ctxs, base, batch, res, trace, merge);
         if(trace) fprintf(stderr, "[eig round %llu] integrated in %.1f ms\n", (unsigned long long)res->stats[3], std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         res->stats[3] += 1;
         active.swap(waiting);

@@ -131,3 +131,18 @@ def test_sixteen_lane_scan_kernel_gives_the_four_lane_kernels_bits(gold, grid, m
             got[hx] = ctx.run(gold["theta"][:n], gold["phi"][:n])
         assert got["1"][1] == got["0"][1] and np.array_equal(got["1"][0], got["0"][0])
 
+
+
+@pytest.mark.parametrize("amp", [0, 1])
+def test_leg_records_do_not_depend_on_the_number_of_bounces(grid, amp):
+    """A ray launched with b bounces goes through the states of the same ray launched with fewer: its records of legs 0 .. a are, bit for bit, the
+    records of the fan with a bounces (a broken ray's later legs are empty either way).  The eigenray scheduler relies on it: inclination scans
+    of one round that differ only in the bounce count are integrated once, with the largest (geoac_eigenray.cpp, serve)."""
+    th = np.linspace(1.0, 40.0, 79); ph = np.full_like(th, -77.0)
+    recs = {}
+    for b in (0, 1, 2):
+        ctx = _ctx(grid, bounces=b, calc_amp=amp, mode=0, src=(0.0, 31.0, 0.0))
+        recs[b] = ctx.run(th, ph)[0].copy(); ctx.close()
+    for a in (0, 1):
+        for b in range(a + 1, 3):
+            assert np.array_equal(recs[b][:, :a + 1].view(np.uint64), recs[a].view(np.uint64)), (a, b)
