@@ -54,11 +54,15 @@ def gather_eigenrays(eig_local, rcvr_index_local, group=None):
     geoac_eig_search; `rcvr_index_local` (the array shard_receivers returned) maps it back to the global one."""
     import torch
     import torch.distributed as dist
-    world = dist.get_world_size(group)
     dev = eig_local.device
     eig = eig_local.clone()
     if eig.shape[0]:
         eig[:, 0] = torch.as_tensor(np.asarray(rcvr_index_local), dtype=eig.dtype, device=dev)[eig[:, 0].long()]
+    if not (dist.is_available() and dist.is_initialized()):          # one process, no group: the local table is the whole one
+        if eig.shape[0]:
+            eig = eig[torch.argsort(eig[:, 0] * 1e6 + eig[:, 1])]
+        return eig
+    world = dist.get_world_size(group)
     counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(counts, torch.tensor([eig.shape[0]], dtype=torch.int64, device=dev), group=group)
     counts = [int(c.item()) for c in counts]

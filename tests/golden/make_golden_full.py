@@ -139,6 +139,28 @@ def cfg4_shares(pool):
     print(f"cfg4 shares 1..7: {sum(len(out[f'sel{r}']) for r in range(1, 8))} rays -> {path} ({os.path.getsize(path) // 1024} KiB)", flush=True)
 
 
+def cfg4_lattice(pool):
+    """config 4, the WHOLE 999 az x 1000 incl fan (what one GPU integrates at N = 1 and the eight ranks together at N = 8): a lattice of
+    100 azimuths x 100 inclinations = 10 000 rays, azimuth indices 5, 15, ..., 995 (every residue mod 8 = every rank's share) x inclination
+    indices 7, 17, ..., 997; none of them is a ray of full_cfg4.npz or full_cfg4_shares.npz"""
+    import tempfile
+    import rngdep_data as RD
+    grid = RD.write_grid(os.path.join(tempfile.gettempdir(), "gf"), thin=1)
+    cfgkw = dict(bounces=1, calc_amp=True, mode=0, src=(0.0, 0.0, 0.0))
+    th, ph = H.fan_angles(theta_min=0.05, theta_max=50.0, theta_step=0.05, phi_min=-180.0, phi_max=-180.0 + 999 * 0.36, phi_step=0.36)
+    n_th = int(np.sum(ph == ph[0])); n_ph = len(th) // n_th
+    assert n_th * n_ph == len(th) and n_ph == 999 and n_th == 1000, (n_th, n_ph)
+    sel = (np.arange(5, n_ph, 10)[:, None] * n_th + np.arange(7, n_th, 10)[None, :]).ravel()
+    assert len(sel) == 10000
+    jobs = [("cfg4", H.EQ_3D_RNGDEP, tuple(grid), cfgkw, th[c], ph[c]) for c in np.array_split(sel, len(sel) // 10)]
+    res = run_jobs(pool, jobs, "cfg4 lattice")
+    steps = np.concatenate([r[0][0] for r in res]); flags = np.concatenate([r[0][1] for r in res]); vals = np.concatenate([r[0][2] for r in res])
+    path = os.path.join(OUT, "full_cfg4_lattice.npz")
+    np.savez_compressed(path, n_rays=len(th), n_theta=n_th, n_phi=n_ph, sel=sel.astype(np.int64), theta=th[sel], phi=ph[sel], bounces=1,
+                        steps=steps, flags=flags, vals=vals, val_fields=np.array(VAL_FIELDS), total_steps=np.int64(steps.sum()))
+    print(f"cfg4 lattice: {len(sel)} of {len(th)} rays, {int(steps.sum())} ray-steps -> {path} ({os.path.getsize(path) // 1024} KiB)", flush=True)
+
+
 SENS_EPS = 1e-12
 
 
@@ -178,6 +200,33 @@ def sens(pool, name):
           f"{int(np.isinf(sv).sum())} change a step count -> {path}", flush=True)
 
 
+def exempt(listfile):
+    """third pass, no integration: name the arrivals whose amplitude no other arithmetic can match to 1e-6.  `listfile` (tools/amp_loose.py on
+    the GPU box) lists per fixture the arrivals where the HIP path's amplitude is beyond 1e-6 of the reference's: (row of the value table, leg,
+    error).  An arrival is admitted into the fixture's `amp_exempt` ONLY on the reference's own evidence - 4 x its amp_sens (running maximum
+    over the ray's legs so far; `sens` pass above: the compiled reference against itself under a 1e-12 change of theta) must cover the error -
+    and the list may not exceed max(3, 1e-4 x arrivals).  tests/parity.py then fails on any loose arrival that is not named here."""
+    import json
+    lists = json.load(open(listfile))
+    for name in ("metric", "cfg2", "cfg3", "cfg4"):
+        path = os.path.join(OUT, f"full_{name}.npz")
+        g = dict(np.load(path))
+        if "amp_sens" not in g:
+            continue
+        sens = np.maximum.accumulate(np.asarray(g["amp_sens"], dtype=np.float64), axis=1)
+        fl = g["flags"][g["vals_idx"]] if "vals_idx" in g else g["flags"]
+        n_arr = int(((fl & 1) > 0).sum())
+        rows = []
+        for row, leg, err, _ in lists.get(name, []):
+            assert np.isfinite(sens[row, leg]) and 1e-6 < err <= 4.0 * sens[row, leg], \
+                f"{name}: arrival (row {row}, leg {leg}) is off by {err:.3e} but the reference's own sensitivity only covers {4.0 * sens[row, leg]:.3e}: not an exemption, a bug"
+            rows.append((row, leg))
+        assert len(rows) <= max(3, 1e-4 * n_arr), f"{name}: {len(rows)} loose arrivals, more than max(3, 1e-4 x {n_arr})"
+        g["amp_exempt"] = np.array(sorted(rows), dtype=np.int32).reshape(-1, 2)
+        np.savez_compressed(path, **g)
+        print(f"{name}: amp_exempt = {g['amp_exempt'].tolist()} ({len(rows)} of {n_arr} arrivals; cap {max(3, int(1e-4 * n_arr))}) -> {path}", flush=True)
+
+
 def ring_receivers(n=64, every=8, lat0=31.0, lon0=0.0, radius_deg=2.5):
     """config 5: n receivers on a ring of 2.5 degrees of arc around the source; rank 0 of an 8-GPU run searches every 8th
     (geoac_amd.sharding.shard_receivers: round robin)"""
@@ -189,7 +238,7 @@ def _run_cfg5(job):
     import shutil, subprocess, tempfile
     import rngdep_data as RD
     k, lat, lon = job
-    out = os.path.join(OUT, "cli", f"cfg5_r{k}")
+    out = os.path.join(OUT, "cli", f"cfg5_{k}" if isinstance(k, str) else f"cfg5_r{k}")
     shutil.rmtree(out, ignore_errors=True); os.makedirs(out)
     args = [f"lat_src=31.0", "lon_src=0.0", f"lat_rcvr={lat!r}", f"lon_rcvr={lon!r}", "bnc_min=0", "bnc_max=2", "verbose=True"]
     with tempfile.TemporaryDirectory() as td:
@@ -225,18 +274,34 @@ def cfg5_ranks(nproc):
             print(f"  cfg5 receiver {k} (ring position {k - 7}): {dt:.0f} s, {files}", flush=True)
 
 
+def cfg5_rest(nproc):
+    """config 5, every ring position the two modes above leave out (8 < p < 64, p not a multiple of 8): the other 49 receivers of the
+    64-ring, kept as cfg5_p<ring position>.  With them every receiver of the ring is pinned to the reference binary."""
+    rc = ring_receivers(every=1)
+    todo = [p for p in range(8, 64) if p % 8 and not os.path.exists(os.path.join(OUT, "cli", f"cfg5_p{p}", "ARGS"))]
+    with mp.get_context("fork").Pool(nproc) as pool:
+        for k, dt, files in pool.imap_unordered(_run_cfg5, [(f"p{p}", float(rc[p, 0]), float(rc[p, 1])) for p in todo]):
+            print(f"  cfg5 ring position {k}: {dt:.0f} s, {files}", flush=True)
+
+
 def main():
     args = sys.argv[1:]
     nproc = 6
     if "-j" in args:
         i = args.index("-j"); nproc = int(args[i + 1]); del args[i:i + 2]
     which = args or ["metric", "cfg2", "cfg4", "cfg3"]
+    if which[0] == "exempt":
+        exempt(which[1])
+        return
     for w in which:
         if w == "cfg5":
             cfg5(nproc)
             continue
         if w == "cfg5_ranks":
             cfg5_ranks(nproc)
+            continue
+        if w == "cfg5_rest":
+            cfg5_rest(nproc)
             continue
         # a fresh pool per configuration: one equation set / atmosphere per reference process
         with mp.get_context("fork").Pool(nproc) as pool:
@@ -246,6 +311,8 @@ def main():
                 cfg4(pool)
             elif w == "cfg4_shares":
                 cfg4_shares(pool)
+            elif w == "cfg4_lattice":
+                cfg4_lattice(pool)
             else:
                 stratified(pool, w)
 

@@ -35,10 +35,11 @@ def _state_floor(E, hidx):
     return f
 
 
-def compare_compact(got_rec, gold, idx=None, rtol=RTOL, check_amp=True):
+def compare_compact(got_rec, gold, idx=None, rtol=RTOL, check_amp=True, collect_loose=False):
     """HIP record table [n][legs][32] against a compact full-size fixture (tests/golden/make_golden_full.py): steps and flags of
     every (ray, leg) exact; TTIME, ATTEN, TURN, INCL, BACKAZ, AMP, RANGE within rtol (rules of compare_records) for the rays the
-    fixture keeps values for.  idx: ray indices of the fan the fixture's rows correspond to (None: all rays in order)."""
+    fixture keeps values for.  idx: ray indices of the fan the fixture's rows correspond to (None: all rays in order).
+    collect_loose: only list the amplitudes beyond rtol (out["AMP_exempt"]) instead of judging them - make_golden_full.py `exempt`."""
     rec = got_rec if idx is None else got_rec[idx]
     steps = rec[..., REC["STEPS"]].astype(np.int64)
     flags = (rec[..., REC["VALID"]] > 0).astype(np.int8) | ((rec[..., REC["BROKE"]] > 0).astype(np.int8) << 1)
@@ -62,20 +63,31 @@ def compare_compact(got_rec, gold, idx=None, rtol=RTOL, check_amp=True):
                 continue
             m = valid; e = _rel(g[m], w[m], 1e-300)
             if "amp_sens" in gold:
-                # conditioning of the reference's own amplitude (make_golden_full.py, `sens` pass): where the compiled reference
-                # itself moves by more than 2.5e-7 when theta changes in its 12th digit, the bound is 4 x that movement
-                # (the response to one perturbation is one sample of a ray's rounding noise, and a later leg inherits the conditioning of the
-                # legs before it: the running maximum over the legs of the ray so far is the estimate used)
+                # Conditioning of the reference's own amplitude (make_golden_full.py, `sens` pass): a handful of arrivals (rays trapped in a
+                # duct, Jacobian 1e3-1e4 x the typical one) answer a 1e-14 change of the launch inclination with a 1e-6 change of amplitude IN
+                # THE COMPILED REFERENCE - no arithmetic but its own bit pattern matches those to 1e-6.  The rule: AMP within 1e-6, except for
+                # the arrivals NAMED in the fixture (`amp_exempt`: row of the fixture's value table, leg - written by make_golden_full.py
+                # `exempt`, which admits an arrival only if the reference's own sensitivity bound covers it, and at most max(3, 1e-4 N) of
+                # them); a named arrival is held to 4 x its sensitivity (the running maximum over the legs of the ray so far: a later leg
+                # inherits the conditioning of the legs before it).  A loose arrival that is not named fails.
                 sens = np.maximum.accumulate(np.asarray(gold["amp_sens"], dtype=np.float64), axis=1)[m]
                 # a perturbation that changed a step count leaves no bound (inf): such an arrival is held to rtol like any other
-                assert not (np.isinf(sens) & (e > rtol)).any(), "AMP: an arrival whose reference sensitivity is unbounded (knife-edge ray) is beyond 1e-6"
                 sens = np.where(np.isinf(sens), 0.0, sens)
+                rows, legs = np.nonzero(m)
                 loose = e > rtol
+                named = np.zeros(e.size, dtype=bool)
+                ex = np.asarray(gold["amp_exempt"]).reshape(-1, 2) if "amp_exempt" in gold else np.zeros((0, 2), dtype=np.int64)
+                assert len(ex) <= max(3, 1e-4 * e.size), f"AMP: the fixture names {len(ex)} exempt arrivals, more than max(3, 1e-4 x {e.size})"
+                if len(ex):
+                    named = np.isin(rows.astype(np.int64) * 64 + legs, ex[:, 0].astype(np.int64) * 64 + ex[:, 1])
                 out["AMP_beyond_rtol"] = int(loose.sum())
                 out["AMP_beyond_rtol_max"] = float(e[loose].max()) if loose.any() else 0.0
-                assert (e <= np.maximum(rtol, 4.0 * sens)).all(), \
-                    f"AMP: {int((e > np.maximum(rtol, 4.0 * sens)).sum())} arrivals beyond max(1e-6, 4 x reference sensitivity); worst {e.max():.3e}"
-                assert loose.sum() <= max(3, 1e-3 * e.size), f"AMP: {int(loose.sum())} of {e.size} arrivals beyond {rtol:g}"
+                out["AMP_exempt"] = [[int(rows[i]), int(legs[i]), float(e[i]), float(4.0 * sens[i])] for i in np.flatnonzero(loose)]     # row, leg, error, bound
+                if not collect_loose:
+                    unnamed = loose & ~named
+                    assert not unnamed.any(), (f"AMP: {int(unnamed.sum())} arrivals beyond {rtol:g} that the fixture does not name as ill-conditioned in the "
+                                               f"reference; first (row, leg, err): {[(int(rows[i]), int(legs[i]), float(e[i])) for i in np.flatnonzero(unnamed)[:5]]}")
+                    assert (e[loose] <= 4.0 * sens[loose]).all(), f"AMP: a named arrival is beyond 4 x the reference's own sensitivity; worst {e.max():.3e}"
                 out[f] = float(e[~loose].max()) if (~loose).any() else 0.0
                 continue
         else:
@@ -137,3 +149,109 @@ def max_rel_errors(got, want, E, hidx="auto"):
         scale = _state_scale(st_w, want, valid, hidx)
         out["STATE"] = float((np.abs(st_g - st_w) / np.maximum(np.abs(st_w), _state_floor(E, hidx) * scale)).max())
     return out
+
+
+def fan_properties(rec, steps, E, nu_slice, c_ratio):
+    """size-independent properties of a fan's record table (no reference needed): count bookkeeping - the legs' step counts add up to the
+    device counter, a leg that broke has no later legs, legs run in order, a row is written exactly for the legs that ran and did not
+    break -, cumulative travel time / attenuation non-decreasing over a ray's legs, and the eikonal (Hamiltonian) residual at EVERY
+    arrival: |nu| = c0 / c(arrival point) (winds are tapered to 0 at the ground); c_ratio: that quotient, a scalar or one value per
+    arrival in record order.  Returns the number of arrivals."""
+    valid = rec[..., REC["VALID"]] > 0
+    ran = rec[..., REC["STEPS"]] > 0
+    broke = rec[..., REC["BROKE"]] > 0
+    assert int(rec[..., REC["STEPS"]].sum()) == steps
+    assert not (broke[:, :-1] & ran[:, 1:]).any()
+    assert (ran[:, 1:] <= ran[:, :-1]).all()
+    assert (valid == (ran & ~broke)).all()
+    tt = rec[..., REC["TTIME"]]; at = rec[..., REC["ATTEN"]]
+    assert ((tt[:, 1:] >= tt[:, :-1]) | ~ran[:, 1:]).all()
+    assert ((at[:, 1:] >= at[:, :-1]) | ~ran[:, 1:]).all()
+    st = rec[..., REC["STATE"]:REC["STATE"] + E][valid]
+    numag = np.sqrt((st[:, nu_slice] ** 2).sum(axis=1))
+    assert np.abs(numag / c_ratio - 1.0).max() < 1e-4          # RK4 truncation error of the reference scheme itself (~1e-6), not a parity bound
+    return int(valid.sum())
+
+
+# ---------------- eigenray searches (config 5): the reference binary's logs and result files ----------------
+def ring_receivers(n=64, lat0=31.0, lon0=0.0, radius_deg=2.5):
+    """config 5: n receivers [lat, lon] on a ring of 2.5 degrees of arc around the source, by ring position"""
+    az = np.arange(n) * (2.0 * np.pi / n)
+    return np.stack([lat0 + radius_deg * np.cos(az), lon0 + radius_deg * np.sin(az) / np.cos(np.radians(lat0))], axis=1)
+
+
+def ring_golden_name(p):
+    """fixture directory (tests/golden/cli/) of ring position p of the 64-ring: the rank-0 receivers of the 8-GPU run were made first
+    (cfg5_r0..r7 = positions 0, 8, ..., 56), then one receiver of each other rank (cfg5_r8..r14 = positions 1..7), then the rest by position"""
+    if p % 8 == 0:
+        return f"cfg5_r{p // 8}"
+    if p < 8:
+        return f"cfg5_r{7 + p}"
+    return f"cfg5_p{p}"
+
+
+def parse_eig_results(path):
+    """[{bounces, theta, phi, ...}] from a reference <title>_results.dat of an eigenray search"""
+    import re
+    out = []
+    for block in open(path).read().split("Eigenray-")[1:]:
+        nums = lambda key: [float(x) for x in re.findall(r"[-+]?\d+\.?\d*(?:[eE][-+]?\d+)?", block.split(key)[1].split("\n")[0])]      # noqa: E731
+        out.append(dict(bounces=int(re.search(r"(\d+) bounce", block).group(1)),
+                        theta=nums("theta, phi =")[0], phi=nums("theta, phi =")[1], ttime=nums("Travel Time =")[0], celerity=nums("Celerity =")[0],
+                        amp=nums("Amplitude (geometric) =")[0], atten=nums("Atmospheric attenuation =")[0], incl=nums("Arrival inclination =")[0],
+                        bearing=nums("Bearing to source =")[0], backaz=nums("Back azimuth of arrival =")[0], azdev=nums("Azimuth deviation =")[0]))
+    return out
+
+
+EIG_COLS = dict(RCVR=0, INDEX=1, BOUNCES=2, THETA=3, PHI=4, TTIME=5, CELERITY=6, AMP_DB=7, ATTEN_DB=8, INCL=9, BEARING=10, BACKAZ=11, AZDEV=12)
+EIG_FIELDS = (("theta", "THETA"), ("phi", "PHI"), ("ttime", "TTIME"), ("celerity", "CELERITY"), ("amp", "AMP_DB"), ("atten", "ATTEN_DB"),
+              ("incl", "INCL"), ("bearing", "BEARING"), ("backaz", "BACKAZ"), ("azdev", "AZDEV"))
+
+
+def compare_eig_rows(got, want, where=""):
+    """eigenray rows of ONE receiver (geoac_eig_fetch layout) against the parsed blocks of the reference's result file: same number of
+    eigenrays, same bounce counts, every printed field to its 8 printed digits"""
+    E = EIG_COLS
+    assert len(got) == len(want), f"{where}: {len(got)} eigenrays vs the reference's {len(want)}"
+    for g, w in zip(got, want):
+        assert int(g[E["BOUNCES"]]) == w["bounces"], f"{where}: bounce count {int(g[E['BOUNCES']])} vs {w['bounces']}"
+        for f, col in EIG_FIELDS:
+            x, y = float(g[E[col]]), w[f]
+            # 8 printed digits; the deviation is a difference of nearly equal bearings: absolute on the scale of a degree
+            assert abs(x - y) <= 2e-7 * max(abs(x), abs(y)) + (2e-6 if f in ("azdev", "phi", "backaz", "bearing") else 1e-12), (where, f, x, y)
+    return len(want)
+
+
+def compare_eig_ring(eig, positions, cli_gold):
+    """a gathered eigenray table (column 0 = ring position) against the reference binary's result files of those ring positions
+    (tests/golden/cli/<ring_golden_name(p)>/g_results.dat).  Returns counts for the bench line; raises on a mismatch."""
+    import os
+    n_ref, checked, missing = 0, 0, []
+    for p in positions:
+        gold = os.path.join(cli_gold, ring_golden_name(int(p)), "g_results.dat")
+        if not os.path.exists(gold):
+            missing.append(int(p))
+            continue
+        n_ref += compare_eig_rows(eig[eig[:, EIG_COLS["RCVR"]] == p], parse_eig_results(gold), where=f"ring position {int(p)}")
+        checked += 1
+    return dict(receivers_checked=checked, eigenrays_matched=n_ref, receivers_without_fixture=missing)
+
+
+def compare_logs(got, want):
+    """an eigenray search's verbose text against the reference binary's, line by line, token by token (numbers to the printed digits)"""
+    gl = [l for l in got.split("\n")]
+    wl = [l for l in want.split("\n")]
+    assert len(gl) == len(wl), f"log: {len(gl)} lines vs {len(wl)}"
+    for i, (g, w) in enumerate(zip(gl, wl)):
+        gt, wt = g.replace("\t", " ").split(" "), w.replace("\t", " ").split(" ")
+        assert len(gt) == len(wt), f"log line {i + 1}: {g!r} vs {w!r}"
+        for a, b in zip(gt, wt):
+            a2, b2 = a.rstrip(",.)").lstrip("(["), b.rstrip(",.)").lstrip("([")
+            if a2 == b2:
+                continue
+            try:
+                x, y = float(a2), float(b2)
+            except ValueError:
+                raise AssertionError(f"log line {i + 1}: {a!r} vs {b!r}")
+            # deviations are differences of nearly equal bearings: compare those on the scale of a degree
+            assert abs(x - y) <= 1.2e-5 * max(abs(x), abs(y)) + 2e-6, f"log line {i + 1}: {a!r} vs {b!r}\n{g}\n{w}"

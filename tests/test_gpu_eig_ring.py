@@ -1,74 +1,107 @@
-"""BASELINE config 5 on the GPU against the reference binary itself: GeoAcGlobal.RngDep -eig_search, bounces 0..2, to the receivers
-rank 0 of an 8-GPU run takes from the 64-receiver ring of 2.5 degrees around the source (every 8th; geoac_amd.sharding.shard_receivers).
-The fixtures (tests/golden/cli/cfg5_r<k>/, tests/golden/make_golden_full.py cfg5) are the reference's verbose iteration log and its
-result files, one process per receiver.  Here the eight searches run as ONE batched geoac_eig_search (the decision rounds of all
-receivers share fan launches): every receiver's log must be the reference's line for line, and its eigenray list the reference's
-(launch angles, travel time, celerity, amplitude, attenuation, arrival angles to their printed 8 digits)."""
+"""BASELINE config 5 on the GPU against the reference binary itself: GeoAcGlobal.RngDep -eig_search, bounces 0..2, to the 64-receiver
+ring of 2.5 degrees around the source.  The fixtures (tests/golden/cli/<parity.ring_golden_name(p)>/, tests/golden/make_golden_full.py
+cfg5 / cfg5_ranks / cfg5_rest) are the reference's verbose iteration log and its result files, one process per receiver - every ring
+position.  Here searches run BATCHED (the decision rounds of all receivers of a geoac_eig_search share fan launches): every receiver's
+log must be the reference's line for line, and its eigenray list the reference's (launch angles, travel time, celerity, amplitude,
+attenuation, arrival angles to their printed 8 digits).
+  * rank0 / ranks1to7: the shares the round-2/3 fixtures were made for (8 and 7 receivers);
+  * the whole ring as ONE search of 64 receivers;
+  * the ring sharded by receiver over two torch.distributed ranks (gloo, both on this GPU): geoac_eig_search per rank on
+    shard_receivers(n, rank, world), gather_eigenrays -> the single-process table, row for row."""
 import os
-import re
+import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
 
 import harness as H
-from test_gpu_eigenray import _compare_logs
+from parity import compare_eig_rows, compare_logs, parse_eig_results, ring_golden_name, ring_receivers
 
 pytestmark = pytest.mark.gpu
 CLI_GOLD = os.path.join(H.GOLDEN_DIR, "cli")
 
 
-def _ring(n=64, every=8, lat0=31.0, lon0=0.0, radius_deg=2.5):
-    az = np.arange(0, n, every) * (2.0 * np.pi / n)
-    return np.stack([lat0 + radius_deg * np.cos(az), lon0 + radius_deg * np.sin(az) / np.cos(np.radians(lat0))], axis=1)
+def _check_receivers(out, positions):
+    """every searched receiver (local index k = ring position positions[k]) against its fixture; returns eigenrays matched"""
+    import geoac_amd as G
+    rc = ring_receivers()
+    n_ref = 0
+    for k, p in enumerate(positions):
+        gold = os.path.join(CLI_GOLD, ring_golden_name(int(p)))
+        # the receiver the fixture was made for (ARGS hold the exact decimal strings the reference parsed)
+        kv = dict(a.split("=") for a in open(os.path.join(gold, "ARGS")).read().split() if "=" in a)
+        assert float(kv["lat_rcvr"]) == rc[p, 0] and float(kv["lon_rcvr"]) == rc[p, 1]
+        compare_logs(out["logs"][k], open(os.path.join(gold, "LOG.txt")).read())
+        got = out["eig"][out["eig"][:, G.EIG["RCVR"]] == k]
+        n_ref += compare_eig_rows(got, parse_eig_results(os.path.join(gold, "g_results.dat")), where=f"ring position {p}")
+    return n_ref
 
 
-def _parse_results(path):
-    """[(bounces, {field: value})] from a reference <title>_results.dat"""
-    out = []
-    for block in open(path).read().split("Eigenray-")[1:]:
-        nums = lambda key: [float(x) for x in re.findall(r"[-+]?\d+\.?\d*(?:[eE][-+]?\d+)?", block.split(key)[1].split("\n")[0])]
-        out.append(dict(bounces=int(re.search(r"(\d+) bounce", block).group(1)),
-                        theta=nums("theta, phi =")[0], phi=nums("theta, phi =")[1], ttime=nums("Travel Time =")[0], celerity=nums("Celerity =")[0],
-                        amp=nums("Amplitude (geometric) =")[0], atten=nums("Atmospheric attenuation =")[0], incl=nums("Arrival inclination =")[0],
-                        bearing=nums("Bearing to source =")[0], backaz=nums("Back azimuth of arrival =")[0], azdev=nums("Azimuth deviation =")[0]))
-    return out
+def _ring_ctx(tmp_path):
+    import geoac_amd as G
+    import rngdep_data as RD
+    ctx = G.FanContext(G.EQ_GLOBAL_RNGDEP, device=0)
+    ctx.load_grid(*RD.write_grid_global(str(tmp_path), short_paths=False))
+    ctx.set_params(src=(0.0, 31.0, 0.0))
+    return ctx
 
 
 @pytest.mark.parametrize("which", ["rank0", "ranks1to7"])
 def test_config5_receivers_vs_reference_binary(tmp_path, which):
-    """rank0: the eight receivers rank 0 of the 8-GPU run searches (ring positions 0, 8, ..., 56; fixtures cfg5_r0..r7).  ranks1to7: the first
-    receiver of each of the other seven ranks (ring positions 1..7; fixtures cfg5_r8..r14), searched as one batch of seven."""
-    import geoac_amd as G
-    import rngdep_data as RD
-    if which == "rank0":
-        rcv, names = _ring(), [f"cfg5_r{k}" for k in range(8)]
-    else:
-        rcv, names = _ring(every=1)[1:8], [f"cfg5_r{7 + r}" for r in range(1, 8)]
-    # the receivers the fixtures were made for (ARGS hold the exact decimal strings the reference parsed)
-    for k in range(len(rcv)):
-        args = open(os.path.join(CLI_GOLD, names[k], "ARGS")).read().split()
-        kv = dict(a.split("=") for a in args if "=" in a)
-        assert float(kv["lat_rcvr"]) == rcv[k, 0] and float(kv["lon_rcvr"]) == rcv[k, 1]
-    ctx = G.FanContext(G.EQ_GLOBAL_RNGDEP, device=0)
-    ctx.load_grid(*RD.write_grid_global(str(tmp_path), short_paths=False))
-    ctx.set_params(src=(0.0, 31.0, 0.0))
-    out = ctx.eig_search(rcv, bnc_min=0, bnc_max=2, verbose=True)
-    print(f"config 5 ({which}), {len(rcv)} receivers:", out["stats"], len(out["eig"]), "eigenrays")
-    E = G.EIG
-    n_ref = 0
-    for k in range(len(rcv)):
-        gold = os.path.join(CLI_GOLD, names[k])
-        _compare_logs(out["logs"][k], open(os.path.join(gold, "LOG.txt")).read())
-        want = _parse_results(os.path.join(gold, "g_results.dat"))
-        got = out["eig"][out["eig"][:, E["RCVR"]] == k]
-        assert len(got) == len(want), f"receiver {k}: {len(got)} eigenrays vs {len(want)}"
-        n_ref += len(want)
-        for g, w in zip(got, want):
-            assert int(g[E["BOUNCES"]]) == w["bounces"]
-            for f, col in (("theta", "THETA"), ("phi", "PHI"), ("ttime", "TTIME"), ("celerity", "CELERITY"), ("amp", "AMP_DB"), ("atten", "ATTEN_DB"),
-                           ("incl", "INCL"), ("bearing", "BEARING"), ("backaz", "BACKAZ"), ("azdev", "AZDEV")):
-                x, y = float(g[E[col]]), w[f]
-                # 8 printed digits; the deviation is a difference of nearly equal bearings: absolute on the scale of a degree
-                assert abs(x - y) <= 2e-7 * max(abs(x), abs(y)) + (2e-6 if f in ("azdev", "phi", "backaz", "bearing") else 1e-12), (k, f, x, y)
+    """rank0: the eight receivers rank 0 of the 8-GPU run searches (ring positions 0, 8, ..., 56).  ranks1to7: the first
+    receiver of each of the other seven ranks (ring positions 1..7), searched as one batch of seven."""
+    pos = np.arange(0, 64, 8) if which == "rank0" else np.arange(1, 8)
+    ctx = _ring_ctx(tmp_path)
+    out = ctx.eig_search(ring_receivers()[pos], bnc_min=0, bnc_max=2, verbose=True)
+    print(f"config 5 ({which}), {len(pos)} receivers:", out["stats"], len(out["eig"]), "eigenrays")
+    n_ref = _check_receivers(out, pos)
     print(f"config 5 ({which}): {n_ref} eigenrays in the reference's result files, all matched; every receiver's iteration log line for line")
     assert n_ref >= 5 or which != "rank0"          # (the seven receivers of ring positions 1..7 lie in the shadow north of the source: the reference finds none, after the same scans)
+
+
+def test_config5_whole_ring_vs_reference_binary(tmp_path):
+    """all 64 receivers in one batched search: every ring position that has a fixture (all of them once make_golden_full.py cfg5_rest
+    has run) - log line for line, eigenrays to the printed digits"""
+    have = [p for p in range(64) if os.path.exists(os.path.join(CLI_GOLD, ring_golden_name(p), "g_results.dat"))]
+    assert len(have) >= 15
+    ctx = _ring_ctx(tmp_path)
+    out = ctx.eig_search(ring_receivers(), bnc_min=0, bnc_max=2, verbose=True)
+    # _check_receivers indexes logs / rows by LOCAL index = ring position here (all 64 searched)
+    import geoac_amd as G
+    n_ref = 0
+    for p in have:
+        gold = os.path.join(CLI_GOLD, ring_golden_name(p))
+        compare_logs(out["logs"][p], open(os.path.join(gold, "LOG.txt")).read())
+        n_ref += compare_eig_rows(out["eig"][out["eig"][:, G.EIG["RCVR"]] == p], parse_eig_results(os.path.join(gold, "g_results.dat")), where=f"ring position {p}")
+    print(f"config 5, 64-receiver ring in one search: {out['stats']}; {len(have)} receivers have reference fixtures, {n_ref} eigenrays matched, logs line for line")
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def test_config5_sharded_by_receiver_over_two_ranks(tmp_path):
+    """the N > 1 flow of config 5 with REAL searches: two gloo ranks (both on this GPU), rank r searches the receivers
+    shard_receivers(4, r, 2) of four ring positions (three of them with eigenrays), gather_eigenrays puts the tables together; the result is the
+    single-process search's table and the reference's result files"""
+    import geoac_amd as G
+    pos = [0, 40, 48, 56]          # positions 40, 48, 56: 3 + 1 + 1 eigenrays in the reference's files; position 0: none (shadow zone)
+    out_file = str(tmp_path / "ring.npz")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(H.ROOT, "tests", "mp_ring_worker.py"), out_file] + [str(p) for p in pos]
+    r = subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    g = np.load(out_file)
+    full = g["eig"]
+    ctx = _ring_ctx(tmp_path)
+    one = ctx.eig_search(ring_receivers()[pos], bnc_min=0, bnc_max=2, verbose=False)
+    # columns up to AZDEV: the sample bookkeeping (NSMP, SMP0) is per search
+    assert full.shape == one["eig"].shape and len(full) == 5
+    assert np.array_equal(full[:, :G.EIG["NSMP"]], one["eig"][:, :G.EIG["NSMP"]]), "sharded + gathered table differs from the single-process search"
+    n = 0
+    for k, p in enumerate(pos):
+        n += compare_eig_rows(full[full[:, 0] == k], parse_eig_results(os.path.join(CLI_GOLD, ring_golden_name(p), "g_results.dat")), where=f"ring position {p}")
+    print(f"config 5 sharded over 2 ranks: {len(full)} eigenrays gathered == single process; {n} matched against the reference's files; per-rank receivers {g['mine0'].tolist()} / {g['mine1'].tolist()}")

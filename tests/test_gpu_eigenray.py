@@ -17,23 +17,7 @@ CLI_GOLD = os.path.join(H.GOLDEN_DIR, "cli")
 BIN = os.path.join(H.ROOT, "geoac_amd", "bin")
 
 
-def _compare_logs(got, want):
-    gl = [l for l in got.split("\n")]
-    wl = [l for l in want.split("\n")]
-    assert len(gl) == len(wl), f"log: {len(gl)} lines vs {len(wl)}"
-    for i, (g, w) in enumerate(zip(gl, wl)):
-        gt, wt = g.replace("\t", " ").split(" "), w.replace("\t", " ").split(" ")
-        assert len(gt) == len(wt), f"log line {i + 1}: {g!r} vs {w!r}"
-        for a, b in zip(gt, wt):
-            a2, b2 = a.rstrip(",.)").lstrip("(["), b.rstrip(",.)").lstrip("([")
-            if a2 == b2:
-                continue
-            try:
-                x, y = float(a2), float(b2)
-            except ValueError:
-                raise AssertionError(f"log line {i + 1}: {a!r} vs {b!r}")
-            # deviations are differences of nearly equal bearings: compare those on the scale of a degree
-            assert abs(x - y) <= 1.2e-5 * max(abs(x), abs(y)) + 2e-6, f"log line {i + 1}: {a!r} vs {b!r}\n{g}\n{w}"
+from parity import compare_logs as _compare_logs  # noqa: E402
 
 
 @pytest.mark.parametrize("case", ["eig_global", "eig_global_direct", "eig_globalrd", "eig_globalrd_direct", "eig_3d", "eig_3d_direct", "eig_3drd", "eig_3drd_direct"])

@@ -24,24 +24,7 @@ def G():
     return geoac_amd
 
 
-def _properties(rec, steps, E, nu_slice, c_ratio):
-    valid = rec[..., REC["VALID"]] > 0
-    ran = rec[..., REC["STEPS"]] > 0
-    broke = rec[..., REC["BROKE"]] > 0
-    assert int(rec[..., REC["STEPS"]].sum()) == steps
-    # a broken leg ends the ray; legs run in order
-    assert not (broke[:, :-1] & ran[:, 1:]).any()
-    assert (ran[:, 1:] <= ran[:, :-1]).all()
-    assert (valid == (ran & ~broke)).all()
-    # cumulative sums grow with the legs
-    tt = rec[..., REC["TTIME"]]; at = rec[..., REC["ATTEN"]]
-    assert ((tt[:, 1:] >= tt[:, :-1]) | ~ran[:, 1:]).all()
-    assert ((at[:, 1:] >= at[:, :-1]) | ~ran[:, 1:]).all()
-    # eikonal residual at arrivals
-    st = rec[..., REC["STATE"]:REC["STATE"] + E][valid]
-    numag = np.sqrt((st[:, nu_slice] ** 2).sum(axis=1))
-    assert np.abs(numag / c_ratio - 1.0).max() < 1e-4          # RK4 truncation error of the reference scheme itself (~1e-6), not a parity bound
-    return int(valid.sum())
+from parity import fan_properties as _properties  # noqa: E402
 
 
 def _sample_vs_oracle(G, eq, ctx_params, theta, phi, rec, E, n=24, seed=3):

@@ -112,3 +112,21 @@ def test_receiver_sharding_gathers_every_eigenray_once(world, n_rcvr):
     for p in procs:
         p.join(timeout=60)
     assert all(ok for _, ok in res), res
+
+
+def test_gather_eigenrays_without_a_process_group_is_the_local_table():
+    """N = 1 (bench.py's config-5 leg on one GPU, no process group): the local table with global receiver indices, ordered"""
+    mine = np.array([5, 2, 7])
+    full = gather_eigenrays(torch.from_numpy(_fake_eigenrays(mine)), mine).numpy()
+    assert [int(x) for x in full[:, 0]] == [2, 2, 5, 5, 7]          # receiver g has g % 3 eigenrays
+    assert [int(x) for x in full[:, 1]] == [0, 1, 0, 1, 0]
+
+
+def test_bench_refuses_a_rank_count_that_is_not_gpus(tmp_path):
+    """bench.py under a launcher whose world size differs from --gpus must not print a line that claims N GPUs"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode != 0 and b"--gpus 8 but the launcher started 1" in r.stderr and b"{" not in r.stdout
