@@ -10,6 +10,7 @@ EQ_2D, EQ_3D, EQ_GLOBAL, EQ_3D_RNGDEP, EQ_GLOBAL_RNGDEP = 0, 1, 2, 3, 4
 REC_STRIDE = 32
 REC = dict(VALID=0, STEPS=1, BROKE=2, TTIME=3, ATTEN=4, TURN=5, INCL=6, BACKAZ=7, AMP=8, RANGE=9, JACOB=10, STATE=12)
 MODE_WRITE_RAYS, MODE_WRITE_CAUSTICS, MODE_INTERACTIVE = 1, 2, 4
+FAN_STEP_LIMIT, FAN_SUB_FALLBACK, FAN_ABS_FALLBACK = 1, 0x100, 0x200          # geoac_fan_status (include/geoac_hip.h)
 
 _dp = ctypes.POINTER(ctypes.c_double)
 
@@ -246,7 +247,8 @@ class FanContext:
 
     def set_angles(self, theta_deg, phi_deg):
         th, ph = _arr(theta_deg), _arr(phi_deg)
-        assert len(th) == len(ph)
+        if th.ndim != 1 or th.shape != ph.shape:
+            raise GeoAcError(f"set_angles: theta and phi must be one-dimensional arrays of one length (got shapes {th.shape} and {ph.shape})")
         self.n_rays = len(th)
         self._chk(self.lib.geoac_fan_set_angles(self._h, len(th), _p(th), _p(ph)))
 
@@ -312,7 +314,7 @@ class FanContext:
         return dict(entries=e.value, flagged=f.value, fixup_segments=int(n.value), worst_rel_err=w.value)
 
     def fan_status(self):
-        """condition flags of the last launch (GEOAC_FAN_STEP_LIMIT = 1)"""
+        """condition flags of the last launch: FAN_STEP_LIMIT, and what the context has withdrawn from its plan (FAN_SUB_FALLBACK, FAN_ABS_FALLBACK)"""
         fl = ctypes.c_uint64(0)
         self._chk(self.lib.geoac_fan_status(self._h, ctypes.byref(fl)))
         return int(fl.value)

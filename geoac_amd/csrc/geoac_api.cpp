@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <ctype.h>
+#include <errno.h>
 #include <algorithm>
 #include <mutex>
 #include <string>
@@ -86,6 +87,10 @@ struct DevBuf {
 struct geoac_ctx {
     int eqset = 0, device = 0;
     GeoacDevParams lastP{};          // parameter block of the last completed launch (device-function probes, include/geoac_probe.h)
+    int  pp_lds_table = -1;          // table post-pass of the spherical set: the table entry in LDS, four waves per SIMD (PP_LDS_TABLE; < 0: the fans that are not hybrid)
+    unsigned long long sticky_flags = 0;   // GEOAC_FAN_*_FALLBACK: plan features this context has withdrawn after a failed attempt (geoac_fan_status)
+    int  launch_repeats = 0;         // fans that were run a second time for that reason
+    bool sub_test_stall = false;     // SUB_TEST_STALL (tests): the cooperative grid kernels' workgroups of sub-epoch 0 do not publish their flag - forces the hand-off time-out
     int  pp_onetrip = -1;            // table post-pass: record + table entry of the neighbouring segment in one trip (PP_ONETRIP; < 0: every fan but the hybrid ones)
     bool tile_rays = true;           // grid sets: Z-order over (inclination, azimuth) ranks instead of the inclination order (GEOAC_TILE=0)
     bool sort_rays = true;           // integrate the rays in order of launch inclination, results in caller order (GEOAC_SORT=0: caller order).
@@ -234,8 +239,8 @@ int geoac_default_params(int eqset, geoac_params* p){
 
 // ---- launch-plan options (A/B measurements, tests; results never depend on them) ----
 static const char* const kOptionNames[] = {
-    "S_ROWS", "NO_OVERLAP", "PP_BLOCKS", "ABS_TABLE", "ABS_TABLE_TOL", "PPFIX_CAP", "DUO", "EV_SLACK", "NO_PAIR", "PAIR_FRAC", "HYBRID_ROWS", "TWO_CHUNKS", "TRACE_EPOCHS", "NO_GATE", "SORT", "TILE", "PP_ONETRIP",
-    "NO_QUAD", "GRID_LANES", "OCT", "HEX", "SPREAD", "COMPACT", "QUAD_CACHE", "GRID_COOP", "SUB_EPOCHS", "SUB_MIN_WAVES", "SMP_CAP", "GRID_BUILD", nullptr };
+    "S_ROWS", "NO_OVERLAP", "PP_BLOCKS", "ABS_TABLE", "ABS_TABLE_TOL", "PPFIX_CAP", "DUO", "EV_SLACK", "NO_PAIR", "PAIR_FRAC", "HYBRID_ROWS", "TWO_CHUNKS", "TRACE_EPOCHS", "NO_GATE", "SORT", "TILE", "PP_ONETRIP", "PP_LDS_TABLE",
+    "NO_QUAD", "GRID_LANES", "OCT", "HEX", "SPREAD", "COMPACT", "QUAD_CACHE", "GRID_COOP", "SUB_EPOCHS", "SUB_MIN_WAVES", "SUB_TEST_STALL", "SMP_CAP", "GRID_BUILD", nullptr };
 const char* const* geoac_option_names(void){ return kOptionNames; }
 
 int geoac_set_option(geoac_ctx* ctx, const char* key, const char* value){
@@ -243,36 +248,46 @@ int geoac_set_option(geoac_ctx* ctx, const char* key, const char* value){
     std::string k(key);
     if(k.rfind("GEOAC_", 0) == 0) k = k.substr(6);
     for(char& c : k) c = (char)toupper((unsigned char)c);
-    const int iv = atoi(value); const double dv = atof(value); const long long lv = atoll(value);
-    if(k == "S_ROWS") ctx->s_rows_override = iv;
-    else if(k == "NO_OVERLAP") ctx->no_overlap = iv != 0;
-    else if(k == "PP_BLOCKS"){ if(iv >= 0) ctx->pp_blocks = iv; }
-    else if(k == "ABS_TABLE") ctx->abs_table = iv != 0;
-    else if(k == "ABS_TABLE_TOL"){ if(dv > 0.0) ctx->atab_tol = dv; }
-    else if(k == "PPFIX_CAP"){ if(iv > 0) ctx->ppfix_cap = iv; }
-    else if(k == "DUO") ctx->duo = iv;
-    else if(k == "EV_SLACK"){ if(iv >= 0) ctx->ev_slack = iv; }
-    else if(k == "NO_PAIR") ctx->no_pair = iv != 0;
-    else if(k == "PAIR_FRAC"){ if(dv >= 0.0) ctx->pair_frac = dv; }
-    else if(k == "HYBRID_ROWS"){ if(dv > 0.0 && dv <= 1.0) ctx->hybrid_rows = dv; }
-    else if(k == "TWO_CHUNKS") ctx->two_chunks = iv != 0;
-    else if(k == "TRACE_EPOCHS") ctx->trace_epochs = iv != 0;
-    else if(k == "NO_GATE") ctx->no_gate = iv != 0;
-    else if(k == "SORT") ctx->sort_rays = iv != 0;
-    else if(k == "TILE") ctx->tile_rays = iv != 0;
-    else if(k == "PP_ONETRIP") ctx->pp_onetrip = iv;
-    else if(k == "NO_QUAD") ctx->no_quad = iv != 0;
-    else if(k == "GRID_LANES"){ if(iv == 0 || iv == 1 || iv == 2 || iv == 4 || iv == 8 || iv == 16) ctx->grid_lanes = iv; else return fail(ctx, GEOAC_E_INVALID, "GRID_LANES: 0, 1, 2, 4, 8 or 16"); }
-    else if(k == "OCT") ctx->oct = iv != 0;
-    else if(k == "HEX") ctx->hex = iv != 0;
-    else if(k == "SPREAD"){ if(iv >= 0) ctx->spread_override = iv; }
-    else if(k == "COMPACT") ctx->compact = iv != 0;
-    else if(k == "QUAD_CACHE") ctx->quad_cache = iv != 0;
-    else if(k == "GRID_COOP") ctx->grid_coop = iv != 0;
-    else if(k == "SUB_EPOCHS") ctx->sub_epochs = std::min(16, std::max(1, iv));
-    else if(k == "SUB_MIN_WAVES"){ if(iv >= 0) ctx->sub_min_waves = iv; }
-    else if(k == "SMP_CAP"){ if(lv > 0) ctx->smp_cap = lv; }
-    else if(k == "GRID_BUILD") ctx->grid_build_host = (strcmp(value, "host") == 0);
+    // A value that does not parse, or lies outside what the knob accepts, is an error (GEOAC_E_INVALID + message) - never a silent 0 or a silently
+    // ignored setting: an A/B run or a schedule-independence test must not measure the default plan while believing a knob was applied
+    bool int_ok = false, dbl_ok = false;
+    long long lv = 0; double dv = 0.0;
+    { char* end = nullptr; errno = 0; lv = strtoll(value, &end, 10); int_ok = (end != value && *end == 0 && errno == 0); }
+    { char* end = nullptr; errno = 0; dv = strtod(value, &end); dbl_ok = (end != value && *end == 0 && errno == 0 && dv == dv); }
+    const int iv = (int)lv;
+    auto bad = [&](const char* want){ return fail(ctx, GEOAC_E_INVALID, "set_option: " + k + "=" + value + ": expected " + want); };
+    auto flag = [&](bool& dst) -> int { if(!int_ok || (lv != 0 && lv != 1)) return bad("0 or 1"); dst = lv != 0; return GEOAC_OK; };
+    if(k == "S_ROWS"){ if(!int_ok || lv < 0 || lv > 0x7fffffff) return bad("a row count >= 0 (0: sized from the free memory)"); ctx->s_rows_override = iv; }
+    else if(k == "NO_OVERLAP") return flag(ctx->no_overlap);
+    else if(k == "PP_BLOCKS"){ if(!int_ok || lv < 0 || lv > 0x7fffffff) return bad("a block count >= 0"); ctx->pp_blocks = iv; }
+    else if(k == "ABS_TABLE") return flag(ctx->abs_table);
+    else if(k == "ABS_TABLE_TOL"){ if(!dbl_ok || !(dv > 0.0)) return bad("a tolerance > 0"); ctx->atab_tol = dv; }
+    else if(k == "PPFIX_CAP"){ if(!int_ok || lv <= 0 || lv > 0x3fffffff) return bad("a capacity > 0"); ctx->ppfix_cap = iv; }
+    else if(k == "DUO"){ if(!int_ok || lv < 0 || lv > 3) return bad("0..3"); ctx->duo = iv; }
+    else if(k == "EV_SLACK"){ if(!int_ok || lv < 0 || lv > 1000000) return bad("a slot count >= 0"); ctx->ev_slack = iv; }
+    else if(k == "NO_PAIR") return flag(ctx->no_pair);
+    else if(k == "PAIR_FRAC"){ if(!dbl_ok || dv < 0.0 || dv > 1.0) return bad("a share in [0, 1]"); ctx->pair_frac = dv; }
+    else if(k == "HYBRID_ROWS"){ if(!dbl_ok || !(dv > 0.0 && dv <= 1.0)) return bad("a ratio in (0, 1]"); ctx->hybrid_rows = dv; }
+    else if(k == "TWO_CHUNKS") return flag(ctx->two_chunks);
+    else if(k == "TRACE_EPOCHS") return flag(ctx->trace_epochs);
+    else if(k == "NO_GATE") return flag(ctx->no_gate);
+    else if(k == "SORT") return flag(ctx->sort_rays);
+    else if(k == "TILE") return flag(ctx->tile_rays);
+    else if(k == "PP_ONETRIP"){ if(!int_ok || lv < -1 || lv > 1) return bad("0, 1 or -1 (by launch plan)"); ctx->pp_onetrip = iv; }
+    else if(k == "PP_LDS_TABLE"){ if(!int_ok || lv < -1 || lv > 1) return bad("0, 1 or -1 (by launch plan)"); ctx->pp_lds_table = iv; }
+    else if(k == "NO_QUAD") return flag(ctx->no_quad);
+    else if(k == "GRID_LANES"){ if(!int_ok || !(iv == 0 || iv == 1 || iv == 2 || iv == 4 || iv == 8 || iv == 16)) return bad("0, 1, 2, 4, 8 or 16"); ctx->grid_lanes = iv; }
+    else if(k == "OCT") return flag(ctx->oct);
+    else if(k == "HEX") return flag(ctx->hex);
+    else if(k == "SPREAD"){ if(!int_ok || lv < 0 || lv > 64 || (lv & (lv - 1))) return bad("0 (by launch plan) or a power of two up to 64"); ctx->spread_override = iv; }
+    else if(k == "COMPACT") return flag(ctx->compact);
+    else if(k == "QUAD_CACHE") return flag(ctx->quad_cache);
+    else if(k == "GRID_COOP") return flag(ctx->grid_coop);
+    else if(k == "SUB_EPOCHS"){ if(!int_ok || lv < 1 || lv > 16) return bad("1..16"); ctx->sub_epochs = iv; }
+    else if(k == "SUB_MIN_WAVES"){ if(!int_ok || lv < 0 || lv > 0x7fffffff) return bad("a wave count >= 0"); ctx->sub_min_waves = iv; }
+    else if(k == "SUB_TEST_STALL") return flag(ctx->sub_test_stall);
+    else if(k == "SMP_CAP"){ if(!int_ok || lv <= 0) return bad("a row capacity > 0"); ctx->smp_cap = lv; }
+    else if(k == "GRID_BUILD"){ if(strcmp(value, "host") != 0 && strcmp(value, "device") != 0) return bad("host or device"); ctx->grid_build_host = (strcmp(value, "host") == 0); }
     else return fail(ctx, GEOAC_E_INVALID, "set_option: unknown key " + k);
     return GEOAC_OK;
 }
@@ -362,7 +377,7 @@ int geoac_clone(geoac_ctx* src, geoac_ctx** out){
         hipError_t e = c->d_consts.ensure(sizeof(double) * 8);
         if(e != hipSuccess){ geoac_destroy(c); return hipfail(src, e, "clone: constants block"); }
     }
-    c->sort_rays = src->sort_rays; c->tile_rays = src->tile_rays; c->pp_onetrip = src->pp_onetrip; c->no_quad = src->no_quad; c->oct = src->oct; c->hex = src->hex; c->grid_lanes = src->grid_lanes; c->spread_override = src->spread_override;
+    c->sort_rays = src->sort_rays; c->tile_rays = src->tile_rays; c->pp_onetrip = src->pp_onetrip; c->pp_lds_table = src->pp_lds_table; c->sub_test_stall = src->sub_test_stall; c->no_quad = src->no_quad; c->oct = src->oct; c->hex = src->hex; c->grid_lanes = src->grid_lanes; c->spread_override = src->spread_override;
     c->compact = src->compact; c->quad_cache = src->quad_cache; c->sub_min_waves = src->sub_min_waves; c->sub_epochs = src->sub_epochs; c->grid_coop = src->grid_coop;
     c->smp_cap = src->smp_cap; c->s_rows_override = src->s_rows_override; c->no_overlap = src->no_overlap; c->pp_blocks = src->pp_blocks; c->pair_frac = src->pair_frac;
     c->hybrid_rows = src->hybrid_rows; c->two_chunks = src->two_chunks; c->no_gate = src->no_gate; c->no_pair = src->no_pair; c->duo = src->duo; c->abs_table = src->abs_table;
@@ -567,8 +582,10 @@ int geoac_fan_set_angles(geoac_ctx* ctx, int n_rays, const double* theta_deg, co
     return GEOAC_OK;
 }
 
-int geoac_fan_launch(geoac_ctx* ctx){
-    if(!ctx) return GEOAC_E_INVALID;
+// one attempt at the fan under the context's current launch plan.  GEOAC_RETRY: the attempt found that a plan feature does not hold on this
+// device / input (sub-epoch hand-off, absorption table), switched it off for this context and wants the fan run again (geoac_fan_launch)
+static const int GEOAC_RETRY = -1000;
+static int fan_launch_once(geoac_ctx* ctx){
     if(!ctx->have_atmo || !ctx->have_angles) return fail(ctx, GEOAC_E_INVALID, "fan_launch: atmosphere and angles must be uploaded first");
     const bool is_grid = (ctx->eqset == GEOAC_EQ_3D_RNGDEP || ctx->eqset == GEOAC_EQ_GLOBAL_RNGDEP);
     if(is_grid != ctx->have_grid) return fail(ctx, GEOAC_E_INVALID, "fan_launch: atmosphere kind does not match the equation set");
@@ -670,15 +687,15 @@ int geoac_fan_launch(geoac_ctx* ctx){
     P.state = (double*)ctx->state.p;
     P.rec = (double*)ctx->rec.p; P.counters = (unsigned long long*)ctx->counters.p;
     // absorption table (stratified sets; k_atab_build): alpha is a function of the height coordinate alone there
-    P.atab = nullptr; P.atab_on = 0; P.atab_D = 0.0; P.ppfix = nullptr; P.ppfix_cap = 0;
+    P.atab = nullptr; P.lat_trig = nullptr; P.atab_on = 0; P.atab_D = 0.0; P.atab_lo = 0.0; P.ppfix = nullptr; P.ppfix_cap = 0;
     P.seg_per_x = (double)P.nseg / (P.x_max - P.x_min);
     if(!is_grid && ctx->abs_table){
         const double D = std::max(std::min(0.05, p.ds_max), p.ds_min), tol = ctx->atab_tol;
         const double key[7] = { P.freq, P.tweak_abs, P.T_o, P.P_o, P.r_earth, D, tol };
-        P.atab_D = D;
+        P.atab_D = D; P.atab_lo = P.x_min - D;
         if(ctx->atab_version != ctx->atmo_version || memcmp(key, ctx->atab_key, sizeof(key)) != 0){
             const size_t n_ent = (size_t)P.nseg + 2;
-            HIPCHK(ctx->atab.ensure(sizeof(double) * GEOAC_ATABW * n_ent));
+            HIPCHK(ctx->atab.ensure(sizeof(double) * (GEOAC_ATABW * n_ent + 2 * (size_t)GEOAC_LAT_N)));      // (+ the latitude table behind it)
             HIPCHK(geoac_launch_atab_build(&P, (double*)ctx->atab.p, tol, ctx->stream));
             std::vector<double> h(GEOAC_ATABW * n_ent);
             HIPCHK(hipMemcpyAsync(h.data(), ctx->atab.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
@@ -694,6 +711,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
         // a profile most of whose segments the interpolant cannot serve (very long segments) keeps the exact post-pass
         if(4 * ctx->atab_flagged <= ctx->atab_entries){
             P.atab = (const double*)ctx->atab.p; P.atab_on = 1;
+            P.lat_trig = P.atab + (size_t)GEOAC_ATABW * ((size_t)P.nseg + 2);
             P.ppfix_cap = ctx->ppfix_cap;
             HIPCHK(ctx->ppfix.ensure(sizeof(int) * 2 * (size_t)P.ppfix_cap));
             P.ppfix = (int*)ctx->ppfix.p;
@@ -852,6 +870,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
             // (see geoac_launch_postpass_tab) hybrid fans: the post-pass off the RK4 CUs, one (spherical set) or two (Cartesian sets) workgroups per free CU
             Pq.pp_lds_pad = !Pq.table_in_lds ? 0 : (hybrid ? (Pq.eqset == GEOAC_EQ_GLOBAL ? 96 : 64) * 1024 : 8 * 1024);
             Pq.pp_onetrip = ctx->pp_onetrip >= 0 ? (ctx->pp_onetrip ? 1 : 0) : (hybrid ? 0 : 1);
+            Pq.pp_lds_table = (Pq.eqset == GEOAC_EQ_GLOBAL && Pq.pp_onetrip) ? (ctx->pp_lds_table >= 0 ? (ctx->pp_lds_table ? 1 : 0) : (hybrid ? 0 : 1)) : 0;
             HIPCHK(hipMemsetAsync((char*)ctx->counters.p + GEOAC_CNT_PPFLAG * sizeof(unsigned long long), 0, sizeof(unsigned long long), sp));   // the fix-up list is empty
             HIPCHK(geoac_launch_postpass_tab(&Pq, Pq.s_rows, sp));
         }
@@ -917,7 +936,7 @@ int geoac_fan_launch(geoac_ctx* ctx){
             // last round of the launch from running on a part-empty chip
             const int waves = (Pe.slot_hi - Pe.slot_lo + 63) / 64;
             if(P.coop && block == 64 && ctx->sub_epochs > 1 && waves > ctx->sub_min_waves && Pe.s_rows >= 16 * ctx->sub_epochs){
-                Pe.sub = ctx->sub_epochs; Pe.sub_w = (waves + 7) / 8 * 8;
+                Pe.sub = ctx->sub_epochs; Pe.sub_w = (waves + 7) / 8 * 8; Pe.sub_test_stall = ctx->sub_test_stall ? 1 : 0;
                 HIPCHK(ctx->sub_flags.ensure(sizeof(int) * ((size_t)P.n_pad / 64 + 16)));
                 Pe.sub_flags = (int*)ctx->sub_flags.p;
             }
@@ -989,14 +1008,14 @@ int geoac_fan_launch(geoac_ctx* ctx){
     ctx->ran = true;
     ctx->lastP = P;
     if(ctx->err_flags & 4ull){
-        // a sub-epoch workgroup gave up waiting for its predecessor: the dispatch order k_rk4 relies on did not hold.  Run the fan again
-        // without sub-epochs (this context keeps them off from now on).
-        if(ctx->sub_epochs > 1){ ctx->sub_epochs = 1; fprintf(stderr, "libgeoac_hip: sub-epoch hand-off timed out, repeating the fan without sub-epochs\n"); return geoac_fan_launch(ctx); }
+        // a sub-epoch workgroup gave up waiting for its predecessor: the dispatch order k_rk4 relies on did not hold.  The fan is run again
+        // without sub-epochs; this context keeps them off from now on and says so in geoac_fan_status (GEOAC_FAN_SUB_FALLBACK)
+        if(ctx->sub_epochs > 1){ ctx->sub_epochs = 1; ctx->sticky_flags |= GEOAC_FAN_SUB_FALLBACK; return GEOAC_RETRY; }
         return fail(ctx, GEOAC_E_HIP, "sub-epoch hand-off timed out");
     }
     if(ctx->err_flags & 16ull){
-        // more segments outside the absorption table than its fix-up list holds: this context keeps the exact post-pass from now on
-        if(ctx->abs_table){ ctx->abs_table = 0; fprintf(stderr, "libgeoac_hip: the absorption table leaves too many segments to the fix-up pass, repeating the fan with the exact post-pass\n"); return geoac_fan_launch(ctx); }
+        // more segments outside the absorption table than its fix-up list holds: this context keeps the exact post-pass from now on (GEOAC_FAN_ABS_FALLBACK)
+        if(ctx->abs_table){ ctx->abs_table = 0; ctx->sticky_flags |= GEOAC_FAN_ABS_FALLBACK; return GEOAC_RETRY; }
         return fail(ctx, GEOAC_E_CAPACITY, "fix-up list of the table post-pass overflowed");
     }
     if(ctx->err_flags & 8ull) return fail(ctx, GEOAC_E_HIP, "k_rk4_duo: a wave waited more than a second for the other wave of its pair");
@@ -1007,6 +1026,17 @@ int geoac_fan_launch(geoac_ctx* ctx){
     // and the mains write the row): the fan is complete and valid, the condition is reported through geoac_fan_status
     if(ctx->err_flags & 1ull) ctx->err = "warning: a ray reached step_limit (GeoAc.Solver.cpp:14) without leaving the region or reaching the ground";
     return GEOAC_OK;
+}
+
+int geoac_fan_launch(geoac_ctx* ctx){
+    if(!ctx) return GEOAC_E_INVALID;
+    // at most one repeat per plan feature that can be withdrawn (sub-epochs, absorption table): a loop, not a recursion
+    for(int attempt = 0; attempt < 3; attempt++){
+        const int rc = fan_launch_once(ctx);
+        if(rc != GEOAC_RETRY) return rc;
+        ctx->launch_repeats++;
+    }
+    return fail(ctx, GEOAC_E_HIP, "fan_launch: still asked to repeat after withdrawing every optional plan feature");
 }
 
 int geoac_abs_table_info(geoac_ctx* ctx, int* entries, int* flagged, uint64_t* fixup_segments, double* worst_rel_err){
@@ -1020,7 +1050,8 @@ int geoac_abs_table_info(geoac_ctx* ctx, int* entries, int* flagged, uint64_t* f
 
 int geoac_fan_status(geoac_ctx* ctx, uint64_t* flags){
     if(!ctx || !flags || !ctx->ran) return GEOAC_E_INVALID;
-    *flags = (uint64_t)ctx->err_flags;
+    // bit 0 of the launch's own flags (the other device-side bits are failures, reported as errors) + what this context has withdrawn from its plan
+    *flags = (uint64_t)(ctx->err_flags & 1ull) | (uint64_t)ctx->sticky_flags;
     return GEOAC_OK;
 }
 

@@ -21,6 +21,8 @@
 #define GEOAC_MAXE      18
 #define GEOAC_MAXLEGS   64      // legs per ray supported by the per-epoch leg-end event list
 #define GEOAC_ATABW     20      // doubles per entry of the absorption table: 2 / h (negative: flagged), 3 x 6 coefficients, worst check-point error
+#define GEOAC_LAT_OFF   1024    // lat_trig: entry of latitude 0
+#define GEOAC_LAT_N     2049    // ... entries (|lat| <= 8 rad; the index is clamped)
 #define GEOAC_PP_ROWS   16      // path segments per thread of k_postpass_tab (consecutive rows of one ray: each row is read once)
 #define GEOAC_CNT_PPFLAG 28     // counters[+0]: entries of the fix-up list of the current k_postpass_tab launch; counters[+1]: path segments of the fan the absorption table did not serve (evaluated exactly by k_ppfix)
 
@@ -88,11 +90,15 @@ struct GeoacDevParams {
     int*    ppfix;                  // fix-up list of k_postpass_tab: (column, chunk row) of the segments the table did not serve, ppfix_cap pairs (k_ppfix evaluates them exactly)
     int     ppfix_cap;
     int     pp_lds_pad;             // bytes of LDS a k_postpass_tab workgroup asks for without using them: keeps it off CUs that hold an RK4 workgroup (> 7 KiB) / to one workgroup per CU (> 80 KiB)
+    int     pp_lds_table;           // k_postpass_tab<.., TBL> (spherical set, one-trip form): the table entry in hand in LDS instead of 38 registers, no row prefetch: 127 registers, four waves per SIMD
     int     pp_onetrip;             // k_postpass_tab: on a change of spline segment fetch the neighbour's record and table entry in one trip (fans that fill the chip); 0: the walk
     const double* atab;             // [nseg + 2][GEOAC_ATABW]: 2/h (negative: flagged), 3 x six coefficients in s = 2 t / h - 1 (atab_eval); entries nseg / nseg + 1: the
                                     // strips of width atab_D below the first / above the last node (medium clamped there, height not)
+    const double* lat_trig;         // spherical set: [GEOAC_LAT_N][2] sin, cos of the multiples of 2^-7 rad (index i: (i - GEOAC_LAT_OFF) / 128), behind the table in the same buffer
+                                    // (k_atab_build): the reference points pp_geom rotates the midpoint latitudes' sin / cos from - read, not recomputed, in k_postpass_tab
     int           atab_on;          // 1: k_postpass_tab + fix-up of the flagged segments; 0: exact evaluation at every midpoint (k_postpass)
     double        atab_D;           // width of the two strips
+    double        atab_lo;          // x_min - atab_D: left end of the lower strip
     double        seg_per_x;        // nseg / (x_max - x_min): first guess of the segment index without a division
     // range-dependent sets: grid of profiles
     int           gnx, gny;         // horizontal node counts
@@ -107,6 +113,7 @@ struct GeoacDevParams {
     const int*    n_cols;           // device: number of valid columns of colmap
     int           n_cols_bound;     // host-side upper bound of the columns in use this epoch (launch sizes of the post-pass / sum kernels); n_pad without compaction
     int           sub;              // cooperative grid kernels: the epoch is cut into `sub` sub-epochs, each a workgroup of its own (k_rk4); 1 = off
+    int           sub_test_stall;   // tests (SUB_TEST_STALL): sub-epoch 0 never publishes its flag and the waiters give up after 20 ms - forces the hand-off time-out path
     int           sub_w;            // workgroups per sub-epoch (multiple of 8: a wave's sub-epochs are dispatched on one XCD, in order)
     int*          sub_flags;        // [sub_w] sub-epochs completed per wave (zeroed before the launch)
     const int*    perm;             // slot -> ray index of the caller's order (records and samples are written in the caller's order); NULL = identity

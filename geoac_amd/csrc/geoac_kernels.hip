@@ -35,6 +35,10 @@
 // then gives different bits in k_rk4<EqGlobal>, k_rk4<EqGlobalPair> and k_rk4_duo, and records must not depend on the launch plan.
 #pragma clang fp contract(off)
 
+#ifndef GEOAC_X
+#define GEOAC_X 0                       // A/B switches of the stratified step loop (bit mask; tools/ab_metric.py builds): see set_ds, seg_locate
+#endif
+
 static constexpr double kPi   = 3.141592653589793238462643;   // GeoAc.Parameters.cpp:27
 static constexpr double kGam  = 1.4;
 static constexpr double kRgas = 287.05;
@@ -61,6 +65,18 @@ DEVINL double frsq(double x){
     double p = __builtin_fma(e, 0.375, 0.5);
     return __builtin_fma(y * e, p, y);
 }
+// a fused multiply-add whose ADDEND must survive (a loop-invariant constant, a coefficient of the spline record in hand): hipcc picks the two-address
+// v_fmac_f64 for these and copies the addend into the destination first - two issue slots where the three-address v_fma_f64 takes one, on a wave
+// that is alone on its SIMD and pays for every slot.  Same operation, same rounding: same bits.
+DEVINL double fma3(double a, double b, double c){
+#if GEOAC_X & 4
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+#else
+    return __builtin_fma(a, b, c);
+#endif
+}
 // exp / exp10 for the absorption integrand (k_postpass): arguments of moderate size and never NaN / inf there, so none of the library
 // routine's special-case work.  k = round(x log2 e), r = x - k ln2 (two-constant Cody-Waite, exact product through FMA), Taylor
 // polynomial of degree 13 on |r| <= ln2 / 2 (truncation 2e-17), result scaled by 2^k: < 1 ulp + the rounding of r.
@@ -79,6 +95,29 @@ DEVINL double exp_poly(double r){
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     return __builtin_fma(p, r, 1.0);
+}
+// the same polynomial with three-address multiply-adds (fma3): the step-size rule of the RK4 kernels
+DEVINL double exp_poly3(double r){
+    double p = 1.0 / 6227020800.0;
+    p = fma3(p, r, 1.0 / 479001600.0);
+    p = fma3(p, r, 1.0 / 39916800.0);
+    p = fma3(p, r, 1.0 / 3628800.0);
+    p = fma3(p, r, 1.0 / 362880.0);
+    p = fma3(p, r, 1.0 / 40320.0);
+    p = fma3(p, r, 1.0 / 5040.0);
+    p = fma3(p, r, 1.0 / 720.0);
+    p = fma3(p, r, 1.0 / 120.0);
+    p = fma3(p, r, 1.0 / 24.0);
+    p = fma3(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_fma(p, r, 1.0);
+}
+DEVINL double fexp3(double x){
+    const double k = __builtin_rint(x * 1.44269504088896338700e+00);
+    double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);
+    r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
+    return __builtin_ldexp(exp_poly3(r), (int)k);
 }
 DEVINL double fexp(double x){
     const double k = __builtin_rint(x * 1.44269504088896338700e+00);
@@ -101,8 +140,12 @@ DEVINL double fexp10(double y){
 // time, with the table value loaded at the top of the step or a step ahead: the constants the full routine moves into place between its dependent
 // multiply-adds fill issue slots that would stay empty anyway, the load and its wait do not.)
 DEVINL double set_ds(double h, double ds_min, double ds_max){
+#if GEOAC_X & 1
+    const double ds = 0.05 - 0.049 * fexp3(h * (-1.0 / 0.75));    // (A/B: no skip - the exponential's chain in the block of stage 0, free to interleave with it)
+#else
     double ds = 0.05;
-    if(!(h > 28.5)) ds = 0.05 - 0.049 * fexp(h * (-1.0 / 0.75));
+    if(!(h > 28.5)) ds = 0.05 - 0.049 * fexp3(h * (-1.0 / 0.75));
+#endif
     return __builtin_fmax(__builtin_fmin(ds, ds_max), ds_min);
 }
 
@@ -177,10 +220,10 @@ DEVINL int seg_find(TabPtr tab, int nseg, double x, int k){
 // cubic in the derivative-friendly form (c0, c1, d2 = 2 c2, e3 = 6 c3): f'' = d2 + e3 t, f' = c1 + t/2 (d2 + f''),
 // f = c0 + t (c1 + t/6 (2 d2 + f'')) - 6 FMA-class operations per function for value + both derivatives
 DEVINL void cubic3(double c0, double c1, double d2, double e3, double t, double th, double t6, double& f, double& f1, double& f2){
-    f2 = __builtin_fma(t, e3, d2);
+    f2 = fma3(t, e3, d2);                                         // (fma3: the coefficients are the record in hand - they must survive)
     const double s2 = d2 + f2;
-    f1 = __builtin_fma(th, s2, c1);
-    f  = __builtin_fma(t, __builtin_fma(t6, d2 + s2, c1), c0);
+    f1 = fma3(th, s2, c1);
+    f  = fma3(t, fma3(t6, d2 + s2, c1), c0);
 }
 
 template <typename TabPtr>
@@ -251,7 +294,13 @@ DEVINL void seg_step_eval(TabPtr tab, const GeoacDevParams& P, double x, int& of
 template <int W = GEOAC_SEGW, typename TabPtr>
 DEVINL void seg_locate(TabPtr tab, const GeoacDevParams& P, double x, int& off, double* r){
     const int last = (P.nseg - 1) * W;
+#if GEOAC_X & 2
+    // x is clamped to [x_min, x_max] = [x0 of the first record, x1 of the last] by every caller: x > r[1] cannot hold in the last segment nor
+    // x < r[0] in the first, the two index guards are redundant (four instructions per stage)
+    const bool up = (x > r[1]), down = (x < r[0]);
+#else
     const bool up = (x > r[1]) & (off < last), down = (x < r[0]) & (off > 0);
+#endif
     if(__builtin_expect(up | down, 0)){
         off += (up ? W : 0) - (down ? W : 0);
         if(!P.seg_safe){
@@ -615,11 +664,30 @@ DEVINL double atab_eval(const double* e, double t){
     const double sq = sqrt(1.0 + N);                              // IEEE, as in suthbass_alpha
     return S + fsqrt((sq - 1.0) * Q);
 }
+// the same with the entry in LDS, coefficient c at e[c * 256] (k_postpass_tab<.., TBL>): one piece after the other, so that six coefficients are
+// in registers at a time and not all nineteen (the scheduler would fetch them together otherwise: 38 registers the kernel does not have)
+DEVINL double atab_poly_lds(const double* e, int c0, double s){
+    double p = e[(c0 + 5) * 256];
+    p = __builtin_fma(p, s, e[(c0 + 4) * 256]); p = __builtin_fma(p, s, e[(c0 + 3) * 256]); p = __builtin_fma(p, s, e[(c0 + 2) * 256]);
+    p = __builtin_fma(p, s, e[(c0 + 1) * 256]); p = __builtin_fma(p, s, e[c0 * 256]);
+    return p;
+}
+DEVINL double atab_eval_lds(const double* e, double e0, double t){
+    const double s = __builtin_fma(t, fabs(e0), -1.0);
+    const double S = atab_poly_lds(e, 1, s);
+    __builtin_amdgcn_sched_barrier(0);
+    const double N = atab_poly_lds(e, 7, s);
+    __builtin_amdgcn_sched_barrier(0);
+    const double Q = atab_poly_lds(e, 13, s);
+    __builtin_amdgcn_sched_barrier(0);
+    const double sq = sqrt(1.0 + N);                              // IEEE, as in suthbass_alpha
+    return S + fsqrt((sq - 1.0) * Q);
+}
 // table entry and offset within it of abscissa x; xe = x clamped to the profile, k / x0 = spline segment of xe and its left node.  t < 0
 // or t > the entry's length: beyond the strips, not served
 DEVINL int atab_locate(const GeoacDevParams& P, double x, double xe, int k, double x0, double& t, bool& out){
     const bool below = x < P.x_min, above = x > P.x_max;
-    t = below ? x - (P.x_min - P.atab_D) : (above ? x - P.x_max : xe - x0);
+    t = below ? x - P.atab_lo : (above ? x - P.x_max : xe - x0);        // (atab_lo = x_min - atab_D, formed on the host)
     out = (t < 0.0) | (above & (t > P.atab_D));
     return below ? P.nseg : (above ? P.nseg + 1 : k);
 }
@@ -904,7 +972,14 @@ template <bool AMP_> struct EqGlobal {
         double sn, cs;
         if(ref){
             const double tq = __builtin_rint(t * 128.0) * (1.0 / 128.0);
-            if(__builtin_expect(tq != ref[0], 0)){ ref[0] = tq; fsincos(tq, ref[1], ref[2]); }
+            if(__builtin_expect(tq != ref[0], 0)){
+                // (a table of the device's own fsincos at these points, k_atab_build: inlined here the routine's fifteen constants were hoisted
+                //  out of the segment loop and cost k_postpass_tab 20 registers for a block that runs once per ~50 km of travel)
+                ref[0] = tq;
+                int iq = (int)(tq * 128.0) + GEOAC_LAT_OFF;          // (ref is only passed with the table on: lat_trig is there)
+                iq = iq < 0 ? 0 : (iq > GEOAC_LAT_N - 1 ? GEOAC_LAT_N - 1 : iq);
+                ref[1] = P.lat_trig[2 * iq]; ref[2] = P.lat_trig[2 * iq + 1];
+            }
             rot_fifth(ref[1], ref[2], t - tq, sn, cs);
         } else fsincos(t, sn, cs);
         double rdt = r * dt;
@@ -1739,7 +1814,7 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
         bool ok = true;
         while(__hip_atomic_load(P.sub_flags + bidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sub_h){
             __builtin_amdgcn_s_sleep(32);
-            if(wall_clock64() - t0 > 200000000ll){ ok = false; break; }          // (100 MHz counter)
+            if(wall_clock64() - t0 > (P.sub_test_stall ? 2000000ll : 200000000ll)){ ok = false; break; }          // (100 MHz counter: 2 s)
         }
         if(!ok){ if(threadIdx.x == 0) atomicOr(&P.counters[2], 4ull); return; }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                      // (invalidates this CU's L1: the state rows another CU stored)
@@ -1841,7 +1916,14 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
         // running turning height: max over rows m < k of the height component   (GeoAcGlobal_main.cpp:294)
         if(EQ::PW == 2 && (P.mode & GEOAC_MODE_INTERACTIVE)){         // GeoAc2D -interactive: max over rows 1..k-1 of solution[m][2] (nu_z)
             if(k >= 1) hmax = (hmax < ya[2]) ? ya[2] : hmax;
-        } else { double h = EQ::height(P, ya); if(EQ::HMAX_PER_LEG && k == 0) hmax = 0.0; hmax = (hmax < h) ? h : hmax; }
+        } else {
+            double h = EQ::height(P, ya); if(EQ::HMAX_PER_LEG && k == 0) hmax = 0.0;
+#if GEOAC_X & 8
+            if(EQ::SEG1D) hmax = __builtin_fmax(hmax, h);         // (one v_max_f64 instead of a compare and two selects; no NaN reaches it: the same value)
+            else
+#endif
+            hmax = (hmax < h) ? h : hmax;
+        }
 
         if(SMP && k >= 1){
             // ya is row m = k (1 <= m < k_final) at chunk row nr-1: the rows the reference's post-pass loop visits
@@ -2110,7 +2192,7 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
         // publish the state this workgroup stored (one wave per workgroup: its stores are ordered before the release by the fence)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // (hipcc may drop the wait behind the write-back: MI355X_MICROARCH.md, inter-workgroup visibility)
-        if(threadIdx.x == 0) __hip_atomic_store(P.sub_flags + bidx, sub_h + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if(threadIdx.x == 0 && !(P.sub_test_stall && sub_h == 0)) __hip_atomic_store(P.sub_flags + bidx, sub_h + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -2235,41 +2317,61 @@ __global__ void __launch_bounds__(256, EQ::PP_WAVES) k_postpass(GeoacDevParams P
 #ifndef GEOAC_PPTAB_GLOBAL_WAVES
 #define GEOAC_PPTAB_GLOBAL_WAVES 2
 #endif
-template <class EQ, bool ONETRIP>
-__global__ void __launch_bounds__(256, EQ::PW == 6 ? GEOAC_PPTAB_GLOBAL_WAVES : 4) k_postpass_tab(GeoacDevParams P, int rows){
+// TBL (the spherical set on fans that fill the chip): the table entry in hand lives in LDS, [coefficient][thread] (19 x 256 doubles = 38 KiB per
+// workgroup, conflict-free), not in 38 registers, and no row is prefetched - with it the kernel fits 128 registers: FOUR waves per SIMD, whose
+// loads cover one another's latency (config 3's post-pass waited in 53 % of its wave cycles at two waves per SIMD).  Same operations on the
+// same operands: same bits.
+template <class EQ, bool ONETRIP, bool TBL = false>
+__global__ void __launch_bounds__(256, (EQ::PW == 6 && !TBL) ? GEOAC_PPTAB_GLOBAL_WAVES : 4) k_postpass_tab(GeoacDevParams P, int rows, int gy0){
     constexpr int PW = EQ::PW, R = GEOAC_PP_ROWS;
+    extern __shared__ double pp_tb_lds[];
+    // TBL: this thread's entry, coefficient c at ltb[c * 256].  The thread index is kept as ONE register, its byte offset into that array (opaque to the
+    // compiler, which would hold the index and the offset otherwise - one register too many for four waves per SIMD)
+    unsigned toff = threadIdx.x << 3;
+    if(TBL) asm volatile("" : "+v"(toff));
+    double* const ltb = (double*)((char*)pp_tb_lds + toff);
+    const int tix = TBL ? (int)(toff >> 3) : (int)threadIdx.x;
     const size_t np = (size_t)P.n_pad;
-    const int bx = (P.n_cols_bound + 255) / 256;
-    const long long total = (long long)bx * ((rows - 1 + R - 1) / R);
     const int ncol = P.colmap ? *P.n_cols : P.n_pad;
-    for(long long w = blockIdx.x; w < total; w += gridDim.x){
-        const int col = (int)(w % bx) * 256 + (int)threadIdx.x;
-        const int i0 = (int)(w / bx) * R;
-        if(col >= ncol) continue;
-        const int nr = P.nrows[col];
-        if(i0 + 1 >= nr) continue;
-        const int slot = P.colmap ? P.colmap[col] : col;
-        double aux[2] = { 0.0, 0.0 };
-        EQ::pp_aux(P, P.state + slot, np, aux);
+    const int col = (int)blockIdx.x * 256 + tix;
+    if(col >= ncol) return;
+    const int nr = P.nrows[col];
+    const int slot = P.colmap ? P.colmap[col] : col;
+    double aux[2] = { 0.0, 0.0 };
+    EQ::pp_aux(P, P.state + slot, np, aux);
+    {   // grid: x = blocks of 256 columns, y = groups of R rows, from group gy0 on (the host cuts a launch at the grid's y limit)
+        const int i0 = (gy0 + (int)blockIdx.y) * R;
+        if(i0 + 1 >= nr) return;
         const int i1 = min(i0 + R, nr - 1);                       // segments i0 .. i1 - 1
         const double* a = P.path + ((size_t)i0 * PW) * np + col;
         // rows i, i + 1 and the prefetched i + 2.  (Three buffers in rotation - three copies of the body, no row copies - were measured in round 3:
         // 12 moves fewer per segment, but the exact fall-back inlined three times takes the kernel from 164 to 268 registers, one wave per SIMD.)
-        double A[PW], B[PW], Bn[PW];
+        double A[PW], B[PW], Bn[TBL ? 1 : PW];
         #pragma unroll
-        for(int c = 0; c < PW; c++){ A[c] = a[(size_t)c * np]; Bn[c] = a[(size_t)(PW + c) * np]; }
-        double rec[GEOAC_SEGW], tb[19];                           // the spline record and the table entry in hand (k, ent: which)
+        for(int c = 0; c < PW; c++){ A[c] = a[(size_t)c * np]; if(!TBL) Bn[c] = a[(size_t)(PW + c) * np]; }
+        double rec[GEOAC_SEGW], tb[TBL ? 1 : 19];                 // the spline record and the table entry in hand (k, ent: which)
         int k = -1, ent = -1;
-        double ref[3] = { 1e300, 0.0, 1.0 };                      // Global: reference point of the midpoint latitudes' sin / cos (pp_geom)
+        double ref[3] = { 0.15915494309189532, 0.0, 1.0 };                      // Global: reference point of the midpoint latitudes' sin / cos (pp_geom)
         rec[0] = 1.0; rec[1] = 0.0;
         #pragma unroll
         for(int c = 2; c < GEOAC_SEGW; c++) rec[c] = 0.0;
-        #pragma unroll
-        for(int c = 0; c < 19; c++) tb[c] = 0.0;
-        for(int i = i0; i < i1; i++){
+        if(TBL){
             #pragma unroll
-            for(int c = 0; c < PW; c++) B[c] = Bn[c];
-            if(i + 2 <= i1){                                      // the row after next, while this segment is evaluated
+            for(int c = 0; c < 19; c++) ltb[c * 256] = 0.0;
+        } else {
+            #pragma unroll
+            for(int c = 0; c < 19; c++) tb[c] = 0.0;
+        }
+        for(int i = i0; i < i1; i++){
+            if(TBL){                                              // (no prefetch: the other three waves of the SIMD cover the wait)
+                const double* b = P.path + ((size_t)(i + 1) * PW) * np + col;
+                #pragma unroll
+                for(int c = 0; c < PW; c++) B[c] = b[(size_t)c * np];
+            } else {
+                #pragma unroll
+                for(int c = 0; c < PW; c++) B[c] = Bn[c];
+            }
+            if(!TBL && i + 2 <= i1){                              // the row after next, while this segment is evaluated
                 const double* b = P.path + ((size_t)(i + 2) * PW) * np + col;
                 #pragma unroll
                 for(int c = 0; c < PW; c++) Bn[c] = b[(size_t)c * np];
@@ -2292,8 +2394,13 @@ __global__ void __launch_bounds__(256, EQ::PW == 6 ? GEOAC_PPTAB_GLOBAL_WAVES : 
                     const double* q = P.atab + (size_t)eg * GEOAC_ATABW;
                     #pragma unroll
                     for(int c = 0; c < GEOAC_SEGW; c++) rec[c] = p[c];
-                    #pragma unroll
-                    for(int c = 0; c < 19; c++) tb[c] = q[c];
+                    if(TBL){
+                        #pragma unroll
+                        for(int c = 0; c < 19; c++) ltb[c * 256] = q[c];
+                    } else {
+                        #pragma unroll
+                        for(int c = 0; c < 19; c++) tb[c] = q[c];
+                    }
                     ent = eg; k = kn;
                     if(__builtin_expect(!(((xe >= rec[0]) | (kn == 0)) & ((xe <= rec[1]) | (kn == P.nseg - 1))), 0)){
                         k = seg_find(P.seg, P.nseg, xe, kn);
@@ -2312,14 +2419,20 @@ __global__ void __launch_bounds__(256, EQ::PW == 6 ? GEOAC_PPTAB_GLOBAL_WAVES : 
             const int e = atab_locate(P, G.x, xe, k, rec[0], t, out);
             if(e != ent){
                 const double* q = P.atab + (size_t)e * GEOAC_ATABW;
-                #pragma unroll
-                for(int c = 0; c < 19; c++) tb[c] = q[c];
+                if(TBL){
+                    #pragma unroll
+                    for(int c = 0; c < 19; c++) ltb[c * 256] = q[c];
+                } else {
+                    #pragma unroll
+                    for(int c = 0; c < 19; c++) tb[c] = q[c];
+                }
                 ent = e;
             }
             double T, u, v; seg_eval_f(rec, xe, T, u, v);
             const double tt = EQ::pp_tt(P, aux, G, T, u, v);
-            const bool bad = out | (tb[0] < 0.0);
-            const double at = atab_eval(tb, t) * G.ds_at;
+            bool bad; double at;
+            if(TBL){ const double e0 = ltb[0]; bad = out | (e0 < 0.0); at = atab_eval_lds(ltb, e0, t) * G.ds_at; }
+            else { bad = out | (tb[0] < 0.0); at = atab_eval(tb, t) * G.ds_at; }
             if(bad){                                              // not served by the table (rare): listed for k_ppfix, which evaluates it exactly
                 atomicAdd(&P.counters[GEOAC_CNT_PPFLAG + 1], 1ull);                     // (statistics: geoac_abs_table_info)
                 const unsigned long long q = atomicAdd(&P.counters[GEOAC_CNT_PPFLAG], 1ull);
@@ -2352,7 +2465,7 @@ __global__ void __launch_bounds__(256) k_ppfix(GeoacDevParams P){
         double A[PW], B[PW];
         #pragma unroll
         for(int c = 0; c < PW; c++){ A[c] = a[(size_t)c * np]; B[c] = a[(size_t)(PW + c) * np]; }
-        double ref[3] = { 1e300, 0.0, 1.0 };
+        double ref[3] = { 0.15915494309189532, 0.0, 1.0 };
         PPGeom G;
         EQ::pp_geom(P, aux, A, B, G, ref);
         const double xe = clampq(G.x, P.x_min, P.x_max);
@@ -2368,7 +2481,15 @@ __global__ void __launch_bounds__(256) k_ppfix(GeoacDevParams P){
 // height x - r_earth unclamped.
 __global__ void __launch_bounds__(64) k_atab_build(GeoacDevParams P, double* __restrict__ tab, double tol){
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if(e >= P.nseg + 2) return;
+    if(e >= P.nseg + 2){
+        // behind the table: sin / cos of the multiples of 2^-7 rad (GeoacDevParams::lat_trig), by the routine pp_geom would call
+        const int i = e - (P.nseg + 2);
+        if(i < GEOAC_LAT_N){
+            double* o = tab + (size_t)(P.nseg + 2) * GEOAC_ATABW + 2 * (size_t)i;
+            fsincos((double)(i - GEOAC_LAT_OFF) * (1.0 / 128.0), o[0], o[1]);
+        }
+        return;
+    }
     double x0, h;
     if(e < P.nseg){ x0 = P.seg[(size_t)e * GEOAC_SEGW]; h = P.seg[(size_t)e * GEOAC_SEGW + 1] - x0; }
     else if(e == P.nseg){ x0 = P.x_min - P.atab_D; h = P.atab_D; }
@@ -2802,17 +2923,22 @@ extern "C" hipError_t geoac_launch_postpass(const GeoacDevParams* P, int rows, h
 extern "C" hipError_t geoac_launch_postpass_tab(const GeoacDevParams* P, int rows, hipStream_t s){
     if(rows < 2) return hipSuccess;
     if(!P->atab || P->gtab) return hipErrorInvalidValue;
-    long long total = (long long)((P->n_cols_bound + 255) / 256) * ((rows - 1 + GEOAC_PP_ROWS - 1) / GEOAC_PP_ROWS);
-    if(total > 0x7fffffffLL) total = 0x7fffffffLL;
-    dim3 b(256), g((unsigned)total);
+    const int gy = (rows - 1 + GEOAC_PP_ROWS - 1) / GEOAC_PP_ROWS;           // groups of GEOAC_PP_ROWS rows: the grid's y (at most 65 535 per launch)
+    dim3 b(256);
     // LDS the kernel never touches (GeoacDevParams::pp_lds_pad, set by the launch plan): a workgroup that asks for more than 7 KiB cannot be placed
     // on a CU that holds an RK4 workgroup with its table (153 KiB of the 160), one that asks for more than 80 KiB is alone on its CU (one wave per
     // SIMD).  With the exact fall-back out of the kernel its waves are small enough to sit beside an RK4 wave on the same SIMD and to run at three
     // or four waves per SIMD: right for a fan whose RK4 launches fill the chip (config 3: +11 %), wrong for the fans whose time is the serial chain of
     // one ray (GeoAc3D 360 x 90: +6 % per pass beside the RK4 waves, +2.5 % at full occupancy on the free CUs, 0 at one wave per SIMD there)
-    const unsigned pad = (unsigned)P->pp_lds_pad;
-    const int v = (P->eqset * 2 + (P->calc_amp ? 1 : 0)) * 2 + (P->pp_onetrip ? 1 : 0);
-    void (*f)(GeoacDevParams, int) = nullptr;
+    unsigned pad = (unsigned)P->pp_lds_pad;
+    int v = (P->eqset * 2 + (P->calc_amp ? 1 : 0)) * 2 + (P->pp_onetrip ? 1 : 0);
+    void (*f)(GeoacDevParams, int, int) = nullptr;
+    if(P->pp_lds_table && P->eqset == GEOAC_EQ_GLOBAL && P->pp_onetrip){
+        // the table entry in LDS (19 x 256 doubles per workgroup), four waves per SIMD: the fans of the spherical set that fill the chip
+        f = P->calc_amp ? k_postpass_tab<EqGlobal<true>, true, true> : k_postpass_tab<EqGlobal<false>, true, true>;
+        if(pad < 19u * 256u * 8u) pad = 19u * 256u * 8u;
+        v = 24 + (P->calc_amp ? 1 : 0);
+    } else
     switch(v){
         case (GEOAC_EQ_GLOBAL * 2 + 1) * 2 + 0: f = k_postpass_tab<EqGlobal<true>, false>; break;
         case (GEOAC_EQ_GLOBAL * 2 + 1) * 2 + 1: f = k_postpass_tab<EqGlobal<true>, true>; break;
@@ -2829,14 +2955,19 @@ extern "C" hipError_t geoac_launch_postpass_tab(const GeoacDevParams* P, int row
         default: return hipErrorNotSupported;
     }
     if(pad > 65536u){
-        static bool raised[32] = {};
-        if(v >= 0 && v < 32 && !raised[v]){
+        static bool raised[64][32] = {};                             // (a function attribute is per device)
+        int dev = 0;
+        if(hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;
+        if(v >= 0 && v < 32 && (dev == 63 || !raised[dev][v])){
             hipError_t err = hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if(err != hipSuccess) return err;
-            raised[v] = true;
+            raised[dev][v] = true;
         }
     }
-    hipLaunchKernelGGL(f, g, b, pad, s, *P, rows);
+    for(int gy0 = 0; gy0 < gy; gy0 += 65535){
+        dim3 g((unsigned)((P->n_cols_bound + 255) / 256), (unsigned)(gy - gy0 > 65535 ? 65535 : gy - gy0));
+        hipLaunchKernelGGL(f, g, b, pad, s, *P, rows, gy0);
+    }
     hipError_t e = hipGetLastError();
     if(e != hipSuccess) return e;
     // the listed segments, exactly (the list's counter was zeroed on this stream before the launch above: geoac_api.cpp)
@@ -2854,7 +2985,7 @@ extern "C" hipError_t geoac_launch_postpass_tab(const GeoacDevParams* P, int row
 }
 
 extern "C" hipError_t geoac_launch_atab_build(const GeoacDevParams* P, double* tab, double tol, hipStream_t s){
-    hipLaunchKernelGGL(k_atab_build, dim3((P->nseg + 2 + 63) / 64), dim3(64), 0, s, *P, tab, tol);
+    hipLaunchKernelGGL(k_atab_build, dim3((P->nseg + 2 + GEOAC_LAT_N + 63) / 64), dim3(64), 0, s, *P, tab, tol);
     return hipGetLastError();
 }
 

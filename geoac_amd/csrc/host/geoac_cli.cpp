@@ -72,11 +72,19 @@ static void parse_gpu_args(int argc, char* argv[]){
         const char* a = argv[i];
         if(strncmp(a, "gpu_devices=", 12) == 0) g_devices = a + 12;
         else if(strncmp(a, "gpu_stats=", 10) == 0) g_stats = a + 10;
-        else if(strncmp(a, "gpu_rays_per_batch=", 19) == 0) g_rays_per_batch = atol(a + 19);
+        else if(strncmp(a, "gpu_rays_per_batch=", 19) == 0){
+            char* end = nullptr; const long v = strtol(a + 19, &end, 10);
+            if(end == a + 19 || *end || v <= 0) cerr << kName << ": warning: " << a << ": expected a ray count > 0 - argument ignored" << '\n';
+            else g_rays_per_batch = v;
+        }
         else if(strncmp(a, "gpu_opt=", 8) == 0){
             const char* c = strchr(a + 8, ':');
-            if(c) g_opts.emplace_back(string(a + 8, c), string(c + 1));
+            if(c && c != a + 8 && c[1]) g_opts.emplace_back(string(a + 8, c), string(c + 1));
+            else cerr << kName << ": warning: " << a << ": expected gpu_opt=<KEY>:<value> - argument ignored" << '\n';
         }
+        // (the reference's parsers skip key=value pairs they do not know, and so do the loops below; an argument that LOOKS like one of this
+        //  build's own and is not - a typo such as gpu_device=1 - would change nothing without a word)
+        else if(strncmp(a, "gpu_", 4) == 0) cerr << kName << ": warning: unknown argument " << a << " (gpu_devices=, gpu_stats=, gpu_rays_per_batch=, gpu_opt=<KEY>:<value>) - ignored" << '\n';
     }
 }
 static int apply_gpu_opts(geoac_ctx* ctx){

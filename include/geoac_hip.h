@@ -163,10 +163,17 @@ int  geoac_fan_sync(geoac_ctx* ctx);
  * kept: GEOAC_REC_STEPS = step_limit as the reference returns it (step_limit - 1 steps were taken; the reference's post-pass then
  * reads one row it never wrote - here the sums end at the last integrated row). */
 #define GEOAC_FAN_STEP_LIMIT 1
+/* GEOAC_FAN_SUB_FALLBACK: a sub-epoch workgroup of the cooperative grid kernels gave up waiting for its predecessor (the in-order workgroup
+ * dispatch the hand-off relies on did not hold on this device); the fan was run again without sub-epochs and this context keeps them off.
+ * GEOAC_FAN_ABS_FALLBACK: the absorption table left more path segments to the exact fix-up pass than its list holds; the fan was run again
+ * with the exact post-pass and this context keeps it.  Both are sticky: reported by every later geoac_fan_status of the context.  Results are
+ * the same bits either way (tests); the flags tell an operator that the faster plan is off. */
+#define GEOAC_FAN_SUB_FALLBACK 0x100
+#define GEOAC_FAN_ABS_FALLBACK 0x200
 int  geoac_fan_status(geoac_ctx* ctx, uint64_t* flags);
 /* Stratified sets: in a stratified medium SuthBass_Alpha (Atmo_State.Absorption{,.Global}.cpp:12-141) depends on the height coordinate
- * alone, so the post-pass does not evaluate it at every path-segment midpoint: per spline segment a table holds degree-7 interpolants of
- * its smooth pieces, built on the device from the exact routine and checked against it (the classical term's sqrt(1 + nu^2) - 1 is formed
+ * alone, so the post-pass does not evaluate it at every path-segment midpoint: per spline segment a table holds degree-5 interpolants (six
+ * coefficients each, Chebyshev nodes) of its three smooth pieces, built on the device from the exact routine and checked against it (the classical term's sqrt(1 + nu^2) - 1 is formed
  * at the midpoint as the reference forms it), and only the path segments the table does not serve are evaluated exactly.  Of the last
  * completed launch: entries of the table (0: table not in use), entries flagged at build time (reassembled alpha off by more than 1e-10
  * relative at a check point), path segments evaluated exactly, largest check-point error of the unflagged entries. */

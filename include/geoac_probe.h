@@ -27,8 +27,10 @@ int geoac_probe_atmo_1d(geoac_ctx* ctx, int n, const double* x, double* out9, do
 /* 1-D sets: SuthBass_Alpha(x[i], freq[i]) * tweak_abs * 8.685889 as the post-pass evaluates it (z_grnd and abs_coeff of geoac_set_params) */
 int geoac_probe_absorption(geoac_ctx* ctx, int n, const double* x, const double* freq, double* alpha);
 
-/* 1-D sets: the same coefficient from the absorption table the post-pass reads (k_atab_build: per spline segment the degree-7 interpolant of
- * the routine above at the frequency of geoac_set_params; Atmo_State.Absorption{,.Global}.cpp:12-141 tabulated, as alpha depends on the
+/* 1-D sets: the same coefficient from the absorption table the post-pass reads (k_atab_build: per spline segment three degree-5 interpolants - six
+ * coefficients each - of the smooth pieces of the routine above at the frequency of geoac_set_params, reassembled with the routine's own
+ * roots; accuracy contract: every entry is checked against the exact routine at eight further points to 1e-10 relative, an entry that fails
+ * is flagged and the post-pass evaluates the segments that fall into it exactly (k_ppfix); Atmo_State.Absorption{,.Global}.cpp:12-141 tabulated, as alpha depends on the
  * height coordinate alone in a stratified medium).  alpha[i] = -1 where the table does not serve x[i] (flagged segment, beyond the strips
  * at the two ends of the profile): the post-pass evaluates such midpoints with the exact routine. */
 int geoac_probe_absorption_table(geoac_ctx* ctx, int n, const double* x, double* alpha);

@@ -154,3 +154,8 @@ def test_options_go_through_the_abi_not_the_environment(monkeypatch):
     assert e3 == e1 and np.array_equal(rec0, rec3)
     with pytest.raises(G.GeoAcError):
         G.FanContext(H.EQ_GLOBAL, device=0, options={"NO_SUCH_KNOB": 1})
+    # a value that does not parse or lies outside the knob's range is an error too - never a silent 0 (SORT=abc used to switch sorting off)
+    for bad in ({"SORT": "abc"}, {"PP_BLOCKS": -1}, {"HYBRID_ROWS": 1.5}, {"PAIR_FRAC": -0.1}, {"PPFIX_CAP": 0}, {"S_ROWS": "12x"}, {"GRID_LANES": 3},
+                {"SUB_EPOCHS": 0}, {"GRID_BUILD": "gpu"}, {"ABS_TABLE_TOL": "0"}, {"COMPACT": 2}):
+        with pytest.raises(G.GeoAcError, match="expected"):
+            G.FanContext(H.EQ_GLOBAL, device=0, options=bad)

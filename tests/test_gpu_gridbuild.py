@@ -130,6 +130,21 @@ def test_fan_on_a_ragged_grid_is_variant_independent(eq, shape, monkeypatch):
     one, st1 = run({"GEOAC_GRID_LANES": "1", "GEOAC_SPREAD": "1", "GEOAC_GRID_COOP": "0"})
     sub, st2 = run({"GEOAC_GRID_LANES": "1", "GEOAC_SPREAD": "1", "GEOAC_SUB_MIN_WAVES": "0", "GEOAC_S_ROWS": "256"})
     assert st1 == st2 and np.array_equal(one, sub)
+    # the hand-off's time-out path: with SUB_TEST_STALL the workgroups of sub-epoch 0 never publish their flag; the waiters give up, the library
+    # repeats the fan without sub-epochs (a loop in geoac_fan_launch), returns the same records and reports the fallback through geoac_fan_status
+    ctx = G.FanContext(eq, device=0, options={"GEOAC_GRID_LANES": "1", "GEOAC_SPREAD": "1", "GEOAC_SUB_MIN_WAVES": "0", "GEOAC_S_ROWS": "256", "SUB_TEST_STALL": "1"})
+    ctx.upload_atmo_3d(x, y, z, T, u, v, rho)
+    ctx.set_params(bounces=1, calc_amp=1, mode=0, src=src)
+    stalled, st4 = ctx.run(th, ph)
+    assert ctx.fan_status() & G.FAN_SUB_FALLBACK, "the stalled hand-off was not reported"
+    assert st4 == st1 and np.array_equal(stalled, one)
+    again, st5 = ctx.run(th, ph)                                   # the context keeps sub-epochs off and keeps saying so
+    assert st5 == st1 and np.array_equal(again, one) and ctx.fan_status() & G.FAN_SUB_FALLBACK
+    ctx.close()
+    plain = G.FanContext(eq, device=0, options={"GEOAC_GRID_LANES": "1", "GEOAC_SPREAD": "1", "GEOAC_SUB_MIN_WAVES": "0", "GEOAC_S_ROWS": "256"})
+    plain.upload_atmo_3d(x, y, z, T, u, v, rho); plain.set_params(bounces=1, calc_amp=1, mode=0, src=src); plain.run(th, ph)
+    assert plain.fan_status() == 0
+    plain.close()
     # one, two and four lanes per ray add the four corners in different orders: equal to rounding
     two, st3 = run({"GEOAC_GRID_LANES": "2"})
     for rec, st in ((one, st1), (two, st3)):

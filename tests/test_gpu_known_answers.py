@@ -1,0 +1,65 @@
+"""GPU: the analytic known-answer checks of tests/known_answers.py applied to the HIP path through the C ABI - straight rays in an isothermal
+windless medium (Cartesian sets: end point on the launch line, travel time = length / c, amplitude = spherical spreading, to 1e-9 / 1e-7; spherical set:
+great-circle plane and eikonal), GeoAc3D = GeoAc2D without wind to the accuracy of the scheme, and the reference's own Hamiltonian residuals at the
+arrivals of a ToyAtmo fan.  tests/test_oracle_known_answers.py holds the oracle to the same closed forms in the CPU suite."""
+import numpy as np
+import pytest
+
+import harness as H
+import known_answers as K
+from test_oracle_known_answers import PH, STRAIGHT, TH
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(eq, z, T, u, v, rho, **params):
+    import geoac_amd as G
+    ctx = G.FanContext(eq, device=0)
+    ctx.upload_atmo_1d(z + (K.R_EARTH if eq == H.EQ_GLOBAL else 0.0), T, u, v, rho)
+    ctx.set_params(**params)
+    return ctx
+
+
+@pytest.mark.parametrize("eq,src", STRAIGHT)
+def test_isothermal_windless_rays_are_straight(eq, src):
+    z, T, u, v, rho = K.isothermal_profile()
+    ctx = _ctx(eq, z, T, u, v, rho, bounces=0, calc_amp=1, mode=0, src=src)
+    rec, steps = ctx.run(TH, PH)
+    n, off, et, ea = K.check_straight_rays(eq, rec, TH, PH, src)
+    print(H.EQ_NAMES[eq], f"{n} arrivals, {steps} steps: off the launch line / great-circle plane {off:.2e}, travel time / eikonal {et:.2e}, amplitude vs spherical spreading {ea:.2e}")
+    # and the oracle's records of the same fan: counts exact, the arrival fields to 1e-6 (the parity rule; the oracle keeps no end state for a leg that broke)
+    O = H.Oracle(eq, met=None); O.load_arrays(z, T, u, v, rho)
+    so, ro, _, _ = O.fan(H.make_cfg(eq, bounces=0, calc_amp=True, src=src), TH, PH)
+    assert so == steps
+    for f in ("VALID", "STEPS", "BROKE"):
+        assert np.array_equal(rec[..., H.REC[f]], ro[..., H.REC[f]]), f
+    ok = ro[..., H.REC["VALID"]] > 0
+    for f in ("TTIME", "ATTEN", "TURN", "AMP", "RANGE"):
+        e = np.abs(rec[..., H.REC[f]][ok] - ro[..., H.REC[f]][ok]) / np.maximum(np.abs(ro[..., H.REC[f]][ok]), 1e-300)
+        assert e.max() <= 1e-6, (f, e.max())
+
+
+def test_3d_equals_2d_without_wind():
+    import geoac_amd as G
+    a = G.met_load(H.TOYATMO, G.EQ_3D)
+    z, T, rho = a["x"], a["T"], a["rho"]
+    zero = np.zeros_like(z)
+    th = np.arange(1.0, 45.0, 2.0); az = np.full_like(th, 37.0)
+    r2, _ = _ctx(H.EQ_2D, z, T, zero, zero, rho, bounces=1, calc_amp=0, mode=0).run(th, az)
+    r3, _ = _ctx(H.EQ_3D, z, T, zero, zero, rho, bounces=1, calc_amp=0, mode=0).run(th, az)
+    n, worst = K.check_2d_equals_3d_without_wind(r2, r3)
+    print(f"{n} arrivals, GeoAc2D vs GeoAc3D without wind: worst relative difference {worst:.2e}")
+    assert n >= 20
+
+
+def test_hamiltonian_residuals_at_every_arrival_of_a_global_fan():
+    """GeoAc_EvalHamiltonian / GeoAc_EvalHamiltonian_Deriv (EquationSets.Global.cpp:447-495) at all arrivals of a 36 x 45 ToyAtmo fan, medium through the
+    device-function probe"""
+    import geoac_amd as G
+    th, ph = G.fan_enumerate(theta_min=1.0, theta_max=45.0, theta_step=1.0, phi_min=-180.0, phi_max=170.0, phi_step=10.0)
+    ctx = G.FanContext(G.EQ_GLOBAL, device=0); ctx.load_met(H.TOYATMO); ctx.set_params(bounces=2, calc_amp=1, mode=0)
+    rec, steps = ctx.run(th, ph)
+    c_src = ctx.probe_atmo_1d(np.array([K.R_EARTH]))[0][0, 0]
+    n, h, hd = K.hamiltonian_residuals(H.EQ_GLOBAL, rec, lambda x: ctx.probe_atmo_1d(x)[0], c_src)
+    print(f"{n} arrivals of {len(th)} rays: |H| <= {h:.2e}, |H_deriv| / |mu| <= {hd:.2e}")
+    assert n > 3000 and h < 1e-4 and hd < 5e-2

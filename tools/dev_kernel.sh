@@ -9,6 +9,7 @@ OUT=/tmp/geoac_dev; mkdir -p $OUT
   echo "#include \"$HERE/geoac_amd/csrc/geoac_kernels.hip\""
   for k in "$@"; do
     case "$k" in
+      k_postpass_tab*) echo "template __global__ void $k(GeoacDevParams, int, int);" ;;
       k_postpass*) echo "template __global__ void $k(GeoacDevParams, int);" ;;
       *)           echo "template __global__ void $k(GeoacDevParams);" ;;
     esac
