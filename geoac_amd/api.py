@@ -141,6 +141,12 @@ class options:
         return False
 
 
+def has_ab_kernels():
+    """True for an A/B build of the library (`make AB=1`): it also holds the diagnostic kernels the launch plan never selects (DUO, GRID_LANES=2)"""
+    lib = load_library()
+    return bool(lib.geoac_build_has_ab())
+
+
 def option_names():
     lib = load_library()
     lib.geoac_option_names.restype = ctypes.POINTER(ctypes.c_char_p)
@@ -158,7 +164,8 @@ def _apply_options(lib, h, opts):
             k = k[6:]
         rc = lib.geoac_set_option(h, k.encode(), str(v).encode())
         if rc:
-            raise GeoAcError(f"geoac_set_option({k}={v}): {lib.geoac_strerror(rc).decode()}")
+            msg = lib.geoac_last_error(h)
+            raise GeoAcError(f"geoac_set_option({k}={v}): {lib.geoac_strerror(rc).decode()}: {msg.decode() if msg else ''}")
 
 
 # ---------------- the GPU fan context ----------------

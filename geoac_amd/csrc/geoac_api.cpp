@@ -22,6 +22,7 @@ extern "C" void geoac_natural_spline_slopes(int n, const double* x, const double
 extern "C" hipError_t geoac_launch_init(const GeoacDevParams* P, hipStream_t s);
 extern "C" hipError_t geoac_launch_rk4(const GeoacDevParams* P, int block, hipStream_t s, unsigned* n_wg);
 extern "C" size_t geoac_duo_lds(int nseg);
+extern "C" int geoac_build_has_ab(void);
 extern "C" size_t geoac_gridbuild_work_doubles(int nx, int ny, int nz);
 extern "C" size_t geoac_gridpack_doubles(int nx, int ny, int nz);
 extern "C" hipError_t geoac_gridpack_launch(int nx, int ny, int nz, const double* d_tab, double* d_tab8, hipStream_t s);
@@ -87,7 +88,9 @@ struct DevBuf {
 struct geoac_ctx {
     int eqset = 0, device = 0;
     GeoacDevParams lastP{};          // parameter block of the last completed launch (device-function probes, include/geoac_probe.h)
-    int  pp_lds_table = -1;          // table post-pass of the spherical set: the table entry in LDS, four waves per SIMD (PP_LDS_TABLE; < 0: the fans that are not hybrid)
+    int  rk4_prefetch = -1;          // RK4_PREFETCH: early segment locate in the one-lane kernel of the stratified Global set; < 0: fans of more waves than the chip has SIMDs
+    int  pp_lds_pad = -1;            // PP_LDS_PAD: bytes of LDS a table post-pass workgroup asks for (its occupancy knob: 160 KiB per CU / this = workgroups of four waves per CU); < 0: by launch plan
+    int  pp_lds_table = -1;          // table post-pass of the spherical set: the table entry in LDS, 127 registers (PP_LDS_TABLE=1; default off: no faster, geoac_fan_launch)
     unsigned long long sticky_flags = 0;   // GEOAC_FAN_*_FALLBACK: plan features this context has withdrawn after a failed attempt (geoac_fan_status)
     int  launch_repeats = 0;         // fans that were run a second time for that reason
     bool sub_test_stall = false;     // SUB_TEST_STALL (tests): the cooperative grid kernels' workgroups of sub-epoch 0 do not publish their flag - forces the hand-off time-out
@@ -239,7 +242,7 @@ int geoac_default_params(int eqset, geoac_params* p){
 
 // ---- launch-plan options (A/B measurements, tests; results never depend on them) ----
 static const char* const kOptionNames[] = {
-    "S_ROWS", "NO_OVERLAP", "PP_BLOCKS", "ABS_TABLE", "ABS_TABLE_TOL", "PPFIX_CAP", "DUO", "EV_SLACK", "NO_PAIR", "PAIR_FRAC", "HYBRID_ROWS", "TWO_CHUNKS", "TRACE_EPOCHS", "NO_GATE", "SORT", "TILE", "PP_ONETRIP", "PP_LDS_TABLE",
+    "S_ROWS", "NO_OVERLAP", "PP_BLOCKS", "ABS_TABLE", "ABS_TABLE_TOL", "PPFIX_CAP", "DUO", "EV_SLACK", "NO_PAIR", "PAIR_FRAC", "HYBRID_ROWS", "TWO_CHUNKS", "TRACE_EPOCHS", "NO_GATE", "SORT", "TILE", "PP_ONETRIP", "PP_LDS_TABLE", "PP_LDS_PAD", "RK4_PREFETCH",
     "NO_QUAD", "GRID_LANES", "OCT", "HEX", "SPREAD", "COMPACT", "QUAD_CACHE", "GRID_COOP", "SUB_EPOCHS", "SUB_MIN_WAVES", "SUB_TEST_STALL", "SMP_CAP", "GRID_BUILD", nullptr };
 const char* const* geoac_option_names(void){ return kOptionNames; }
 
@@ -263,7 +266,11 @@ int geoac_set_option(geoac_ctx* ctx, const char* key, const char* value){
     else if(k == "ABS_TABLE") return flag(ctx->abs_table);
     else if(k == "ABS_TABLE_TOL"){ if(!dbl_ok || !(dv > 0.0)) return bad("a tolerance > 0"); ctx->atab_tol = dv; }
     else if(k == "PPFIX_CAP"){ if(!int_ok || lv <= 0 || lv > 0x3fffffff) return bad("a capacity > 0"); ctx->ppfix_cap = iv; }
-    else if(k == "DUO"){ if(!int_ok || lv < 0 || lv > 3) return bad("0..3"); ctx->duo = iv; }
+    else if(k == "DUO"){
+        if(!int_ok || lv < 0 || lv > 3) return bad("0..3");
+        if(lv && !geoac_build_has_ab()) return fail(ctx, GEOAC_E_UNSUPPORTED, "set_option: DUO: the wave-specialised kernel is part of A/B builds only (make AB=1)");
+        ctx->duo = iv;
+    }
     else if(k == "EV_SLACK"){ if(!int_ok || lv < 0 || lv > 1000000) return bad("a slot count >= 0"); ctx->ev_slack = iv; }
     else if(k == "NO_PAIR") return flag(ctx->no_pair);
     else if(k == "PAIR_FRAC"){ if(!dbl_ok || dv < 0.0 || dv > 1.0) return bad("a share in [0, 1]"); ctx->pair_frac = dv; }
@@ -274,9 +281,15 @@ int geoac_set_option(geoac_ctx* ctx, const char* key, const char* value){
     else if(k == "SORT") return flag(ctx->sort_rays);
     else if(k == "TILE") return flag(ctx->tile_rays);
     else if(k == "PP_ONETRIP"){ if(!int_ok || lv < -1 || lv > 1) return bad("0, 1 or -1 (by launch plan)"); ctx->pp_onetrip = iv; }
+    else if(k == "RK4_PREFETCH"){ if(!int_ok || lv < -1 || lv > 1) return bad("0, 1 or -1 (by launch plan)"); ctx->rk4_prefetch = iv; }
+    else if(k == "PP_LDS_PAD"){ if(!int_ok || lv < -1 || lv > 160 * 1024) return bad("bytes of LDS in 0 .. 163840, or -1 (by launch plan)"); ctx->pp_lds_pad = iv; }
     else if(k == "PP_LDS_TABLE"){ if(!int_ok || lv < -1 || lv > 1) return bad("0, 1 or -1 (by launch plan)"); ctx->pp_lds_table = iv; }
     else if(k == "NO_QUAD") return flag(ctx->no_quad);
-    else if(k == "GRID_LANES"){ if(!int_ok || !(iv == 0 || iv == 1 || iv == 2 || iv == 4 || iv == 8 || iv == 16)) return bad("0, 1, 2, 4, 8 or 16"); ctx->grid_lanes = iv; }
+    else if(k == "GRID_LANES"){
+        if(!int_ok || !(iv == 0 || iv == 1 || iv == 2 || iv == 4 || iv == 8 || iv == 16)) return bad("0, 1, 2, 4, 8 or 16");
+        if(iv == 2 && !geoac_build_has_ab()) return fail(ctx, GEOAC_E_UNSUPPORTED, "set_option: GRID_LANES=2: the grid sets' two-lane kernels are part of A/B builds only (make AB=1)");
+        ctx->grid_lanes = iv;
+    }
     else if(k == "OCT") return flag(ctx->oct);
     else if(k == "HEX") return flag(ctx->hex);
     else if(k == "SPREAD"){ if(!int_ok || lv < 0 || lv > 64 || (lv & (lv - 1))) return bad("0 (by launch plan) or a power of two up to 64"); ctx->spread_override = iv; }
@@ -377,7 +390,7 @@ int geoac_clone(geoac_ctx* src, geoac_ctx** out){
         hipError_t e = c->d_consts.ensure(sizeof(double) * 8);
         if(e != hipSuccess){ geoac_destroy(c); return hipfail(src, e, "clone: constants block"); }
     }
-    c->sort_rays = src->sort_rays; c->tile_rays = src->tile_rays; c->pp_onetrip = src->pp_onetrip; c->pp_lds_table = src->pp_lds_table; c->sub_test_stall = src->sub_test_stall; c->no_quad = src->no_quad; c->oct = src->oct; c->hex = src->hex; c->grid_lanes = src->grid_lanes; c->spread_override = src->spread_override;
+    c->sort_rays = src->sort_rays; c->tile_rays = src->tile_rays; c->pp_onetrip = src->pp_onetrip; c->pp_lds_table = src->pp_lds_table; c->pp_lds_pad = src->pp_lds_pad; c->rk4_prefetch = src->rk4_prefetch; c->sub_test_stall = src->sub_test_stall; c->no_quad = src->no_quad; c->oct = src->oct; c->hex = src->hex; c->grid_lanes = src->grid_lanes; c->spread_override = src->spread_override;
     c->compact = src->compact; c->quad_cache = src->quad_cache; c->sub_min_waves = src->sub_min_waves; c->sub_epochs = src->sub_epochs; c->grid_coop = src->grid_coop;
     c->smp_cap = src->smp_cap; c->s_rows_override = src->s_rows_override; c->no_overlap = src->no_overlap; c->pp_blocks = src->pp_blocks; c->pair_frac = src->pair_frac;
     c->hybrid_rows = src->hybrid_rows; c->two_chunks = src->two_chunks; c->no_gate = src->no_gate; c->no_pair = src->no_pair; c->duo = src->duo; c->abs_table = src->abs_table;
@@ -810,6 +823,8 @@ static int fan_launch_once(geoac_ctx* ctx){
     }
     bool split = hybrid && n_pair > 0 && n_pair < P.n_pad;      // n_pair == 0 (GEOAC_PAIR_FRAC=0): everything on the one-lane kernel, one launch
     if(hybrid && n_pair == 0) P.lanes_per_ray = 1;
+    // one-lane kernel of the stratified Global set on a fan of more waves than the chip has SIMDs (config 3): the next stage's spline segment located early (k_rk4<EqGlobal<AMP, true>>)
+    P.rk4_prefetch = (is_global && !is_grid && !hybrid && P.lanes_per_ray == 1 && (ctx->rk4_prefetch >= 0 ? ctx->rk4_prefetch != 0 : (long long)P.n_pad / 64 > 1024)) ? 1 : 0;
     // live-ray compaction between epochs (single-launch fans; a hybrid fan assigns its two kernels by slot range): epoch e > 0 runs
     // over the dense list of the rays alive after epoch e-1, built on the device (k_compact) right before its RK4 launch
     const bool compact = ctx->compact && !hybrid;
@@ -869,8 +884,14 @@ static int fan_launch_once(geoac_ctx* ctx){
         if(Pq.atab_on){
             // (see geoac_launch_postpass_tab) hybrid fans: the post-pass off the RK4 CUs, one (spherical set) or two (Cartesian sets) workgroups per free CU
             Pq.pp_lds_pad = !Pq.table_in_lds ? 0 : (hybrid ? (Pq.eqset == GEOAC_EQ_GLOBAL ? 96 : 64) * 1024 : 8 * 1024);
+            // fans of the spherical set that fill the chip: TWO post-pass workgroups per CU (two waves per SIMD).  Since round 4 the kernel needs 146 registers (three waves per
+            // SIMD; 127 with the table entry in LDS: four) - and config 3 is SLOWER the more of them are resident: 358 ms per pass at two waves per SIMD, 378 at three, 385
+            // at four, 369 at one (profiles/r04_c_cfg3_occupancy.txt).  RK4 (one wave per SIMD, 442 registers) and the post-pass cannot share a SIMD; every SIMD a
+            // post-pass wave sits on is one an RK4 wave of the next round is not placed on, and RK4 is the longer of the two.
+            if(!hybrid && Pq.eqset == GEOAC_EQ_GLOBAL) Pq.pp_lds_pad = 60 * 1024;
+            if(ctx->pp_lds_pad >= 0) Pq.pp_lds_pad = ctx->pp_lds_pad;
             Pq.pp_onetrip = ctx->pp_onetrip >= 0 ? (ctx->pp_onetrip ? 1 : 0) : (hybrid ? 0 : 1);
-            Pq.pp_lds_table = (Pq.eqset == GEOAC_EQ_GLOBAL && Pq.pp_onetrip) ? (ctx->pp_lds_table >= 0 ? (ctx->pp_lds_table ? 1 : 0) : (hybrid ? 0 : 1)) : 0;
+            Pq.pp_lds_table = (Pq.eqset == GEOAC_EQ_GLOBAL && Pq.pp_onetrip) ? (ctx->pp_lds_table > 0 ? 1 : 0) : 0;      // (opt-in: measured no faster at any occupancy, see above)
             HIPCHK(hipMemsetAsync((char*)ctx->counters.p + GEOAC_CNT_PPFLAG * sizeof(unsigned long long), 0, sizeof(unsigned long long), sp));   // the fix-up list is empty
             HIPCHK(geoac_launch_postpass_tab(&Pq, Pq.s_rows, sp));
         }

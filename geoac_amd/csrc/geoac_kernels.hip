@@ -35,8 +35,8 @@
 // then gives different bits in k_rk4<EqGlobal>, k_rk4<EqGlobalPair> and k_rk4_duo, and records must not depend on the launch plan.
 #pragma clang fp contract(off)
 
-#ifndef GEOAC_X
-#define GEOAC_X 0                       // A/B switches of the stratified step loop (bit mask; tools/ab_metric.py builds): see set_ds, seg_locate
+#ifndef GEOAC_AB
+#define GEOAC_AB 0                      // 1: A/B build (`make AB=1`) - also holds the diagnostic kernels the launch plan never selects
 #endif
 
 static constexpr double kPi   = 3.141592653589793238462643;   // GeoAc.Parameters.cpp:27
@@ -65,18 +65,6 @@ DEVINL double frsq(double x){
     double p = __builtin_fma(e, 0.375, 0.5);
     return __builtin_fma(y * e, p, y);
 }
-// a fused multiply-add whose ADDEND must survive (a loop-invariant constant, a coefficient of the spline record in hand): hipcc picks the two-address
-// v_fmac_f64 for these and copies the addend into the destination first - two issue slots where the three-address v_fma_f64 takes one, on a wave
-// that is alone on its SIMD and pays for every slot.  Same operation, same rounding: same bits.
-DEVINL double fma3(double a, double b, double c){
-#if GEOAC_X & 4
-    double d;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-#else
-    return __builtin_fma(a, b, c);
-#endif
-}
 // exp / exp10 for the absorption integrand (k_postpass): arguments of moderate size and never NaN / inf there, so none of the library
 // routine's special-case work.  k = round(x log2 e), r = x - k ln2 (two-constant Cody-Waite, exact product through FMA), Taylor
 // polynomial of degree 13 on |r| <= ln2 / 2 (truncation 2e-17), result scaled by 2^k: < 1 ulp + the rounding of r.
@@ -95,29 +83,6 @@ DEVINL double exp_poly(double r){
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     return __builtin_fma(p, r, 1.0);
-}
-// the same polynomial with three-address multiply-adds (fma3): the step-size rule of the RK4 kernels
-DEVINL double exp_poly3(double r){
-    double p = 1.0 / 6227020800.0;
-    p = fma3(p, r, 1.0 / 479001600.0);
-    p = fma3(p, r, 1.0 / 39916800.0);
-    p = fma3(p, r, 1.0 / 3628800.0);
-    p = fma3(p, r, 1.0 / 362880.0);
-    p = fma3(p, r, 1.0 / 40320.0);
-    p = fma3(p, r, 1.0 / 5040.0);
-    p = fma3(p, r, 1.0 / 720.0);
-    p = fma3(p, r, 1.0 / 120.0);
-    p = fma3(p, r, 1.0 / 24.0);
-    p = fma3(p, r, 1.0 / 6.0);
-    p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p, r, 1.0);
-    return __builtin_fma(p, r, 1.0);
-}
-DEVINL double fexp3(double x){
-    const double k = __builtin_rint(x * 1.44269504088896338700e+00);
-    double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);
-    r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
-    return __builtin_ldexp(exp_poly3(r), (int)k);
 }
 DEVINL double fexp(double x){
     const double k = __builtin_rint(x * 1.44269504088896338700e+00);
@@ -140,12 +105,10 @@ DEVINL double fexp10(double y){
 // time, with the table value loaded at the top of the step or a step ahead: the constants the full routine moves into place between its dependent
 // multiply-adds fill issue slots that would stay empty anyway, the load and its wait do not.)
 DEVINL double set_ds(double h, double ds_min, double ds_max){
-#if GEOAC_X & 1
-    const double ds = 0.05 - 0.049 * fexp3(h * (-1.0 / 0.75));    // (A/B: no skip - the exponential's chain in the block of stage 0, free to interleave with it)
-#else
-    double ds = 0.05;
-    if(!(h > 28.5)) ds = 0.05 - 0.049 * fexp3(h * (-1.0 / 0.75));
-#endif
+    // (round 4: no skip of the exponential above 28.5 km any more - there 0.049 e is below half the spacing of the doubles at 0.05 and the difference IS 0.05, the
+    //  same bits with or without it - : the skip was a branch, and a branch ends the scheduling region; without it the exponential's dependent chain sits in the block
+    //  of stage 0 and interleaves with that stage's own chains.  Metric pass 118.7 -> 117.6 ms together with the two items in seg_locate / open_step, A/B in turn.)
+    const double ds = 0.05 - 0.049 * fexp(h * (-1.0 / 0.75));
     return __builtin_fmax(__builtin_fmin(ds, ds_max), ds_min);
 }
 
@@ -220,10 +183,10 @@ DEVINL int seg_find(TabPtr tab, int nseg, double x, int k){
 // cubic in the derivative-friendly form (c0, c1, d2 = 2 c2, e3 = 6 c3): f'' = d2 + e3 t, f' = c1 + t/2 (d2 + f''),
 // f = c0 + t (c1 + t/6 (2 d2 + f'')) - 6 FMA-class operations per function for value + both derivatives
 DEVINL void cubic3(double c0, double c1, double d2, double e3, double t, double th, double t6, double& f, double& f1, double& f2){
-    f2 = fma3(t, e3, d2);                                         // (fma3: the coefficients are the record in hand - they must survive)
+    f2 = __builtin_fma(t, e3, d2);
     const double s2 = d2 + f2;
-    f1 = fma3(th, s2, c1);
-    f  = fma3(t, fma3(t6, d2 + s2, c1), c0);
+    f1 = __builtin_fma(th, s2, c1);
+    f  = __builtin_fma(t, __builtin_fma(t6, d2 + s2, c1), c0);
 }
 
 template <typename TabPtr>
@@ -294,13 +257,10 @@ DEVINL void seg_step_eval(TabPtr tab, const GeoacDevParams& P, double x, int& of
 template <int W = GEOAC_SEGW, typename TabPtr>
 DEVINL void seg_locate(TabPtr tab, const GeoacDevParams& P, double x, int& off, double* r){
     const int last = (P.nseg - 1) * W;
-#if GEOAC_X & 2
     // x is clamped to [x_min, x_max] = [x0 of the first record, x1 of the last] by every caller: x > r[1] cannot hold in the last segment nor
-    // x < r[0] in the first, the two index guards are redundant (four instructions per stage)
+    // x < r[0] in the first - no index guards (four instructions per stage less)
     const bool up = (x > r[1]), down = (x < r[0]);
-#else
-    const bool up = (x > r[1]) & (off < last), down = (x < r[0]) & (off > 0);
-#endif
+    (void)last;
     if(__builtin_expect(up | down, 0)){
         off += (up ? W : 0) - (down ? W : 0);
         if(!P.seg_safe){
@@ -480,10 +440,16 @@ DEVINL void global_aux(const GlobalStage& S, const GlobalDerived& D, const doubl
 
 // NQ = number of launch-angle derivative systems carried in y after the 6 base components: 2 = the reference layout
 // (theta then phi), 1 = the two-lanes-per-ray kernel where each lane of a pair carries the base ray and ONE of the two systems.
-template <bool AMP, int NQ, bool ROT0 = false, typename TabPtr>
-DEVINL void global_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, double* rec, const double* y, double sth0, double cth0, double dlat, double* dy){
+// PF (GEOAC_PF): once the base ray's slopes are known, the abscissa of the NEXT stage - r0 + w_next dy[0], exactly what the step loop forms later - is located
+// and, if it lies in another spline segment, that record's LDS reads are issued HERE, under the ~75 instructions per launch-angle system that follow (they read the
+// stage values, not the record).  A dense fan of steep rays (config 3: a node every two or three steps per ray, so some lane of a wave crosses in nearly every
+// stage) then finds its record in hand at the top of the next stage instead of waiting for it there.  Same operations on the same operands: same bits.
+template <bool AMP, int NQ, bool ROT0 = false, bool PF = false, typename TabPtr>
+DEVINL void global_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, double* rec, const double* y, double sth0, double cth0, double dlat, double* dy,
+                       double r0 = 0.0, double w_next = 0.0){
     GlobalStage S;
     global_base<AMP, GEOAC_SEGW, TabPtr, NoHook, ROT0>(tab, P, seg, rec, y, sth0, cth0, dlat, dy, S);
+    if(PF) seg_locate(tab, P, clampq(__builtin_fma(dy[0], w_next, r0), P.x_min, P.x_max), seg, rec);
     if(AMP){
         GlobalDerived D;
         global_derive(S, D);
@@ -733,6 +699,7 @@ struct RayCtx {
     double t[4];      // Global: proposed sin/cos for the row under test
     double cur[4];    // Global (stratified): sin/cos(lat), sin/cos(lon - lon_src) of the current row - a[] then holds the REFERENCE point they are
                       // rotated from: lat_ref, sin, cos, (lon - lon_src)_ref, sin, cos (EqGlobal::checks)
+    double pf_w;      // stratified Global set: weight of the current stage's slopes in the next stage's abscissa (EqGlobal::rhs, early locate)
     mutable double rec[GEOAC_SEGW];   // 1-D sets: the spline record of the segment the ray is in (x0, x1, cubics of T, u, v), seg_cached_eval
     mutable int ckey; // record-cache kernels: (segment, node) key of the records this lane holds in LDS (-1: none)
     mutable int kxy;  // grid sets: horizontal cell of the previous evaluation, kx << 16 | ky (-1: none), grid_locate's hint
@@ -819,10 +786,14 @@ DEVINL void cart2_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCt
 // ================================================================================================
 // Equation-set policies: everything the generic kernels need to know about a set
 // ================================================================================================
-template <bool AMP_> struct EqGlobal {
+template <bool AMP_, bool PF_ = false> struct EqGlobal {
     static constexpr bool AMP = AMP_;
     static constexpr bool SEG1D = true;                             // the ray keeps the spline record of its segment in registers (RayCtx::rec)
     static constexpr int AUX_SAVE = 6;                              // entries of RayCtx::a the RK4 kernel changes (the reference point of the carried sin / cos)
+    // PF_: locate the next stage's spline segment under the launch-angle systems of this one (global_rhs).  Its own instantiation of k_rk4, picked by the launch plan
+    // (GeoacDevParams::rk4_prefetch) for the fans that fill the chip: config 3 385 -> 373 ms per pass.  NOT for the hybrid fans: there the pass is the serial chain of one
+    // ray, whose segment changes rarely, and the 40 instructions per step of the early tests cost the metric pass 117 -> 122 ms (in its one-lane launch; 132 in both).
+    static constexpr bool PREFETCH = PF_;
     static constexpr bool COOP = false; static constexpr bool CACHE = false; static constexpr bool LDS_STATE = false; static constexpr int XCHG_BYTES = 0; static constexpr bool PP_TILE = false; static constexpr bool PP_DEDUP = false; static constexpr int SYS_SHIFT = 0; static constexpr bool ROW_SPLIT = false;
     static constexpr int PP_WAVES = 3;                              // post-pass waves per SIMD (168 registers; at 128 it spills 148 B and runs 1.5 x slower)
     static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 0, LANES = 1;
@@ -872,8 +843,10 @@ template <bool AMP_> struct EqGlobal {
     template <typename TabPtr>
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
         // (stage 0 - a constant where the step loop peels it: the stage latitude is the step's, no rotation)
-        if(stage == 0) global_rhs<AMP, 2, true>(tab, P, seg, C.rec, yt, C.cur[0], C.cur[1], 0.0, dy);
-        else global_rhs<AMP, 2>(tab, P, seg, C.rec, yt, C.cur[0], C.cur[1], yt[1] - y0[1], dy);
+        // (C.pf_w: the weight the step loop will give this stage's slopes in the next stage's abscissa - ds/2, ds/2, ds; stage 3: none, the loop locates the new row)
+        if(stage == 0) global_rhs<AMP, 2, true, PREFETCH>(tab, P, seg, C.rec, yt, C.cur[0], C.cur[1], 0.0, dy, y0[0], C.pf_w);
+        else if(stage == 3) global_rhs<AMP, 2>(tab, P, seg, C.rec, yt, C.cur[0], C.cur[1], yt[1] - y0[1], dy);
+        else global_rhs<AMP, 2, false, PREFETCH>(tab, P, seg, C.rec, yt, C.cur[0], C.cur[1], yt[1] - y0[1], dy, y0[0], C.pf_w);
     }
     // GeoAc_BreakCheck / GeoAc_GroundCheck on the new row (Global.cpp:500-522)
     static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, int k, bool& brk, bool& gnd){
@@ -1737,7 +1710,9 @@ DEVINL void pp_exact(const GeoacDevParams& P, const double* aux, const double* A
 }
 
 #pragma clang fp contract(off)
-#include "geoac_duo.h"
+#if GEOAC_AB
+#include "geoac_duo.h"                // (A/B builds only, `make AB=1`: the wave-specialised kernel - correct, bit-identical, measured slower)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // k_init: launch angles -> initial conditions + per-ray state
@@ -1918,11 +1893,8 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
             if(k >= 1) hmax = (hmax < ya[2]) ? ya[2] : hmax;
         } else {
             double h = EQ::height(P, ya); if(EQ::HMAX_PER_LEG && k == 0) hmax = 0.0;
-#if GEOAC_X & 8
             if(EQ::SEG1D) hmax = __builtin_fmax(hmax, h);         // (one v_max_f64 instead of a compare and two selects; no NaN reaches it: the same value)
-            else
-#endif
-            hmax = (hmax < h) ? h : hmax;
+            else hmax = (hmax < h) ? h : hmax;                    // (grid kernels: the select form they were tuned with)
         }
 
         if(SMP && k >= 1){
@@ -2033,13 +2005,15 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
                 const double ds_2 = 0.5 * ds, ds_6 = (1.0 / 6.0) * ds, ds_3 = (1.0 / 3.0) * ds;
                 // k_s = ds f(y + a_s k_{s-1}), a = {0, 1/2, 1/2, 1};  y' = y + k1/6 + k2/3 + k3/3 + k4/6  (Solver.cpp:33-54)
                 double yt[E];
+                C.pf_w = ds_2;
                 if(LDS) EQ::rhs(lds_tab, P, seg, C, y, y, 0, dy); else EQ::rhs(gtab, P, seg, C, y, y, 0, dy);
                 #pragma unroll
                 for(int e = 0; e < E; e++){ ys[e] = __builtin_fma(dy[e], ds_6, y[e]); yt[e] = __builtin_fma(dy[e], ds_2, y[e]); }
                 #pragma unroll 1
                 for(int stage = 1; stage < 3; stage++){
-                    if(LDS) EQ::rhs(lds_tab, P, seg, C, y, yt, stage, dy); else EQ::rhs(gtab, P, seg, C, y, yt, stage, dy);
                     const double wa = (stage == 2) ? ds : ds_2;
+                    C.pf_w = wa;
+                    if(LDS) EQ::rhs(lds_tab, P, seg, C, y, yt, stage, dy); else EQ::rhs(gtab, P, seg, C, y, yt, stage, dy);
                     #pragma unroll
                     for(int e = 0; e < E; e++){ ys[e] = __builtin_fma(dy[e], ds_3, ys[e]); yt[e] = __builtin_fma(dy[e], wa, y[e]); }
                 }
@@ -2776,6 +2750,32 @@ __global__ void __launch_bounds__(64) k_probe_grid(GeoacDevParams P, int n, cons
         case GEOAC_EQ_GLOBAL_RNGDEP * 2 + 0: { using EQ = EqGlobalRngDep<false>; CALL; } break; \
         default: return hipErrorNotSupported; }
 
+// the grid sets' four-lane kernels without the record cache (fans of 4 097 - 16 384 rays with amplitudes, whose records do not fit the LDS: in the launch
+// plan) and, in A/B builds only, their two-lane kernels (GRID_LANES=2)
+#define GEOAC_DISPATCH_GRID4(P, CALL) \
+    else if((P)->lanes_per_ray == 4){ \
+        switch((P)->eqset * 2 + ((P)->calc_amp ? 1 : 0)){ \
+            case GEOAC_EQ_3D_RNGDEP * 2 + 1: { using EQ = Eq3DRngDep<true, 4>;  CALL; } break; \
+            case GEOAC_EQ_3D_RNGDEP * 2 + 0: { using EQ = Eq3DRngDep<false, 4>; CALL; } break; \
+            case GEOAC_EQ_GLOBAL_RNGDEP * 2 + 1: { using EQ = EqGlobalRngDep<true, 4>;  CALL; } break; \
+            case GEOAC_EQ_GLOBAL_RNGDEP * 2 + 0: { using EQ = EqGlobalRngDep<false, 4>; CALL; } break; \
+            default: return hipErrorNotSupported; } \
+    }
+#if GEOAC_AB
+#define GEOAC_DISPATCH_AB_GRID(P, CALL) GEOAC_DISPATCH_GRID4(P, CALL) \
+    else if((P)->lanes_per_ray == 2 && (P)->gtab){ \
+        switch((P)->eqset * 2 + ((P)->calc_amp ? 1 : 0)){ \
+            case GEOAC_EQ_3D_RNGDEP * 2 + 1: { using EQ = Eq3DRngDep<true, 2>;  CALL; } break; \
+            case GEOAC_EQ_3D_RNGDEP * 2 + 0: { using EQ = Eq3DRngDep<false, 2>; CALL; } break; \
+            case GEOAC_EQ_GLOBAL_RNGDEP * 2 + 1: { using EQ = EqGlobalRngDep<true, 2>;  CALL; } break; \
+            case GEOAC_EQ_GLOBAL_RNGDEP * 2 + 0: { using EQ = EqGlobalRngDep<false, 2>; CALL; } break; \
+            default: return hipErrorNotSupported; } \
+    }
+#else
+#define GEOAC_DISPATCH_AB_GRID(P, CALL) GEOAC_DISPATCH_GRID4(P, CALL) \
+    else if((P)->lanes_per_ray == 2 && (P)->gtab){ return hipErrorNotSupported; }
+#endif
+
 // RK4 only: the grid sets have four-lanes-per-ray variants (small fans)
 #define GEOAC_DISPATCH_EQ_RK4(P, CALL) \
     if((P)->lanes_per_ray == 16){ \
@@ -2793,21 +2793,8 @@ __global__ void __launch_bounds__(64) k_probe_grid(GeoacDevParams P, int n, cons
             case GEOAC_EQ_GLOBAL_RNGDEP * 2 + 1: { using EQ = EqGlobalRngDep<true, 4, false, true>;  CALL; } break; \
             case GEOAC_EQ_GLOBAL_RNGDEP * 2 + 0: { using EQ = EqGlobalRngDep<false, 4, false, true>; CALL; } break; \
             default: return hipErrorNotSupported; } \
-    } else if((P)->lanes_per_ray == 4){ \
-        switch((P)->eqset * 2 + ((P)->calc_amp ? 1 : 0)){ \
-            case GEOAC_EQ_3D_RNGDEP * 2 + 1: { using EQ = Eq3DRngDep<true, 4>;  CALL; } break; \
-            case GEOAC_EQ_3D_RNGDEP * 2 + 0: { using EQ = Eq3DRngDep<false, 4>; CALL; } break; \
-            case GEOAC_EQ_GLOBAL_RNGDEP * 2 + 1: { using EQ = EqGlobalRngDep<true, 4>;  CALL; } break; \
-            case GEOAC_EQ_GLOBAL_RNGDEP * 2 + 0: { using EQ = EqGlobalRngDep<false, 4>; CALL; } break; \
-            default: return hipErrorNotSupported; } \
-    } else if((P)->lanes_per_ray == 2 && (P)->gtab){ \
-        switch((P)->eqset * 2 + ((P)->calc_amp ? 1 : 0)){ \
-            case GEOAC_EQ_3D_RNGDEP * 2 + 1: { using EQ = Eq3DRngDep<true, 2>;  CALL; } break; \
-            case GEOAC_EQ_3D_RNGDEP * 2 + 0: { using EQ = Eq3DRngDep<false, 2>; CALL; } break; \
-            case GEOAC_EQ_GLOBAL_RNGDEP * 2 + 1: { using EQ = EqGlobalRngDep<true, 2>;  CALL; } break; \
-            case GEOAC_EQ_GLOBAL_RNGDEP * 2 + 0: { using EQ = EqGlobalRngDep<false, 2>; CALL; } break; \
-            default: return hipErrorNotSupported; } \
-    } else if((P)->coop && (P)->gtab && (P)->lanes_per_ray == 1 && (P)->spread <= 1){ \
+    } GEOAC_DISPATCH_AB_GRID(P, CALL) \
+    else if((P)->coop && (P)->gtab && (P)->lanes_per_ray == 1 && (P)->spread <= 1){ \
         switch((P)->eqset * 2 + ((P)->calc_amp ? 1 : 0)){ \
             case GEOAC_EQ_3D_RNGDEP * 2 + 1: { using EQ = Eq3DRngDep<true, 1, true>;  CALL; } break; \
             case GEOAC_EQ_3D_RNGDEP * 2 + 0: { using EQ = Eq3DRngDep<false, 1, true>; CALL; } break; \
@@ -2856,6 +2843,11 @@ static hipError_t launch_rk4_t(const GeoacDevParams* P, int block, hipStream_t s
     return hipGetLastError();
 }
 
+// A/B builds (`make AB=1`, -DGEOAC_AB=1) also hold the kernels that were built, measured slower and kept only for comparisons and the schedule-independence
+// tests: the wave-specialised k_rk4_duo and the grid sets' two-lane kernels.  The shipped library holds the kernels the launch plan
+// can select (and the exact post-pass, its fallback when a table does not serve a profile); geoac_build_has_ab() tells which build this is.
+extern "C" int geoac_build_has_ab(void){ return GEOAC_AB ? 1 : 0; }
+#if GEOAC_AB
 // the wave-specialised kernel of the stratified Global set with amplitudes (geoac_duo.h): 128 rays per workgroup
 extern "C" size_t geoac_duo_lds(int nseg){ return geoac_duo_lds_bytes(nseg); }
 static hipError_t launch_rk4_duo(const GeoacDevParams* P, hipStream_t s, unsigned* n_wg){
@@ -2879,9 +2871,15 @@ static hipError_t launch_rk4_duo(const GeoacDevParams* P, hipStream_t s, unsigne
     return hipGetLastError();
 }
 
+#else
+extern "C" size_t geoac_duo_lds(int nseg){ (void)nseg; return (size_t)1 << 40; }          // (never fits: the plan cannot pick the kernel)
+static hipError_t launch_rk4_duo(const GeoacDevParams*, hipStream_t, unsigned*){ return hipErrorNotSupported; }
+#endif
 extern "C" hipError_t geoac_launch_rk4(const GeoacDevParams* P, int block, hipStream_t s, unsigned* n_wg){
     if(P->duo) return launch_rk4_duo(P, s, n_wg);
     if(P->lanes_per_ray == 2 && !P->gtab && P->eqset == GEOAC_EQ_GLOBAL) return launch_rk4_t<EqGlobalPair>(P, block, s, n_wg);
+    if(P->rk4_prefetch && P->lanes_per_ray == 1 && !P->gtab && P->eqset == GEOAC_EQ_GLOBAL)
+        return P->calc_amp ? launch_rk4_t<EqGlobal<true, true>>(P, block, s, n_wg) : launch_rk4_t<EqGlobal<false, true>>(P, block, s, n_wg);
     if(P->lanes_per_ray == 2 && !P->gtab && P->eqset == GEOAC_EQ_3D) return launch_rk4_t<Eq3DPair>(P, block, s, n_wg);
     GEOAC_DISPATCH_EQ_RK4(P, return launch_rk4_t<EQ>(P, block, s, n_wg));
     return hipErrorNotSupported;

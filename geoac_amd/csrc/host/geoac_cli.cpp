@@ -24,6 +24,11 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <atomic>
+#include <charconv>
+#include <condition_variable>
+#include <mutex>
+#include <sstream>
 
 #include "../../../include/geoac_hip.h"
 #include "../../../include/geoac_host.h"
@@ -56,10 +61,44 @@ static bool string2bool(const string& v){          // GeoAc.Interface.cpp:125-12
 //   gpu_devices=0,1,...      HIP devices an arrivals-only -prop fan is dealt over (default: device 0)
 //   gpu_stats=<file>         run summary as JSON (rays, RK4 ray-steps, GPU seconds, per-device shares)
 //   gpu_rays_per_batch=<n>   rays per azimuth group of a -prop run that keeps raypath / caustic rows (default 8192)
+//   gpu_fmt_threads=<n>      threads formatting the text of a -prop run (default: the host's cores, at most 16; 1: the single-thread path)
 //   gpu_opt=<KEY>:<value>    a launch-plan option of the library (geoac_set_option), repeatable
 // The environment (GEOAC_DEVICES, GEOAC_STATS, GEOAC_CLI_RAYS_PER_BATCH) is honoured only with GEOAC_DEBUG_ENV=1.
 static string g_devices, g_stats;
 static long g_rays_per_batch = 0;
+static int g_fmt_threads = 0;            // gpu_fmt_threads=<n>: threads that format a -prop run's text (default: the host's cores, at most 16)
+static uint64_t g_text_bytes = 0;        // of the last -prop run: bytes of text written, seconds spent formatting + writing them (gpu_stats)
+static double g_text_seconds = 0.0;
+
+// a double as an iostream in its default float format prints it at precision `prec`: `%.{prec}g` (std::num_put, C locale).  std::to_chars with
+// chars_format::general and a precision is specified as exactly that conversion; -format_selftest compares the two on a few million values.
+static inline int fmt_g(char* buf, double v, int prec){
+    auto r = std::to_chars(buf, buf + 48, v, std::chars_format::general, prec);
+    return (int)(r.ptr - buf);
+}
+static int format_selftest(long n){
+    // every power of ten and its neighbours, the precision boundaries, specials, then pseudo-random bit patterns and magnitudes
+    vector<double> vals = { 0.0, -0.0, 1.0, -1.0, 0.1, 1e-5, 9.9999995e-5, 1e-4, 99999.95, 999999.5, 1e6, 1e21, 1e-300, 1e300, 123456789.0, 0.000123456789,
+                            5e-324, 1.7976931348623157e308, INFINITY, -INFINITY, NAN, 9.5, 99.5, 0.5, 2.5, 1.5e-7, 12345.678901234, 30.213245250789637, -179.99999999 };
+    for(int e = -30; e <= 30; e++){ const double p = pow(10.0, e); vals.push_back(p); vals.push_back(nextafter(p, 0.0)); vals.push_back(nextafter(p, INFINITY)); vals.push_back(-9.999999 * p); vals.push_back(9.9999995 * p); }
+    uint64_t x = 0x9e3779b97f4a7c15ull;
+    for(long i = 0; i < n; i++){
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        double v;
+        if(i & 1){ memcpy(&v, &x, 8); }                                   // any bit pattern
+        else { v = ((double)(x >> 11) / 9007199254740992.0 - 0.5) * pow(10.0, (double)((x >> 3) % 25) - 12.0); }   // magnitudes the files hold
+        vals.push_back(v);
+    }
+    long bad = 0;
+    char buf[64];
+    for(double v : vals) for(int prec : {6, 8}){
+        ostringstream os; os << setprecision(prec) << v;
+        const int len = fmt_g(buf, v, prec);
+        if(os.str() != string(buf, (size_t)len)){ if(bad < 10) cout << "MISMATCH precision " << prec << ": iostream " << os.str() << " to_chars " << string(buf, (size_t)len) << '\n'; bad++; }
+    }
+    cout << kName << ": -format_selftest: " << vals.size() * 2 << " conversions, " << bad << " mismatches" << '\n';
+    return bad ? 1 : 0;
+}
 static vector<std::pair<string, string>> g_opts;
 static void parse_gpu_args(int argc, char* argv[]){
     const char* dbg = getenv("GEOAC_DEBUG_ENV");
@@ -77,6 +116,11 @@ static void parse_gpu_args(int argc, char* argv[]){
             if(end == a + 19 || *end || v <= 0) cerr << kName << ": warning: " << a << ": expected a ray count > 0 - argument ignored" << '\n';
             else g_rays_per_batch = v;
         }
+        else if(strncmp(a, "gpu_fmt_threads=", 16) == 0){
+            char* end = nullptr; const long v = strtol(a + 16, &end, 10);
+            if(end == a + 16 || *end || v <= 0 || v > 256) cerr << kName << ": warning: " << a << ": expected a thread count in 1..256 - argument ignored" << '\n';
+            else g_fmt_threads = (int)v;
+        }
         else if(strncmp(a, "gpu_opt=", 8) == 0){
             const char* c = strchr(a + 8, ':');
             if(c && c != a + 8 && c[1]) g_opts.emplace_back(string(a + 8, c), string(c + 1));
@@ -84,7 +128,7 @@ static void parse_gpu_args(int argc, char* argv[]){
         }
         // (the reference's parsers skip key=value pairs they do not know, and so do the loops below; an argument that LOOKS like one of this
         //  build's own and is not - a typo such as gpu_device=1 - would change nothing without a word)
-        else if(strncmp(a, "gpu_", 4) == 0) cerr << kName << ": warning: unknown argument " << a << " (gpu_devices=, gpu_stats=, gpu_rays_per_batch=, gpu_opt=<KEY>:<value>) - ignored" << '\n';
+        else if(strncmp(a, "gpu_", 4) == 0) cerr << kName << ": warning: unknown argument " << a << " (gpu_devices=, gpu_stats=, gpu_rays_per_batch=, gpu_fmt_threads=, gpu_opt=<KEY>:<value>) - ignored" << '\n';
     }
 }
 static int apply_gpu_opts(geoac_ctx* ctx){
@@ -119,7 +163,9 @@ static void write_stats(const char* mode, long rays, uint64_t steps, double seco
     if(!*path) return;
     ofstream js(path);
     js << "{\"program\": \"" << kName << "\", \"mode\": \"" << mode << "\", \"rays\": " << rays << ", \"rk4_ray_steps\": " << steps
-       << ", \"gpu_seconds\": " << setprecision(9) << seconds << ", \"ray_steps_per_s\": " << (seconds > 0 ? steps / seconds : 0.0) << ", \"devices\": [";
+       << ", \"gpu_seconds\": " << setprecision(9) << seconds << ", \"ray_steps_per_s\": " << (seconds > 0 ? steps / seconds : 0.0)
+       << ", \"text_bytes\": " << g_text_bytes << ", \"text_seconds\": " << g_text_seconds << ", \"text_MB_per_s\": " << (g_text_seconds > 0 ? g_text_bytes / g_text_seconds / 1e6 : 0.0)
+       << ", \"devices\": [";
     for(size_t i = 0; i < devs.size(); i++) js << (i ? ", " : "") << devs[i];
     js << "], \"per_device\": [";
     for(size_t i = 0; i < d_rays.size(); i++)
@@ -394,81 +440,144 @@ static int run_prop(char* inputs[], int count){
         }
     }
 
+    // ---- the text of the files.  The reference's loop (GeoAcGlobal_main.cpp:256-317 and twins) prints through iostreams in their default float format,
+    //      `%.{precision}g`; every stream starts at precision 6 and the spherical mains switch a stream to 8 at its first latitude field, where it
+    //      STICKS (Q14): whatever a stream prints before its first setprecision(8) - the height of the first raypath / caustic row, theta and phi of the first
+    //      results row - has 6 digits, everything after 8.  Formatting is the whole cost of a WriteRays run (1.1 GB of text for 16 200 rays against
+    //      0.1 s of GPU time), so a batch is cut into chunks of rays that are formatted on several threads into buffers - std::to_chars, the same
+    //      `%.{p}g` digits as the streams' (self-test: -format_selftest) - and written in order.  A chunk cannot know whether an earlier one has already
+    //      switched a stream, so it formats the sticky form and, of its FIRST row per stream, also the fresh form; the writer picks. ----
+    struct StreamText { string text; size_t first_len = 0; string first_fresh; bool any = false; };      // text = sticky form; its first row is text[0 .. first_len)
+    struct ChunkText { string progress; StreamText ray, res; vector<StreamText> cau; };
+    const int p_lead_sticky = kSph ? 8 : 6, p_rest = kSph ? 8 : 6;
+    auto format_chunk = [&](long i0, long i1, long base, const vector<double>& rec, const vector<double>& smp, const vector<size_t>& smp_of_ray, ChunkText& out){
+        out.cau.resize(WriteCaustics ? (size_t)legs : 0);
+        char tmp[64];
+        auto num = [&](string& d, double v, int prec){ d.append(tmp, (size_t)fmt_g(tmp, v, prec)); };
+        // one row into stream st: `lead` writes the fields printed before the row's first setprecision(8) at precision p, `rest` the others
+        auto row = [&](StreamText& st, auto&& lead, auto&& rest){
+            const size_t at = st.text.size();
+            lead(st.text, p_lead_sticky); rest(st.text);
+            if(!st.any){
+                st.any = true; st.first_len = st.text.size() - at;            // (at == 0)
+                lead(st.first_fresh, 6); rest(st.first_fresh);
+            }
+        };
+        for(long i = i0; i < i1; i++){
+            out.progress += "Plotting ray path w/ theta = "; num(out.progress, th[(size_t)i], 6); out.progress += ", phi = "; num(out.progress, ph[(size_t)i], 6);
+            out.progress += kRngC ? ".\n" : "\n";
+            // raypath / caustic rows of this ray (sorted by ray, leg, m)
+            for(size_t sp = smp_of_ray[(size_t)(i - base)]; sp < smp_of_ray[(size_t)(i - base) + 1]; sp++){
+                const double* S = &smp[sp * GEOAC_SMP_STRIDE];
+                const int leg = (int)S[GEOAC_SMP_LEG], kind = (int)S[GEOAC_SMP_KIND];
+                const double* v = S + GEOAC_SMP_V0;
+                if(kind == 0 && WriteRays){
+                    const int nv = (kSph || kCart3) ? 6 : 5;
+                    row(out.ray, [&](string& d, int p){ num(d, v[0], p); },
+                                 [&](string& d){ for(int q = 1; q < nv; q++){ d += '\t'; num(d, v[q], p_rest); } d += '\n'; });
+                } else if(kind == 1 && WriteCaustics && leg < legs){
+                    // (the range-dependent Cartesian main writes a literal 0.0 column before the time, :270-274; the sample row carries it)
+                    const int nv = kSph ? 4 : (kRngC ? 5 : (kEq == GEOAC_EQ_3D ? 4 : 3));
+                    row(out.cau[(size_t)leg], [&](string& d, int p){ num(d, v[0], p); },
+                                              [&](string& d){ for(int q = 1; q < nv; q++){ d += '\t'; num(d, v[q], p_rest); } d += '\n'; });
+                }
+            }
+            for(int b = 0; b < legs; b++){
+                const double* R = &rec[((size_t)(i - base) * legs + b) * GEOAC_REC_STRIDE];
+                if(R[GEOAC_REC_VALID] == 0.0) break;                    // BreakCheck: no row for this and later legs
+                row(out.res, [&](string& d, int p){ num(d, th[(size_t)i], p); d += '\t'; num(d, ph[(size_t)i], p); d += '\t'; d += to_string(b); },
+                    [&](string& d){
+                        auto f = [&](double x){ d += '\t'; num(d, x, p_rest); };
+                        if(kSph){
+                            f(R[GEOAC_REC_STATE + 1] * 180.0 / Pi); f(R[GEOAC_REC_STATE + 2] * 180.0 / Pi); f(R[GEOAC_REC_TTIME]); f(R[GEOAC_REC_RANGE] / R[GEOAC_REC_TTIME]);
+                            f(R[GEOAC_REC_TURN]); f(R[GEOAC_REC_INCL]); f(R[GEOAC_REC_BACKAZ]);
+                        } else if(kCart3){
+                            f(R[GEOAC_REC_STATE + 0]); f(R[GEOAC_REC_STATE + 1]); f(R[GEOAC_REC_TTIME]); f(R[GEOAC_REC_TURN]); f(R[GEOAC_REC_INCL]); f(R[GEOAC_REC_BACKAZ]);
+                        } else {
+                            f(R[GEOAC_REC_STATE + 0]); f(R[GEOAC_REC_TTIME]); f(R[GEOAC_REC_TURN]); f(R[GEOAC_REC_INCL]);
+                        }
+                        f(CalcAmp ? 20.0 * log10(R[GEOAC_REC_AMP]) : 0.0);
+                        f(-R[GEOAC_REC_ATTEN]);
+                        d += '\n';
+                    });
+            }
+            if(WriteRays) out.ray.text += '\n';                          // blank line after each ray
+            // blank line after each azimuth in results (not in GeoAc2D)
+            if(kEq != GEOAC_EQ_2D && (i + 1 == nr || ph[(size_t)i + 1] != ph[(size_t)i])) out.res.text += '\n';
+        }
+    };
+    // stream state across the whole run: has the stream seen its first setprecision(8) (spherical mains: its first row)?
+    bool ray_switched = false, res_switched = false;
+    vector<char> cau_switched((size_t)legs, 0);
+    uint64_t text_bytes = 0;
+    double text_seconds = 0.0;
+    auto emit = [&](ostream& os, const StreamText& st, bool& switched){
+        if(st.any && kSph && !switched){
+            os.write(st.first_fresh.data(), (streamsize)st.first_fresh.size());
+            os.write(st.text.data() + st.first_len, (streamsize)(st.text.size() - st.first_len));
+            text_bytes += st.first_fresh.size() + st.text.size() - st.first_len;
+            switched = true;
+        } else {
+            os.write(st.text.data(), (streamsize)st.text.size());
+            text_bytes += st.text.size();
+        }
+    };
+    const int n_fmt_threads = max(1, g_fmt_threads > 0 ? g_fmt_threads : (int)min(16u, max(1u, std::thread::hardware_concurrency())));
     // one batch of rays [i0, i1) of the fan: rec = its records, smp = its sample rows (ray index relative to i0)
     auto write_batch = [&](long i0, long i1, const vector<double>& rec, const vector<double>& smp){
-    size_t sp = 0;
-    const size_t nsmp = smp.size() / GEOAC_SMP_STRIDE;
-    for(long i = i0; i < i1; i++){
-        cout << "Plotting ray path w/ theta = " << th[(size_t)i] << ", phi = " << ph[(size_t)i] << (kRngC ? "." : "") << '\n';
-        // raypath / caustic rows of this ray (sorted by ray, leg, m)
-        while(sp < nsmp && (long)smp[sp * GEOAC_SMP_STRIDE + GEOAC_SMP_RAY] == i - i0){
-            const double* S = &smp[sp * GEOAC_SMP_STRIDE];
-            const int leg = (int)S[GEOAC_SMP_LEG], kind = (int)S[GEOAC_SMP_KIND];
-            const double* v = S + GEOAC_SMP_V0;
-            if(kind == 0 && WriteRays){
-                if(kSph){
-                    raypath << v[0];
-                    raypath << '\t' << setprecision(8) << v[1];
-                    raypath << '\t' << setprecision(8) << v[2];
-                    raypath << '\t' << v[3] << '\t' << v[4] << '\t' << v[5] << '\n';
-                } else if(kCart3){
-                    raypath << v[0] << '\t' << v[1] << '\t' << v[2] << '\t' << v[3] << '\t' << v[4] << '\t' << v[5] << '\n';
-                } else {
-                    raypath << v[0] << '\t' << v[1] << '\t' << v[2] << '\t' << v[3] << '\t' << v[4] << '\n';
-                }
-            } else if(kind == 1 && WriteCaustics && leg < legs){
-                ofstream& c = caustics[(size_t)leg];
-                if(kSph){
-                    c << v[0];
-                    c << '\t' << setprecision(8) << v[1];
-                    c << '\t' << setprecision(8) << v[2];
-                    c << '\t' << v[3] << '\n';
-                } else if(kRngC){                                    // the range-dependent main writes a literal 0.0 column before the time (:270-274); the sample row carries it
-                    c << v[0] << '\t' << v[1] << '\t' << v[2] << '\t' << v[3] << '\t' << v[4] << '\n';
-                } else if(kEq == GEOAC_EQ_3D){
-                    c << v[0] << '\t' << v[1] << '\t' << v[2] << '\t' << v[3] << '\n';
-                } else {
-                    c << v[0] << '\t' << v[1] << '\t' << v[2] << '\n';
+        const auto t0 = std::chrono::steady_clock::now();
+        const size_t nsmp = smp.size() / GEOAC_SMP_STRIDE;
+        vector<size_t> smp_of_ray((size_t)(i1 - i0) + 1, nsmp);           // first sample row of every ray of the batch (rows are sorted by ray)
+        {
+            size_t sp = 0;
+            for(long i = i0; i < i1; i++){
+                smp_of_ray[(size_t)(i - i0)] = sp;
+                while(sp < nsmp && (long)smp[sp * GEOAC_SMP_STRIDE + GEOAC_SMP_RAY] == i - i0) sp++;
+            }
+            smp_of_ray[(size_t)(i1 - i0)] = sp;
+        }
+        const long chunk = 64;                                             // rays per chunk: ~4 MB of text with raypaths
+        const long n_chunks = (i1 - i0 + chunk - 1) / chunk;
+        vector<ChunkText> texts((size_t)n_chunks);
+        vector<char> ready((size_t)n_chunks, 0);
+        std::mutex mu; std::condition_variable cv;
+        std::atomic<long> next{0};
+        auto worker = [&]{
+            for(;;){
+                const long c = next.fetch_add(1);
+                if(c >= n_chunks) return;
+                format_chunk(i0 + c * chunk, min(i1, i0 + (c + 1) * chunk), i0, rec, smp, smp_of_ray, texts[(size_t)c]);
+                { std::lock_guard<std::mutex> lk(mu); ready[(size_t)c] = 1; }
+                cv.notify_all();
+            }
+        };
+        vector<std::thread> pool;
+        const int nt = (int)min<long>(n_fmt_threads, n_chunks);
+        for(int t = 1; t < nt; t++) pool.emplace_back(worker);
+        if(nt <= 1) worker();
+        // in order, as soon as a chunk is ready (this thread writes; with one thread it has formatted everything above)
+        for(long c = 0; c < n_chunks; c++){
+            if(nt > 1){
+                std::unique_lock<std::mutex> lk(mu);
+                // (this thread formats too while it would otherwise wait for chunk c)
+                while(!ready[(size_t)c]){
+                    lk.unlock();
+                    const long mine = next.fetch_add(1);
+                    if(mine < n_chunks){
+                        format_chunk(i0 + mine * chunk, min(i1, i0 + (mine + 1) * chunk), i0, rec, smp, smp_of_ray, texts[(size_t)mine]);
+                        lk.lock(); ready[(size_t)mine] = 1; cv.notify_all();
+                    } else { lk.lock(); cv.wait(lk, [&]{ return ready[(size_t)c] != 0; }); }
                 }
             }
-            sp++;
+            ChunkText& T = texts[(size_t)c];
+            cout.write(T.progress.data(), (streamsize)T.progress.size());
+            if(WriteRays) emit(raypath, T.ray, ray_switched);
+            emit(results, T.res, res_switched);
+            for(size_t l = 0; l < T.cau.size(); l++){ bool sw = cau_switched[l] != 0; emit(caustics[l], T.cau[l], sw); cau_switched[l] = sw ? 1 : 0; }
+            T = ChunkText();                                                // (release the text)
         }
-        for(int b = 0; b < legs; b++){
-            const double* R = &rec[((size_t)(i - i0) * legs + b) * GEOAC_REC_STRIDE];
-            if(R[GEOAC_REC_VALID] == 0.0) break;                    // BreakCheck: no row for this and later legs
-            results << th[(size_t)i];
-            results << '\t' << ph[(size_t)i];
-            results << '\t' << b;
-            if(kSph){
-                results << '\t' << setprecision(8) << R[GEOAC_REC_STATE + 1] * 180.0 / Pi;
-                results << '\t' << setprecision(8) << R[GEOAC_REC_STATE + 2] * 180.0 / Pi;
-                results << '\t' << R[GEOAC_REC_TTIME];
-                results << '\t' << R[GEOAC_REC_RANGE] / R[GEOAC_REC_TTIME];
-                results << '\t' << R[GEOAC_REC_TURN];
-                results << '\t' << R[GEOAC_REC_INCL];
-                results << '\t' << R[GEOAC_REC_BACKAZ];
-            } else if(kCart3){
-                results << '\t' << R[GEOAC_REC_STATE + 0];
-                results << '\t' << R[GEOAC_REC_STATE + 1];
-                results << '\t' << R[GEOAC_REC_TTIME];
-                results << '\t' << R[GEOAC_REC_TURN];
-                results << '\t' << R[GEOAC_REC_INCL];
-                results << '\t' << R[GEOAC_REC_BACKAZ];
-            } else {
-                results << '\t' << R[GEOAC_REC_STATE + 0];
-                results << '\t' << R[GEOAC_REC_TTIME];
-                results << '\t' << R[GEOAC_REC_TURN];
-                results << '\t' << R[GEOAC_REC_INCL];
-            }
-            if(CalcAmp) results << '\t' << 20.0 * log10(R[GEOAC_REC_AMP]);
-            else        results << '\t' << 0.0;
-            results << '\t' << -R[GEOAC_REC_ATTEN];
-            results << '\n';
-        }
-        if(WriteRays) raypath << '\n';                              // blank line after each ray
-        // blank line after each azimuth in results (not in GeoAc2D)
-        if(kEq != GEOAC_EQ_2D && (i + 1 == nr || ph[(size_t)i + 1] != ph[(size_t)i])) results << '\n';
-    }
+        for(auto& t : pool) t.join();
+        text_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     };
 
     // ---- the fan on the GPU, the files on a writer thread.  Arrivals-only runs (WriteRays=False, no caustics) are ONE fan launch.
@@ -503,6 +612,7 @@ static int run_prop(char* inputs[], int count){
         write_batch(0, nr, rec, smp);
         vector<uint64_t> dr(devs.size()), ds(devs.size()), dg(devs.size());
         geoac_pool_last_shares(pool, dr.data(), ds.data(), dg.data());
+        g_text_bytes = text_bytes; g_text_seconds = text_seconds;
         write_stats("-prop", nr, steps, secs, devs, dr, ds, dg);
         geoac_pool_destroy(pool);
         results.close();
@@ -550,6 +660,7 @@ static int run_prop(char* inputs[], int count){
     if(WriteRays) raypath.close();
     results.close();
     for(auto& c : caustics) c.close();
+    g_text_bytes = text_bytes; g_text_seconds = text_seconds;
     write_stats("-prop", nr, steps, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_gpu0).count(), vector<int>(1, devs[0]),
                 vector<uint64_t>(1, (uint64_t)nr), vector<uint64_t>(1, steps), vector<uint64_t>(1, (uint64_t)nb));
     cerr << kName << ": " << nr << " rays, " << steps << " RK4 ray-steps on the GPU" << '\n';
@@ -1016,6 +1127,7 @@ static int run_eig(char* inputs[], int count, bool direct){
 }
 
 int main(int argc, char* argv[]){
+    if(argc >= 2 && strcmp(argv[1], "-format_selftest") == 0) return format_selftest(argc >= 3 ? atol(argv[2]) : 1000000L);
     if(argc < (kRng ? 5 : 3)){ usage(); return 0; }
     parse_gpu_args(argc, argv);
     if(strncmp(argv[1], "-prop", 5) == 0) return run_prop(argv, argc);

@@ -151,25 +151,29 @@ def max_rel_errors(got, want, E, hidx="auto"):
     return out
 
 
-def fan_properties(rec, steps, E, nu_slice, c_ratio):
+def fan_properties(rec, steps, E, nu_slice, c_ratio, eik_tol=1e-4):
     """size-independent properties of a fan's record table (no reference needed): count bookkeeping - the legs' step counts add up to the
     device counter, a leg that broke has no later legs, legs run in order, a row is written exactly for the legs that ran and did not
     break -, cumulative travel time / attenuation non-decreasing over a ray's legs, and the eikonal (Hamiltonian) residual at EVERY
     arrival: |nu| = c0 / c(arrival point) (winds are tapered to 0 at the ground); c_ratio: that quotient, a scalar or one value per
-    arrival in record order.  Returns the number of arrivals."""
+    arrival in record order; eik_tol: bound of that residual.  Returns the number of arrivals."""
     valid = rec[..., REC["VALID"]] > 0
     ran = rec[..., REC["STEPS"]] > 0
     broke = rec[..., REC["BROKE"]] > 0
-    assert int(rec[..., REC["STEPS"]].sum()) == steps
-    assert not (broke[:, :-1] & ran[:, 1:]).any()
-    assert (ran[:, 1:] <= ran[:, :-1]).all()
-    assert (valid == (ran & ~broke)).all()
+    assert int(rec[..., REC["STEPS"]].sum()) == steps, f"step counts of the records add up to {int(rec[..., REC['STEPS']].sum())}, the device counted {steps}"
+    assert not (broke[:, :-1] & ran[:, 1:]).any(), "a leg ran after a broken one"
+    assert (ran[:, 1:] <= ran[:, :-1]).all(), "legs out of order"
+    assert (valid == (ran & ~broke)).all(), "a result row without a completed leg (or the reverse)"
     tt = rec[..., REC["TTIME"]]; at = rec[..., REC["ATTEN"]]
-    assert ((tt[:, 1:] >= tt[:, :-1]) | ~ran[:, 1:]).all()
-    assert ((at[:, 1:] >= at[:, :-1]) | ~ran[:, 1:]).all()
+    assert ((tt[:, 1:] >= tt[:, :-1]) | ~ran[:, 1:]).all(), "travel time decreases over the legs of a ray"
+    assert ((at[:, 1:] >= at[:, :-1]) | ~ran[:, 1:]).all(), "attenuation decreases over the legs of a ray"
     st = rec[..., REC["STATE"]:REC["STATE"] + E][valid]
     numag = np.sqrt((st[:, nu_slice] ** 2).sum(axis=1))
-    assert np.abs(numag / c_ratio - 1.0).max() < 1e-4          # RK4 truncation error of the reference scheme itself (~1e-6), not a parity bound
+    eik = np.abs(numag / c_ratio - 1.0)
+    # stratified sets: the RK4 truncation error of the reference scheme itself (~1e-6).  Grid sets: the reference's interpolant takes the derivatives of c from splines of
+    # finite differences of the node values (Q11 / Q12), not from the interpolated c itself, so its own rays conserve the Hamiltonian to ~1e-3 only (measured: median 7e-5,
+    # maximum 1.1e-3 over the 1.5 M arrivals of config 4; the same rays agree with the compiled reference to 1e-9) - callers pass eik_tol = 5e-3 there.  Not a parity bound.
+    assert eik.max() < eik_tol, f"eikonal residual {eik.max():.3e} at an arrival"
     return int(valid.sum())
 
 

@@ -1,6 +1,7 @@
 """GPU test of the drop-in surface: the GeoAc2D / GeoAc3D / GeoAcGlobal / GeoAc3D.RngDep / GeoAcGlobal.RngDep -prop drivers of this repo (GPU fan behind
 the C ABI) must write the same files as the reference's own binaries: same file set, same line structure, every
 number equal to the printed precision (6-8 significant digits) up to one unit in the last printed place."""
+import json
 import os
 import shutil
 import subprocess
@@ -40,7 +41,7 @@ def _compare_files(got, want):
     return nsame, ntok
 
 
-@pytest.mark.parametrize("case", ["global", "3d", "2d", "cfg1", "global_norays", "3drd", "globalrd", "global+groups", "3drd+groups", "3drd+sub"])
+@pytest.mark.parametrize("case", ["global", "3d", "2d", "cfg1", "global_norays", "3drd", "globalrd", "global+groups", "3drd+groups", "3drd+sub", "global+1thread", "globalrd+1thread"])
 def test_cli_files_match_reference_binaries(case, tmp_path):
     """"+groups": the same fan integrated one azimuth group at a time (the path large WriteRays fans take: bounded sample list, text of
     group g written while group g+1 is on the GPU) must give the same files.  "+sub": the launch plan of saturated grid fans forced on the
@@ -51,6 +52,9 @@ def test_cli_files_match_reference_binaries(case, tmp_path):
     if case.endswith("+groups"):
         case = case[:-len("+groups")]
         gpu_args = ["gpu_rays_per_batch=2"]
+    if case.endswith("+1thread"):                 # (the text formatted by one thread instead of the host's cores: the same bytes, test below)
+        case = case[:-len("+1thread")]
+        gpu_args = ["gpu_fmt_threads=1"]
     if case.endswith("+sub"):
         case = case[:-len("+sub")]
         gpu_args = ["gpu_opt=GRID_LANES:1", "gpu_opt=SPREAD:1", "gpu_opt=SUB_MIN_WAVES:0", "gpu_opt=SUB_EPOCHS:4", "gpu_opt=S_ROWS:512"]
@@ -82,6 +86,41 @@ def test_cli_files_match_reference_binaries(case, tmp_path):
         same += s; tot += t
     print(f"{case}: {same}/{tot} tokens textually identical")
     assert same >= 0.995 * tot
+
+
+@pytest.mark.parametrize("binary", ["GeoAcGlobal", "GeoAc3D"])
+def test_files_do_not_depend_on_the_formatter_threads_or_the_groups(binary, tmp_path):
+    """the -prop text is formatted in chunks of 64 rays on several threads and written in order; a chunk formats its first row per stream both ways -
+    before and after the stream's sticky setprecision(8) (Q14) - and the writer picks.  A 12 x 23 fan with raypaths and caustics (five chunks, rays that
+    break without a results row, legs without caustics) must give the SAME BYTES with 1, 3 and 16 threads, whole or in azimuth groups of 40 rays."""
+    exe = os.path.join(BIN, binary)
+    args = ["-prop", "ToyAtmo.met", "theta_min=1", "theta_max=45", "theta_step=2", "phi_min=-180", "phi_max=150", "phi_step=30", "bounces=2", "WriteCaustics=True"]
+    outs = {}
+    for tag, extra in (("t1", ["gpu_fmt_threads=1"]), ("t3", ["gpu_fmt_threads=3"]), ("t16", ["gpu_fmt_threads=16"]), ("t3g", ["gpu_fmt_threads=3", "gpu_rays_per_batch=40"])):
+        d = tmp_path / tag; d.mkdir()
+        shutil.copy(H.TOYATMO, d / "ToyAtmo.met")
+        r = subprocess.run([exe] + args + extra + ["gpu_stats=" + str(d / "stats.json")], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()
+        outs[tag] = {f: open(d / f, "rb").read() for f in sorted(os.listdir(d)) if f.endswith(".dat")}
+        outs[tag]["stdout"] = r.stdout
+        st = json.load(open(d / "stats.json"))
+        assert st["text_bytes"] == sum(len(v) for k, v in outs[tag].items() if k.endswith(".dat") and k != "atmo.dat") - _header_bytes(outs[tag]) and st["text_MB_per_s"] > 0
+    names = set(outs["t1"])
+    assert {"ToyAtmo_results.dat", "ToyAtmo_raypaths.dat", "ToyAtmo_caustics-path0.dat", "ToyAtmo_caustics-path2.dat"} <= names
+    assert len(outs["t1"]["ToyAtmo_raypaths.dat"]) > 1000000
+    for tag in ("t3", "t16", "t3g"):
+        assert set(outs[tag]) == names
+        for f in names:
+            assert outs[tag][f] == outs["t1"][f], f"{f} differs between one formatter thread and {tag}"
+
+
+def _header_bytes(files):
+    """bytes of the header lines ('# ...') of the result / raypath / caustic files: written when the files are opened, not by the formatter"""
+    n = 0
+    for k, v in files.items():
+        if k.endswith(".dat") and k != "atmo.dat" and v.startswith(b"#"):
+            n += v.index(b"\n") + 1
+    return n
 
 
 _NUM = __import__("re").compile(r"[-+]?(?:\d+\.?\d*|\.\d+)(?:[eE][-+]?\d+)?")

@@ -78,6 +78,10 @@ def test_every_lanes_per_ray_variant_vs_golden(gold, grid, lanes, monkeypatch):
         monkeypatch.setitem(OPT, "SUB_EPOCHS", "4")
         monkeypatch.setitem(OPT, "S_ROWS", "512")
         lanes = "coop"
+    if lanes == 2:
+        import geoac_amd
+        if not geoac_amd.has_ab_kernels():
+            pytest.skip("the two-lane grid kernels are part of A/B builds only (make AB=1; GEOAC_LIB=<that build> runs this case)")
     if lanes in ("coop", "dense"):
         # one lane per ray without lane thinning, as a large fan runs: "coop" = wave-cooperative table gather through LDS (58 of the
         # wave's 64 lanes are helpers without a ray here), "dense" = the same launch with per-lane gathers

@@ -101,3 +101,15 @@ def test_drivers_print_usage_without_arguments(lib):
         assert os.path.exists(exe), exe
         r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
         assert r.returncode == 0 and b"Usage: " + name.encode() in r.stdout and b"-interactive" in r.stdout
+
+
+def test_text_formatter_prints_what_the_iostreams_print():
+    """the -prop drivers format their files with std::to_chars(general, precision) on several threads; the reference prints through iostreams in
+    the default float format at precision 6 or 8 (Q14).  -format_selftest of a driver compares the two conversions on 400 000 values (powers of ten and their
+    neighbours, the precision boundaries, zeros, infinities, NaN, random bit patterns and the magnitudes the files hold)"""
+    import subprocess
+    exe = os.path.join(H.ROOT, "geoac_amd", "bin", "GeoAcGlobal")
+    if not os.path.exists(exe):
+        pytest.skip("drivers not built")
+    r = subprocess.run([exe, "-format_selftest", "200000"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0 and b" 0 mismatches" in r.stdout, r.stdout.decode()[-2000:]

@@ -13,9 +13,10 @@ BUILD = os.path.join(ROOT, "geoac_amd", "csrc", "build")
 
 # instantiations no default launch plan reaches (the knob that does), and set-up kernels that run once per atmosphere / parameter change
 NOT_ON_THE_LAUNCH_PLAN = [
-    (r"k_rk4<Eq(3D|Global)RngDep<(true|false), 1, false, false>", "GEOAC_GRID_COOP=0 / GEOAC_GRID_LANES=1 with thinning: per-lane gathers, A/B only"),
-    (r"k_rk4<Eq(3D|Global)RngDep<(true|false), 2, false, false>", "GEOAC_GRID_LANES=2: two lanes per ray, A/B only (fans of 16 385 - 32 768 rays take the cooperative kernel)"),
-    (r"k_postpass<Eq(Global|3D|2D)<(true|false)> >", "GEOAC_ABS_TABLE=0: exact Sutherland-Bass evaluation at every midpoint (the default is k_postpass_tab)"),
+    (r"k_rk4<Eq(3D|Global)RngDep<(true|false), 1, false, false>", "one lane per ray with per-lane gathers: GEOAC_GRID_COOP=0 / GEOAC_GRID_LANES=1 with thinning, and the plan's "
+                                                                    "fallback for evaluation tables of 4 GiB and more (100 x 100 x 1400 grids), which the cooperative kernel's 32-bit record offsets do not reach"),
+    (r"k_postpass<Eq(Global|3D|2D)<(true|false)> >", "exact Sutherland-Bass evaluation at every midpoint: GEOAC_ABS_TABLE=0, and the plan's fallback when a table does not serve a profile "
+                                                     "(GEOAC_FAN_ABS_FALLBACK); the default is k_postpass_tab"),
     (r"k_atab_build|k_gb_|k_probe_", "set-up / probe kernels, not per launch"),
 ]
 
@@ -48,7 +49,9 @@ def _rows():
 
 def test_launch_plan_kernels_use_no_scratch():
     rows = _rows()
-    assert len(rows) > 100                                            # the whole family of instantiations was seen
+    # the shipped build holds launch-plan kernels only: the diagnostic ones (k_rk4_duo, the grid sets' two-lane kernels) are compiled by `make AB=1`
+    assert not [r["name"] for r in rows if "k_rk4_duo" in r["name"] or re.search(r"k_rk4<Eq(3D|Global)RngDep<(true|false), 2,", r["name"])]
+    assert len(rows) > 80                                            # the whole family of instantiations was seen
     offenders, excused, known = [], 0, []
     for r in rows:
         if r.get("ScratchSize", 0) == 0:

@@ -23,7 +23,8 @@ def run(lib_path, passes):
     for _ in range(passes):
         t0 = time.perf_counter(); ctx.launch(); ts.append((time.perf_counter() - t0) * 1e3)
     tm = ctx.timing()
-    print(os.path.basename(lib_path), "ms per pass: min %.2f median %.2f" % (min(ts), float(np.median(ts))), "rk4 %.2f epochs %d" % (tm["ms_rk4"], tm["epochs"]), flush=True)
+    print(os.path.dirname(lib_path).split("/")[-1] + "/" + os.path.basename(lib_path), os.environ.get("GEOAC_AB_TAG", ""), "ms per pass: min %.2f median %.2f" % (min(ts), float(np.median(ts))),
+          "rk4 %.2f post %.2f epochs %d" % (tm["ms_rk4"], tm["ms_post"], tm["epochs"]), flush=True)
     ctx.close()
 
 

@@ -10,6 +10,6 @@ for set in "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ
 done
 cd $R && python3 tools/pmc_summary.py $O/pmc_summary.json $O/pmc/SQ_INSTS_VALU_ADD_F64 $O/pmc/SQ_INSTS_VALU $O/pmc/FETCH_SIZE $O/pmc/WRITE_SIZE > $O/pmc_summary.txt
 steps=$(python3 -c "import json;print(json.load(open('$O/pmc/FETCH_SIZE.json'))['config']['ray_steps_per_pass'])")
-python3 tools/pmc_derive.py $O/pmc_summary.json $steps $O/pmc_traffic.json > /dev/null
+python3 tools/pmc_derive.py $O/pmc_summary.json $steps $O/pmc_traffic.json $R/geoac_amd/libgeoac_hip.so > /dev/null
 find $O/pmc -name "*counter_collection.csv" -size +1M -delete; find $O -name "*kernel_trace.csv" -size +4M -delete
 cat $O/bench.json; cat $O/bench_under_rocprof.json; grep -E "flop_per|bytes_per|valu" $O/pmc_traffic.json; ls $O/stats/* | head
