@@ -88,7 +88,6 @@ struct DevBuf {
 struct geoac_ctx {
     int eqset = 0, device = 0;
     GeoacDevParams lastP{};          // parameter block of the last completed launch (device-function probes, include/geoac_probe.h)
-    int  rk4_prefetch = -1;          // RK4_PREFETCH: early segment locate in the one-lane kernel of the stratified Global set; < 0: fans of more waves than the chip has SIMDs
     int  pp_lds_pad = -1;            // PP_LDS_PAD: bytes of LDS a table post-pass workgroup asks for (its occupancy knob: 160 KiB per CU / this = workgroups of four waves per CU); < 0: by launch plan
     int  pp_lds_table = -1;          // table post-pass of the spherical set: the table entry in LDS, 127 registers (PP_LDS_TABLE=1; default off: no faster, geoac_fan_launch)
     unsigned long long sticky_flags = 0;   // GEOAC_FAN_*_FALLBACK: plan features this context has withdrawn after a failed attempt (geoac_fan_status)
@@ -242,7 +241,7 @@ int geoac_default_params(int eqset, geoac_params* p){
 
 // ---- launch-plan options (A/B measurements, tests; results never depend on them) ----
 static const char* const kOptionNames[] = {
-    "S_ROWS", "NO_OVERLAP", "PP_BLOCKS", "ABS_TABLE", "ABS_TABLE_TOL", "PPFIX_CAP", "DUO", "EV_SLACK", "NO_PAIR", "PAIR_FRAC", "HYBRID_ROWS", "TWO_CHUNKS", "TRACE_EPOCHS", "NO_GATE", "SORT", "TILE", "PP_ONETRIP", "PP_LDS_TABLE", "PP_LDS_PAD", "RK4_PREFETCH",
+    "S_ROWS", "NO_OVERLAP", "PP_BLOCKS", "ABS_TABLE", "ABS_TABLE_TOL", "PPFIX_CAP", "DUO", "EV_SLACK", "NO_PAIR", "PAIR_FRAC", "HYBRID_ROWS", "TWO_CHUNKS", "TRACE_EPOCHS", "NO_GATE", "SORT", "TILE", "PP_ONETRIP", "PP_LDS_TABLE", "PP_LDS_PAD",
     "NO_QUAD", "GRID_LANES", "OCT", "HEX", "SPREAD", "COMPACT", "QUAD_CACHE", "GRID_COOP", "SUB_EPOCHS", "SUB_MIN_WAVES", "SUB_TEST_STALL", "SMP_CAP", "GRID_BUILD", nullptr };
 const char* const* geoac_option_names(void){ return kOptionNames; }
 
@@ -281,7 +280,6 @@ int geoac_set_option(geoac_ctx* ctx, const char* key, const char* value){
     else if(k == "SORT") return flag(ctx->sort_rays);
     else if(k == "TILE") return flag(ctx->tile_rays);
     else if(k == "PP_ONETRIP"){ if(!int_ok || lv < -1 || lv > 1) return bad("0, 1 or -1 (by launch plan)"); ctx->pp_onetrip = iv; }
-    else if(k == "RK4_PREFETCH"){ if(!int_ok || lv < -1 || lv > 1) return bad("0, 1 or -1 (by launch plan)"); ctx->rk4_prefetch = iv; }
     else if(k == "PP_LDS_PAD"){ if(!int_ok || lv < -1 || lv > 160 * 1024) return bad("bytes of LDS in 0 .. 163840, or -1 (by launch plan)"); ctx->pp_lds_pad = iv; }
     else if(k == "PP_LDS_TABLE"){ if(!int_ok || lv < -1 || lv > 1) return bad("0, 1 or -1 (by launch plan)"); ctx->pp_lds_table = iv; }
     else if(k == "NO_QUAD") return flag(ctx->no_quad);
@@ -390,7 +388,7 @@ int geoac_clone(geoac_ctx* src, geoac_ctx** out){
         hipError_t e = c->d_consts.ensure(sizeof(double) * 8);
         if(e != hipSuccess){ geoac_destroy(c); return hipfail(src, e, "clone: constants block"); }
     }
-    c->sort_rays = src->sort_rays; c->tile_rays = src->tile_rays; c->pp_onetrip = src->pp_onetrip; c->pp_lds_table = src->pp_lds_table; c->pp_lds_pad = src->pp_lds_pad; c->rk4_prefetch = src->rk4_prefetch; c->sub_test_stall = src->sub_test_stall; c->no_quad = src->no_quad; c->oct = src->oct; c->hex = src->hex; c->grid_lanes = src->grid_lanes; c->spread_override = src->spread_override;
+    c->sort_rays = src->sort_rays; c->tile_rays = src->tile_rays; c->pp_onetrip = src->pp_onetrip; c->pp_lds_table = src->pp_lds_table; c->pp_lds_pad = src->pp_lds_pad; c->sub_test_stall = src->sub_test_stall; c->no_quad = src->no_quad; c->oct = src->oct; c->hex = src->hex; c->grid_lanes = src->grid_lanes; c->spread_override = src->spread_override;
     c->compact = src->compact; c->quad_cache = src->quad_cache; c->sub_min_waves = src->sub_min_waves; c->sub_epochs = src->sub_epochs; c->grid_coop = src->grid_coop;
     c->smp_cap = src->smp_cap; c->s_rows_override = src->s_rows_override; c->no_overlap = src->no_overlap; c->pp_blocks = src->pp_blocks; c->pair_frac = src->pair_frac;
     c->hybrid_rows = src->hybrid_rows; c->two_chunks = src->two_chunks; c->no_gate = src->no_gate; c->no_pair = src->no_pair; c->duo = src->duo; c->abs_table = src->abs_table;
@@ -823,8 +821,6 @@ static int fan_launch_once(geoac_ctx* ctx){
     }
     bool split = hybrid && n_pair > 0 && n_pair < P.n_pad;      // n_pair == 0 (GEOAC_PAIR_FRAC=0): everything on the one-lane kernel, one launch
     if(hybrid && n_pair == 0) P.lanes_per_ray = 1;
-    // one-lane kernel of the stratified Global set on a fan of more waves than the chip has SIMDs (config 3): the next stage's spline segment located early (k_rk4<EqGlobal<AMP, true>>)
-    P.rk4_prefetch = (is_global && !is_grid && !hybrid && P.lanes_per_ray == 1 && (ctx->rk4_prefetch >= 0 ? ctx->rk4_prefetch != 0 : (long long)P.n_pad / 64 > 1024)) ? 1 : 0;
     // live-ray compaction between epochs (single-launch fans; a hybrid fan assigns its two kernels by slot range): epoch e > 0 runs
     // over the dense list of the rays alive after epoch e-1, built on the device (k_compact) right before its RK4 launch
     const bool compact = ctx->compact && !hybrid;

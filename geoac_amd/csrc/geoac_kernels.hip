@@ -107,7 +107,8 @@ DEVINL double fexp10(double y){
 DEVINL double set_ds(double h, double ds_min, double ds_max){
     // (round 4: no skip of the exponential above 28.5 km any more - there 0.049 e is below half the spacing of the doubles at 0.05 and the difference IS 0.05, the
     //  same bits with or without it - : the skip was a branch, and a branch ends the scheduling region; without it the exponential's dependent chain sits in the block
-    //  of stage 0 and interleaves with that stage's own chains.  Metric pass 118.7 -> 117.6 ms together with the two items in seg_locate / open_step, A/B in turn.)
+    //  of stage 0 and interleaves with that stage's own chains.  Metric pass 120.6 -> 117.6 ms together with the items in seg_locate / open_step, A/B in turn against
+    //  the round-3 build; config 3, whose waves are mostly up there, is unchanged: 355-357 ms with and without, profiles/r04_b_cfg3_ab.txt)
     const double ds = 0.05 - 0.049 * fexp(h * (-1.0 / 0.75));
     return __builtin_fmax(__builtin_fmin(ds, ds_max), ds_min);
 }
@@ -440,16 +441,13 @@ DEVINL void global_aux(const GlobalStage& S, const GlobalDerived& D, const doubl
 
 // NQ = number of launch-angle derivative systems carried in y after the 6 base components: 2 = the reference layout
 // (theta then phi), 1 = the two-lanes-per-ray kernel where each lane of a pair carries the base ray and ONE of the two systems.
-// PF (GEOAC_PF): once the base ray's slopes are known, the abscissa of the NEXT stage - r0 + w_next dy[0], exactly what the step loop forms later - is located
-// and, if it lies in another spline segment, that record's LDS reads are issued HERE, under the ~75 instructions per launch-angle system that follow (they read the
-// stage values, not the record).  A dense fan of steep rays (config 3: a node every two or three steps per ray, so some lane of a wave crosses in nearly every
-// stage) then finds its record in hand at the top of the next stage instead of waiting for it there.  Same operations on the same operands: same bits.
-template <bool AMP, int NQ, bool ROT0 = false, bool PF = false, typename TabPtr>
-DEVINL void global_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, double* rec, const double* y, double sth0, double cth0, double dlat, double* dy,
-                       double r0 = 0.0, double w_next = 0.0){
+// (Measured and dropped, round 4: locating the NEXT stage's spline segment here, under the launch-angle systems - the abscissa r0 + w dy[0] is known once the base
+//  ray's slopes are - so that a dense fan of steep rays, where some lane of a wave changes segment in nearly every stage, finds its record in hand at the top of the
+//  next stage.  Same bits, but 40 instructions per step: config 3 355-357 -> 366-368 ms per pass, metric pass 117 -> 122 ms; profiles/r04_b_cfg3_ab.txt.)
+template <bool AMP, int NQ, bool ROT0 = false, typename TabPtr>
+DEVINL void global_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, double* rec, const double* y, double sth0, double cth0, double dlat, double* dy){
     GlobalStage S;
     global_base<AMP, GEOAC_SEGW, TabPtr, NoHook, ROT0>(tab, P, seg, rec, y, sth0, cth0, dlat, dy, S);
-    if(PF) seg_locate(tab, P, clampq(__builtin_fma(dy[0], w_next, r0), P.x_min, P.x_max), seg, rec);
     if(AMP){
         GlobalDerived D;
         global_derive(S, D);
@@ -699,7 +697,6 @@ struct RayCtx {
     double t[4];      // Global: proposed sin/cos for the row under test
     double cur[4];    // Global (stratified): sin/cos(lat), sin/cos(lon - lon_src) of the current row - a[] then holds the REFERENCE point they are
                       // rotated from: lat_ref, sin, cos, (lon - lon_src)_ref, sin, cos (EqGlobal::checks)
-    double pf_w;      // stratified Global set: weight of the current stage's slopes in the next stage's abscissa (EqGlobal::rhs, early locate)
     mutable double rec[GEOAC_SEGW];   // 1-D sets: the spline record of the segment the ray is in (x0, x1, cubics of T, u, v), seg_cached_eval
     mutable int ckey; // record-cache kernels: (segment, node) key of the records this lane holds in LDS (-1: none)
     mutable int kxy;  // grid sets: horizontal cell of the previous evaluation, kx << 16 | ky (-1: none), grid_locate's hint
@@ -786,14 +783,10 @@ DEVINL void cart2_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCt
 // ================================================================================================
 // Equation-set policies: everything the generic kernels need to know about a set
 // ================================================================================================
-template <bool AMP_, bool PF_ = false> struct EqGlobal {
+template <bool AMP_> struct EqGlobal {
     static constexpr bool AMP = AMP_;
     static constexpr bool SEG1D = true;                             // the ray keeps the spline record of its segment in registers (RayCtx::rec)
     static constexpr int AUX_SAVE = 6;                              // entries of RayCtx::a the RK4 kernel changes (the reference point of the carried sin / cos)
-    // PF_: locate the next stage's spline segment under the launch-angle systems of this one (global_rhs).  Its own instantiation of k_rk4, picked by the launch plan
-    // (GeoacDevParams::rk4_prefetch) for the fans that fill the chip: config 3 385 -> 373 ms per pass.  NOT for the hybrid fans: there the pass is the serial chain of one
-    // ray, whose segment changes rarely, and the 40 instructions per step of the early tests cost the metric pass 117 -> 122 ms (in its one-lane launch; 132 in both).
-    static constexpr bool PREFETCH = PF_;
     static constexpr bool COOP = false; static constexpr bool CACHE = false; static constexpr bool LDS_STATE = false; static constexpr int XCHG_BYTES = 0; static constexpr bool PP_TILE = false; static constexpr bool PP_DEDUP = false; static constexpr int SYS_SHIFT = 0; static constexpr bool ROW_SPLIT = false;
     static constexpr int PP_WAVES = 3;                              // post-pass waves per SIMD (168 registers; at 128 it spills 148 B and runs 1.5 x slower)
     static constexpr int E = AMP_ ? 18 : 6, PW = 6, HIDX = 0, LANES = 1;
@@ -843,10 +836,8 @@ template <bool AMP_, bool PF_ = false> struct EqGlobal {
     template <typename TabPtr>
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
         // (stage 0 - a constant where the step loop peels it: the stage latitude is the step's, no rotation)
-        // (C.pf_w: the weight the step loop will give this stage's slopes in the next stage's abscissa - ds/2, ds/2, ds; stage 3: none, the loop locates the new row)
-        if(stage == 0) global_rhs<AMP, 2, true, PREFETCH>(tab, P, seg, C.rec, yt, C.cur[0], C.cur[1], 0.0, dy, y0[0], C.pf_w);
-        else if(stage == 3) global_rhs<AMP, 2>(tab, P, seg, C.rec, yt, C.cur[0], C.cur[1], yt[1] - y0[1], dy);
-        else global_rhs<AMP, 2, false, PREFETCH>(tab, P, seg, C.rec, yt, C.cur[0], C.cur[1], yt[1] - y0[1], dy, y0[0], C.pf_w);
+        if(stage == 0) global_rhs<AMP, 2, true>(tab, P, seg, C.rec, yt, C.cur[0], C.cur[1], 0.0, dy);
+        else global_rhs<AMP, 2>(tab, P, seg, C.rec, yt, C.cur[0], C.cur[1], yt[1] - y0[1], dy);
     }
     // GeoAc_BreakCheck / GeoAc_GroundCheck on the new row (Global.cpp:500-522)
     static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, int k, bool& brk, bool& gnd){
@@ -2005,15 +1996,13 @@ __global__ void __launch_bounds__(EQ::COOP ? 64 : 256, EQ::COOP ? GEOAC_COOP_WAV
                 const double ds_2 = 0.5 * ds, ds_6 = (1.0 / 6.0) * ds, ds_3 = (1.0 / 3.0) * ds;
                 // k_s = ds f(y + a_s k_{s-1}), a = {0, 1/2, 1/2, 1};  y' = y + k1/6 + k2/3 + k3/3 + k4/6  (Solver.cpp:33-54)
                 double yt[E];
-                C.pf_w = ds_2;
                 if(LDS) EQ::rhs(lds_tab, P, seg, C, y, y, 0, dy); else EQ::rhs(gtab, P, seg, C, y, y, 0, dy);
                 #pragma unroll
                 for(int e = 0; e < E; e++){ ys[e] = __builtin_fma(dy[e], ds_6, y[e]); yt[e] = __builtin_fma(dy[e], ds_2, y[e]); }
                 #pragma unroll 1
                 for(int stage = 1; stage < 3; stage++){
-                    const double wa = (stage == 2) ? ds : ds_2;
-                    C.pf_w = wa;
                     if(LDS) EQ::rhs(lds_tab, P, seg, C, y, yt, stage, dy); else EQ::rhs(gtab, P, seg, C, y, yt, stage, dy);
+                    const double wa = (stage == 2) ? ds : ds_2;
                     #pragma unroll
                     for(int e = 0; e < E; e++){ ys[e] = __builtin_fma(dy[e], ds_3, ys[e]); yt[e] = __builtin_fma(dy[e], wa, y[e]); }
                 }
@@ -2878,8 +2867,6 @@ static hipError_t launch_rk4_duo(const GeoacDevParams*, hipStream_t, unsigned*){
 extern "C" hipError_t geoac_launch_rk4(const GeoacDevParams* P, int block, hipStream_t s, unsigned* n_wg){
     if(P->duo) return launch_rk4_duo(P, s, n_wg);
     if(P->lanes_per_ray == 2 && !P->gtab && P->eqset == GEOAC_EQ_GLOBAL) return launch_rk4_t<EqGlobalPair>(P, block, s, n_wg);
-    if(P->rk4_prefetch && P->lanes_per_ray == 1 && !P->gtab && P->eqset == GEOAC_EQ_GLOBAL)
-        return P->calc_amp ? launch_rk4_t<EqGlobal<true, true>>(P, block, s, n_wg) : launch_rk4_t<EqGlobal<false, true>>(P, block, s, n_wg);
     if(P->lanes_per_ray == 2 && !P->gtab && P->eqset == GEOAC_EQ_3D) return launch_rk4_t<Eq3DPair>(P, block, s, n_wg);
     GEOAC_DISPATCH_EQ_RK4(P, return launch_rk4_t<EQ>(P, block, s, n_wg));
     return hipErrorNotSupported;

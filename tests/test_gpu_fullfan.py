@@ -9,7 +9,8 @@ inclination, back azimuth, amplitude and range within 1e-6 relative (tests/parit
   cfg4     GeoAc3D.RngDep, 5x5x1400 grid, the rank-0 share (125 azimuths x 1000 inclinations = 124 000 rays) of the 1000 x 1000 fan:
            the GPU integrates the whole share; the reference's lattice of 2000 of its rays (every 8th azimuth x every 8th inclination)
            + 250 rays of each of the other seven ranks' shares (five of the rank's azimuths x every 20th inclination)
-  cfg5     GeoAcGlobal.RngDep -eig_search, the rank-0 receivers of the 64-ring: tests/test_gpu_eig_ring.py
+           + a 10 000-ray lattice of the whole 999 x 1000 fan (100 azimuths x 100 inclinations)
+  cfg5     GeoAcGlobal.RngDep -eig_search, all 64 receivers of the ring: tests/test_gpu_eig_ring.py
 """
 import os
 
@@ -101,6 +102,33 @@ def test_config4_other_ranks_shares_vs_reference(G, tmp_path):
             if not isinstance(v, list):
                 worst[k] = max(worst.get(k, 0.0), v)
     print("cfg4 shares of ranks 1..7:", steps, "ray-steps on the GPU;", 7 * 250, "rays vs reference, max rel err", {k: f"{v:.2e}" for k, v in worst.items()})
+
+
+def test_config4_whole_fan_lattice_vs_reference(G, tmp_path):
+    """a lattice over the WHOLE 999 x 1000 fan of config 4 (tests/golden/full_cfg4_lattice.npz, make_golden_full.py cfg4_lattice: azimuth indices 5, 15, ..., 995 -
+    every residue mod 8, i.e. every rank's share of the 8-GPU run - x inclination indices 7, 17, ..., 997 = 10 000 rays integrated by the compiled reference):
+    the GPU integrates those 100 azimuths with all their 1000 inclinations (100 000 rays: the cooperative one-lane kernel of the full fan) and every lattice ray
+    must match - counts exact, values to 1e-6.  bench.py checks the same fixture against the 999 000-ray fan itself."""
+    import rngdep_data as RD
+    g = np.load(os.path.join(H.GOLDEN_DIR, "full_cfg4_lattice.npz"))
+    grid = RD.write_grid(str(tmp_path), short_paths=False, thin=1)
+    ctx = G.FanContext(G.EQ_3D_RNGDEP, device=0)
+    ctx.load_grid(*grid)
+    ctx.set_params(bounces=int(g["bounces"]), calc_amp=1, mode=0, src=(0.0, 0.0, 0.0))
+    th, ph = G.fan_enumerate(theta_min=0.05, theta_max=50.0, theta_step=0.05, phi_min=-180.0, phi_max=-180.0 + 999 * 0.36, phi_step=0.36)
+    n_th = int(g["n_theta"])
+    assert len(th) == n_th * int(g["n_phi"]) == int(g["n_rays"])
+    sel = g["sel"]
+    assert len(sel) == 10000 and np.array_equal(th[sel], g["theta"]) and np.array_equal(ph[sel], g["phi"])
+    az = np.unique(sel // n_th)
+    assert len(az) == 100 and set(az % 8) == set(range(8))
+    rays = (az[:, None] * n_th + np.arange(n_th)[None, :]).ravel()
+    rec, steps = ctx.run(th[rays], ph[rays])
+    assert int(rec[..., H.REC["STEPS"]].sum()) == steps
+    pos = {int(a): i for i, a in enumerate(az)}
+    local = np.array([pos[int(q // n_th)] * n_th + int(q % n_th) for q in sel])
+    err = compare_compact(rec, {k: g[k] for k in ("steps", "flags", "vals", "val_fields")}, idx=local)
+    print("cfg4 lattice of the whole fan:", steps, "ray-steps on the GPU;", len(sel), "rays vs reference, max rel err", {k: (f"{v:.2e}" if isinstance(v, float) else v) for k, v in err.items()})
 
 
 def test_config4_share_is_schedule_independent(G, tmp_path):
