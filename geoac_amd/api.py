@@ -201,6 +201,18 @@ class FanContext:
         except Exception:
             pass
 
+    def clone(self):
+        """geoac_clone: a second context on the same device sharing this one's atmosphere tables (several fans at once); valid until this context uploads another
+        atmosphere or is closed - after that the clone's launches fail"""
+        c = object.__new__(FanContext)
+        c.lib, c.eqset, c._h = self.lib, self.eqset, ctypes.c_void_p()
+        self._chk(self.lib.geoac_clone(self._h, ctypes.byref(c._h)))
+        c.params = Params.from_buffer_copy(bytes(self.params))
+        c.n_rays = 0
+        if hasattr(self, "_grid_dims"):
+            c._grid_dims = self._grid_dims
+        return c
+
     def upload_atmo_1d(self, x, T, u, v, rho, slopes4=None):
         x, T, u, v, rho = (_arr(a) for a in (x, T, u, v, rho))
         if slopes4 is None:

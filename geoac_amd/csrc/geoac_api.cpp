@@ -9,8 +9,11 @@
 #include <ctype.h>
 #include <errno.h>
 #include <algorithm>
+#include <atomic>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/geoac_hip.h"
@@ -65,8 +68,16 @@ struct DeferredFrees {
         {   std::lock_guard<std::mutex> lk(mu); now.swap(ptrs); bytes = 0; }
         for(void* q : now) hipFree(q);
     }
+    // the last context to leave geoac_fan_launch: no launch of this library is in flight, hipFree has nothing of ours to wait for (a long-lived single context -
+    // bench.py, a pool - would otherwise keep up to 256 MB of outgrown buffers until it is destroyed)
+    void drain_if_any(){
+        bool any;
+        {   std::lock_guard<std::mutex> lk(mu); any = !ptrs.empty(); }
+        if(any) drain();
+    }
 };
 DeferredFrees g_deferred;
+std::atomic<int> g_launching{0};       // contexts inside geoac_fan_launch: the last one out empties the deferred list (nobody's launches left for hipFree to wait on)
 
 struct DevBuf {
     void* p = nullptr; size_t bytes = 0;
@@ -90,6 +101,11 @@ struct geoac_ctx {
     GeoacDevParams lastP{};          // parameter block of the last completed launch (device-function probes, include/geoac_probe.h)
     int  pp_lds_pad = -1;            // PP_LDS_PAD: bytes of LDS a table post-pass workgroup asks for (its occupancy knob: 160 KiB per CU / this = workgroups of four waves per CU); < 0: by launch plan
     int  pp_lds_table = -1;          // table post-pass of the spherical set: the table entry in LDS, 127 registers (PP_LDS_TABLE=1; default off: no faster, geoac_fan_launch)
+    // atmosphere generation, shared with the clones of this context (geoac_clone: they hold VIEWS of its tables): bumped by every upload, set to ~0 when the context is
+    // destroyed.  A clone remembers the value it was made at and refuses to launch once it differs - its views would dangle or show another atmosphere.
+    std::shared_ptr<std::atomic<unsigned long long>> atmo_gen = std::make_shared<std::atomic<unsigned long long>>(1);
+    std::shared_ptr<std::atomic<unsigned long long>> src_gen;      // clones: the source's generation counter ...
+    unsigned long long src_gen_at_clone = 0;                       // ... and its value when the clone was made
     unsigned long long sticky_flags = 0;   // GEOAC_FAN_*_FALLBACK: plan features this context has withdrawn after a failed attempt (geoac_fan_status)
     int  launch_repeats = 0;         // fans that were run a second time for that reason
     bool sub_test_stall = false;     // SUB_TEST_STALL (tests): the cooperative grid kernels' workgroups of sub-epoch 0 do not publish their flag - forces the hand-off time-out
@@ -344,6 +360,7 @@ int geoac_create(geoac_ctx** out, int eqset, int device){
 
 int geoac_destroy(geoac_ctx* ctx){
     if(!ctx) return GEOAC_E_INVALID;
+    ctx->atmo_gen->store(~0ull);                                  // (clones of this context must not launch on its freed tables)
     hipSetDevice(ctx->device);
     if(ctx->stream) hipStreamSynchronize(ctx->stream);
     DevBuf* bufs[] = { &ctx->seg, &ctx->rhot, &ctx->theta, &ctx->phi, &ctx->state, &ctx->rec, &ctx->counters, &ctx->perm,
@@ -382,6 +399,7 @@ int geoac_clone(geoac_ctx* src, geoac_ctx** out){
     c->prm = src->prm; c->have_params = src->have_params; c->have_atmo = true; c->have_grid = src->have_grid;
     c->x = src->x; c->T = src->T; c->u = src->u; c->v = src->v; c->rho = src->rho; c->sl = src->sl; c->n_nodes = src->n_nodes;
     c->gnx = src->gnx; c->gny = src->gny; c->gx = src->gx; c->gy = src->gy; c->gtab_bytes = src->gtab_bytes;
+    c->src_gen = src->atmo_gen; c->src_gen_at_clone = src->atmo_gen->load();
     c->seg.view_of(src->seg); c->rhot.view_of(src->rhot);
     c->d_gx.view_of(src->d_gx); c->d_gy.view_of(src->d_gy); c->d_gz.view_of(src->d_gz); c->d_gtab.view_of(src->d_gtab); c->d_gtab8.view_of(src->d_gtab8);
     if(src->have_grid){                                           // (k_init writes the absorption model's reference state here: one block per context)
@@ -433,7 +451,7 @@ int geoac_upload_atmo_1d(geoac_ctx* ctx, int n, const double* x, const double* T
     // GeoAc_SetPropRegion (G2S_Spline1D.cpp:22-28 / G2S_GlobalSpline1D.cpp:22-30): vert_limit = top node
     if(!(ctx->prm.vert_limit == ctx->prm.vert_limit)) ctx->prm.vert_limit = x[n - 1];
     ctx->have_atmo = true;
-    ctx->atmo_version++;
+    ctx->atmo_version++; ctx->atmo_gen->fetch_add(1);
     ctx->ran = false;                             // (the probes launch with the tables of the last fan: not after a new upload)
     return GEOAC_OK;
 }
@@ -491,7 +509,7 @@ int geoac_upload_atmo_3d(geoac_ctx* ctx, int nx, int ny, int nz, const double* x
     const double ext[4] = { x[0], x[nx - 1], y[0], y[ny - 1] };
     for(int q = 0; q < 4; q++) if(!(ctx->prm.xy_limits[q] == ctx->prm.xy_limits[q])) ctx->prm.xy_limits[q] = ext[q];
     ctx->have_grid = true; ctx->have_atmo = true;
-    ctx->atmo_version++;
+    ctx->atmo_version++; ctx->atmo_gen->fetch_add(1);
     ctx->ran = false;                             // (the probes launch with the tables of the last fan: not after a new upload)
     return GEOAC_OK;
 }
@@ -1047,6 +1065,10 @@ static int fan_launch_once(geoac_ctx* ctx){
 
 int geoac_fan_launch(geoac_ctx* ctx){
     if(!ctx) return GEOAC_E_INVALID;
+    if(ctx->src_gen && ctx->src_gen->load() != ctx->src_gen_at_clone)
+        return fail(ctx, GEOAC_E_INVALID, "fan_launch: this context is a clone (geoac_clone) and its source has uploaded another atmosphere or was destroyed since - "
+                                          "the clone's views of the source's tables are no longer valid; clone again");
+    struct Guard { Guard(){ g_launching.fetch_add(1); } ~Guard(){ if(g_launching.fetch_sub(1) == 1) g_deferred.drain_if_any(); } } guard;
     // at most one repeat per plan feature that can be withdrawn (sub-epochs, absorption table): a loop, not a recursion
     for(int attempt = 0; attempt < 3; attempt++){
         const int rc = fan_launch_once(ctx);
@@ -1124,19 +1146,44 @@ int geoac_fan_fetch_samples(geoac_ctx* ctx, double* smp_host, int64_t cap){
     if(cap < n) return fail(ctx, GEOAC_E_CAPACITY, "fan_fetch_samples: buffer too small");
     if(n == 0) return GEOAC_OK;
     HIPCHK(hipSetDevice(ctx->device));
-    std::vector<double> tmp((size_t)n * GEOAC_SMP_STRIDE);
-    HIPCHK(hipMemcpyAsync(tmp.data(), ctx->smp_out.p, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost, ctx->stream));
+    std::unique_ptr<double[]> tmp(new double[(size_t)n * GEOAC_SMP_STRIDE]);              // (not zeroed: 80 B x up to 16 Mi rows)
+    HIPCHK(hipMemcpyAsync(tmp.get(), ctx->smp_out.p, sizeof(double) * (size_t)n * GEOAC_SMP_STRIDE, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    // the device list is in completion order; the files are in (ray, leg, m) order, raypath rows before caustic rows
-    std::vector<int64_t> idx((size_t)n);
-    for(int64_t i = 0; i < n; i++) idx[(size_t)i] = i;
-    const double* t = tmp.data();
-    std::sort(idx.begin(), idx.end(), [t](int64_t a, int64_t b){
+    // The device list is in completion order; the files are in (ray, leg, m) order, raypath rows before caustic rows.  One thread of k_accum emits a ray's rows of an
+    // epoch in that order and the epochs' launches are stream-ordered, so the rows of ONE ray already arrive sorted: a stable counting sort by ray (O(n)) puts the table
+    // in order; every ray's run is then checked and, should it ever not be sorted, sorted on its own.  (Until round 4: one std::sort of all rows through an indirect
+    // four-key comparison - 2 s per 8 M rows, the largest single cost of a WriteRays run once the text was formatted in parallel.)
+    const double* t = tmp.get();
+    const int64_t nray = (int64_t)ctx->n_rays;
+    std::vector<int64_t> start((size_t)nray + 1, 0);
+    for(int64_t i = 0; i < n; i++){
+        const int64_t r = (int64_t)t[i * GEOAC_SMP_STRIDE + GEOAC_SMP_RAY];
+        if(r < 0 || r >= nray) return fail(ctx, GEOAC_E_HIP, "fan_fetch_samples: a sample row names a ray outside the fan");
+        start[(size_t)r + 1]++;
+    }
+    for(int64_t r = 0; r < nray; r++) start[(size_t)r + 1] += start[(size_t)r];
+    std::vector<int64_t> idx((size_t)n), fill(start.begin(), start.end() - 1);
+    for(int64_t i = 0; i < n; i++) idx[(size_t)fill[(size_t)(int64_t)t[i * GEOAC_SMP_STRIDE + GEOAC_SMP_RAY]]++] = i;
+    auto less = [t](int64_t a, int64_t b){
         const double* A = t + a * GEOAC_SMP_STRIDE; const double* B = t + b * GEOAC_SMP_STRIDE;
         for(int q = 0; q < 4; q++){ if(A[q] != B[q]) return A[q] < B[q]; }
         return a < b;
-    });
-    for(int64_t i = 0; i < n; i++) memcpy(smp_host + i * GEOAC_SMP_STRIDE, t + idx[(size_t)i] * GEOAC_SMP_STRIDE, sizeof(double) * GEOAC_SMP_STRIDE);
+    };
+    // check / repair and copy out, rays dealt to a few threads (the copy is 80-byte rows from all over a table of up to 1.3 GB)
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(8, n / 200000));
+    auto work = [&](int w){
+        const int64_t r0 = nray * w / nt, r1 = nray * (w + 1) / nt;
+        for(int64_t r = r0; r < r1; r++){
+            int64_t* b = idx.data() + start[(size_t)r]; int64_t* e = idx.data() + start[(size_t)r + 1];
+            if(!std::is_sorted(b, e, less)) std::sort(b, e, less);
+        }
+        for(int64_t i = start[(size_t)r0]; i < start[(size_t)r1]; i++)
+            memcpy(smp_host + i * GEOAC_SMP_STRIDE, t + idx[(size_t)i] * GEOAC_SMP_STRIDE, sizeof(double) * GEOAC_SMP_STRIDE);
+    };
+    std::vector<std::thread> pool;
+    for(int w = 1; w < nt; w++) pool.emplace_back(work, w);
+    work(0);
+    for(auto& th : pool) th.join();
     return GEOAC_OK;
 }
 

@@ -69,6 +69,7 @@ static long g_rays_per_batch = 0;
 static int g_fmt_threads = 0;            // gpu_fmt_threads=<n>: threads that format a -prop run's text (default: the host's cores, at most 16)
 static uint64_t g_text_bytes = 0;        // of the last -prop run: bytes of text written, seconds spent formatting + writing them (gpu_stats)
 static double g_text_seconds = 0.0;
+static double g_fan_seconds = 0.0, g_fetch_seconds = 0.0, g_wait_seconds = 0.0;     // ... seconds in geoac_fan_run, in fetching the sample rows, waiting for the writer of the group before
 
 // a double as an iostream in its default float format prints it at precision `prec`: `%.{prec}g` (std::num_put, C locale).  std::to_chars with
 // chars_format::general and a precision is specified as exactly that conversion; -format_selftest compares the two on a few million values.
@@ -165,6 +166,7 @@ static void write_stats(const char* mode, long rays, uint64_t steps, double seco
     js << "{\"program\": \"" << kName << "\", \"mode\": \"" << mode << "\", \"rays\": " << rays << ", \"rk4_ray_steps\": " << steps
        << ", \"gpu_seconds\": " << setprecision(9) << seconds << ", \"ray_steps_per_s\": " << (seconds > 0 ? steps / seconds : 0.0)
        << ", \"text_bytes\": " << g_text_bytes << ", \"text_seconds\": " << g_text_seconds << ", \"text_MB_per_s\": " << (g_text_seconds > 0 ? g_text_bytes / g_text_seconds / 1e6 : 0.0)
+       << ", \"fan_run_seconds\": " << g_fan_seconds << ", \"sample_fetch_seconds\": " << g_fetch_seconds << ", \"writer_wait_seconds\": " << g_wait_seconds
        << ", \"devices\": [";
     for(size_t i = 0; i < devs.size(); i++) js << (i ? ", " : "") << devs[i];
     js << "], \"per_device\": [";
@@ -628,7 +630,9 @@ static int run_prop(char* inputs[], int count){
         const long i0 = az_start[(size_t)a0], i1 = az_start[(size_t)a1];
         vector<double> rec((size_t)(i1 - i0) * legs * GEOAC_REC_STRIDE, 0.0), smp;
         uint64_t st = 0;
+        const auto t_f0 = std::chrono::steady_clock::now();
         rc = geoac_fan_run(ctx, (int)(i1 - i0), th.data() + i0, ph.data() + i0, rec.data(), &st);
+        g_fan_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_f0).count();
         if(rc == GEOAC_E_CAPACITY && sampling && capacity_retries < 8){
             // GEOAC_E_CAPACITY has three causes; only a sample list that was too small is cured by splitting the group or growing the
             // list (need > current capacity).  A ray at step_limit or an overflow of the per-epoch event list come back with
@@ -645,10 +649,14 @@ static int run_prop(char* inputs[], int count){
         steps += st;
         int64_t ns = 0;
         geoac_fan_sample_count(ctx, &ns);
+        const auto t_s0 = std::chrono::steady_clock::now();
         smp.resize((size_t)max<int64_t>(ns, 1) * GEOAC_SMP_STRIDE);
         if(ns > 0 && geoac_fan_fetch_samples(ctx, smp.data(), ns)){ cout << kName << ": " << geoac_last_error(ctx) << '\n'; fail_rc = 2; break; }
         smp.resize((size_t)ns * GEOAC_SMP_STRIDE);
+        g_fetch_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_s0).count();
+        const auto t_w0 = std::chrono::steady_clock::now();
         if(writer.joinable()) writer.join();                           // batches are written in order, one at a time
+        g_wait_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_w0).count();
         B.i0 = i0; B.i1 = i1; B.rec.swap(rec); B.smp.swap(smp);
         writer = std::thread([&write_batch, &B]{ write_batch(B.i0, B.i1, B.rec, B.smp); });
         nb++;

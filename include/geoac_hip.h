@@ -112,7 +112,8 @@ int  geoac_default_params(int eqset, geoac_params* p);
 int  geoac_create(geoac_ctx** out, int eqset, int device);
 int  geoac_destroy(geoac_ctx* ctx);
 /* a second context on the same device sharing src's atmosphere tables (read-only device memory), with src's parameters and options: several
- * independent fans at once (one fan in flight per context).  Valid until src uploads another atmosphere or is destroyed; destroy clones first. */
+ * independent fans at once (one fan in flight per context).  Valid until src uploads another atmosphere or is destroyed (destroy clones first): a clone
+ * whose source has done either fails its next geoac_fan_launch with GEOAC_E_INVALID instead of reading freed or replaced tables. */
 int  geoac_clone(geoac_ctx* src, geoac_ctx** out);
 
 /* Launch-plan options (epoch length, kernel variants, overlap): for A/B measurements and the schedule-independence tests - a fan's records

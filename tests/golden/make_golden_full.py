@@ -141,7 +141,7 @@ def cfg4_shares(pool):
 
 def cfg4_lattice(pool):
     """config 4, the WHOLE 999 az x 1000 incl fan (what one GPU integrates at N = 1 and the eight ranks together at N = 8): a lattice of
-    100 azimuths x 100 inclinations = 10 000 rays, azimuth indices 5, 15, ..., 995 (every residue mod 8 = every rank's share) x inclination
+    100 azimuths x 100 inclinations = 10 000 rays, azimuth indices 5, 15, ..., 995 (all round the circle; the odd residues mod 8 = the shares of four of the eight ranks) x inclination
     indices 7, 17, ..., 997; none of them is a ray of full_cfg4.npz or full_cfg4_shares.npz"""
     import tempfile
     import rngdep_data as RD

@@ -159,3 +159,24 @@ def test_options_go_through_the_abi_not_the_environment(monkeypatch):
                 {"SUB_EPOCHS": 0}, {"GRID_BUILD": "gpu"}, {"ABS_TABLE_TOL": "0"}, {"COMPACT": 2}):
         with pytest.raises(G.GeoAcError, match="expected"):
             G.FanContext(H.EQ_GLOBAL, device=0, options=bad)
+
+
+def test_a_clone_refuses_to_launch_after_its_source_changed_its_atmosphere():
+    """geoac_clone shares the source's atmosphere tables as views; once the source uploads another atmosphere (or is destroyed) the views show other data or freed
+    memory - the clone's next launch must fail loudly instead"""
+    import geoac_amd as G
+    th = np.array([4.0, 21.0]); ph = np.array([-90.0, 33.0])
+    src = G.FanContext(H.EQ_GLOBAL, device=0); src.load_met(H.TOYATMO); src.set_params(bounces=0, calc_amp=1)
+    want, _ = src.run(th, ph)
+    c = src.clone()
+    got, _ = c.run(th, ph)
+    assert np.array_equal(got, want)                                  # the clone integrates the same fan on the shared tables
+    src.load_met(H.TOYATMO)                                           # a new upload (same file: the tables are rebuilt all the same)
+    with pytest.raises(G.GeoAcError, match="clone"):
+        c.run(th, ph)
+    c2 = src.clone()
+    assert np.array_equal(c2.run(th, ph)[0], want)
+    src.close()
+    with pytest.raises(G.GeoAcError, match="clone"):
+        c2.run(th, ph)
+    c.close(); c2.close()

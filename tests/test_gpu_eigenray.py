@@ -126,3 +126,56 @@ def test_more_receivers_than_one_group_and_parallel_bounce_counts():
         # eigenrays are numbered in the reference's order: by bounce count, then by inclination
         assert list(sel[:, G.EIG["INDEX"]]) == list(range(len(sel)))
         assert list(sel[:, G.EIG["BOUNCES"]]) == sorted(sel[:, G.EIG["BOUNCES"]])
+
+
+@pytest.mark.parametrize("eqname,amp", [("EQ_GLOBAL", 1), ("EQ_GLOBAL", 0), ("EQ_3D", 1), ("EQ_3D", 0), ("EQ_3D_RNGDEP", 1), ("EQ_3D_RNGDEP", 0)])
+def test_leg_records_do_not_depend_on_the_number_of_bounces(eqname, amp, tmp_path):
+    """The eigenray scheduler integrates the inclination scans of one round that differ only in the bounce count ONCE, with the largest count, and hands the others their
+    legs (geoac_eigenray.cpp, serve) - for all four equation sets that have searches.  That is only right if a ray launched with b bounces leaves, for its legs 0 .. a,
+    bit for bit the records of the same ray launched with a bounces: pinned here for the stratified spherical and Cartesian sets (pair, one-lane and hybrid plans, table
+    post-pass) and the Cartesian grid set, with and without amplitudes (tests/test_gpu_globalrd.py holds the same test for the spherical grid set)."""
+    import numpy as np
+    import geoac_amd as G
+    eq = getattr(G, eqname)
+    th = np.linspace(1.0, 40.0, 79); ph = np.full_like(th, -77.0)
+    recs = {}
+    for b in (0, 1, 2):
+        ctx = G.FanContext(eq, device=0)
+        if eqname == "EQ_3D_RNGDEP":
+            import rngdep_data as RD
+            ctx.load_grid(*RD.write_grid(str(tmp_path), short_paths=False))
+            ctx.set_params(bounces=b, calc_amp=amp, mode=0, src=(0.0, 0.0, 0.0))
+        else:
+            ctx.load_met(H.TOYATMO)
+            ctx.set_params(bounces=b, calc_amp=amp, mode=0)
+        recs[b] = ctx.run(th, ph)[0].copy(); ctx.close()
+    assert (recs[2][..., G.REC["VALID"]] > 0).sum() > 40
+    for a in (0, 1):
+        for b in range(a + 1, 3):
+            assert np.array_equal(recs[b][:, :a + 1].view(np.uint64), recs[a].view(np.uint64)), (eqname, amp, a, b)
+
+
+@pytest.mark.parametrize("binary", ["GeoAcGlobal", "GeoAc3D"])
+def test_search_over_several_bounce_counts_does_not_depend_on_the_scan_merge(binary, tmp_path):
+    """-eig_search with bnc_min < bnc_max on a STRATIFIED set: the scans of the three bounce counts are merged into one fan (serve); with the merge off
+    (GEOAC_EIG_MERGE=0 under GEOAC_DEBUG_ENV=1: every request integrates its own rays) the log and the result files must be the same bytes."""
+    exe = os.path.join(BIN, binary)
+    if binary == "GeoAcGlobal":
+        params = ["lat_src=30.0", "lon_src=0.0", "lat_rcvr=30.0", "lon_rcvr=-3.2", "bnc_min=0", "bnc_max=2", "verbose=True"]
+    else:
+        params = ["x_rcvr=-320.0", "y_rcvr=15.0", "bnc_min=0", "bnc_max=2", "verbose=True"]
+    outs = {}
+    for tag, env in (("merge", {}), ("nomerge", {"GEOAC_DEBUG_ENV": "1", "GEOAC_EIG_MERGE": "0"})):
+        d = tmp_path / tag; d.mkdir()
+        shutil.copy(H.TOYATMO, d / "ToyAtmo.met")
+        r = subprocess.run([exe, "-eig_search", "ToyAtmo.met"] + params, cwd=d, env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        outs[tag] = (r.stdout, {f: open(d / f, "rb").read() for f in sorted(os.listdir(d)) if f.endswith(".dat") and f != "atmo.dat"}, r.stderr.decode())
+    assert outs["merge"][0] == outs["nomerge"][0], "verbose log differs with the scan merge off"
+    assert outs["merge"][1] == outs["nomerge"][1] and len(outs["merge"][1]) >= 1
+    assert len(outs["merge"][0]) > 2000
+    # (the merge really happened: fewer rays integrated with it on)
+    import re
+    rays = {k: int(re.search(r"(\d+) rays in", v[2]).group(1)) for k, v in outs.items()}
+    print(binary, "rays integrated with / without the merge:", rays)
+    assert rays["merge"] < rays["nomerge"]
