@@ -52,7 +52,7 @@ def classify(op):
     return "other"
 
 
-def trace(ins, labels, head, tail, skip_execz):
+def trace(ins, labels, head, tail, skip_execz, back_trips=1):
     """walk the loop body from `head` to the back edge at `tail` along the fall-through path: s_cbranch_execnz (a rare block, laid out out of
     line) is never taken; a backward branch inside (the rolled stage loop) is taken ONCE (two trips); a forward s_cbranch_execz over an in-line
     block is taken or not by `skip_execz`; other forward uniform branches (vcc / scc) are not taken unless their target lies beyond an
@@ -74,11 +74,16 @@ def trace(ins, labels, head, tail, skip_execz):
             if op == "s_branch":
                 if t == head:
                     break
+                if t <= i:                               # unconditional backward branch: the rolled stage loop's latch
+                    trips[i] += 1
+                    if trips[i] > back_trips:
+                        i += 1
+                        continue
                 i = t
                 continue
             if t <= i:                                   # backward conditional: the rolled stage loop
                 trips[i] += 1
-                if trips[i] == 1:
+                if trips[i] <= back_trips:
                     i = t
                     continue
             elif op == "s_cbranch_execz" and skip_execz and t - i < 120:
@@ -87,7 +92,7 @@ def trace(ins, labels, head, tail, skip_execz):
             elif op in ("s_cbranch_vccnz", "s_cbranch_vccz", "s_cbranch_scc1", "s_cbranch_scc0") and t > i:
                 # the exit of the rolled loop after its second trip: taken when we have been here before
                 trips[i] += 1
-                if trips[i] >= 2:
+                if trips[i] >= back_trips + 1:
                     i = t
                     continue
         i += 1
@@ -120,9 +125,15 @@ def main():
                 if best is None or score > best[2]:
                     best = (h, i, score)
         h, t, _ = best
-        out = {"kernel": name, "step_loop": [h, t]}
+        trips = 1
+        for a in sys.argv:
+            if a.startswith("--loop="):
+                h, t = (int(x) for x in a[7:].split(","))
+            if a.startswith("--trips="):
+                trips = int(a[8:])                        # times the rolled stage loop's back edge is taken (1: two stages rolled; 2: three)
+        out = {"kernel": name, "step_loop": [h, t], "rolled_loop_back_edges_taken": trips}
         for key, skip in (("in_line_blocks_run", False), ("in_line_blocks_skipped", True)):
-            cnt, pth = trace(ins, labels, h, t, skip)
+            cnt, pth = trace(ins, labels, h, t, skip, trips)
             tot = sum(cnt.values())
             out[key] = {"instructions": tot, "mix": dict(cnt.most_common()), "issue_floor_us_at_4_cycles": round(tot * 4 / 2.4e3, 4),
                         "fp64_only_floor_us": round(cnt["fp64"] * 4 / 2.4e3, 4)}
