@@ -41,7 +41,8 @@ def newest_pmc():
     """per-ray-step figures of the dominant kernel from the newest committed rocprofv3 PMC summary (profiles/rNN_*_pmc_traffic.json:
     separate FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU_*_F64 passes of this same command, tools/profile_round.sh; FETCH_SIZE x 2 as
     MI355X_MICROARCH.md prescribes for gfx950); {} if absent.  Counters cannot be collected inside this run, so the file names the code
-    object it was measured on (lib_sha256): `_stale` is True when the library loaded now is another build."""
+    build it was measured on (lib_build_id = geoac_build_id(): a hash of the library's sources and flags; hipcc's output is not
+    bit-reproducible, so a file hash would call a rebuild of the same tree another build): `_stale` is True when the library loaded now is another build."""
     import glob
     import hashlib
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
@@ -50,10 +51,9 @@ def newest_pmc():
                 d = json.load(fh)
             d["_source"] = os.path.basename(f)
             import geoac_amd
-            with open(geoac_amd.library_path(), "rb") as fh:
-                now = hashlib.sha256(fh.read()).hexdigest()
-            d["_stale"] = (d.get("lib_sha256") != now)
-            d["_lib_sha256_now"] = now
+            now = geoac_amd.build_id()                          # hash of the sources and flags the loaded library was compiled from
+            d["_stale"] = (d.get("lib_build_id") != now)
+            d["_build_id_now"] = now
             return d
         except Exception:
             pass
@@ -605,7 +605,7 @@ def main():
                          "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS,
                          "traffic": (bps * steps_per_launch) if bps else None, "traffic_unit": "bytes per launch",
-                         "traffic_source": pmc.get("_source"), "traffic_stale": pmc.get("_stale"),
+                         "traffic_source": pmc.get("_source"), "traffic_stale": pmc.get("_stale"), "build_id": pmc.get("_build_id_now"),
                          "traffic_note": "PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 passes of this command) cannot be collected inside the run: "
                                          "they come from the named profile; traffic_stale = the profiled library is not the one loaded now",
                          "achieved_bytes_per_launch": B_ALG_PER_STEP * steps_per_launch,

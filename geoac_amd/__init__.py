@@ -7,5 +7,5 @@ every compute call raises.
 """
 from .api import (  # noqa: F401
     EQ_2D, EQ_3D, EQ_GLOBAL, EQ_3D_RNGDEP, EQ_GLOBAL_RNGDEP, EIG, EIG_STRIDE, REC, REC_STRIDE, FAN_STEP_LIMIT, FAN_SUB_FALLBACK, FAN_ABS_FALLBACK, GeoAcError, Params, FanContext, FanPool, load_library, library_path,
-    met_load, natural_spline_slopes, fan_enumerate, default_params, options, option_names, has_ab_kernels, DEFAULT_OPTIONS,
+    met_load, natural_spline_slopes, fan_enumerate, default_params, options, option_names, has_ab_kernels, build_id, DEFAULT_OPTIONS,
 )

@@ -141,6 +141,13 @@ class options:
         return False
 
 
+def build_id(path=None):
+    """geoac_build_id of the loaded library (or of the library at `path`): the hash of the sources and flags it was compiled from"""
+    lib = load_library() if path is None else ctypes.CDLL(path)
+    lib.geoac_build_id.restype = ctypes.c_char_p
+    return lib.geoac_build_id().decode()
+
+
 def has_ab_kernels():
     """True for an A/B build of the library (`make AB=1`): it also holds the diagnostic kernels the launch plan never selects (DUO, GRID_LANES=2)"""
     lib = load_library()

@@ -99,6 +99,7 @@ struct DevBuf {
 struct geoac_ctx {
     int eqset = 0, device = 0;
     GeoacDevParams lastP{};          // parameter block of the last completed launch (device-function probes, include/geoac_probe.h)
+    int  accum_batch = -1;           // ACCUM_BATCH: k_accum fetches eight rows' contributions together; < 0: in the late epochs (few waves alive)
     int  chunk_gib = 40;             // CHUNK_GIB: largest path chunk (three of them + their contribution buffers at 1/3 of that each: <= 160 GiB of the 288 by default)
     int  pp_lds_pad = -1;            // PP_LDS_PAD: bytes of LDS a table post-pass workgroup asks for (its occupancy knob: 160 KiB per CU / this = workgroups of four waves per CU); < 0: by launch plan
     int  pp_lds_table = -1;          // table post-pass of the spherical set: the table entry in LDS, 127 registers (PP_LDS_TABLE=1; default off: no faster, geoac_fan_launch)
@@ -258,9 +259,14 @@ int geoac_default_params(int eqset, geoac_params* p){
 
 // ---- launch-plan options (A/B measurements, tests; results never depend on them) ----
 static const char* const kOptionNames[] = {
-    "S_ROWS", "NO_OVERLAP", "PP_BLOCKS", "ABS_TABLE", "ABS_TABLE_TOL", "PPFIX_CAP", "DUO", "EV_SLACK", "NO_PAIR", "PAIR_FRAC", "HYBRID_ROWS", "TWO_CHUNKS", "TRACE_EPOCHS", "NO_GATE", "SORT", "TILE", "PP_ONETRIP", "PP_LDS_TABLE", "PP_LDS_PAD", "CHUNK_GIB",
+    "S_ROWS", "NO_OVERLAP", "PP_BLOCKS", "ABS_TABLE", "ABS_TABLE_TOL", "PPFIX_CAP", "DUO", "EV_SLACK", "NO_PAIR", "PAIR_FRAC", "HYBRID_ROWS", "TWO_CHUNKS", "TRACE_EPOCHS", "NO_GATE", "SORT", "TILE", "PP_ONETRIP", "PP_LDS_TABLE", "PP_LDS_PAD", "CHUNK_GIB", "ACCUM_BATCH",
     "NO_QUAD", "GRID_LANES", "OCT", "HEX", "SPREAD", "COMPACT", "QUAD_CACHE", "GRID_COOP", "SUB_EPOCHS", "SUB_MIN_WAVES", "SUB_TEST_STALL", "SMP_CAP", "GRID_BUILD", nullptr };
 const char* const* geoac_option_names(void){ return kOptionNames; }
+
+#ifndef GEOAC_SOURCE_ID
+#define GEOAC_SOURCE_ID "unknown"
+#endif
+const char* geoac_build_id(void){ return GEOAC_SOURCE_ID; }
 
 int geoac_set_option(geoac_ctx* ctx, const char* key, const char* value){
     if(!ctx || !key || !value) return GEOAC_E_INVALID;
@@ -298,6 +304,7 @@ int geoac_set_option(geoac_ctx* ctx, const char* key, const char* value){
     else if(k == "TILE") return flag(ctx->tile_rays);
     else if(k == "PP_ONETRIP"){ if(!int_ok || lv < -1 || lv > 1) return bad("0, 1 or -1 (by launch plan)"); ctx->pp_onetrip = iv; }
     else if(k == "CHUNK_GIB"){ if(!int_ok || lv < 1 || lv > 256) return bad("GiB per path chunk in 1 .. 256"); ctx->chunk_gib = iv; }
+    else if(k == "ACCUM_BATCH"){ if(!int_ok || lv < -1 || lv > 1) return bad("0, 1 or -1 (by launch plan: the late epochs)"); ctx->accum_batch = iv; }
     else if(k == "PP_LDS_PAD"){ if(!int_ok || lv < -1 || lv > 160 * 1024) return bad("bytes of LDS in 0 .. 163840, or -1 (by launch plan)"); ctx->pp_lds_pad = iv; }
     else if(k == "PP_LDS_TABLE"){ if(!int_ok || lv < -1 || lv > 1) return bad("0, 1 or -1 (by launch plan)"); ctx->pp_lds_table = iv; }
     else if(k == "NO_QUAD") return flag(ctx->no_quad);
@@ -408,7 +415,7 @@ int geoac_clone(geoac_ctx* src, geoac_ctx** out){
         hipError_t e = c->d_consts.ensure(sizeof(double) * 8);
         if(e != hipSuccess){ geoac_destroy(c); return hipfail(src, e, "clone: constants block"); }
     }
-    c->sort_rays = src->sort_rays; c->tile_rays = src->tile_rays; c->pp_onetrip = src->pp_onetrip; c->pp_lds_table = src->pp_lds_table; c->pp_lds_pad = src->pp_lds_pad; c->chunk_gib = src->chunk_gib; c->sub_test_stall = src->sub_test_stall; c->no_quad = src->no_quad; c->oct = src->oct; c->hex = src->hex; c->grid_lanes = src->grid_lanes; c->spread_override = src->spread_override;
+    c->sort_rays = src->sort_rays; c->tile_rays = src->tile_rays; c->pp_onetrip = src->pp_onetrip; c->pp_lds_table = src->pp_lds_table; c->pp_lds_pad = src->pp_lds_pad; c->chunk_gib = src->chunk_gib; c->accum_batch = src->accum_batch; c->sub_test_stall = src->sub_test_stall; c->no_quad = src->no_quad; c->oct = src->oct; c->hex = src->hex; c->grid_lanes = src->grid_lanes; c->spread_override = src->spread_override;
     c->compact = src->compact; c->quad_cache = src->quad_cache; c->sub_min_waves = src->sub_min_waves; c->sub_epochs = src->sub_epochs; c->grid_coop = src->grid_coop;
     c->smp_cap = src->smp_cap; c->s_rows_override = src->s_rows_override; c->no_overlap = src->no_overlap; c->pp_blocks = src->pp_blocks; c->pair_frac = src->pair_frac;
     c->hybrid_rows = src->hybrid_rows; c->two_chunks = src->two_chunks; c->no_gate = src->no_gate; c->no_pair = src->no_pair; c->duo = src->duo; c->abs_table = src->abs_table;
@@ -938,6 +945,7 @@ static int fan_launch_once(geoac_ctx* ctx){
         while(ctx->evj.size() < 2 * e + 2){ hipEvent_t ev; HIPCHK(hipEventCreate(&ev)); ctx->evj.push_back(ev); }
         GeoacDevParams Pe = P;
         Pe.s_rows = rows_now;
+        Pe.accum_batch = (ctx->accum_batch >= 0) ? (ctx->accum_batch ? 1 : 0) : ((rows_now == rows_late && rows_late != P.s_rows) ? 1 : 0);   // (few waves alive: the sums are the tail)
         Pe.path = (double*)ctx->path[b].p; Pe.contrib = (double*)ctx->contrib[b].p;
         Pe.nrows = (int*)ctx->nrows[b].p; Pe.legend = (int*)ctx->legend[b].p; Pe.nlegend = (int*)ctx->nlegend[b].p;
         if(sampling){ Pe.ev_row = (int*)ctx->ev_row[b].p; Pe.ev_m = (int*)ctx->ev_m[b].p; Pe.ev_amp = (double*)ctx->ev_amp[b].p; Pe.nev = (int*)ctx->nev[b].p; }

@@ -90,6 +90,7 @@ struct GeoacDevParams {
     int*    ppfix;                  // fix-up list of k_postpass_tab: (column, chunk row) of the segments the table did not serve, ppfix_cap pairs (k_ppfix evaluates them exactly)
     int     ppfix_cap;
     int     pp_lds_pad;             // bytes of LDS a k_postpass_tab workgroup asks for without using them: keeps it off CUs that hold an RK4 workgroup (> 7 KiB) / to one workgroup per CU (> 80 KiB)
+    int     accum_batch;            // k_accum: fetch the contributions of eight rows together (late epochs of arrivals-only fans: the sums are the fan's uncovered tail)
     int     pp_lds_table;           // k_postpass_tab<.., TBL> (spherical set, one-trip form): the table entry in hand in LDS instead of 38 registers, no row prefetch: 127 registers, four waves per SIMD
     int     pp_onetrip;             // k_postpass_tab: on a change of spline segment fetch the neighbour's record and table entry in one trip (fans that fill the chip); 0: the walk
     const double* atab;             // [nseg + 2][GEOAC_ATABW]: 2/h (negative: flagged), 3 x six coefficients in s = 2 t / h - 1 (atab_eval); entries nseg / nseg + 1: the

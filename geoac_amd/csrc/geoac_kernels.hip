@@ -35,6 +35,9 @@
 // then gives different bits in k_rk4<EqGlobal>, k_rk4<EqGlobalPair> and k_rk4_duo, and records must not depend on the launch plan.
 #pragma clang fp contract(off)
 
+#ifndef GEOAC_RCPC
+#define GEOAC_RCPC 1                     // 1/r and 1/cos(lat) of stages 1-3 by a Newton step from stage 0's values (global_base); 0: a fresh seed per stage (A/B)
+#endif
 #ifndef GEOAC_AB
 #define GEOAC_AB 0                      // 1: A/B build (`make AB=1`) - also holds the diagnostic kernels the launch plan never selects
 #endif
@@ -326,7 +329,7 @@ struct NoHook { DEVINL void operator()() const {} };
 // when the stage's message is published); ROT0: stage 0 of a step - the stage latitude IS the step's, no rotation (bit-identical to a rotation by 0)
 // LOCATED: rec already is the record of the stage's segment (seg_locate done by the caller: the skewed stage loop of k_rk4)
 template <bool AMP, int W, typename TabPtr, class HOOK = NoHook, bool ROT0 = false, bool LOCATED = false>
-DEVINL void global_base(TabPtr tab, const GeoacDevParams& P, int& seg, double* rec, const double* y, double sth0, double cth0, double dlat, double* dy, GlobalStage& S, const HOOK& hook = HOOK()){
+DEVINL void global_base(TabPtr tab, const GeoacDevParams& P, int& seg, double* rec, const double* y, double sth0, double cth0, double dlat, double* dy, GlobalStage& S, const HOOK& hook = HOOK(), double* rcp0 = nullptr){
     const double r = y[0];
     const double n0 = y[3], n1 = y[4], n2 = y[5];
     const double xe = clampq(r, P.x_min, P.x_max);
@@ -336,8 +339,20 @@ DEVINL void global_base(TabPtr tab, const GeoacDevParams& P, int& seg, double* r
     // |nu|   (Global.cpp:249)
     const double nn  = __builtin_fma(n0, n0, __builtin_fma(n1, n1, n2 * n2));
     const double inm0 = frsq(nn);
+#if GEOAC_RCPC
+    // 1/r and 1/cos(lat) of stages 1-3 by ONE third-order Newton step from the step's stage-0 values (r and cos(lat) move by < 1e-5 of themselves within a step: e^3 < 1e-15),
+    // not from a fresh transcendental seed (17 issue cycles each against 4.4 for a multiply-add)
+    double ir, ico;
+    if(ROT0){ ir = frcp(r); ico = frcp(cth); rcp0[0] = ir; rcp0[1] = ico; }
+    else {
+        const double e1 = __builtin_fma(-r, rcp0[0], 1.0), e2 = __builtin_fma(-cth, rcp0[1], 1.0);
+        ir = __builtin_fma(rcp0[0], __builtin_fma(e1, e1, e1), rcp0[0]);
+        ico = __builtin_fma(rcp0[1], __builtin_fma(e2, e2, e2), rcp0[1]);
+    }
+#else
     const double ir  = frcp(r);
     const double ico = frcp(cth);
+#endif
     Atm9 a;
     if(LOCATED) seg_eval_at(rec, xe, a); else seg_cached_eval<W>(tab, P, xe, seg, rec, a);
     hook();
@@ -445,9 +460,9 @@ DEVINL void global_aux(const GlobalStage& S, const GlobalDerived& D, const doubl
 //  ray's slopes are - so that a dense fan of steep rays, where some lane of a wave changes segment in nearly every stage, finds its record in hand at the top of the
 //  next stage.  Same bits, but 40 instructions per step: config 3 355-357 -> 366-368 ms per pass, metric pass 117 -> 122 ms; profiles/r04_b_cfg3_ab.txt.)
 template <bool AMP, int NQ, bool ROT0 = false, typename TabPtr>
-DEVINL void global_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, double* rec, const double* y, double sth0, double cth0, double dlat, double* dy){
+DEVINL void global_rhs(TabPtr tab, const GeoacDevParams& P, int& seg, double* rec, const double* y, double sth0, double cth0, double dlat, double* dy, double* rcp0 = nullptr){
     GlobalStage S;
-    global_base<AMP, GEOAC_SEGW, TabPtr, NoHook, ROT0>(tab, P, seg, rec, y, sth0, cth0, dlat, dy, S);
+    global_base<AMP, GEOAC_SEGW, TabPtr, NoHook, ROT0>(tab, P, seg, rec, y, sth0, cth0, dlat, dy, S, NoHook(), rcp0);
     if(AMP){
         GlobalDerived D;
         global_derive(S, D);
@@ -697,6 +712,7 @@ struct RayCtx {
     double t[4];      // Global: proposed sin/cos for the row under test
     double cur[4];    // Global (stratified): sin/cos(lat), sin/cos(lon - lon_src) of the current row - a[] then holds the REFERENCE point they are
                       // rotated from: lat_ref, sin, cos, (lon - lon_src)_ref, sin, cos (EqGlobal::checks)
+    mutable double rcp0[2];           // stratified Global set (GEOAC_RCPC): 1/r, 1/cos(lat) of the step's stage 0
     mutable double rec[GEOAC_SEGW];   // 1-D sets: the spline record of the segment the ray is in (x0, x1, cubics of T, u, v), seg_cached_eval
     mutable int ckey; // record-cache kernels: (segment, node) key of the records this lane holds in LDS (-1: none)
     mutable int kxy;  // grid sets: horizontal cell of the previous evaluation, kx << 16 | ky (-1: none), grid_locate's hint
@@ -836,8 +852,8 @@ template <bool AMP_> struct EqGlobal {
     template <typename TabPtr>
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
         // (stage 0 - a constant where the step loop peels it: the stage latitude is the step's, no rotation)
-        if(stage == 0) global_rhs<AMP, 2, true>(tab, P, seg, C.rec, yt, C.cur[0], C.cur[1], 0.0, dy);
-        else global_rhs<AMP, 2>(tab, P, seg, C.rec, yt, C.cur[0], C.cur[1], yt[1] - y0[1], dy);
+        if(stage == 0) global_rhs<AMP, 2, true>(tab, P, seg, C.rec, yt, C.cur[0], C.cur[1], 0.0, dy, C.rcp0);
+        else global_rhs<AMP, 2>(tab, P, seg, C.rec, yt, C.cur[0], C.cur[1], yt[1] - y0[1], dy, C.rcp0);
     }
     // GeoAc_BreakCheck / GeoAc_GroundCheck on the new row (Global.cpp:500-522)
     static DEVINL void checks(const GeoacDevParams& P, RayCtx& C, const double* y, const double* yn, int k, bool& brk, bool& gnd){
@@ -981,8 +997,8 @@ struct EqGlobalPair : EqGlobal<true> {
     static constexpr bool SPLIT = true; static constexpr bool ROW_SPLIT = true;      // (the two lanes also store half a path row each)
     template <typename TabPtr>
     static DEVINL void rhs(TabPtr tab, const GeoacDevParams& P, int& seg, const RayCtx& C, const double* y0, const double* yt, int stage, double* dy){
-        if(stage == 0) global_rhs<true, 1, true>(tab, P, seg, C.rec, yt, C.cur[0], C.cur[1], 0.0, dy);
-        else global_rhs<true, 1>(tab, P, seg, C.rec, yt, C.cur[0], C.cur[1], yt[1] - y0[1], dy);
+        if(stage == 0) global_rhs<true, 1, true>(tab, P, seg, C.rec, yt, C.cur[0], C.cur[1], 0.0, dy, C.rcp0);
+        else global_rhs<true, 1>(tab, P, seg, C.rec, yt, C.cur[0], C.cur[1], yt[1] - y0[1], dy, C.rcp0);
     }
     // reflection of the base ray and of this lane's derivative system (Global.cpp:140-205, Q1 linear intercept)
     static DEVINL void reflect(const GeoacDevParams& P, const RayCtx& C, const double* yn, double* y, const double* ym2){
@@ -2592,7 +2608,37 @@ __global__ void __launch_bounds__(256) k_accum(GeoacDevParams P){
     emit_events(0);             // events on the carry row (the row a previous epoch ended on)
     // (measured, round 3: a separate summation loop for arrivals-only fans with eight rows' loads in flight - config 3 373 -> 388 ms per pass: the sums
     //  run beside the next epoch's RK4 and post-pass, and pulling their rows faster only takes bandwidth from those)
-    for(int i = 0; i + 1 < nr; i++){
+    int i_begin = 0;
+    if(P.accum_batch && !rays_form && nev == 0){
+        // Late epochs of an arrivals-only fan (a few rays still alive: nothing else for the loads to compete with, and these sums are the uncovered tail of the fan): the
+        // contributions of eight rows are fetched together and added one after the other in the same order - the plain loop below waits out a trip to memory per row
+        // (~0.7 us x 2 048 rows = 1.5 ms behind the last RK4 epoch of the metric fan).  The same sums, the same bits.
+        for(int i0 = 0; i0 + 1 < nr; i0 += 8){
+            double c0[8], c1[8];
+            #pragma unroll
+            for(int j = 0; j < 8; j++){
+                const int i = i0 + j;
+                const double* cpt = P.contrib + ((size_t)(i + 1 < nr ? i : 0) * 2) * np + col;
+                c0[j] = cpt[0]; c1[j] = cpt[np];
+            }
+            #pragma unroll
+            for(int j = 0; j < 8; j++){
+                const int i = i0 + j;
+                if(i + 1 >= nr || i == cur_end) continue;
+                ltt += c0[j]; lat += c1[j];
+                if(i + 1 == next_end){
+                    tt += ltt; at += lat; ltt = 0.0; lat = 0.0;
+                    double* R = P.rec + ((size_t)(P.perm ? P.perm[slot] : slot) * (P.bounces + 1) + leg) * GEOAC_REC_STRIDE;
+                    R[GEOAC_REC_TTIME] = tt;
+                    R[GEOAC_REC_ATTEN] = at;
+                    leg++; cur_end = i + 1; e++;
+                    next_end = (e < ne) ? P.legend[(size_t)e * np + col] : 0x7fffffff;
+                }
+            }
+        }
+        i_begin = nr;
+    }
+    for(int i = i_begin; i + 1 < nr; i++){
         if(i == cur_end) continue;                              // (leg-end row -> next leg's start row): not a segment
         const double* cpt = P.contrib + ((size_t)i * 2) * np + col;
         const bool last = (i + 1 == next_end);

@@ -206,6 +206,11 @@ int  geoac_last_timing(geoac_ctx* ctx, double ms[3], uint64_t stats[3]);
 const char* geoac_strerror(int code);
 const char* geoac_last_error(geoac_ctx* ctx);
 const char* geoac_version(void);
+/* identity of this build: a hash of the sources, headers and flags the library was compiled from (hipcc's output is not bit-reproducible, a file hash is not an
+ * identity).  Profiles taken on a build carry it (tools/pmc_derive.py); bench.py marks counter-derived figures stale when the loaded library's differs. */
+const char* geoac_build_id(void);
+/* 1: an A/B build (make AB=1) that also holds the diagnostic kernels the launch plan never selects (options DUO, GRID_LANES=2); 0: the shipped build */
+int         geoac_build_has_ab(void);
 
 #ifdef __cplusplus
 }

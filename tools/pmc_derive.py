@@ -5,12 +5,20 @@ All k_rk4<...> instantiations of the run are summed (a hybrid fan runs k_rk4<EqG
 HBM bytes: FETCH_SIZE and WRITE_SIZE come from separate passes.  On gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read
 (MI355X_MICROARCH.md, HBM: the counter tallies 128-B requests at 64 B), WRITE_SIZE is exact: read bytes = 2 x FETCH_SIZE.  The guide calibrated the factor on
 16-B-per-lane accesses; these kernels read 8 B per lane (512 contiguous bytes per wave instruction: whole 128-B lines), so the corrected figure is the one to
-compare with a byte count and the raw one is kept beside it.  `lib_sha256`: the code object the counters belong to - bench.py marks the figures stale when the
-library it loaded is another one."""
+compare with a byte count and the raw one is kept beside it.  `lib_build_id`: the build the counters belong to (geoac_build_id: a hash of its sources and flags; `lib_sha256` is the file's,
+which a rebuild of the same tree changes) - bench.py marks the figures stale when the library it loaded is another build."""
 import hashlib, json, sys
 
 summ, steps, out = json.load(open(sys.argv[1])), float(sys.argv[2]), sys.argv[3]
 lib = sys.argv[4] if len(sys.argv) > 4 else None
+
+
+def build_id(path):
+    """geoac_build_id() of the profiled library: the hash of the sources and flags it was compiled from (a rebuild of the same tree is the same build)"""
+    import ctypes
+    L = ctypes.CDLL(path)
+    L.geoac_build_id.restype = ctypes.c_char_p
+    return L.geoac_build_id().decode()
 FETCH_CORRECTION = 2.0
 
 
@@ -41,6 +49,7 @@ res = {
     "all_kernels_hbm_bytes_per_ray_step": (FETCH_CORRECTION * tot("", "FETCH_SIZE") + tot("", "WRITE_SIZE")) / steps,
     "raw_counters_per_ray_step": {k: {"FETCH_SIZE": tot(k, "FETCH_SIZE") / steps, "WRITE_SIZE": tot(k, "WRITE_SIZE") / steps} for k in ("k_rk4", "k_postpass", "k_accum")},
     "lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest() if lib else None,
+    "lib_build_id": build_id(lib) if lib else None,
     "fp64_vector_peak_tflops": 78.6,
 }
 json.dump(res, open(out, "w"), indent=1)
