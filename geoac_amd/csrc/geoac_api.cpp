@@ -263,11 +263,6 @@ static const char* const kOptionNames[] = {
     "NO_QUAD", "GRID_LANES", "OCT", "HEX", "SPREAD", "COMPACT", "QUAD_CACHE", "GRID_COOP", "SUB_EPOCHS", "SUB_MIN_WAVES", "SUB_TEST_STALL", "SMP_CAP", "GRID_BUILD", nullptr };
 const char* const* geoac_option_names(void){ return kOptionNames; }
 
-#ifndef GEOAC_SOURCE_ID
-#define GEOAC_SOURCE_ID "unknown"
-#endif
-const char* geoac_build_id(void){ return GEOAC_SOURCE_ID; }
-
 int geoac_set_option(geoac_ctx* ctx, const char* key, const char* value){
     if(!ctx || !key || !value) return GEOAC_E_INVALID;
     std::string k(key);
