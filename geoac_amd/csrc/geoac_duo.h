@@ -190,7 +190,7 @@ DEVINL void duo_base(const GeoacDevParams& P, const double* tab13, DuoPort& pt, 
         auto peek_hook = [&](){ if(V & 2) peek = duo_peek_ack(pt); };
         auto stage_body = [&](int stage, auto rot0){
             GlobalStage S;
-            global_base<true, 13, const double*, decltype(peek_hook), decltype(rot0)::value>(tab13, P, seg, C.rec, yt, C.cur[0], C.cur[1], yt[1] - y[1], dy, S, peek_hook);
+            global_base<true, 13, const double*, decltype(peek_hook), decltype(rot0)::value>(tab13, P, seg, C.rec, yt, C.cur[0], C.cur[1], yt[1] - y[1], dy, S, peek_hook, C.rcp0, stage == 0);
             if(!(V & 32)){
                 if(V & 2) duo_wait_free_peeked(pt, peek); else duo_wait_free(pt);
                 duo_put_stage(pt, S);

@@ -329,7 +329,7 @@ struct NoHook { DEVINL void operator()() const {} };
 // when the stage's message is published); ROT0: stage 0 of a step - the stage latitude IS the step's, no rotation (bit-identical to a rotation by 0)
 // LOCATED: rec already is the record of the stage's segment (seg_locate done by the caller: the skewed stage loop of k_rk4)
 template <bool AMP, int W, typename TabPtr, class HOOK = NoHook, bool ROT0 = false, bool LOCATED = false>
-DEVINL void global_base(TabPtr tab, const GeoacDevParams& P, int& seg, double* rec, const double* y, double sth0, double cth0, double dlat, double* dy, GlobalStage& S, const HOOK& hook = HOOK(), double* rcp0 = nullptr){
+DEVINL void global_base(TabPtr tab, const GeoacDevParams& P, int& seg, double* rec, const double* y, double sth0, double cth0, double dlat, double* dy, GlobalStage& S, const HOOK& hook = HOOK(), double* rcp0 = nullptr, bool first = false){
     const double r = y[0];
     const double n0 = y[3], n1 = y[4], n2 = y[5];
     const double xe = clampq(r, P.x_min, P.x_max);
@@ -343,7 +343,7 @@ DEVINL void global_base(TabPtr tab, const GeoacDevParams& P, int& seg, double* r
     // 1/r and 1/cos(lat) of stages 1-3 by ONE third-order Newton step from the step's stage-0 values (r and cos(lat) move by < 1e-5 of themselves within a step: e^3 < 1e-15),
     // not from a fresh transcendental seed (17 issue cycles each against 4.4 for a multiply-add)
     double ir, ico;
-    if(ROT0){ ir = frcp(r); ico = frcp(cth); rcp0[0] = ir; rcp0[1] = ico; }
+    if(ROT0 || first){ ir = frcp(r); ico = frcp(cth); rcp0[0] = ir; rcp0[1] = ico; }     // (first: k_rk4_duo rolls all four stages into one loop - stage 0 by a run-time flag)
     else {
         const double e1 = __builtin_fma(-r, rcp0[0], 1.0), e2 = __builtin_fma(-cth, rcp0[1], 1.0);
         ir = __builtin_fma(rcp0[0], __builtin_fma(e1, e1, e1), rcp0[0]);
