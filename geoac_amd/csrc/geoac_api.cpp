@@ -3,6 +3,7 @@
 // exists here: every compute entry point needs a HIP device and fails loudly without one.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <cmath>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -25,6 +26,7 @@ extern "C" void geoac_natural_spline_slopes(int n, const double* x, const double
 extern "C" hipError_t geoac_launch_init(const GeoacDevParams* P, hipStream_t s);
 extern "C" hipError_t geoac_launch_rk4(const GeoacDevParams* P, int block, hipStream_t s, unsigned* n_wg);
 extern "C" size_t geoac_duo_lds(int nseg);
+extern "C" size_t geoac_trio_lds(int nseg);
 extern "C" int geoac_build_has_ab(void);
 extern "C" size_t geoac_gridbuild_work_doubles(int nx, int ny, int nz);
 extern "C" size_t geoac_gridpack_doubles(int nx, int ny, int nz);
@@ -172,6 +174,7 @@ struct geoac_ctx {
     bool no_pair = false;                         // GEOAC_NO_PAIR=1: force one lane per ray (A/B measurements)
     bool grid_build_host = false;                 // GRID_BUILD=host: evaluation table of the grid sets by the host twin (geoac_grid_table_eq) instead of on the device
     int ev_slack = 72;                            // GEOAC_EV_SLACK: per-epoch event rows of a ray beyond its raypath samples (caustics); tests lower it to reach the overflow path
+    int trio = 0;                                 // TRIO=1: slots that would take two lanes per ray run the wave-specialised kernel k_rk4_trio (the ray on one wave, one launch-angle system on each of two more)
     int duo = 0;                                  // GEOAC_DUO=1: the wave-specialised kernel k_rk4_duo for Global fans with amplitudes (measured SLOWER than the two-lane
                                                   // kernel on MI355X - 3.0 vs 2.7 us per step, DESIGN 3 - kept for A/B runs and the schedule-independence tests); 32, 66: timing diagnostics
     // absorption table of the stratified sets (k_atab_build): rebuilt when the atmosphere or one of the parameters it depends on changes
@@ -259,7 +262,7 @@ int geoac_default_params(int eqset, geoac_params* p){
 
 // ---- launch-plan options (A/B measurements, tests; results never depend on them) ----
 static const char* const kOptionNames[] = {
-    "S_ROWS", "NO_OVERLAP", "PP_BLOCKS", "ABS_TABLE", "ABS_TABLE_TOL", "PPFIX_CAP", "DUO", "EV_SLACK", "NO_PAIR", "PAIR_FRAC", "HYBRID_ROWS", "TWO_CHUNKS", "TRACE_EPOCHS", "NO_GATE", "SORT", "TILE", "PP_ONETRIP", "PP_LDS_TABLE", "PP_LDS_PAD", "CHUNK_GIB", "ACCUM_BATCH",
+    "S_ROWS", "NO_OVERLAP", "PP_BLOCKS", "ABS_TABLE", "ABS_TABLE_TOL", "PPFIX_CAP", "DUO", "TRIO", "EV_SLACK", "NO_PAIR", "PAIR_FRAC", "HYBRID_ROWS", "TWO_CHUNKS", "TRACE_EPOCHS", "NO_GATE", "SORT", "TILE", "PP_ONETRIP", "PP_LDS_TABLE", "PP_LDS_PAD", "CHUNK_GIB", "ACCUM_BATCH",
     "NO_QUAD", "GRID_LANES", "OCT", "HEX", "SPREAD", "COMPACT", "QUAD_CACHE", "GRID_COOP", "SUB_EPOCHS", "SUB_MIN_WAVES", "SUB_TEST_STALL", "SMP_CAP", "GRID_BUILD", nullptr };
 const char* const* geoac_option_names(void){ return kOptionNames; }
 
@@ -287,6 +290,11 @@ int geoac_set_option(geoac_ctx* ctx, const char* key, const char* value){
         if(!int_ok || lv < 0 || lv > 3) return bad("0..3");
         if(lv && !geoac_build_has_ab()) return fail(ctx, GEOAC_E_UNSUPPORTED, "set_option: DUO: the wave-specialised kernel is part of A/B builds only (make AB=1)");
         ctx->duo = iv;
+    }
+    else if(k == "TRIO"){
+        if(!int_ok || lv < 0 || lv > 31) return bad("0, 1 (3, 5, 11, 27: timing diagnostics)");
+        if(lv && !geoac_build_has_ab()) return fail(ctx, GEOAC_E_UNSUPPORTED, "set_option: TRIO: the three-wave kernel is part of A/B builds only (make AB=1)");
+        ctx->trio = iv;
     }
     else if(k == "EV_SLACK"){ if(!int_ok || lv < 0 || lv > 1000000) return bad("a slot count >= 0"); ctx->ev_slack = iv; }
     else if(k == "NO_PAIR") return flag(ctx->no_pair);
@@ -413,7 +421,7 @@ int geoac_clone(geoac_ctx* src, geoac_ctx** out){
     c->sort_rays = src->sort_rays; c->tile_rays = src->tile_rays; c->pp_onetrip = src->pp_onetrip; c->pp_lds_table = src->pp_lds_table; c->pp_lds_pad = src->pp_lds_pad; c->chunk_gib = src->chunk_gib; c->accum_batch = src->accum_batch; c->sub_test_stall = src->sub_test_stall; c->no_quad = src->no_quad; c->oct = src->oct; c->hex = src->hex; c->grid_lanes = src->grid_lanes; c->spread_override = src->spread_override;
     c->compact = src->compact; c->quad_cache = src->quad_cache; c->sub_min_waves = src->sub_min_waves; c->sub_epochs = src->sub_epochs; c->grid_coop = src->grid_coop;
     c->smp_cap = src->smp_cap; c->s_rows_override = src->s_rows_override; c->no_overlap = src->no_overlap; c->pp_blocks = src->pp_blocks; c->pair_frac = src->pair_frac;
-    c->hybrid_rows = src->hybrid_rows; c->two_chunks = src->two_chunks; c->no_gate = src->no_gate; c->no_pair = src->no_pair; c->duo = src->duo; c->abs_table = src->abs_table;
+    c->hybrid_rows = src->hybrid_rows; c->two_chunks = src->two_chunks; c->no_gate = src->no_gate; c->no_pair = src->no_pair; c->duo = src->duo; c->trio = src->trio; c->abs_table = src->abs_table;
     c->ev_slack = src->ev_slack; c->grid_build_host = src->grid_build_host; c->atab_tol = src->atab_tol; c->ppfix_cap = src->ppfix_cap;
     *out = c;
     return GEOAC_OK;
@@ -593,8 +601,32 @@ int geoac_fan_set_angles(geoac_ctx* ctx, int n_rays, const double* theta_deg, co
                 code[(size_t)i] = (spread_bits(rt) << 1) | spread_bits(rp);
             }
             std::stable_sort(sorted.begin(), sorted.end(), [&](int a, int b){ return code[(size_t)a] < code[(size_t)b]; });
-        } else
-        std::stable_sort(sorted.begin(), sorted.end(), [&](int a, int b){ return theta_deg[a] < theta_deg[b]; });
+        } else {
+            // stable sort of the rays by launch inclination, as an LSD radix sort on the order-preserving integer image of the doubles (four 16-bit digits): the same
+            // permutation std::stable_sort with `theta[a] < theta[b]` gives, in 0.15 ms instead of 1 ms for the metric fan's 32 400 rays - inside the timed region
+            auto key_of = [](double v){ uint64_t u; memcpy(&u, &v, 8); return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull); };
+            bool plain = true;                                        // (NaN or -0.0 / +0.0 mixtures would order differently than `<`: leave those to the comparison sort)
+            std::vector<uint64_t> key((size_t)n_rays);
+            for(int i = 0; i < n_rays; i++){
+                const double v = theta_deg[i];
+                if(!(v == v) || (v == 0.0 && std::signbit(v))) plain = false;
+                key[(size_t)i] = key_of(v);
+            }
+            if(plain){
+                std::vector<int> tmp((size_t)n_rays);
+                std::vector<uint32_t> cnt(65536);
+                for(int pass = 0; pass < 4; pass++){
+                    const int sh = 16 * pass;
+                    std::fill(cnt.begin(), cnt.end(), 0u);
+                    for(int i = 0; i < n_rays; i++) cnt[(key[(size_t)sorted[(size_t)i]] >> sh) & 0xffff]++;
+                    uint32_t run = 0;
+                    for(auto& c : cnt){ const uint32_t n = c; c = run; run += n; }
+                    for(int i = 0; i < n_rays; i++){ const int r = sorted[(size_t)i]; tmp[cnt[(key[(size_t)r] >> sh) & 0xffff]++] = r; }
+                    sorted.swap(tmp);
+                }
+            } else
+            std::stable_sort(sorted.begin(), sorted.end(), [&](int a, int b){ return theta_deg[a] < theta_deg[b]; });
+        }
         // slot -> ray (-1: a slot without a ray: the tail padding of the last wave)
         order.assign(sorted.begin(), sorted.end());
         ths.resize((size_t)n_rays); phs.resize((size_t)n_rays);
@@ -769,6 +801,8 @@ static int fan_launch_once(geoac_ctx* ctx){
     P.duo = (is_global && p.calc_amp && !sampling && ctx->duo && !ctx->no_pair && P.table_in_lds && geoac_duo_lds(P.nseg) <= 160 * 1024 &&
              (long long)P.n_pad <= 256ll * 128) ? ctx->duo : 0;
     if(P.duo) P.lanes_per_ray = 1;
+    // ... or the three-wave one (geoac_trio.h) for the slots the plan gives two lanes per ray: 64 rays per workgroup
+    P.trio = (!P.duo && is_global && p.calc_amp && !sampling && ctx->trio && P.lanes_per_ray == 2 && P.table_in_lds && geoac_trio_lds(P.nseg) <= 160 * 1024) ? ctx->trio : 0;
     // grid sets, small fans: four lanes per ray (one cell corner each) while that still leaves one wave per SIMD
     // (16 385 - 32 768 rays used to take two lanes per ray: measured on MI355X, profiles/r03_midfans.txt, the cooperative one-lane kernel is faster
     // there for the Cartesian set - 4.8e8 against 4.1e8 ray-steps/s at 24 000 rays - and within 5 % for the spherical one, and it uses no scratch)
@@ -1018,6 +1052,11 @@ static int fan_launch_once(geoac_ctx* ctx){
     {   unsigned long long fx = 0;
         HIPCHK(hipMemcpy(&fx, (const unsigned long long*)ctx->counters.p + GEOAC_CNT_PPFLAG + 1, sizeof(fx), hipMemcpyDeviceToHost));
         ctx->pp_fixup_segments = fx; }
+    if(ctx->trace_epochs && P.trio){
+        unsigned long long v = 0;
+        HIPCHK(hipMemcpy(&v, (const unsigned long long*)ctx->counters.p + 30, sizeof(v), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[trio] workgroups whose three waves sat on three SIMDs: %llu, others: %llu\n", v & 0xffffffffull, v >> 32);
+    }
 #ifdef GEOAC_KSTAT
     {   // diagnostic build (geoac_rngdep.h): distinct (segment, cell) keys per live wave-stage
         unsigned long long h[16];

@@ -60,6 +60,8 @@ struct GeoacDevParams {
     int     lanes_per_ray;          // 2: Global + CalcAmp without sample capture runs the two-lanes-per-ray kernel
     int     duo;                    // 1: the wave-specialised kernel k_rk4_duo (geoac_duo.h): one wave integrates 64 rays, a second one their
                                     // launch-angle derivative systems from per-stage messages in LDS (lanes_per_ray = 1: the one-lane state layout)
+    int     trio;                   // 1: slots the plan gives two lanes per ray run the wave-specialised kernel k_rk4_trio instead (geoac_trio.h: the ray on one wave, one
+                                    // launch-angle system on each of two more; the same state layout)
     int     spread;                 // grid sets: only every spread-th lane of a wave carries a ray (power of two, 1..64): a small fan is
                                     // spread over more waves so that each divergent table gather touches fewer cache lines per instruction
     int     quad_cache;             // grid sets, four lanes per ray, at most 256 waves: per-lane record cache and z nodes in LDS (grid_cache_fill)

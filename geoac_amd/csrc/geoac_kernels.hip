@@ -1718,7 +1718,8 @@ DEVINL void pp_exact(const GeoacDevParams& P, const double* aux, const double* A
 
 #pragma clang fp contract(off)
 #if GEOAC_AB
-#include "geoac_duo.h"                // (A/B builds only, `make AB=1`: the wave-specialised kernel - correct, bit-identical, measured slower)
+#include "geoac_duo.h"                // (A/B builds only, `make AB=1`: the two-wave kernel of round 3 - correct, bit-identical, measured slower)
+#include "geoac_trio.h"               // (A/B builds only: the three-wave kernel of round 4 - the ray on one wave, one launch-angle system on each of two more; the same verdict)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -2906,12 +2907,38 @@ static hipError_t launch_rk4_duo(const GeoacDevParams* P, hipStream_t s, unsigne
     return hipGetLastError();
 }
 
+// the wave-specialised kernel of the stratified Global set with amplitudes (geoac_trio.h): 64 rays per workgroup of three waves
+extern "C" size_t geoac_trio_lds(int nseg){ return geoac_trio_lds_bytes(nseg); }
+static hipError_t launch_rk4_trio(const GeoacDevParams* P, hipStream_t s, unsigned* n_wg){
+    if(P->eqset != GEOAC_EQ_GLOBAL || !P->calc_amp || P->gtab || (P->mode & (GEOAC_MODE_WRITE_RAYS | GEOAC_MODE_WRITE_CAUSTICS))) return hipErrorNotSupported;
+    if(P->slot_lo < 0 || P->slot_hi > P->n_pad || P->slot_lo >= P->slot_hi) return hipErrorInvalidValue;
+    const size_t lds = geoac_trio_lds_bytes(P->nseg);
+    if(lds > 160 * 1024) return hipErrorInvalidValue;
+    dim3 b(192), g((unsigned)((P->slot_hi - P->slot_lo + 63) / 64));
+    if(n_wg) *n_wg = g.x;
+    #define GEOAC_TRIO_LAUNCH(VV) do { \
+        hipError_t err = hipFuncSetAttribute((const void*)k_rk4_trio<VV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if(err != hipSuccess) return err; \
+        hipLaunchKernelGGL(k_rk4_trio<VV>, g, b, lds, s, *P); } while(0)
+    switch(P->trio){
+        case 3: GEOAC_TRIO_LAUNCH(3); break;     // (timing diagnostics, tools/perf_trio.py: records are NOT valid)
+        case 5: GEOAC_TRIO_LAUNCH(5); break;
+        case 11: GEOAC_TRIO_LAUNCH(11); break;
+        case 27: GEOAC_TRIO_LAUNCH(27); break;
+        default: GEOAC_TRIO_LAUNCH(1); break;
+    }
+    #undef GEOAC_TRIO_LAUNCH
+    return hipGetLastError();
+}
 #else
 extern "C" size_t geoac_duo_lds(int nseg){ (void)nseg; return (size_t)1 << 40; }          // (never fits: the plan cannot pick the kernel)
+extern "C" size_t geoac_trio_lds(int nseg){ (void)nseg; return (size_t)1 << 40; }
 static hipError_t launch_rk4_duo(const GeoacDevParams*, hipStream_t, unsigned*){ return hipErrorNotSupported; }
+static hipError_t launch_rk4_trio(const GeoacDevParams*, hipStream_t, unsigned*){ return hipErrorNotSupported; }
 #endif
 extern "C" hipError_t geoac_launch_rk4(const GeoacDevParams* P, int block, hipStream_t s, unsigned* n_wg){
     if(P->duo) return launch_rk4_duo(P, s, n_wg);
+    if(P->trio && P->lanes_per_ray == 2 && !P->gtab && P->eqset == GEOAC_EQ_GLOBAL) return launch_rk4_trio(P, s, n_wg);
     if(P->lanes_per_ray == 2 && !P->gtab && P->eqset == GEOAC_EQ_GLOBAL) return launch_rk4_t<EqGlobalPair>(P, block, s, n_wg);
     if(P->lanes_per_ray == 2 && !P->gtab && P->eqset == GEOAC_EQ_3D) return launch_rk4_t<Eq3DPair>(P, block, s, n_wg);
     GEOAC_DISPATCH_EQ_RK4(P, return launch_rk4_t<EQ>(P, block, s, n_wg));

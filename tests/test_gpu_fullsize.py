@@ -114,6 +114,9 @@ def test_full_fan_is_schedule_independent(G, eqname, total):
     plans += [{"GEOAC_ACCUM_BATCH": "1"}, {"GEOAC_ACCUM_BATCH": "0"}, {"GEOAC_CHUNK_GIB": "1", "GEOAC_ACCUM_BATCH": "1"}]
     if eqname == "EQ_GLOBAL" and G.has_ab_kernels():              # (A/B builds only: `make AB=1`, GEOAC_LIB=<that build>)
         plans += [{"GEOAC_DUO": "1"}, {"GEOAC_DUO": "1", "GEOAC_COMPACT": "0"}, {"GEOAC_DUO": "1", "GEOAC_TWO_CHUNKS": "1", "GEOAC_S_ROWS": "3000"}]
+        # TRIO=1: the three-wave kernel of round 4 (k_rk4_trio: the ray on one wave, ONE launch-angle system on each of two more, a ring of two message slots) on the
+        # share of the fan that otherwise takes two lanes per ray - the shallow tenth, all of it, and with short epochs
+        plans += [{"GEOAC_TRIO": "1"}, {"GEOAC_TRIO": "1", "GEOAC_PAIR_FRAC": "1.0"}, {"GEOAC_TRIO": "1", "GEOAC_TWO_CHUNKS": "1", "GEOAC_S_ROWS": "3000"}]
     for env in plans:
         rec, st = run(env)
         assert st == steps, env

@@ -50,7 +50,7 @@ def _rows():
 def test_launch_plan_kernels_use_no_scratch():
     rows = _rows()
     # the shipped build holds launch-plan kernels only: the diagnostic ones (k_rk4_duo, the grid sets' two-lane kernels) are compiled by `make AB=1`
-    assert not [r["name"] for r in rows if "k_rk4_duo" in r["name"] or re.search(r"k_rk4<Eq(3D|Global)RngDep<(true|false), 2,", r["name"])]
+    assert not [r["name"] for r in rows if "k_rk4_duo" in r["name"] or "k_rk4_trio" in r["name"] or re.search(r"k_rk4<Eq(3D|Global)RngDep<(true|false), 2,", r["name"])]
     assert len(rows) > 80                                            # the whole family of instantiations was seen
     offenders, excused, known = [], 0, []
     for r in rows:
