@@ -103,6 +103,11 @@ struct geoac_ctx {
     GeoacDevParams lastP{};          // parameter block of the last completed launch (device-function probes, include/geoac_probe.h)
     int  accum_batch = -1;           // ACCUM_BATCH: k_accum fetches eight rows' contributions together; < 0: in the late epochs (few waves alive)
     int  chunk_gib = 40;             // CHUNK_GIB: largest path chunk (three of them + their contribution buffers at 1/3 of that each: <= 160 GiB of the 288 by default)
+    int  cu_split = -1;              // CU_SPLIT: compute units of the device set aside for the post-pass (streams with a CU mask, hipExtStreamCreateWithCUMask): the RK4 launches run on the others;
+                                     // 0: no partition (the post-pass goes where the RK4 workgroups leave room); < 0: by launch plan
+    int  cu_split_made = 0;          // ... the split the two masked streams below were created for (0: none yet)
+    hipStream_t rk4_cu_stream = nullptr, pp_cu_stream = nullptr;
+    hipEvent_t ev_cu = nullptr;      // orders the masked RK4 stream behind the context's own
     int  pp_lds_pad = -1;            // PP_LDS_PAD: bytes of LDS a table post-pass workgroup asks for (its occupancy knob: 160 KiB per CU / this = workgroups of four waves per CU); < 0: by launch plan
     int  pp_lds_table = -1;          // table post-pass of the spherical set: the table entry in LDS, 127 registers (PP_LDS_TABLE=1; default off: no faster, geoac_fan_launch)
     // atmosphere generation, shared with the clones of this context (geoac_clone: they hold VIEWS of its tables): bumped by every upload, set to ~0 when the context is
@@ -262,7 +267,7 @@ int geoac_default_params(int eqset, geoac_params* p){
 
 // ---- launch-plan options (A/B measurements, tests; results never depend on them) ----
 static const char* const kOptionNames[] = {
-    "S_ROWS", "NO_OVERLAP", "PP_BLOCKS", "ABS_TABLE", "ABS_TABLE_TOL", "PPFIX_CAP", "DUO", "TRIO", "EV_SLACK", "NO_PAIR", "PAIR_FRAC", "HYBRID_ROWS", "TWO_CHUNKS", "TRACE_EPOCHS", "NO_GATE", "SORT", "TILE", "PP_ONETRIP", "PP_LDS_TABLE", "PP_LDS_PAD", "CHUNK_GIB", "ACCUM_BATCH",
+    "S_ROWS", "NO_OVERLAP", "PP_BLOCKS", "ABS_TABLE", "ABS_TABLE_TOL", "PPFIX_CAP", "DUO", "TRIO", "EV_SLACK", "NO_PAIR", "PAIR_FRAC", "HYBRID_ROWS", "TWO_CHUNKS", "TRACE_EPOCHS", "NO_GATE", "SORT", "TILE", "PP_ONETRIP", "PP_LDS_TABLE", "PP_LDS_PAD", "CU_SPLIT", "CHUNK_GIB", "ACCUM_BATCH",
     "NO_QUAD", "GRID_LANES", "OCT", "HEX", "SPREAD", "COMPACT", "QUAD_CACHE", "GRID_COOP", "SUB_EPOCHS", "SUB_MIN_WAVES", "SUB_TEST_STALL", "SMP_CAP", "GRID_BUILD", nullptr };
 const char* const* geoac_option_names(void){ return kOptionNames; }
 
@@ -308,6 +313,7 @@ int geoac_set_option(geoac_ctx* ctx, const char* key, const char* value){
     else if(k == "PP_ONETRIP"){ if(!int_ok || lv < -1 || lv > 1) return bad("0, 1 or -1 (by launch plan)"); ctx->pp_onetrip = iv; }
     else if(k == "CHUNK_GIB"){ if(!int_ok || lv < 1 || lv > 256) return bad("GiB per path chunk in 1 .. 256"); ctx->chunk_gib = iv; }
     else if(k == "ACCUM_BATCH"){ if(!int_ok || lv < -1 || lv > 1) return bad("0, 1 or -1 (by launch plan: the late epochs)"); ctx->accum_batch = iv; }
+    else if(k == "CU_SPLIT"){ if(!int_ok || lv < -1 || lv > 248) return bad("compute units for the post-pass, 0 .. 248 (0: no partition), or -1 (by launch plan)"); ctx->cu_split = iv; }
     else if(k == "PP_LDS_PAD"){ if(!int_ok || lv < -1 || lv > 160 * 1024) return bad("bytes of LDS in 0 .. 163840, or -1 (by launch plan)"); ctx->pp_lds_pad = iv; }
     else if(k == "PP_LDS_TABLE"){ if(!int_ok || lv < -1 || lv > 1) return bad("0, 1 or -1 (by launch plan)"); ctx->pp_lds_table = iv; }
     else if(k == "NO_QUAD") return flag(ctx->no_quad);
@@ -393,6 +399,9 @@ int geoac_destroy(geoac_ctx* ctx){
     if(ctx->acc_stream) hipStreamDestroy(ctx->acc_stream);
     if(ctx->rk4b_stream) hipStreamDestroy(ctx->rk4b_stream);
     if(ctx->pp_stream) hipStreamDestroy(ctx->pp_stream);
+    if(ctx->ev_cu) hipEventDestroy(ctx->ev_cu);
+    if(ctx->rk4_cu_stream) hipStreamDestroy(ctx->rk4_cu_stream);
+    if(ctx->pp_cu_stream) hipStreamDestroy(ctx->pp_cu_stream);
     if(ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return GEOAC_OK;
@@ -418,7 +427,7 @@ int geoac_clone(geoac_ctx* src, geoac_ctx** out){
         hipError_t e = c->d_consts.ensure(sizeof(double) * 8);
         if(e != hipSuccess){ geoac_destroy(c); return hipfail(src, e, "clone: constants block"); }
     }
-    c->sort_rays = src->sort_rays; c->tile_rays = src->tile_rays; c->pp_onetrip = src->pp_onetrip; c->pp_lds_table = src->pp_lds_table; c->pp_lds_pad = src->pp_lds_pad; c->chunk_gib = src->chunk_gib; c->accum_batch = src->accum_batch; c->sub_test_stall = src->sub_test_stall; c->no_quad = src->no_quad; c->oct = src->oct; c->hex = src->hex; c->grid_lanes = src->grid_lanes; c->spread_override = src->spread_override;
+    c->sort_rays = src->sort_rays; c->tile_rays = src->tile_rays; c->pp_onetrip = src->pp_onetrip; c->pp_lds_table = src->pp_lds_table; c->pp_lds_pad = src->pp_lds_pad; c->cu_split = src->cu_split; c->chunk_gib = src->chunk_gib; c->accum_batch = src->accum_batch; c->sub_test_stall = src->sub_test_stall; c->no_quad = src->no_quad; c->oct = src->oct; c->hex = src->hex; c->grid_lanes = src->grid_lanes; c->spread_override = src->spread_override;
     c->compact = src->compact; c->quad_cache = src->quad_cache; c->sub_min_waves = src->sub_min_waves; c->sub_epochs = src->sub_epochs; c->grid_coop = src->grid_coop;
     c->smp_cap = src->smp_cap; c->s_rows_override = src->s_rows_override; c->no_overlap = src->no_overlap; c->pp_blocks = src->pp_blocks; c->pair_frac = src->pair_frac;
     c->hybrid_rows = src->hybrid_rows; c->two_chunks = src->two_chunks; c->no_gate = src->no_gate; c->no_pair = src->no_pair; c->duo = src->duo; c->trio = src->trio; c->abs_table = src->abs_table;
@@ -918,7 +927,36 @@ static int fan_launch_once(geoac_ctx* ctx){
     // ---- epoch pipeline: RK4 of epoch e on the context's stream, post-pass of epoch e on a second stream, chunk
     //      buffers alternate, so k_rk4(e+1) runs beside k_postpass(e)/k_accum(e).  The host only waits for the
     //      live-ray count of each RK4 launch (it must know when to stop). ----
-    hipStream_t s = ctx->stream, sp = ctx->no_overlap ? ctx->stream : ctx->pp_stream, sa = ctx->no_overlap ? ctx->stream : ctx->acc_stream;
+    // CU partition (CU_SPLIT): fans whose RK4 waves and post-pass cannot share a SIMD (442 + 146 registers) and that fill the chip alternate between the two otherwise - an
+    // RK4 workgroup needs a whole CU (the table in LDS), so a round of them waits until post-pass workgroups have drained from enough CUs, and the post-pass gets what
+    // a round leaves over.  With two streams confined to disjoint sets of CUs (hipExtStreamCreateWithCUMask; the mask's bits go round robin over the XCDs, so either set is
+    // spread evenly over the eight of them) both run all the time, each at the occupancy that suits it.
+    int cu_split = ctx->cu_split >= 0 ? ctx->cu_split : 0;
+    if(ctx->no_overlap || hybrid || !P.table_in_lds || is_grid) cu_split = 0;
+    if(cu_split > 0){
+        int n_cu = 0;
+        HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device));
+        cu_split = std::min(std::max(cu_split / 8 * 8, 8), n_cu - 8);
+        if(n_cu < 32 || n_cu > 256) cu_split = 0;
+        else if(ctx->cu_split_made != cu_split){
+            if(ctx->rk4_cu_stream){ hipStreamSynchronize(ctx->rk4_cu_stream); hipStreamDestroy(ctx->rk4_cu_stream); ctx->rk4_cu_stream = nullptr; }
+            if(ctx->pp_cu_stream){ hipStreamSynchronize(ctx->pp_cu_stream); hipStreamDestroy(ctx->pp_cu_stream); ctx->pp_cu_stream = nullptr; }
+            ctx->cu_split_made = 0;
+            uint32_t m_pp[8] = {0}, m_rk[8] = {0};
+            for(int i = 0; i < n_cu; i++) (i < cu_split ? m_pp : m_rk)[i / 32] |= 1u << (i % 32);
+            if(hipExtStreamCreateWithCUMask(&ctx->rk4_cu_stream, 8, m_rk) != hipSuccess || hipExtStreamCreateWithCUMask(&ctx->pp_cu_stream, 8, m_pp) != hipSuccess){
+                (void)hipGetLastError();                          // (a device / driver without CU masks: no partition)
+                if(ctx->rk4_cu_stream){ hipStreamDestroy(ctx->rk4_cu_stream); ctx->rk4_cu_stream = nullptr; }
+                ctx->pp_cu_stream = nullptr; cu_split = 0;
+            } else ctx->cu_split_made = cu_split;
+        }
+    }
+    hipStream_t s = cu_split ? ctx->rk4_cu_stream : ctx->stream, sp = ctx->no_overlap ? ctx->stream : (cu_split ? ctx->pp_cu_stream : ctx->pp_stream), sa = ctx->no_overlap ? ctx->stream : ctx->acc_stream;
+    if(cu_split){                                                 // (whatever the caller queued on the context's stream comes first)
+        if(!ctx->ev_cu) HIPCHK(hipEventCreateWithFlags(&ctx->ev_cu, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(ctx->ev_cu, ctx->stream));
+        HIPCHK(hipStreamWaitEvent(s, ctx->ev_cu, 0));
+    }
     HIPCHK(hipMemsetAsync(ctx->counters.p, 0, 32 * sizeof(unsigned long long), s));
     HIPCHK(hipEventRecord(ctx->ev0, s));
     HIPCHK(geoac_launch_init(&P, s));
@@ -932,7 +970,7 @@ static int fan_launch_once(geoac_ctx* ctx){
     // post-pass of one epoch on the second stream; gate_expected > 0: only after that many RK4 workgroups of this fan are resident
     auto enqueue_post = [&](GeoacDevParams Pq, size_t e, unsigned long long gate_expected) -> int {
         HIPCHK(hipStreamWaitEvent(sp, ctx->evs[4 * e + 1], 0));
-        if(gate_expected > 0 && sp != s && !ctx->no_gate) HIPCHK(geoac_launch_gate(&Pq, gate_expected, sp));
+        if(gate_expected > 0 && sp != s && !ctx->no_gate && !cu_split) HIPCHK(geoac_launch_gate(&Pq, gate_expected, sp));
         HIPCHK(hipEventRecord(ctx->evs[4 * e + 2], sp));
         if(Pq.atab_on){
             // (see geoac_launch_postpass_tab) hybrid fans: the post-pass off the RK4 CUs, one (spherical set) or two (Cartesian sets) workgroups per free CU
@@ -942,6 +980,7 @@ static int fan_launch_once(geoac_ctx* ctx){
             // at four, 369 at one (profiles/r04_c_cfg3_occupancy.txt).  RK4 (one wave per SIMD, 442 registers) and the post-pass cannot share a SIMD; every SIMD a
             // post-pass wave sits on is one an RK4 wave of the next round is not placed on, and RK4 is the longer of the two.
             if(!hybrid && Pq.eqset == GEOAC_EQ_GLOBAL) Pq.pp_lds_pad = 60 * 1024;
+            if(cu_split) Pq.pp_lds_pad = 0;                   // (its own CUs: as many waves as its registers allow)
             if(ctx->pp_lds_pad >= 0) Pq.pp_lds_pad = ctx->pp_lds_pad;
             Pq.pp_onetrip = ctx->pp_onetrip >= 0 ? (ctx->pp_onetrip ? 1 : 0) : (hybrid ? 0 : 1);
             Pq.pp_lds_table = (Pq.eqset == GEOAC_EQ_GLOBAL && Pq.pp_onetrip) ? (ctx->pp_lds_table > 0 ? 1 : 0) : 0;      // (opt-in: measured no faster at any occupancy, see above)

@@ -112,6 +112,8 @@ def test_full_fan_is_schedule_independent(G, eqname, total):
              {"GEOAC_TWO_CHUNKS": "1", "GEOAC_S_ROWS": "4096"}, {"GEOAC_PAIR_FRAC": "1.0"}, {"GEOAC_PAIR_FRAC": "0"}]
     # k_accum with the contributions of eight rows fetched together in EVERY epoch / in none (default: the late epochs only), and small path chunks (CHUNK_GIB: a shared device)
     plans += [{"GEOAC_ACCUM_BATCH": "1"}, {"GEOAC_ACCUM_BATCH": "0"}, {"GEOAC_CHUNK_GIB": "1", "GEOAC_ACCUM_BATCH": "1"}]
+    # the post-pass and the RK4 launches on disjoint sets of compute units (CU-masked streams; fans that are not hybrid)
+    plans += [{"GEOAC_NO_PAIR": "1", "GEOAC_CU_SPLIT": "64"}]
     if eqname == "EQ_GLOBAL" and G.has_ab_kernels():              # (A/B builds only: `make AB=1`, GEOAC_LIB=<that build>)
         plans += [{"GEOAC_DUO": "1"}, {"GEOAC_DUO": "1", "GEOAC_COMPACT": "0"}, {"GEOAC_DUO": "1", "GEOAC_TWO_CHUNKS": "1", "GEOAC_S_ROWS": "3000"}]
         # TRIO=1: the three-wave kernel of round 4 (k_rk4_trio: the ray on one wave, ONE launch-angle system on each of two more, a ring of two message slots) on the
