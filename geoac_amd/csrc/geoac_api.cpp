@@ -172,6 +172,9 @@ struct geoac_ctx {
                                                   // Measured: a short full-occupancy burst disturbs k_rk4 LESS than a long thin sweep
                                                   // (avg k_rk4 launch 10.9 ms vs 11.7-12.8 ms at 8192-256 blocks).
     double pair_frac = -1.0;                      // hybrid fans: share of the inclination-sorted rays that get two lanes (PAIR_FRAC; >= 1: all; < 0: the set's own default, plan_pair_frac)
+    double stagger_frac = -1.0;                   // staggered epochs (fans of the stratified sets with more waves than the chip has wave slots): share of the inclination-sorted rays - the shallow,
+                                                  // long ones - that get a whole epoch's rows per launch while the others get stagger_rows of them (STAGGER_FRAC; 0: off; < 0: by launch plan)
+    double stagger_rows = -1.0;                   // ... STAGGER_ROWS (< 0: by launch plan)
     double hybrid_rows = -1.0;                    // hybrid fans: rows per epoch of the one-lane launch relative to the two-lane launch (HYBRID_ROWS; < 0: the set's own default, plan_hybrid_rows)
     bool two_chunks = false;                      // GEOAC_TWO_CHUNKS=1: two path chunks in rotation instead of three (A/B measurements)
     bool trace_epochs = false;                    // GEOAC_TRACE_EPOCHS=1: per-epoch live counts on stderr
@@ -267,7 +270,7 @@ int geoac_default_params(int eqset, geoac_params* p){
 
 // ---- launch-plan options (A/B measurements, tests; results never depend on them) ----
 static const char* const kOptionNames[] = {
-    "S_ROWS", "NO_OVERLAP", "PP_BLOCKS", "ABS_TABLE", "ABS_TABLE_TOL", "PPFIX_CAP", "DUO", "TRIO", "EV_SLACK", "NO_PAIR", "PAIR_FRAC", "HYBRID_ROWS", "TWO_CHUNKS", "TRACE_EPOCHS", "NO_GATE", "SORT", "TILE", "PP_ONETRIP", "PP_LDS_TABLE", "PP_LDS_PAD", "CU_SPLIT", "CHUNK_GIB", "ACCUM_BATCH",
+    "S_ROWS", "NO_OVERLAP", "PP_BLOCKS", "ABS_TABLE", "ABS_TABLE_TOL", "PPFIX_CAP", "DUO", "TRIO", "EV_SLACK", "NO_PAIR", "PAIR_FRAC", "HYBRID_ROWS", "STAGGER_FRAC", "STAGGER_ROWS", "TWO_CHUNKS", "TRACE_EPOCHS", "NO_GATE", "SORT", "TILE", "PP_ONETRIP", "PP_LDS_TABLE", "PP_LDS_PAD", "CU_SPLIT", "CHUNK_GIB", "ACCUM_BATCH",
     "NO_QUAD", "GRID_LANES", "OCT", "HEX", "SPREAD", "COMPACT", "QUAD_CACHE", "GRID_COOP", "SUB_EPOCHS", "SUB_MIN_WAVES", "SUB_TEST_STALL", "SMP_CAP", "GRID_BUILD", nullptr };
 const char* const* geoac_option_names(void){ return kOptionNames; }
 
@@ -304,6 +307,8 @@ int geoac_set_option(geoac_ctx* ctx, const char* key, const char* value){
     else if(k == "EV_SLACK"){ if(!int_ok || lv < 0 || lv > 1000000) return bad("a slot count >= 0"); ctx->ev_slack = iv; }
     else if(k == "NO_PAIR") return flag(ctx->no_pair);
     else if(k == "PAIR_FRAC"){ if(!dbl_ok || dv < 0.0 || dv > 1.0) return bad("a share in [0, 1]"); ctx->pair_frac = dv; }
+    else if(k == "STAGGER_FRAC"){ if(!dbl_ok || dv < -1.0 || dv > 0.9) return bad("a share in [0, 0.9] (0: off), or -1 (by launch plan)"); ctx->stagger_frac = dv; }
+    else if(k == "STAGGER_ROWS"){ if(!dbl_ok || !(dv > 0.0 && dv <= 1.0)) return bad("a ratio in (0, 1]"); ctx->stagger_rows = dv; }
     else if(k == "HYBRID_ROWS"){ if(!dbl_ok || !(dv > 0.0 && dv <= 1.0)) return bad("a ratio in (0, 1]"); ctx->hybrid_rows = dv; }
     else if(k == "TWO_CHUNKS") return flag(ctx->two_chunks);
     else if(k == "TRACE_EPOCHS") return flag(ctx->trace_epochs);
@@ -429,7 +434,7 @@ int geoac_clone(geoac_ctx* src, geoac_ctx** out){
     }
     c->sort_rays = src->sort_rays; c->tile_rays = src->tile_rays; c->pp_onetrip = src->pp_onetrip; c->pp_lds_table = src->pp_lds_table; c->pp_lds_pad = src->pp_lds_pad; c->cu_split = src->cu_split; c->chunk_gib = src->chunk_gib; c->accum_batch = src->accum_batch; c->sub_test_stall = src->sub_test_stall; c->no_quad = src->no_quad; c->oct = src->oct; c->hex = src->hex; c->grid_lanes = src->grid_lanes; c->spread_override = src->spread_override;
     c->compact = src->compact; c->quad_cache = src->quad_cache; c->sub_min_waves = src->sub_min_waves; c->sub_epochs = src->sub_epochs; c->grid_coop = src->grid_coop;
-    c->smp_cap = src->smp_cap; c->s_rows_override = src->s_rows_override; c->no_overlap = src->no_overlap; c->pp_blocks = src->pp_blocks; c->pair_frac = src->pair_frac;
+    c->smp_cap = src->smp_cap; c->s_rows_override = src->s_rows_override; c->no_overlap = src->no_overlap; c->pp_blocks = src->pp_blocks; c->pair_frac = src->pair_frac; c->stagger_frac = src->stagger_frac; c->stagger_rows = src->stagger_rows;
     c->hybrid_rows = src->hybrid_rows; c->two_chunks = src->two_chunks; c->no_gate = src->no_gate; c->no_pair = src->no_pair; c->duo = src->duo; c->trio = src->trio; c->abs_table = src->abs_table;
     c->ev_slack = src->ev_slack; c->grid_build_host = src->grid_build_host; c->atab_tol = src->atab_tol; c->ppfix_cap = src->ppfix_cap;
     *out = c;
@@ -890,6 +895,18 @@ static int fan_launch_once(geoac_ctx* ctx){
     // live-ray compaction between epochs (single-launch fans; a hybrid fan assigns its two kernels by slot range): epoch e > 0 runs
     // over the dense list of the rays alive after epoch e-1, built on the device (k_compact) right before its RK4 launch
     const bool compact = ctx->compact && !hybrid;
+    // ---- staggered epochs (stratified sets, fans with more waves than the chip has wave slots): every live ray advances one epoch per launch, a launch takes
+    //      ceil(waves / 1024) rounds - so a ray that is twice as long as the average is still on its way when the chip has long run empty (config 3: 2 025 waves, rays of
+    //      34 000 steps on average and 55 000 at most - the shallowest: a tail of seven epochs with a few dozen waves, 12 % of the RK4 time).  The launch is therefore cut in
+    //      two in COLUMN space (the compacted list keeps the inclination order, the shallow rays come first): the leading share gets the epoch's rows, the others
+    //      stagger_rows of them on a second stream - per unit of time the long rays advance further, and all of them end together.  Which columns got how many rows
+    //      changes nothing in the records (test_full_fan_is_schedule_independent). ----
+    //      Measured (tools/sweep_cu_split.py, profiles/r04_f_stagger.txt): config 3 354-362 -> 326-336 ms per pass, flat over shares of 0.10-0.30 and row ratios of 0.5-0.7;
+    //      a 72 000-ray fan 253 -> 213 ms, a 200 000-ray one 415 -> 376, GeoAc3D 720 x 180 312-331 -> 297-303.
+    const double plan_stagger_frac = ctx->stagger_frac >= 0.0 ? ctx->stagger_frac : 0.12;
+    const double plan_stagger_rows = ctx->stagger_rows > 0.0 ? ctx->stagger_rows : 0.6;
+    bool stagger = compact && !is_grid && P.table_in_lds && ctx->have_perm && !ctx->no_overlap && plan_stagger_frac > 0.0 && P.lanes_per_ray == 1 && (long long)P.n_pad / 64 > 1024;
+    unsigned long long long_bound = (unsigned long long)(plan_stagger_frac * ctx->n_rays);      // live rays of the leading share (an upper bound: what its last launch counted)
     if(compact){
         for(int b = 0; b < 3; b++) HIPCHK(ctx->colmap[b].ensure(sizeof(int) * (size_t)P.n_pad));
         HIPCHK(ctx->ncols.ensure(4 * sizeof(int)));
@@ -1045,6 +1062,19 @@ static int fan_launch_once(geoac_ctx* ctx){
             HIPCHK(geoac_launch_rk4(&Pe, 256, s, &n_wg));
             HIPCHK(hipStreamWaitEvent(s, ctx->evj[2 * e], 0));
             Pe.slot_hi = P.n_pad;
+        } else if(stagger && (int)((long_bound + 255ull) / 256ull * 256ull) < Pe.slot_hi && long_bound > 0){
+            const int kb = (int)((long_bound + 255ull) / 256ull * 256ull);       // columns [0, kb): the epoch's rows; [kb, slot_hi): fewer, on the second stream
+            GeoacDevParams P1 = Pe;
+            P1.slot_lo = kb; P1.live_slot = 6;
+            P1.s_rows = std::max(8, (int)(plan_stagger_rows * rows_now));
+            HIPCHK(hipStreamWaitEvent(ctx->rk4b_stream, ctx->evs[eb], 0));
+            HIPCHK(geoac_launch_rk4(&P1, block, ctx->rk4b_stream, &n_wg1));
+            HIPCHK(hipEventRecord(ctx->evj[2 * e], ctx->rk4b_stream));
+            const int hi = Pe.slot_hi;
+            Pe.slot_hi = kb;
+            HIPCHK(geoac_launch_rk4(&Pe, block, s, &n_wg));
+            HIPCHK(hipStreamWaitEvent(s, ctx->evj[2 * e], 0));
+            Pe.slot_hi = hi;
         } else {
             // cooperative grid kernels with more waves than the chip has wave slots (1024: one per SIMD): sub-epochs (k_rk4) keep the
             // last round of the launch from running on a part-empty chip
@@ -1077,6 +1107,7 @@ static int fan_launch_once(geoac_ctx* ctx){
             // kernel, whole epochs (same state layout): whatever is still running now sets the finish time - also when the shallow
             // rays were NOT the longest ones
             if(split && (hc[1] == 0 || hc[4] + 2 * hc[7] <= 512)) split = false;
+            if(stagger){ long_bound = hc[1]; if(hc[4] + hc[7] <= 1024) stagger = false; }      // (everything fits one round now: one launch, whole epochs)
             if(hc[4] + hc[7] <= 256) rows_now = rows_late;
             if(ctx->trace_epochs) fprintf(stderr, "[epoch %zu] waves launched %u, after it: live rays %llu + %llu in %llu + %llu waves, split %d, rows next %d\n", e - 1, waves_launched_prev, hc[1], hc[6], hc[4], hc[7], (int)split, rows_now);
         }

@@ -85,6 +85,16 @@ def test_config3_global_720x180_bounces3(G):
     rec, steps = ctx.run(th, ph)
     _properties(rec, steps, 18, slice(3, 6), c_ratio=1.0)
     _sample_vs_oracle(G, H.EQ_GLOBAL, params, th, ph, rec, E=18, n=16)
+    # staggered epochs (fans with more waves than the chip has wave slots: the shallow share of the compacted list gets a whole epoch's rows per launch, the rest fewer
+    # on a second stream - the default plan here): off, and with another share and ratio - which columns got how many rows changes nothing in the records
+    ref = rec.copy(); ctx.close()
+    for env in ({"GEOAC_STAGGER_FRAC": "0"}, {"GEOAC_STAGGER_FRAC": "0.3", "GEOAC_STAGGER_ROWS": "0.45"}):
+        with G.options(**env):
+            c2 = G.FanContext(G.EQ_GLOBAL, device=0)
+            c2.load_met(H.TOYATMO); c2.set_params(**params)
+            r2, s2 = c2.run(th, ph); c2.close()
+        assert s2 == steps, env
+        assert np.array_equal(r2.view(np.uint64), ref.view(np.uint64)), env
 
 
 @pytest.mark.parametrize("eqname,total", [("EQ_GLOBAL", 874273730), ("EQ_3D", 871080426)])

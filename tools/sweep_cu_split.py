@@ -10,6 +10,12 @@ which = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
 passes = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 if which == "cfg3":
     th, ph = G.fan_enumerate(theta_min=0.25, theta_max=45.0, theta_step=0.25, phi_min=-180.0, phi_max=179.5, phi_step=0.5); params = dict(bounces=3, calc_amp=1, mode=0, src=(0.0, 30.0, 0.0))
+elif which == "g72k":
+    th, ph = G.fan_enumerate(theta_min=0.25, theta_max=45.0, theta_step=0.25, phi_min=-180.0, phi_max=179.1, phi_step=0.9); params = dict(bounces=3, calc_amp=1, mode=0, src=(0.0, 30.0, 0.0))
+elif which == "g200k":
+    th, ph = G.fan_enumerate(theta_min=0.2, theta_max=50.0, theta_step=0.2, phi_min=-180.0, phi_max=179.55, phi_step=0.45); params = dict(bounces=2, calc_amp=1, mode=0, src=(0.0, 30.0, 0.0))
+elif which == "3dbig":
+    th, ph = G.fan_enumerate(theta_min=0.25, theta_max=45.0, theta_step=0.25, phi_min=-180.0, phi_max=179.5, phi_step=0.5); params = dict(bounces=3, calc_amp=1, mode=0)
 elif which == "cfg2":
     th, ph = G.fan_enumerate(theta_min=0.5, theta_max=45.0, theta_step=0.5, phi_min=-180.0, phi_max=179.0, phi_step=1.0); params = dict(bounces=10, calc_amp=1, mode=0, src=(0.0, 30.0, 0.0))
 else:
@@ -19,7 +25,7 @@ plans = [{}] + [{"CU_SPLIT": str(n)} for n in (48, 64, 72, 80, 88, 96, 112)] + [
 if len(sys.argv) > 3:
     plans = [{}] + [dict(kv.split("=") for kv in a.split(",")) for a in sys.argv[3:]] + [{}]
 for opts in plans:
-    ctx = G.FanContext(G.EQ_GLOBAL, device=0, options=opts); ctx.load_met(H.TOYATMO); ctx.set_params(**params)
+    ctx = G.FanContext(G.EQ_3D if which == "3dbig" else G.EQ_GLOBAL, device=0, options=opts); ctx.load_met(H.TOYATMO); ctx.set_params(**params)
     ctx.set_angles(th, ph); ctx.launch()
     ts = []
     for _ in range(passes):
