@@ -905,7 +905,7 @@ static int fan_launch_once(geoac_ctx* ctx){
     //      a 72 000-ray fan 253 -> 213 ms, a 200 000-ray one 415 -> 376, GeoAc3D 720 x 180 312-331 -> 297-303.
     const double plan_stagger_frac = ctx->stagger_frac >= 0.0 ? ctx->stagger_frac : 0.12;
     const double plan_stagger_rows = ctx->stagger_rows > 0.0 ? ctx->stagger_rows : 0.6;
-    bool stagger = compact && !is_grid && P.table_in_lds && ctx->have_perm && !ctx->no_overlap && plan_stagger_frac > 0.0 && P.lanes_per_ray == 1 && (long long)P.n_pad / 64 > 1024;
+    bool stagger = compact && !is_grid && !sampling && P.table_in_lds && ctx->have_perm && !ctx->no_overlap && plan_stagger_frac > 0.0 && P.lanes_per_ray == 1 && (long long)P.n_pad / 64 > 1024;   // (arrivals-only fans: what the plan was measured on)
     unsigned long long long_bound = (unsigned long long)(plan_stagger_frac * ctx->n_rays);      // live rays of the leading share (an upper bound: what its last launch counted)
     if(compact){
         for(int b = 0; b < 3; b++) HIPCHK(ctx->colmap[b].ensure(sizeof(int) * (size_t)P.n_pad));
