@@ -906,6 +906,11 @@ static int fan_launch_once(geoac_ctx* ctx){
     const double plan_stagger_frac = ctx->stagger_frac >= 0.0 ? ctx->stagger_frac : 0.12;
     const double plan_stagger_rows = ctx->stagger_rows > 0.0 ? ctx->stagger_rows : 0.6;
     bool stagger = compact && !is_grid && !sampling && P.table_in_lds && ctx->have_perm && !ctx->no_overlap && plan_stagger_frac > 0.0 && P.lanes_per_ray == 1 && (long long)P.n_pad / 64 > 1024;   // (arrivals-only fans: what the plan was measured on)
+    const bool stagger_plan = stagger;
+    // fans that start with one lane per ray because two would not fit the chip (more than 1 024 two-lane waves): once the rays still alive do fit, the remaining epochs - the
+    // serial chain of the few longest rays - run on the two-lane kernel (the same state layout; what a hybrid fan does when its two-lane share has finished)
+    const bool late_pair_able = compact && !is_grid && (is_global || ctx->eqset == GEOAC_EQ_3D) && p.calc_amp && !sampling && !ctx->no_pair && P.table_in_lds && P.lanes_per_ray == 1 && !P.duo;
+    bool late_pair = false;
     unsigned long long long_bound = (unsigned long long)(plan_stagger_frac * ctx->n_rays);      // live rays of the leading share (an upper bound: what its last launch counted)
     if(compact){
         for(int b = 0; b < 3; b++) HIPCHK(ctx->colmap[b].ensure(sizeof(int) * (size_t)P.n_pad));
@@ -1030,7 +1035,8 @@ static int fan_launch_once(geoac_ctx* ctx){
         while(ctx->evj.size() < 2 * e + 2){ hipEvent_t ev; HIPCHK(hipEventCreate(&ev)); ctx->evj.push_back(ev); }
         GeoacDevParams Pe = P;
         Pe.s_rows = rows_now;
-        Pe.accum_batch = (ctx->accum_batch >= 0) ? (ctx->accum_batch ? 1 : 0) : ((rows_now == rows_late && rows_late != P.s_rows) ? 1 : 0);   // (few waves alive: the sums are the tail)
+        Pe.accum_batch = (ctx->accum_batch >= 0) ? (ctx->accum_batch ? 1 : 0) : (((rows_now == rows_late && rows_late != P.s_rows) || stagger_plan) ? 1 : 0);   // (few waves alive: the sums are the tail; staggered fans: measured 0-2 % faster in every epoch)
+        if(late_pair) Pe.lanes_per_ray = 2;
         Pe.path = (double*)ctx->path[b].p; Pe.contrib = (double*)ctx->contrib[b].p;
         Pe.nrows = (int*)ctx->nrows[b].p; Pe.legend = (int*)ctx->legend[b].p; Pe.nlegend = (int*)ctx->nlegend[b].p;
         if(sampling){ Pe.ev_row = (int*)ctx->ev_row[b].p; Pe.ev_m = (int*)ctx->ev_m[b].p; Pe.ev_amp = (double*)ctx->ev_amp[b].p; Pe.nev = (int*)ctx->nev[b].p; }
@@ -1107,7 +1113,8 @@ static int fan_launch_once(geoac_ctx* ctx){
             // kernel, whole epochs (same state layout): whatever is still running now sets the finish time - also when the shallow
             // rays were NOT the longest ones
             if(split && (hc[1] == 0 || hc[4] + 2 * hc[7] <= 512)) split = false;
-            if(stagger){ long_bound = hc[1]; if(hc[4] + hc[7] <= 1024) stagger = false; }      // (everything fits one round now: one launch, whole epochs)
+            if(stagger){ long_bound = hc[1]; if(hc[4] + hc[7] <= 1024) stagger = false; }
+            if(late_pair_able && !stagger && !late_pair && 2 * (hc[4] + hc[7]) <= 768) late_pair = true;     // (live one-lane waves; as two-lane waves they take three quarters of the chip at most: the post-pass of the epochs before keeps the rest)      // (everything fits one round now: one launch, whole epochs)
             if(hc[4] + hc[7] <= 256) rows_now = rows_late;
             if(ctx->trace_epochs) fprintf(stderr, "[epoch %zu] waves launched %u, after it: live rays %llu + %llu in %llu + %llu waves, split %d, rows next %d\n", e - 1, waves_launched_prev, hc[1], hc[6], hc[4], hc[7], (int)split, rows_now);
         }

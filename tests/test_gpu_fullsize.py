@@ -88,7 +88,8 @@ def test_config3_global_720x180_bounces3(G):
     # staggered epochs (fans with more waves than the chip has wave slots: the shallow share of the compacted list gets a whole epoch's rows per launch, the rest fewer
     # on a second stream - the default plan here): off, and with another share and ratio - which columns got how many rows changes nothing in the records
     ref = rec.copy(); ctx.close()
-    for env in ({"GEOAC_STAGGER_FRAC": "0"}, {"GEOAC_STAGGER_FRAC": "0.3", "GEOAC_STAGGER_ROWS": "0.45"}):
+    # (... and NO_PAIR: the last epochs stay on the one-lane kernel instead of changing to the two-lane one; ACCUM_BATCH=0: the sums row by row)
+    for env in ({"GEOAC_STAGGER_FRAC": "0"}, {"GEOAC_STAGGER_FRAC": "0.3", "GEOAC_STAGGER_ROWS": "0.45"}, {"GEOAC_NO_PAIR": "1", "GEOAC_ACCUM_BATCH": "0"}):
         with G.options(**env):
             c2 = G.FanContext(G.EQ_GLOBAL, device=0)
             c2.load_met(H.TOYATMO); c2.set_params(**params)
