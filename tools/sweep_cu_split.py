@@ -14,6 +14,8 @@ elif which == "g72k":
     th, ph = G.fan_enumerate(theta_min=0.25, theta_max=45.0, theta_step=0.25, phi_min=-180.0, phi_max=179.1, phi_step=0.9); params = dict(bounces=3, calc_amp=1, mode=0, src=(0.0, 30.0, 0.0))
 elif which == "g200k":
     th, ph = G.fan_enumerate(theta_min=0.2, theta_max=50.0, theta_step=0.2, phi_min=-180.0, phi_max=179.55, phi_step=0.45); params = dict(bounces=2, calc_amp=1, mode=0, src=(0.0, 30.0, 0.0))
+elif which == "3dmetric":        # BASELINE config 2: GeoAc3D 360 az x 90 incl, 2 bounces
+    th, ph = G.fan_enumerate(phi_min=-180.0, phi_max=179.0, phi_step=1.0); params = dict(bounces=2, calc_amp=1, mode=0)
 elif which == "3dbig":
     th, ph = G.fan_enumerate(theta_min=0.25, theta_max=45.0, theta_step=0.25, phi_min=-180.0, phi_max=179.5, phi_step=0.5); params = dict(bounces=3, calc_amp=1, mode=0)
 elif which == "cfg2":
@@ -25,7 +27,7 @@ plans = [{}] + [{"CU_SPLIT": str(n)} for n in (48, 64, 72, 80, 88, 96, 112)] + [
 if len(sys.argv) > 3:
     plans = [{}] + [dict(kv.split("=") for kv in a.split(",")) for a in sys.argv[3:]] + [{}]
 for opts in plans:
-    ctx = G.FanContext(G.EQ_3D if which == "3dbig" else G.EQ_GLOBAL, device=0, options=opts); ctx.load_met(H.TOYATMO); ctx.set_params(**params)
+    ctx = G.FanContext(G.EQ_3D if which in ("3dbig", "3dmetric") else G.EQ_GLOBAL, device=0, options=opts); ctx.load_met(H.TOYATMO); ctx.set_params(**params)
     ctx.set_angles(th, ph); ctx.launch()
     ts = []
     for _ in range(passes):
