@@ -71,6 +71,24 @@ def test_context_reuse_and_caller_order():
     assert np.array_equal(rec3, rec1)                                 # and back: bit-identical to the first launch
 
 
+def test_ray_order_of_the_sort_does_not_reach_the_records():
+    """geoac_fan_set_angles orders the rays by inclination (a radix sort on the doubles' integer image; a comparison sort when a -0.0 or a NaN is among them) and the
+    records come back in the caller's order: a few thousand rays in random order with many equal inclinations against the same fan in sorted order, and an
+    inclination of -0.0 (the comparison-sort path) against +0.0"""
+    rng = np.random.default_rng(5)
+    th = np.round(rng.uniform(1.0, 40.0, 3000), 0); ph = np.round(rng.uniform(-180.0, 180.0, 3000), 1)
+    order = np.lexsort((ph, th))
+    ctx = _gpu(H.EQ_GLOBAL, bounces=1, calc_amp=1)
+    rec_sorted, s1 = ctx.run(th[order], ph[order])
+    rec_sorted = rec_sorted.copy()
+    rec_any, s2 = ctx.run(th, ph)
+    assert s1 == s2
+    assert np.array_equal(rec_any[order].view(np.uint64), rec_sorted.view(np.uint64))
+    a, _ = ctx.run(np.array([5.0, -0.0, 12.0, 5.0]), np.array([10.0, 20.0, 30.0, 10.0])); a = a.copy()
+    b, _ = ctx.run(np.array([5.0, 0.0, 12.0, 5.0]), np.array([10.0, 20.0, 30.0, 10.0]))
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
 def test_error_paths():
     import geoac_amd as G
     ctx = G.FanContext(G.EQ_GLOBAL, device=0)
