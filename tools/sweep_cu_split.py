@@ -10,6 +10,8 @@ which = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
 passes = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 if which == "cfg3":
     th, ph = G.fan_enumerate(theta_min=0.25, theta_max=45.0, theta_step=0.25, phi_min=-180.0, phi_max=179.5, phi_step=0.5); params = dict(bounces=3, calc_amp=1, mode=0, src=(0.0, 30.0, 0.0))
+elif which == "g48k":
+    th, ph = G.fan_enumerate(theta_min=0.5, theta_max=45.0, theta_step=0.5, phi_min=-180.0, phi_max=179.4, phi_step=0.675); params = dict(bounces=2, calc_amp=1, mode=0, src=(0.0, 30.0, 0.0))
 elif which == "g72k":
     th, ph = G.fan_enumerate(theta_min=0.25, theta_max=45.0, theta_step=0.25, phi_min=-180.0, phi_max=179.1, phi_step=0.9); params = dict(bounces=3, calc_amp=1, mode=0, src=(0.0, 30.0, 0.0))
 elif which == "g200k":
